@@ -1,0 +1,572 @@
+"""ORACLE — TEST INFRASTRUCTURE ONLY (CPU, pure torch + oracle/knn_ref.c).
+
+A restatement of the reference's point-cloud-encoder -> panel-sequence-decoder
+path, used ONLY as the checker in tests/, in __graft_entry__.smoke() and as the
+`cpu_baseline` leg of bench.py.  The product path (the HIP library behind
+`garment-pattern-estimation_amd/`) never imports this module.
+
+What it follows (paths relative to /root/reference):
+  * nn/net_blocks.py:43-47     MLP = [Linear -> ReLU -> BatchNorm1d] x n (BN after ReLU, last layer too)
+  * nn/net_blocks.py:93-191    EdgeConvFeatures (defaults, 2x DynamicEdgeConv, pool, Linear)
+  * nn/net_blocks.py:302-333   _init_tenzor / _init_weights
+  * nn/net_blocks.py:363-402   LSTMDecoderModule
+  * nn/nets.py:11-184          BaseModule, GarmentFullPattern3D
+  * nn/nets.py:187-299         GarmentSegmentPattern3D
+  * nn/metrics/composed_loss.py:222-334, nn/metrics/losses.py:8-51  main loss terms (backward seed)
+  * nn/trainer.py:92-99        the fwd -> loss -> bwd step
+
+Pinning status:
+  * The torch-native parts (module construction order, config logic, init, LSTM
+    decoders, output slicing, loss) are checked against the reference's OWN code
+    imported in the build container (oracle/refgen/make_golden.py ->
+    tests/golden/*.pt, tests/test_oracle_golden.py).
+  * torch_geometric.DynamicEdgeConv / global_mean_pool, torch_cluster.knn and
+    sparsemax.Sparsemax are third-party, un-vendored, version-unpinned
+    (docs/Installation.md:46-48,67; requirements.txt:2).  Their arithmetic is
+    restated here from the published definitions -> PARITY UNPINNED at those
+    call sites (nn/net_blocks.py:127-135,145-150,184; nn/nets.py:225,272).
+
+fp64 mode: `model.double()` + fp64 input gives a high-precision reference; the
+random LSTM states are always drawn as fp32 (like the reference) and then cast.
+"""
+import ctypes
+import os
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def _oracle_lib():
+    """ctypes handle on oracle/libgpe_oracle.so (built by oracle/Makefile or __graft_entry__.build())."""
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(_HERE, 'libgpe_oracle.so')
+        if not os.path.exists(path):
+            raise RuntimeError(
+                'oracle/libgpe_oracle.so is missing: run `make -C oracle` or __graft_entry__.build()')
+        lib = ctypes.CDLL(path)
+        lib.gpe_oracle_knn.restype = ctypes.c_int
+        lib.gpe_oracle_knn.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                       ctypes.c_int, ctypes.c_void_p]
+        lib.gpe_oracle_sqdist.restype = ctypes.c_int
+        lib.gpe_oracle_sqdist.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+        _LIB = lib
+    return _LIB
+
+
+# ---------------------------------------------------------------------------------------------
+# third-party ops restated (parity unpinned, see module docstring)
+# ---------------------------------------------------------------------------------------------
+def knn_local(x, n_clouds, k):
+    """Per-cloud exact kNN incl. self; x: [B*N, C] (any float dtype, evaluated in fp32).
+    Returns LongTensor [B*N, k] of indices LOCAL to each cloud, ascending distance, ties -> lower index.
+    Restates torch_cluster.knn as used by DynamicEdgeConv (call sites nn/net_blocks.py:127-135)."""
+    total, C = x.shape
+    N = total // n_clouds
+    xf = np.ascontiguousarray(x.detach().to(torch.float32).cpu().numpy())
+    out = np.empty((total, k), dtype=np.int32)
+    rc = _oracle_lib().gpe_oracle_knn(xf.ctypes.data, n_clouds, N, C, k, out.ctypes.data)
+    if rc != 0:
+        raise ValueError('gpe_oracle_knn: bad arguments (B=%d N=%d C=%d k=%d)' % (n_clouds, N, C, k))
+    return torch.from_numpy(out.astype(np.int64))
+
+
+def sqdist_one_cloud(x):
+    """[N,C] -> [N,N] fp32 squared distances with the oracle's arithmetic (debug aid for tie analysis)."""
+    N, C = x.shape
+    xf = np.ascontiguousarray(x.detach().to(torch.float32).cpu().numpy())
+    d = np.empty((N, N), dtype=np.float32)
+    _oracle_lib().gpe_oracle_sqdist(xf.ctypes.data, N, C, d.ctypes.data)
+    return torch.from_numpy(d)
+
+
+def global_pool(x, batch, size, kind):
+    """torch_geometric.nn.global_{mean,max,add}_pool restated: segment reduce by `batch`."""
+    C = x.shape[1]
+    if kind == 'max':
+        out = torch.full((size, C), float('-inf'), dtype=x.dtype)
+        return out.scatter_reduce(0, batch[:, None].expand(-1, C), x, reduce='amax', include_self=True)
+    out = torch.zeros((size, C), dtype=x.dtype).index_add(0, batch, x)
+    if kind == 'add':
+        return out
+    counts = torch.zeros(size, dtype=x.dtype).index_add(0, batch, torch.ones_like(batch, dtype=x.dtype))
+    return out / counts.clamp(min=1)[:, None]
+
+
+def global_mean_pool(x, batch, size=None):
+    return global_pool(x, batch, int(batch.max()) + 1 if size is None else size, 'mean')
+
+
+def global_max_pool(x, batch, size=None):
+    return global_pool(x, batch, int(batch.max()) + 1 if size is None else size, 'max')
+
+
+def global_add_pool(x, batch, size=None):
+    return global_pool(x, batch, int(batch.max()) + 1 if size is None else size, 'add')
+
+
+class DynamicEdgeConv(nn.Module):
+    """torch_geometric.nn.DynamicEdgeConv restated (DGCNN EdgeConv on a kNN graph rebuilt from the
+    current features): out_i = aggr_{j in kNN(i)} nn(cat[x_i, x_j - x_i]).  `nn` attribute name kept so
+    state-dict keys read `conv_layers.{i}.nn....` like the reference's."""
+
+    def __init__(self, nn_module, k, aggr='max'):
+        super().__init__()
+        self.nn = nn_module
+        self.k = k
+        self.aggr = aggr
+        self.last_knn = None      # local indices used by the last forward (for stage-wise parity)
+        self.knn_override = None  # inject a graph (LongTensor [B*N,k], local) instead of searching
+
+    def forward(self, x, batch):
+        total = x.shape[0]
+        n_clouds = int(batch.max()) + 1
+        N = total // n_clouds
+        if self.knn_override is not None:
+            local = self.knn_override
+        else:
+            local = knn_local(x, n_clouds, self.k)
+        self.last_knn = local
+        glob = local + (torch.arange(total) // N * N)[:, None]
+        x_i = x[:, None, :].expand(-1, self.k, -1)
+        x_j = x[glob]
+        msg = self.nn(torch.cat([x_i, x_j - x_i], dim=-1).reshape(total * self.k, -1))
+        msg = msg.view(total, self.k, -1)
+        if self.aggr == 'max':
+            return msg.max(dim=1).values
+        if self.aggr == 'mean':
+            return msg.mean(dim=1)
+        if self.aggr == 'add':
+            return msg.sum(dim=1)
+        raise ValueError('unsupported aggregation {}'.format(self.aggr))
+
+
+class _SparsemaxFn(torch.autograd.Function):
+    """sparsemax (Martins & Astudillo 2016) over the last dim: Euclidean projection onto the simplex;
+    backward nz * (g - sum(g*nz)/|nz|).  Restates sparsemax.Sparsemax (nn/nets.py:3,225)."""
+
+    @staticmethod
+    def forward(ctx, z):
+        zs, _ = torch.sort(z, dim=-1, descending=True)
+        rng = torch.arange(1, z.shape[-1] + 1, dtype=z.dtype)
+        cs = zs.cumsum(-1)
+        support = (1 + rng * zs) > cs
+        ksup = support.to(z.dtype).sum(-1, keepdim=True)
+        tau = (torch.gather(cs, -1, ksup.long() - 1) - 1) / ksup
+        out = torch.clamp(z - tau, min=0)
+        ctx.save_for_backward(out)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        out, = ctx.saved_tensors
+        nz = (out > 0).to(g.dtype)
+        return nz * (g - (g * nz).sum(-1, keepdim=True) / nz.sum(-1, keepdim=True))
+
+
+class Sparsemax(nn.Module):
+    def __init__(self, dim=-1):
+        super().__init__()
+        self.dim = dim
+
+    def forward(self, z):
+        z = z.transpose(self.dim, -1)
+        return _SparsemaxFn.apply(z).transpose(self.dim, -1)
+
+
+# ---------------------------------------------------------------------------------------------
+# nn/net_blocks.py restated
+# ---------------------------------------------------------------------------------------------
+def MLP(channels, batch_norm=True):
+    """nn/net_blocks.py:43-47 — BN sits AFTER the ReLU, also on the last layer; `batch_norm` is ignored."""
+    return nn.Sequential(*[
+        nn.Sequential(nn.Linear(channels[i - 1], channels[i]), nn.ReLU(), nn.BatchNorm1d(channels[i]))
+        for i in range(1, len(channels))])
+
+
+def _init_tenzor(*shape, device='cpu', init_type=''):
+    """nn/net_blocks.py:302-315."""
+    if not init_type or len(shape) == 1:
+        t = torch.zeros(shape)
+    elif 'kaiming_normal' in init_type:
+        t = torch.empty(shape)
+        nn.init.kaiming_normal_(t)
+    else:
+        raise NotImplementedError('{} tenzor initialization is not implemented'.format(init_type))
+    return t.to(device)
+
+
+def _init_weights(module, init_type=''):
+    """nn/net_blocks.py:318-333 (1-D 'weight' params are left untouched: the reference rebinds a local)."""
+    if not init_type:
+        return
+    for name, param in module.named_parameters():
+        if 'weight' in name:
+            if 'kaiming_normal' in init_type:
+                if len(param.shape) > 1:
+                    nn.init.kaiming_normal_(param)
+            else:
+                raise NotImplementedError('{} weight initialization is not implemented'.format(init_type))
+
+
+class EdgeConvFeatures(nn.Module):
+    """nn/net_blocks.py:93-191 (graph_pooling branch not restated: no shipped config enables it)."""
+
+    def __init__(self, out_size, config={}):
+        super().__init__()
+        self.config = {
+            'conv_depth': 2, 'k_neighbors': 5, 'EConv_hidden': 200, 'EConv_hidden_depth': 2,
+            'EConv_feature': 112, 'EConv_aggr': 'max', 'global_pool': 'mean',
+            'skip_connections': False, 'graph_pooling': False, 'pool_ratio': 0.1}
+        self.config.update(config)
+        if self.config['graph_pooling']:
+            raise NotImplementedError('graph_pooling is outside the restated path')
+        depth = self.config['conv_depth']
+        feat = [self.config['EConv_feature']] * depth
+        hid = [self.config['EConv_hidden']] * depth
+        mlp_depth = self.config['EConv_hidden_depth']
+        self.conv_layers = nn.ModuleList()
+        self.conv_layers.append(DynamicEdgeConv(
+            MLP([2 * 3] + [hid[0]] * mlp_depth + [feat[0]]),
+            k=self.config['k_neighbors'], aggr=self.config['EConv_aggr']))
+        for c in range(1, depth):
+            self.conv_layers.append(DynamicEdgeConv(
+                MLP([2 * feat[c - 1]] + [hid[c]] * mlp_depth + [feat[c]]),
+                k=self.config['k_neighbors'], aggr=self.config['EConv_aggr']))
+        if self.config['global_pool'] == 'max':
+            self.global_pool = global_max_pool
+        elif self.config['global_pool'] == 'mean':
+            self.global_pool = global_mean_pool
+        elif self.config['global_pool'] == 'add':
+            self.global_pool = global_add_pool
+        else:
+            raise ValueError('{} pooling is not supported'.format(self.config['global_pool']))
+        out_features = self.config['EConv_feature'] + 3 if self.config['skip_connections'] \
+            else self.config['EConv_feature']
+        self.lin = nn.Linear(out_features, out_size)
+        self.trace = {}  # per-layer outputs of the last forward (stage-wise parity)
+
+    def forward(self, positions, global_pool=True):
+        B, N = positions.size(0), positions.size(1)
+        pos_flat = positions.reshape(-1, positions.size(-1))
+        batch = torch.arange(B).repeat_interleave(N)
+        out = pos_flat
+        for c in range(self.config['conv_depth']):
+            out = self.conv_layers[c](out, batch)
+            self.trace['conv%d' % c] = out
+        if self.config['skip_connections']:
+            out = torch.cat([out, pos_flat], dim=-1)
+        if global_pool:
+            pooled = self.global_pool(out, batch, B)
+            self.trace['pooled'] = pooled
+            return self.lin(pooled), out, batch
+        return None, out, batch
+
+
+class LSTMDecoderModule(nn.Module):
+    """nn/net_blocks.py:363-402."""
+
+    def __init__(self, encoding_size, hidden_size, out_elem_size, n_layers, dropout=0,
+                 custom_init='kaiming_normal', **kwargs):
+        super().__init__()
+        self.custom_init = custom_init
+        self.n_layers = n_layers
+        self.encoding_size = encoding_size
+        self.hidden_size = hidden_size
+        self.out_elem_size = out_elem_size
+        self.lstm = nn.LSTM(encoding_size, hidden_size, n_layers, dropout=dropout, batch_first=True)
+        self.lin = nn.Linear(hidden_size, out_elem_size)
+        _init_weights(self.lstm, init_type=custom_init)
+        self.last_states = None
+
+    def forward(self, batch_enc, out_len):
+        bs = batch_enc.size(0)
+        dec_input = batch_enc.unsqueeze(1).repeat(1, out_len, 1)
+        # reference order: hidden first, then cell (nn/net_blocks.py:391-392); fp32 draw, then cast
+        h0 = _init_tenzor(self.n_layers, bs, self.hidden_size, init_type=self.custom_init).to(batch_enc.dtype)
+        c0 = _init_tenzor(self.n_layers, bs, self.hidden_size, init_type=self.custom_init).to(batch_enc.dtype)
+        self.last_states = (h0, c0)
+        out, _ = self.lstm(dec_input, (h0, c0))
+        out = self.lin(out.contiguous().view(-1, self.hidden_size))
+        return out.contiguous().view(bs, out_len, -1)
+
+
+_BLOCKS = {'EdgeConvFeatures': EdgeConvFeatures, 'LSTMDecoderModule': LSTMDecoderModule}
+
+
+# ---------------------------------------------------------------------------------------------
+# nn/metrics: the loss terms active in the shipped configs at epoch < epoch_with_stitches
+# ---------------------------------------------------------------------------------------------
+class PanelLoopLoss:
+    """nn/metrics/losses.py:8-51 — per-panel loop over B*P panels, data-dependent skip for < 3 edges."""
+
+    def __init__(self, pad_vector):
+        self.pad_vector = pad_vector
+
+    def __call__(self, predicted_panels, gt_panel_num_edges):
+        panels = predicted_panels.reshape(-1, predicted_panels.shape[-2], predicted_panels.shape[-1])
+        pad = self.pad_vector.to(panels.dtype)
+        sums = torch.zeros((panels.shape[0], 2), dtype=panels.dtype)
+        rows = []
+        for el in range(panels.shape[0]):
+            n = int(gt_panel_num_edges[el])
+            if n < 3:
+                rows.append(sums[el])
+                continue
+            rows.append((panels[el][:n, :2] - pad[:2]).sum(dim=0))
+        sums = torch.stack(rows)
+        sq = sums ** 2
+        return sq.sum() / (sq.shape[0] * sq.shape[1])
+
+
+def eval_pad_vector(data_stats):
+    """nn/metrics/eval_utils.py (pad vector = -shift/scale when GT is standardised, zeros otherwise)."""
+    if data_stats:
+        shift = torch.as_tensor(data_stats['shift'], dtype=torch.float32)
+        scale = torch.as_tensor(data_stats['scale'], dtype=torch.float32)
+        return -shift / scale
+    return torch.zeros(4)
+
+
+class ComposedPatternLoss:
+    """nn/metrics/composed_loss.py:129-334 restricted to the components the shipped YAMLs evaluate before
+    `epoch_with_stitches`: shape / loop / rotation / translation, with order- and origin-matching off
+    (models/att/att.yaml:124-137).  Anything else raises, so a silent mismatch is impossible."""
+
+    def __init__(self, data_config, in_config={}):
+        self.config = {
+            'loss_components': ['shape'], 'quality_components': [], 'loop_loss_weight': 1.,
+            'segm_loss_weight': 0.05, 'stitch_tags_margin': 0.3, 'epoch_with_stitches': 40,
+            'stitch_supervised_weight': 0.1, 'stitch_hardnet_version': False,
+            'panel_origin_invariant_loss': True, 'panel_order_inariant_loss': True,
+            'order_by': 'placement', 'epoch_with_order_matching': 0}
+        self.config.update(in_config)
+        self.with_quality_eval = False
+        self.training = False
+        self.debug_prints = False
+        self.l_components = self.config['loss_components']
+        self.max_panel_len = data_config['max_panel_len']
+        self.max_pattern_size = data_config['max_pattern_len']
+        stats = data_config.get('standardize')
+        outl = {'shift': stats['gt_shift']['outlines'], 'scale': stats['gt_scale']['outlines']} if stats else {}
+        self.loop_loss = PanelLoopLoss(eval_pad_vector(outl))
+
+    def __call__(self, preds, ground_truth, names=None, epoch=1000):
+        if self.config['panel_order_inariant_loss'] or self.config['panel_origin_invariant_loss']:
+            raise NotImplementedError('oracle restates the loss with order/origin matching off '
+                                      '(as in the shipped YAMLs)')
+        if epoch >= self.config['epoch_with_stitches'] and any(
+                c in self.l_components for c in ('stitch', 'stitch_supervised', 'free_class')):
+            raise NotImplementedError('stitch losses are outside the restated path')
+        if 'segmentation' in self.l_components:
+            raise NotImplementedError('segmentation loss is outside the restated path')
+        dt = preds['outlines'].dtype
+        num_edges = ground_truth['num_edges'].int().view(-1)
+        loss, d = 0., {}
+        mse = nn.functional.mse_loss
+        if 'shape' in self.l_components:
+            d['pattern_loss'] = mse(preds['outlines'], ground_truth['outlines'].to(dt))
+            loss = loss + d['pattern_loss']
+        if 'loop' in self.l_components:
+            d['loop_loss'] = self.loop_loss(preds['outlines'], num_edges)
+            loss = loss + self.config['loop_loss_weight'] * d['loop_loss']
+        if 'rotation' in self.l_components:
+            d['rotation_loss'] = mse(preds['rotations'], ground_truth['rotations'].to(dt))
+            loss = loss + d['rotation_loss']
+        if 'translation' in self.l_components:
+            d['translation_loss'] = mse(preds['translations'], ground_truth['translations'].to(dt))
+            loss = loss + d['translation_loss']
+        return loss, d, False
+
+    def train(self, mode=True):
+        self.training = mode
+
+    def eval(self):
+        self.training = False
+
+
+# ---------------------------------------------------------------------------------------------
+# nn/nets.py restated
+# ---------------------------------------------------------------------------------------------
+class BaseModule(nn.Module):
+    """nn/nets.py:11-37."""
+
+    def __init__(self):
+        super().__init__()
+        self.config = {'loss': 'MSELoss', 'model': self.__class__.__name__}
+
+    def train(self, mode=True):
+        super().train(mode)
+        if isinstance(self.loss, object):
+            self.loss.train(mode)
+        return self
+
+    def eval(self):
+        super().eval()
+        if isinstance(self.loss, object):
+            self.loss.eval()
+        return self
+
+
+class GarmentFullPattern3D(BaseModule):
+    """nn/nets.py:41-184: encoder -> pattern LSTM -> panel LSTM + placement Linear."""
+
+    def __init__(self, data_config, config={}, in_loss_config={}):
+        super().__init__()
+        self.panel_elem_len = data_config['element_size']
+        self.max_panel_len = data_config['max_panel_len']
+        self.max_pattern_size = data_config['max_pattern_len']
+        self.rotation_size = data_config['rotation_size']
+        self.translation_size = data_config['translation_size']
+        self.config.update({
+            'panel_encoding_size': 250, 'panel_hidden_size': 250, 'panel_n_layers': 3,
+            'pattern_encoding_size': 250, 'pattern_hidden_size': 250, 'pattern_n_layers': 2,
+            'dropout': 0, 'lstm_init': 'kaiming_normal_', 'feature_extractor': 'EdgeConvFeatures',
+            'panel_decoder': 'LSTMDecoderModule', 'pattern_decoder': 'LSTMDecoderModule',
+            'stitch_tag_dim': 3})
+        if 'panel_hidden_size' not in config:          # nn/nets.py:75-78 mutate the CALLER's dict
+            config['panel_hidden_size'] = config['panel_encoding_size']
+        if 'pattern_hidden_size' not in config:
+            config['pattern_hidden_size'] = config['pattern_encoding_size']
+        self.config.update(config)
+        self.config['loss'] = {
+            'loss_components': ['shape', 'loop', 'rotation', 'translation'],
+            'quality_components': ['shape', 'discrete', 'rotation', 'translation'],
+            'loop_loss_weight': 1., 'stitch_tags_margin': 0.3, 'epoch_with_stitches': 40,
+            'stitch_supervised_weight': 0.1, 'stitch_hardnet_version': False,
+            'panel_origin_invariant_loss': True}
+        self.config['loss'].update(in_loss_config)
+        self.loss = ComposedPatternLoss(data_config, self.config['loss'])
+        self.config['loss'] = self.loss.config
+
+        self.feature_extractor = _BLOCKS[self.config['feature_extractor']](
+            self.config['pattern_encoding_size'], self.config)
+        self.config.update(self.feature_extractor.config)
+        self.panel_decoder = _BLOCKS[self.config['panel_decoder']](
+            encoding_size=self.config['panel_encoding_size'], hidden_size=self.config['panel_hidden_size'],
+            out_elem_size=self.panel_elem_len + self.config['stitch_tag_dim'] + 1,
+            n_layers=self.config['panel_n_layers'], out_len=self.max_panel_len,
+            dropout=self.config['dropout'], custom_init=self.config['lstm_init'])
+        self.pattern_decoder = _BLOCKS[self.config['pattern_decoder']](
+            encoding_size=self.config['pattern_encoding_size'], hidden_size=self.config['pattern_hidden_size'],
+            out_elem_size=self.config['panel_encoding_size'], n_layers=self.config['pattern_n_layers'],
+            out_len=self.max_pattern_size, dropout=self.config['dropout'],
+            custom_init=self.config['lstm_init'])
+        self.placement_decoder = nn.Linear(self.config['panel_encoding_size'],
+                                           self.rotation_size + self.translation_size)
+        self.trace = {}
+
+    def forward_encode(self, positions_batch):
+        return self.feature_extractor(positions_batch)[0]
+
+    def forward_pattern_decode(self, garment_encodings):
+        enc = self.pattern_decoder(garment_encodings, self.max_pattern_size)
+        return enc.contiguous().view(-1, enc.shape[-1])
+
+    def forward_panel_decode(self, flat_panel_encodings, batch_size):
+        self.trace['panel_encodings'] = flat_panel_encodings
+        flat_panels = self.panel_decoder(flat_panel_encodings, self.max_panel_len)
+        flat_placement = self.placement_decoder(flat_panel_encodings)
+        flat_rot = flat_placement[:, :self.rotation_size]
+        flat_tr = flat_placement[:, self.rotation_size:]
+        pp = flat_panels.contiguous().view(batch_size, self.max_pattern_size, self.max_panel_len, -1)
+        return {
+            'outlines': pp[:, :, :, :self.panel_elem_len],
+            'rotations': flat_rot.contiguous().view(batch_size, self.max_pattern_size, -1),
+            'translations': flat_tr.contiguous().view(batch_size, self.max_pattern_size, -1),
+            'stitch_tags': pp[:, :, :, self.panel_elem_len:-1],
+            'free_edges_mask': pp[:, :, :, -1]}
+
+    def forward_decode(self, garment_encodings):
+        self.trace['encoding'] = garment_encodings
+        return self.forward_panel_decode(self.forward_pattern_decode(garment_encodings),
+                                         garment_encodings.size(0))
+
+    def forward(self, positions_batch, **kwargs):
+        return self.forward_decode(self.forward_encode(positions_batch))
+
+
+class GarmentSegmentPattern3D(GarmentFullPattern3D):
+    """nn/nets.py:187-299: per-point sparsemax attention -> per-panel pooled encodings -> panel LSTM."""
+
+    def __init__(self, data_config, config={}, in_loss_config={}):
+        if 'loss_components' not in in_loss_config:
+            in_loss_config.update(loss_components=['shape', 'loop', 'rotation', 'translation'],
+                                  quality_components=['shape', 'discrete', 'rotation', 'translation'])
+        super().__init__(data_config, config, in_loss_config)
+        self.save_att_weights = 'segmentation' in self.loss.config['loss_components']
+        if 'local_attention' not in self.config:
+            self.config['local_attention'] = False
+        att_in = self.feature_extractor.config['EConv_feature']
+        if not self.config['local_attention']:
+            att_in += self.config['pattern_encoding_size']
+        if self.config['skip_connections']:
+            att_in += 3
+        self.point_segment_mlp = nn.Sequential(
+            MLP([att_in, att_in, att_in, self.max_pattern_size]), Sparsemax(dim=1))
+        panel_att_out = self.feature_extractor.config['EConv_feature']
+        if self.config['skip_connections']:
+            panel_att_out += 3
+        self.panel_dec_lin = nn.Linear(panel_att_out, self.feature_extractor.config['panel_encoding_size'])
+        del self.pattern_decoder
+
+    def forward_panel_enc_from_3d(self, positions_batch):
+        B = positions_batch.shape[0]
+        init_enc, feats, batch = self.feature_extractor(positions_batch, not self.config['local_attention'])
+        n_pts = feats.shape[0] // B
+        if self.config['local_attention']:
+            w = self.point_segment_mlp(feats)
+        else:
+            glob = init_enc.unsqueeze(1).repeat(1, n_pts, 1).view([-1, init_enc.shape[-1]])
+            w = self.point_segment_mlp(torch.cat([glob, feats], dim=-1))
+        self.trace['point_features'] = feats
+        self.trace['att_weights'] = w
+        per_panel = []
+        for p in range(w.shape[-1]):                          # nn/nets.py:263-276
+            pf = self.feature_extractor.global_pool(w[:, p].unsqueeze(-1) * feats, batch, B)
+            pf = self.panel_dec_lin(pf)
+            per_panel.append(pf.view(B, -1, pf.shape[-1]))
+        enc = torch.cat(per_panel, dim=1)
+        enc = enc.view(B, -1, enc.shape[-1])
+        w = w.view(B, -1, w.shape[-1]) if self.save_att_weights else []
+        return enc, w
+
+    def forward(self, positions_batch, **kwargs):
+        B = positions_batch.shape[0]
+        enc, att = self.forward_panel_enc_from_3d(positions_batch)
+        panels = self.forward_panel_decode(enc.view(-1, enc.shape[-1]), B)
+        if len(att) > 0:
+            panels.update(att_weights=att)
+        return panels
+
+
+# ---------------------------------------------------------------------------------------------
+# the timed unit: nn/trainer.py:92-99
+# ---------------------------------------------------------------------------------------------
+def train_step(model, features, gt, epoch=0, seed=None):
+    """One fwd -> loss -> bwd pass (no optimizer step).  `seed` is set right before the forward so the
+    random LSTM states are reproducible."""
+    if seed is not None:
+        torch.manual_seed(seed)
+    preds = model(features, log_step=0, epoch=epoch)
+    loss, loss_dict, _ = model.loss(preds, gt, epoch=epoch)
+    loss.backward()
+    return preds, loss, loss_dict
+
+
+def synthetic_batch(B, N, data_config, seed=0, dtype=torch.float32):
+    """SURVEY.md §8(d) synthetic inputs: randn cloud, randn targets, num_edges in [3, max_panel_len]."""
+    g = torch.Generator().manual_seed(seed)
+    P, L = data_config['max_pattern_len'], data_config['max_panel_len']
+    feats = torch.randn(B, N, 3, generator=g).to(dtype)
+    gt = {
+        'outlines': torch.randn(B, P, L, data_config['element_size'], generator=g),
+        'rotations': torch.randn(B, P, data_config['rotation_size'], generator=g),
+        'translations': torch.randn(B, P, data_config['translation_size'], generator=g),
+        'num_edges': torch.randint(3, L + 1, (B, P), generator=g),
+    }
+    return feats, gt
