@@ -1,0 +1,13 @@
+"""garment-pattern-estimation_amd — MI355X-native (gfx950) implementation of the NeuralTailor hot path:
+point-cloud encoder (dynamic-kNN EdgeConv) -> panel-sequence decoder (LSTM), forward + backward.
+
+`nets` / `net_blocks` mirror the class names, constructor signatures, config keys, output dict and state-dict
+layout of the reference's nn/nets.py and nn/net_blocks.py, so `getattr(nets, config['NN']['model'])`
+(nn/train.py:120) resolves against this package unchanged.  All arithmetic runs in libgpe_hip.so
+(include/gpe_hip.h); see DESIGN.md.
+
+The directory name contains '-', so import it with importlib or through the `gpe_amd` alias module at the
+repository root:  `import gpe_amd; from gpe_amd import nets`."""
+from . import _lib, ops, net_blocks, nets, metrics, parallel  # noqa: F401
+
+__all__ = ['_lib', 'ops', 'net_blocks', 'nets', 'metrics', 'parallel']

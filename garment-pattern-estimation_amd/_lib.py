@@ -1,0 +1,80 @@
+"""ctypes binding of libgpe_hip.so (C ABI: include/gpe_hip.h).  Signatures are parsed from the header itself, so
+the binding cannot drift from the declared ABI.  There is NO fallback: if the HIP library is missing or a call
+fails, this raises — the product path never routes around the kernels."""
+import ctypes
+import os
+import re
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libgpe_hip.so')
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), 'include', 'gpe_hip.h')
+
+_CT = {'p': ctypes.c_void_p, 'i': ctypes.c_int, 'l': ctypes.c_long, 'f': ctypes.c_float, 'd': ctypes.c_double}
+
+
+def _code(ctype):
+    t = ctype.strip()
+    if '*' in t:
+        return 'p'
+    t = t.replace('const', '').strip()
+    return {'int': 'i', 'long': 'l', 'float': 'f', 'double': 'd'}[t]
+
+
+def parse_header(path=HEADER_PATH):
+    """-> {symbol: (restype code, [arg codes])} for every function declared in include/gpe_hip.h"""
+    src = open(path).read()
+    src = re.sub(r'/\*.*?\*/', ' ', src, flags=re.S)
+    src = re.sub(r'//[^\n]*', ' ', src)
+    sigs = {}
+    for m in re.finditer(r'\b(int|long)\s+(gpe_\w+)\s*\(([^)]*)\)\s*;', src):
+        res, name, args = m.group(1), m.group(2), m.group(3).strip()
+        codes = []
+        if args and args != 'void':
+            for a in args.split(','):
+                a = a.strip()
+                ctype = a[:a.rfind(' ')] if '*' not in a else a[:a.rfind('*') + 1]
+                codes.append(_code(ctype))
+        sigs[name] = (_code(res), codes)
+    return sigs
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                'libgpe_hip.so not built: run `python -c "import __graft_entry__ as g; g.build()"` '
+                '(hipcc --offload-arch=gfx950).  There is no CPU fallback for the product path.')
+        l = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in parse_header().items():
+            fn = getattr(l, name)          # AttributeError here = header/library mismatch: fail loudly
+            fn.restype = _CT[res]
+            fn.argtypes = [_CT[a] for a in args]
+        _lib = l
+    return _lib
+
+
+def _conv(a):
+    if a is None:
+        return None
+    if isinstance(a, torch.Tensor):
+        return a.data_ptr()
+    return a
+
+
+def call(name, *args):
+    """Invoke a C-ABI entry point on torch's current HIP stream (appended as the trailing `stream` argument)."""
+    fn = getattr(lib(), name)
+    rc = fn(*[_conv(a) for a in args], torch.cuda.current_stream().cuda_stream)
+    if rc != 0:
+        raise RuntimeError('%s failed with code %d' % (name, rc))
+
+
+def query(name, *args):
+    """Host-only entry points (sizes / constants)."""
+    return getattr(lib(), name)(*args)

@@ -1,0 +1,60 @@
+"""Builds libgpe_hip.so (gfx950) in-tree with hipcc.  No torch extension machinery: the library is a plain
+C-ABI shared object (include/gpe_hip.h) loaded through ctypes by _lib.py."""
+import concurrent.futures
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, 'csrc')
+OUT = os.path.join(HERE, 'libgpe_hip.so')
+HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function',
+         '-Wno-unused-variable', '-Wno-unused-but-set-variable']
+
+
+def _sources():
+    return sorted(f for f in os.listdir(CSRC) if f.endswith('.hip'))
+
+
+def _stale(obj, src):
+    if not os.path.exists(obj):
+        return True
+    t = os.path.getmtime(obj)
+    deps = [os.path.join(CSRC, src)] + [os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith('.h')]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def _compile(src):
+    obj = os.path.join(CSRC, src[:-4] + '.o')
+    if _stale(obj, src):
+        cmd = [HIPCC] + FLAGS + ['-c', os.path.join(CSRC, src), '-o', obj]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError('hipcc failed on %s:\n%s' % (src, r.stderr[-6000:]))
+        if r.stderr.strip():
+            sys.stderr.write(r.stderr[-3000:])
+    return obj
+
+
+def build(force=False, verbose=True):
+    srcs = _sources()
+    if force:
+        for s in srcs:
+            o = os.path.join(CSRC, s[:-4] + '.o')
+            if os.path.exists(o):
+                os.remove(o)
+    with concurrent.futures.ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
+        objs = list(ex.map(_compile, srcs))
+    if (not os.path.exists(OUT)) or any(os.path.getmtime(o) > os.path.getmtime(OUT) for o in objs):
+        cmd = [HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', OUT] + objs
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError('link failed:\n' + r.stderr[-4000:])
+        if verbose:
+            print('built', OUT)
+    return OUT
+
+
+if __name__ == '__main__':
+    build(force='--force' in sys.argv)

@@ -1,0 +1,145 @@
+// Per-cloud exact kNN for gfx950 (replaces torch_cluster.knn as reached from
+// /root/reference/nn/net_blocks.py:127-135,174 through PyG's DynamicEdgeConv).
+//
+// One workgroup = 64 query points of one cloud against all N candidates of that cloud.
+//   phase 1 (VALU): 64x64 tile of squared distances, 4x4 register micro-tile per lane, operands staged
+//                   channel-major in LDS so every LDS read is a conflict-free / broadcast ds_read_b128;
+//                   arithmetic is exactly oracle/knn_ref.c's: acc = fmaf(q_c - p_c, q_c - p_c, acc), c ascending.
+//   phase 2 (wave ballot/shuffle): each wave owns 16 of the 64 queries.  A query's running top-k list is
+//                   DISTRIBUTED OVER THE LANES of the wave (lane s holds the s-th best (dist, idx)); a tile's 64
+//                   candidate distances are compared against the k-th best with one v_cmp + ballot, and only the
+//                   (rare) survivors are inserted with a lane-shift.  No per-lane sorted arrays, no scratch.
+// Ordering rule: ascending (dist, candidate index); an equal-distance candidate never displaces an earlier one.
+#include "gpe_common.h"
+#include <math.h>
+
+#define KNN_TQ 64
+#define KNN_TC 64
+#define KNN_CCH 32          // channels staged per step for the candidate tile
+#define KNN_LD 68           // row stride (floats) of channel-major LDS tiles: 16-B aligned, rows shifted by 1 slot
+
+__global__ __launch_bounds__(256) void gpe_knn_kernel(const float* __restrict__ x, int N, int C, int ldx, int k,
+                                                      int32_t* __restrict__ idx, int Cq /* C rounded up to CCH */)
+{
+    extern __shared__ __align__(16) float smem[];
+    float* qT = smem;                          // [Cq][KNN_LD]   query tile, channel-major (resident)
+    float* cT = qT + (size_t)Cq * KNN_LD;      // [CCH][KNN_LD]  candidate chunk
+    float* dist = cT + KNN_CCH * KNN_LD;       // [64][KNN_LD]   distance tile (query-major)
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int b = blockIdx.y;
+    const int q0 = blockIdx.x * KNN_TQ;
+    const float* cloud = x + (size_t)b * N * ldx;
+
+    // ---- stage the query tile, transposed to channel-major -------------------------------------------------
+    for (int e = tid; e < KNN_TQ * Cq; e += 256) {
+        int q = e / Cq, c = e - q * Cq;        // consecutive threads walk the channels of one row: coalesced
+        float v = 0.f;
+        if (q0 + q < N && c < C) v = cloud[(size_t)(q0 + q) * ldx + c];
+        qT[c * KNN_LD + q] = v;
+    }
+
+    // lane-distributed top-k lists for the 16 queries this wave selects for
+    float ld_[16];
+    int li_[16];
+    float thr[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { ld_[i] = INFINITY; li_[i] = -1; thr[i] = INFINITY; }
+
+    const int tq = tid & 15;        // query micro-row: queries 4*tq .. 4*tq+3
+    const int tc = tid >> 4;        // candidate micro-col: candidates 4*tc .. 4*tc+3
+
+    for (int c0 = 0; c0 < N; c0 += KNN_TC) {
+        float acc[4][4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int bb = 0; bb < 4; ++bb) acc[a][bb] = 0.f;
+
+        for (int ch = 0; ch < Cq; ch += KNN_CCH) {
+            __syncthreads();   // previous chunk (and, on the first pass, the previous tile's dist reads) done
+            for (int e = tid; e < KNN_TC * KNN_CCH; e += 256) {
+                int p = e / KNN_CCH, c = e - p * KNN_CCH;
+                float v = 0.f;
+                if (c0 + p < N && ch + c < C) v = cloud[(size_t)(c0 + p) * ldx + ch + c];
+                cT[c * KNN_LD + p] = v;
+            }
+            __syncthreads();
+            const int cend = (C - ch < KNN_CCH) ? (C - ch) : KNN_CCH;   // skip the zero-padded channels
+#pragma unroll 4
+            for (int c = 0; c < cend; ++c) {
+                const float4 qv = *reinterpret_cast<const float4*>(&qT[(ch + c) * KNN_LD + 4 * tq]);
+                const float4 pv = *reinterpret_cast<const float4*>(&cT[c * KNN_LD + 4 * tc]);
+                const float qa[4] = {qv.x, qv.y, qv.z, qv.w};
+                const float pa[4] = {pv.x, pv.y, pv.z, pv.w};
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int bb = 0; bb < 4; ++bb) {
+                        float d = qa[a] - pa[bb];
+                        acc[a][bb] = __builtin_fmaf(d, d, acc[a][bb]);
+                    }
+            }
+        }
+        // padded channels contribute fmaf(0,0,acc) = acc exactly, so chunking does not change the chain
+
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            float4 o = make_float4(acc[a][0], acc[a][1], acc[a][2], acc[a][3]);
+            *reinterpret_cast<float4*>(&dist[(4 * tq + a) * KNN_LD + 4 * tc]) = o;
+        }
+        __syncthreads();
+
+        // ---- selection: wave `wave` owns queries 16*wave .. 16*wave+15; lane = candidate of this tile -------
+        const int cand = c0 + lane;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            float d = dist[(16 * wave + i) * KNN_LD + lane];
+            if (cand >= N) d = INFINITY;
+            unsigned long long m = __ballot(d < thr[i]);
+            while (m) {
+                const int src = __builtin_ctzll(m);
+                m &= m - 1;
+                const float dn = __shfl(d, src);
+                if (!(dn < thr[i])) continue;               // the threshold may have tightened meanwhile
+                const int jn = c0 + src;
+                // number of list entries that stay in front: all with dist <= dn (they have lower indices)
+                const int pos = __builtin_popcountll(__ballot(ld_[i] <= dn));
+                const float upd = __shfl_up(ld_[i], 1);
+                const int upi = __shfl_up(li_[i], 1);
+                if (lane == pos) { ld_[i] = dn; li_[i] = jn; }
+                else if (lane > pos) { ld_[i] = upd; li_[i] = upi; }
+                thr[i] = __shfl(ld_[i], k - 1);
+            }
+        }
+    }
+
+    // ---- write the k indices of each query ---------------------------------------------------------------
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int q = q0 + 16 * wave + i;
+        if (q < N && lane < k) idx[((size_t)b * N + q) * k + lane] = li_[i];
+    }
+}
+
+extern "C" int gpe_knn(const float* x, int B, int N, int C, int ldx, int k, int32_t* idx, void* stream)
+{
+    if (!x || !idx || B < 0 || N <= 0 || C <= 0 || ldx < C || k <= 0 || k > 64 || k > N) return GPE_EINVAL;
+    if (B == 0) return GPE_OK;
+    const int Cq = gpe_round_up(C, KNN_CCH);
+    const size_t lds = ((size_t)Cq * KNN_LD + KNN_CCH * KNN_LD + 64 * KNN_LD) * sizeof(float);
+    if (lds > 160 * 1024) return GPE_EINVAL;   // C up to ~500 channels
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gpe_knn_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            return GPE_ELAUNCH;
+        attr_set = true;
+    }
+    dim3 grid(gpe_cdiv(N, KNN_TQ), B);
+    hipLaunchKernelGGL(gpe_knn_kernel, grid, dim3(256), lds, (hipStream_t)stream, x, N, C, ldx, k, idx, Cq);
+    GPE_CHECK_LAUNCH();
+    return GPE_OK;
+}

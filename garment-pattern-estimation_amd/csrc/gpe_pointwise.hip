@@ -1,0 +1,660 @@
+// Bandwidth-bound kernels of the path for gfx950: weight packing / BatchNorm folding, the EdgeConv neighbourhood
+// gather with fp64 BN statistics, BN finalisation (forward + backward coefficient algebra), max-aggregation
+// finish, kNN graph transposition + deterministic pull-style scatter, segment mean pool, LSTM cell pointwise.
+// Reference lines each one replaces are listed in include/gpe_hip.h.
+#include "gpe_common.h"
+#include <math.h>
+
+extern "C" int gpe_abi_version(void) { return 1; }
+
+__device__ __forceinline__ float4 pw_ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void pw_st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+
+// ---------------------------------------------------------------------------------------------------------
+// weight packing: packed[(kc*4 + plane)*Npad*4 + n*4 + t] = w(n, 16*kc + 4*plane + t) * col_scale
+// ---------------------------------------------------------------------------------------------------------
+extern "C" long gpe_packed_size(int N, int K) { return (long)gpe_round_up(N, 16) * gpe_round_up(K, 16); }
+
+__global__ void gpe_pack_kernel(const float* __restrict__ w, int ldw, int N, int K, int transpose,
+                                const float* __restrict__ col_scale, float* __restrict__ wp, int Npad, long total)
+{
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= total) return;
+    const int t = (int)(e & 3);
+    const long r = e >> 2;
+    const int n = (int)(r % Npad);
+    const long kq = r / Npad;                 // = kc*4 + plane
+    const int k = (int)(kq * 4 + t);
+    float v = 0.f;
+    if (n < N && k < K) {
+        v = transpose ? w[(size_t)k * ldw + n] : w[(size_t)n * ldw + k];
+        if (col_scale) v *= col_scale[k];
+    }
+    wp[e] = v;
+}
+
+extern "C" int gpe_pack_weight(const float* w, int ldw, int N, int K, int transpose, const float* col_scale,
+                               float* wp, void* stream)
+{
+    if (!w || !wp || N <= 0 || K <= 0 || ldw < (transpose ? N : K)) return GPE_EINVAL;
+    const int Npad = gpe_round_up(N, 16);
+    const long total = (long)Npad * gpe_round_up(K, 16);
+    hipLaunchKernelGGL(gpe_pack_kernel, dim3(gpe_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, w, ldw, N, K,
+                       transpose, col_scale, wp, Npad, total);
+    GPE_CHECK_LAUNCH();
+    return GPE_OK;
+}
+
+__global__ void gpe_fold_bias_kernel(const float* __restrict__ w, int ldw, int N, int K,
+                                     const float* __restrict__ bias, const float* __restrict__ t, float* out)
+{
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    double s = bias ? (double)bias[n] : 0.0;
+    for (int k = 0; k < K; ++k) s += (double)w[(size_t)n * ldw + k] * (double)t[k];
+    out[n] = (float)s;
+}
+
+extern "C" int gpe_fold_bias(const float* w, int ldw, int N, int K, const float* bias, const float* t, float* out,
+                             void* stream)
+{
+    if (!w || !t || !out || N <= 0 || K <= 0 || ldw < K) return GPE_EINVAL;
+    hipLaunchKernelGGL(gpe_fold_bias_kernel, dim3(gpe_cdiv(N, 64)), dim3(64), 0, (hipStream_t)stream, w, ldw, N, K,
+                       bias, t, out);
+    GPE_CHECK_LAUNCH();
+    return GPE_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// EdgeConv neighbourhood gather + fp64 statistics of a1 = relu(P_i + Q_j)
+//   one wave per point at a time: lanes span the H channels as float4, the k neighbour rows are fetched with
+//   wave-uniform (shuffle-broadcast) row bases and all k loads in flight before the first use.
+// ---------------------------------------------------------------------------------------------------------
+#define GS_BLOCKS 512
+template <int KU>
+__global__ __launch_bounds__(256) void gpe_gather_stats_kernel(const float* __restrict__ pq, int ldpq, int H,
+                                                               const int32_t* __restrict__ idx, int npts, int k,
+                                                               long total_pts, double* __restrict__ part)
+{
+    __shared__ double red[4][2][256];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = 4 * lane;
+    const bool active = c < H;
+    double s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
+    const long nw = (long)gridDim.x * 4;
+    for (long i = (long)blockIdx.x * 4 + wave; i < total_pts; i += nw) {
+        const long cloud0 = (i / npts) * (long)npts;
+        const int myidx = (lane < k) ? idx[i * k + lane] : 0;
+        float4 p4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (active) p4 = pw_ld4(pq + i * ldpq + c);
+        for (int s0 = 0; s0 < k; s0 += KU) {
+            float4 nb[KU];
+#pragma unroll
+            for (int u = 0; u < KU; ++u) {
+                nb[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (s0 + u < k) {
+                    const long jrow = cloud0 + __shfl(myidx, s0 + u);
+                    if (active) nb[u] = pw_ld4(pq + jrow * ldpq + H + c);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < KU; ++u) {
+                if (s0 + u < k) {
+                    const float a0 = fmaxf(p4.x + nb[u].x, 0.f), a1 = fmaxf(p4.y + nb[u].y, 0.f);
+                    const float a2 = fmaxf(p4.z + nb[u].z, 0.f), a3 = fmaxf(p4.w + nb[u].w, 0.f);
+                    s[0] += a0; q[0] += (double)a0 * a0;
+                    s[1] += a1; q[1] += (double)a1 * a1;
+                    s[2] += a2; q[2] += (double)a2 * a2;
+                    s[3] += a3; q[3] += (double)a3 * a3;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { red[wave][0][c + t] = s[t]; red[wave][1][c + t] = q[t]; }
+    __syncthreads();
+    if (tid < H) {
+        double a = 0, b = 0;
+        for (int w = 0; w < 4; ++w) { a += red[w][0][tid]; b += red[w][1][tid]; }
+        part[(size_t)blockIdx.x * 2 * H + tid] = a;
+        part[(size_t)blockIdx.x * 2 * H + H + tid] = b;
+    }
+}
+
+extern "C" int gpe_edge_gather_stats(const float* pq, int ldpq, int H, const int32_t* idx, int B, int N, int k,
+                                     double* part, void* stream)
+{
+    if (!pq || !idx || !part || B <= 0 || N <= 0 || k <= 0 || k > 64 || H <= 0 || H > 256 || (H & 3) || (ldpq & 3) ||
+        ldpq < 2 * H)
+        return GPE_EINVAL;
+    hipLaunchKernelGGL(gpe_gather_stats_kernel<8>, dim3(GS_BLOCKS), dim3(256), 0, (hipStream_t)stream, pq, ldpq, H,
+                       idx, N, k, (long)B * N, part);
+    GPE_CHECK_LAUNCH();
+    return GPE_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// BatchNorm finalisation
+// ---------------------------------------------------------------------------------------------------------
+__global__ void gpe_bn_finalize_kernel(const double* __restrict__ part, int nblk, int C, double count,
+                                       const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                       float momentum, float* running_mean, float* running_var,
+                                       int64_t* num_batches, float* __restrict__ stats)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c == 0 && num_batches) *num_batches += 1;
+    if (c >= C) return;
+    double s = 0, q = 0;
+    for (int b = 0; b < nblk; ++b) {
+        s += part[(size_t)b * 2 * C + c];
+        q += part[(size_t)b * 2 * C + C + c];
+    }
+    const double mean = s / count;
+    double var = q / count - mean * mean;
+    if (var < 0) var = 0;
+    const double rstd = 1.0 / sqrt(var + (double)eps);
+    const float sc = (float)((double)gamma[c] * rstd);
+    stats[c] = (float)mean;
+    stats[C + c] = (float)rstd;
+    stats[2 * C + c] = sc;
+    stats[3 * C + c] = (float)((double)beta[c] - mean * (double)sc);
+    if (running_mean) {
+        const double unbiased = (count > 1) ? var * count / (count - 1) : var;
+        running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mean);
+        running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unbiased);
+    }
+}
+
+extern "C" int gpe_bn_finalize(const double* part, int nblk, int C, double count, const float* gamma,
+                               const float* beta, float eps, float momentum, float* running_mean,
+                               float* running_var, int64_t* num_batches, float* stats_out, void* stream)
+{
+    if (!part || !gamma || !beta || !stats_out || nblk <= 0 || C <= 0 || count <= 0) return GPE_EINVAL;
+    hipLaunchKernelGGL(gpe_bn_finalize_kernel, dim3(gpe_cdiv(C, 64)), dim3(64), 0, (hipStream_t)stream, part, nblk,
+                       C, count, gamma, beta, eps, momentum, running_mean, running_var, num_batches, stats_out);
+    GPE_CHECK_LAUNCH();
+    return GPE_OK;
+}
+
+__global__ void gpe_bn_from_running_kernel(const float* rm, const float* rv, int C, const float* gamma,
+                                           const float* beta, float eps, float* stats)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const double rstd = 1.0 / sqrt((double)rv[c] + (double)eps);
+    const float sc = (float)((double)gamma[c] * rstd);
+    stats[c] = rm[c];
+    stats[C + c] = (float)rstd;
+    stats[2 * C + c] = sc;
+    stats[3 * C + c] = (float)((double)beta[c] - (double)rm[c] * (double)sc);
+}
+
+extern "C" int gpe_bn_from_running(const float* running_mean, const float* running_var, int C, const float* gamma,
+                                   const float* beta, float eps, float* stats_out, void* stream)
+{
+    if (!running_mean || !running_var || !gamma || !beta || !stats_out || C <= 0) return GPE_EINVAL;
+    hipLaunchKernelGGL(gpe_bn_from_running_kernel, dim3(gpe_cdiv(C, 64)), dim3(64), 0, (hipStream_t)stream,
+                       running_mean, running_var, C, gamma, beta, eps, stats_out);
+    GPE_CHECK_LAUNCH();
+    return GPE_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// max aggregation finish: y = s*(s>=0 ? max : min) + t
+// ---------------------------------------------------------------------------------------------------------
+__global__ void gpe_edge_finish_kernel(const float* __restrict__ mx, const float* __restrict__ mn, int ldagg,
+                                       const float* __restrict__ stats, long rows, int C, float* __restrict__ y,
+                                       int ldy)
+{
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= rows * C) return;
+    const long r = e / C;
+    const int c = (int)(e - r * C);
+    const float s = stats[2 * C + c], t = stats[3 * C + c];
+    const float v = (s >= 0.f) ? mx[r * ldagg + c] : mn[r * ldagg + c];
+    y[r * ldy + c] = s * v + t;
+}
+
+extern "C" int gpe_edge_finish(const float* mx, const float* mn, int ldagg, const float* stats, long rows, int C,
+                               float* y, int ldy, void* stream)
+{
+    if (!mx || !mn || !stats || !y || rows < 0 || C <= 0 || ldagg < C || ldy < C) return GPE_EINVAL;
+    if (rows == 0) return GPE_OK;
+    hipLaunchKernelGGL(gpe_edge_finish_kernel, dim3(gpe_cdiv(rows * C, 256)), dim3(256), 0, (hipStream_t)stream, mx,
+                       mn, ldagg, stats, rows, C, y, ldy);
+    GPE_CHECK_LAUNCH();
+    return GPE_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// EdgeConv backward: per-point sums for the last BN (partials [PS_BLOCKS][2][C] fp64)
+// ---------------------------------------------------------------------------------------------------------
+#define PS_BLOCKS 128
+__global__ __launch_bounds__(256) void gpe_point_sums_kernel(const float* __restrict__ g, int ldg,
+                                                             const float* __restrict__ mx,
+                                                             const float* __restrict__ mn, int ldagg,
+                                                             const float* __restrict__ stats, long rows, int C,
+                                                             double* __restrict__ part)
+{
+    const int c = threadIdx.x;
+    double s1 = 0, s2 = 0;
+    if (c < C) {
+        const float mean = stats[c], rstd = stats[C + c], s = stats[2 * C + c];
+        for (long r = blockIdx.x; r < rows; r += gridDim.x) {
+            const float gv = g[r * ldg + c];
+            const float sel = (s >= 0.f) ? mx[r * ldagg + c] : mn[r * ldagg + c];
+            s1 += (double)gv;
+            s2 += (double)gv * (double)((sel - mean) * rstd);
+        }
+        part[(size_t)blockIdx.x * 2 * C + c] = s1;
+        part[(size_t)blockIdx.x * 2 * C + C + c] = s2;
+    }
+}
+
+extern "C" int gpe_point_sums_blocks(void) { return PS_BLOCKS; }
+
+extern "C" int gpe_edge_bwd_point_sums(const float* g, int ldg, const float* mx, const float* mn, int ldagg,
+                                       const float* stats, long rows, int C, double* part, void* stream)
+{
+    if (!g || !mx || !mn || !stats || !part || rows <= 0 || C <= 0 || C > 256) return GPE_EINVAL;
+    hipLaunchKernelGGL(gpe_point_sums_kernel, dim3(PS_BLOCKS), dim3(256), 0, (hipStream_t)stream, g, ldg, mx, mn,
+                       ldagg, stats, rows, C, part);
+    GPE_CHECK_LAUNCH();
+    return GPE_OK;
+}
+
+__global__ void gpe_bn_bwd_coef_kernel(const double* __restrict__ part, int nblk, const float* __restrict__ stats,
+                                       int C, double count, float* __restrict__ coef, float* dgamma, float* dbeta)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s1 = 0, s2 = 0;
+    for (int b = 0; b < nblk; ++b) {
+        s1 += part[(size_t)b * 2 * C + c];
+        s2 += part[(size_t)b * 2 * C + C + c];
+    }
+    const double mean = stats[c], rstd = stats[C + c], s = stats[2 * C + c];
+    const double m1 = s1 / count, m2 = s2 / count;
+    const double k2 = s * rstd * m2;
+    const double k1 = s * m1 - mean * k2;
+    coef[c] = (float)s;
+    coef[C + c] = (float)k1;
+    coef[2 * C + c] = (float)k2;
+    if (dgamma) dgamma[c] = (float)s2;
+    if (dbeta) dbeta[c] = (float)s1;
+}
+
+extern "C" int gpe_bn_bwd_coef(const double* part, int nblk, const float* stats, int C, double count, float* coef,
+                               float* dgamma, float* dbeta, void* stream)
+{
+    if (!part || !stats || !coef || nblk <= 0 || C <= 0 || count <= 0) return GPE_EINVAL;
+    hipLaunchKernelGGL(gpe_bn_bwd_coef_kernel, dim3(gpe_cdiv(C, 64)), dim3(64), 0, (hipStream_t)stream, part, nblk,
+                       stats, C, count, coef, dgamma, dbeta);
+    GPE_CHECK_LAUNCH();
+    return GPE_OK;
+}
+
+// sums for an inner BN + true weight gradient of the next Linear, from G = dz_next^T a and db = colsum(dz_next)
+__global__ void gpe_bn_bwd_from_G_kernel(const float* __restrict__ G, int ldG, const float* __restrict__ db,
+                                         const float* __restrict__ w, int ldw, int Cn, int C,
+                                         const float* __restrict__ stats, double* __restrict__ sums,
+                                         float* __restrict__ dw, int lddw)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const double mean = stats[c], rstd = stats[C + c];
+    const float s = stats[2 * C + c], t = stats[3 * C + c];
+    double a = 0, b = 0;
+    for (int f = 0; f < Cn; ++f) {
+        const double wf = w[(size_t)f * ldw + c];
+        const double gf = G[(size_t)f * ldG + c];
+        const double dbf = db[f];
+        a += wf * dbf;
+        b += wf * (gf - mean * dbf);
+        if (dw) dw[(size_t)f * lddw + c] = (float)(gf * (double)s + dbf * (double)t);
+    }
+    sums[c] = a;
+    sums[C + c] = b * rstd;
+}
+
+extern "C" int gpe_bn_bwd_from_G(const float* G, int ldG, const float* db, const float* w_next, int ldw, int Cn,
+                                 int C, const float* stats, double* sums, float* dw, int lddw, void* stream)
+{
+    if (!G || !db || !w_next || !stats || !sums || Cn <= 0 || C <= 0 || ldG < C || ldw < C) return GPE_EINVAL;
+    hipLaunchKernelGGL(gpe_bn_bwd_from_G_kernel, dim3(gpe_cdiv(C, 64)), dim3(64), 0, (hipStream_t)stream, G, ldG, db,
+                       w_next, ldw, Cn, C, stats, sums, dw, lddw);
+    GPE_CHECK_LAUNCH();
+    return GPE_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// kNN graph transposition (one workgroup per cloud) and the pull-style scatter it enables
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void gpe_knn_reverse_kernel(const int32_t* __restrict__ idx, int N, int k,
+                                                               int32_t* __restrict__ rev_off,
+                                                               int32_t* __restrict__ rev_edge)
+{
+    extern __shared__ int sm[];
+    int* cnt = sm;                 // [N]
+    int* off = sm + N;             // [N+1]
+    __shared__ int wsum[16];
+    const int tid = threadIdx.x, b = blockIdx.x;
+    const int32_t* id = idx + (size_t)b * N * k;
+    int32_t* ro = rev_off + (size_t)b * (N + 1);
+    int32_t* re = rev_edge + (size_t)b * N * k;
+    const int E = N * k;
+    for (int i = tid; i < N; i += 1024) cnt[i] = 0;
+    __syncthreads();
+    for (int e = tid; e < E; e += 1024) atomicAdd(&cnt[id[e]], 1);
+    __syncthreads();
+    // exclusive scan of cnt: each thread owns a contiguous run of `per` entries
+    const int per = (N + 1023) / 1024;
+    const int beg = tid * per;
+    int local = 0;
+    for (int i = 0; i < per; ++i) if (beg + i < N) local += cnt[beg + i];
+    // block scan of `local` (wave scan + cross-wave)
+    int x = local;
+    const int lane = tid & 63, wv = tid >> 6;
+    for (int d = 1; d < 64; d <<= 1) { int y = __shfl_up(x, d); if (lane >= d) x += y; }
+    if (lane == 63) wsum[wv] = x;
+    __syncthreads();
+    if (tid == 0) { int a = 0; for (int w = 0; w < 16; ++w) { int t = wsum[w]; wsum[w] = a; a += t; } }
+    __syncthreads();
+    int run = x - local + wsum[wv];
+    for (int i = 0; i < per; ++i) if (beg + i < N) { off[beg + i] = run; run += cnt[beg + i]; }
+    if (tid == 1023) off[N] = E;
+    __syncthreads();
+    for (int i = tid; i <= N; i += 1024) ro[i] = off[i];
+    for (int i = tid; i < N; i += 1024) cnt[i] = 0;
+    __syncthreads();
+    for (int e = tid; e < E; e += 1024) {
+        const int jn = id[e];
+        const int pos = atomicAdd(&cnt[jn], 1);
+        re[off[jn] + pos] = e;
+    }
+    __threadfence_block();
+    __syncthreads();
+    // deterministic order inside each bucket: ascending edge id
+    for (int jn = tid; jn < N; jn += 1024) {
+        const int a = off[jn], z = off[jn + 1];
+        for (int i = a + 1; i < z; ++i) {
+            const int v = re[i];
+            int h = i - 1;
+            while (h >= a && re[h] > v) { re[h + 1] = re[h]; --h; }
+            re[h + 1] = v;
+        }
+    }
+}
+
+extern "C" int gpe_knn_reverse(const int32_t* idx, int B, int N, int k, int32_t* rev_off, int32_t* rev_edge,
+                               void* stream)
+{
+    if (!idx || !rev_off || !rev_edge || B <= 0 || N <= 0 || k <= 0) return GPE_EINVAL;
+    const size_t lds = (size_t)(2 * N + 1) * sizeof(int);
+    if (lds > 150 * 1024) return GPE_EINVAL;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gpe_knn_reverse_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess)
+            return GPE_ELAUNCH;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(gpe_knn_reverse_kernel, dim3(B), dim3(1024), lds, (hipStream_t)stream, idx, N, k, rev_off,
+                       rev_edge);
+    GPE_CHECK_LAUNCH();
+    return GPE_OK;
+}
+
+__global__ __launch_bounds__(256) void gpe_pull_dq_kernel(const float* __restrict__ dz, int lddz,
+                                                          const int32_t* __restrict__ rev_off,
+                                                          const int32_t* __restrict__ rev_edge, int N, int k, int H,
+                                                          long total_pts, float* __restrict__ dQ, int lddq)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = 4 * lane;
+    const bool active = c < H;
+    const long nw = (long)gridDim.x * 4;
+    for (long pt = (long)blockIdx.x * 4 + wave; pt < total_pts; pt += nw) {
+        const long b = pt / N;
+        const int jn = (int)(pt - b * N);
+        const int32_t* ro = rev_off + b * (N + 1);
+        const int32_t* re = rev_edge + b * (long)N * k;
+        const long e0 = b * (long)N * k;
+        const int a = ro[jn], z = ro[jn + 1];
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int i = a; i < z; i += 4) {
+            float4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (i + u < z && active) v[u] = pw_ld4(dz + (e0 + re[i + u]) * lddz + c);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+        }
+        if (active) pw_st4(dQ + pt * lddq + c, acc);
+    }
+}
+
+extern "C" int gpe_edge_pull_dq(const float* dz, int lddz, const int32_t* rev_off, const int32_t* rev_edge, int B,
+                                int N, int k, int H, float* dQ, int lddq, void* stream)
+{
+    if (!dz || !rev_off || !rev_edge || !dQ || B <= 0 || N <= 0 || k <= 0 || H <= 0 || H > 256 || (H & 3) ||
+        (lddz & 3) || (lddq & 3))
+        return GPE_EINVAL;
+    const long pts = (long)B * N;
+    const int blocks = (int)((pts + 3) / 4 < 2048 ? (pts + 3) / 4 : 2048);
+    hipLaunchKernelGGL(gpe_pull_dq_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dz, lddz, rev_off,
+                       rev_edge, N, k, H, pts, dQ, lddq);
+    GPE_CHECK_LAUNCH();
+    return GPE_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// segment mean pool (equal-sized segments: every cloud has N points)
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void gpe_segment_mean_fwd_kernel(const float* __restrict__ x, int ldx, int N,
+                                                                    int C, float* __restrict__ y, int ldy)
+{
+    __shared__ double red[4][256];
+    const int c = threadIdx.x & 255, rg = threadIdx.x >> 8;
+    const int b = blockIdx.x;
+    for (int c0 = 0; c0 < C; c0 += 256) {
+        double s = 0;
+        if (c0 + c < C)
+            for (int n = rg; n < N; n += 4) s += (double)x[((size_t)b * N + n) * ldx + c0 + c];
+        red[rg][c] = s;
+        __syncthreads();
+        if (rg == 0 && c0 + c < C)
+            y[(size_t)b * ldy + c0 + c] = (float)((red[0][c] + red[1][c] + red[2][c] + red[3][c]) / (double)N);
+        __syncthreads();
+    }
+}
+
+extern "C" int gpe_segment_mean_fwd(const float* x, int ldx, int B, int N, int C, float* y, int ldy, void* stream)
+{
+    if (!x || !y || B <= 0 || N <= 0 || C <= 0 || ldx < C || ldy < C) return GPE_EINVAL;
+    hipLaunchKernelGGL(gpe_segment_mean_fwd_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, x, ldx, N, C, y,
+                       ldy);
+    GPE_CHECK_LAUNCH();
+    return GPE_OK;
+}
+
+__global__ void gpe_segment_mean_bwd_kernel(const float* __restrict__ gy, int ldgy, int N, int C, long rows,
+                                            float* __restrict__ gx, int ldgx, int accumulate)
+{
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= rows * C) return;
+    const long r = e / C;
+    const int c = (int)(e - r * C);
+    const float v = gy[(r / N) * ldgy + c] / (float)N;
+    float* d = gx + r * ldgx + c;
+    *d = accumulate ? (*d + v) : v;
+}
+
+extern "C" int gpe_segment_mean_bwd(const float* gy, int ldgy, int B, int N, int C, float* gx, int ldgx,
+                                    int accumulate, void* stream)
+{
+    if (!gy || !gx || B <= 0 || N <= 0 || C <= 0) return GPE_EINVAL;
+    const long rows = (long)B * N;
+    hipLaunchKernelGGL(gpe_segment_mean_bwd_kernel, dim3(gpe_cdiv(rows * C, 256)), dim3(256), 0,
+                       (hipStream_t)stream, gy, ldgy, N, C, rows, gx, ldgx, accumulate);
+    GPE_CHECK_LAUNCH();
+    return GPE_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// LSTM cell pointwise (gate order i, f, g, o as in torch.nn.LSTM)
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float gpe_sigmoid(float x) { return 1.f / (1.f + expf(-x)); }
+
+__global__ void gpe_lstm_cell_fwd_kernel(float* __restrict__ gates, const float* __restrict__ c_prev, long ldc_prev,
+                                         float* __restrict__ c, float* __restrict__ h, long h_stride, int Bn, int H)
+{
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (long)Bn * H) return;
+    const long b = e / H;
+    const int u = (int)(e - b * H);
+    float* gr = gates + b * 4 * H;
+    const float ig = gpe_sigmoid(gr[u]);
+    const float fg = gpe_sigmoid(gr[H + u]);
+    const float gg = tanhf(gr[2 * H + u]);
+    const float og = gpe_sigmoid(gr[3 * H + u]);
+    const float cn = fg * c_prev[b * ldc_prev + u] + ig * gg;
+    gr[u] = ig; gr[H + u] = fg; gr[2 * H + u] = gg; gr[3 * H + u] = og;
+    c[b * H + u] = cn;
+    h[b * h_stride + u] = og * tanhf(cn);
+}
+
+extern "C" int gpe_lstm_cell_fwd(float* gates, const float* c_prev, long ldc_prev, float* c, float* h,
+                                 long h_stride, int Bn, int H, void* stream)
+{
+    if (!gates || !c_prev || !c || !h || Bn <= 0 || H <= 0) return GPE_EINVAL;
+    hipLaunchKernelGGL(gpe_lstm_cell_fwd_kernel, dim3(gpe_cdiv((long)Bn * H, 256)), dim3(256), 0,
+                       (hipStream_t)stream, gates, c_prev, ldc_prev, c, h, h_stride, Bn, H);
+    GPE_CHECK_LAUNCH();
+    return GPE_OK;
+}
+
+__global__ void gpe_lstm_cell_bwd_kernel(const float* __restrict__ dh_out, long dho_stride,
+                                         const float* __restrict__ dh_rec, const float* __restrict__ dc_next,
+                                         const float* __restrict__ gates, const float* __restrict__ c,
+                                         const float* __restrict__ c_prev, long ldc_prev,
+                                         float* __restrict__ dgates, long dg_stride, float* __restrict__ dc_prev,
+                                         int Bn, int H)
+{
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (long)Bn * H) return;
+    const long b = e / H;
+    const int u = (int)(e - b * H);
+    const float* gr = gates + b * 4 * H;
+    const float ig = gr[u], fg = gr[H + u], gg = gr[2 * H + u], og = gr[3 * H + u];
+    float dh = dh_out ? dh_out[b * dho_stride + u] : 0.f;
+    if (dh_rec) dh += dh_rec[b * H + u];
+    const float tc = tanhf(c[b * H + u]);
+    float dc = dh * og * (1.f - tc * tc);
+    if (dc_next) dc += dc_next[b * H + u];
+    float* dg = dgates + b * dg_stride;
+    dg[u] = dc * gg * ig * (1.f - ig);
+    dg[H + u] = dc * c_prev[b * ldc_prev + u] * fg * (1.f - fg);
+    dg[2 * H + u] = dc * ig * (1.f - gg * gg);
+    dg[3 * H + u] = dh * tc * og * (1.f - og);
+    dc_prev[b * H + u] = dc * fg;
+}
+
+extern "C" int gpe_lstm_cell_bwd(const float* dh_out, long dho_stride, const float* dh_rec, const float* dc_next,
+                                 const float* gates, const float* c, const float* c_prev, long ldc_prev,
+                                 float* dgates, long dg_stride, float* dc_prev, int Bn, int H, void* stream)
+{
+    if (!gates || !c || !c_prev || !dgates || !dc_prev || Bn <= 0 || H <= 0) return GPE_EINVAL;
+    hipLaunchKernelGGL(gpe_lstm_cell_bwd_kernel, dim3(gpe_cdiv((long)Bn * H, 256)), dim3(256), 0,
+                       (hipStream_t)stream, dh_out, dho_stride, dh_rec, dc_next, gates, c, c_prev, ldc_prev, dgates,
+                       dg_stride, dc_prev, Bn, H);
+    GPE_CHECK_LAUNCH();
+    return GPE_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// small helpers
+// ---------------------------------------------------------------------------------------------------------
+__global__ void gpe_reduce_inner_kernel(const float* __restrict__ x, long x_so, long x_si, int T, int R, int C,
+                                        float* __restrict__ y, int ldy, int accumulate)
+{
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (long)R * C) return;
+    const long r = e / C;
+    const int c = (int)(e - r * C);
+    float s = 0.f;
+    for (int t = 0; t < T; ++t) s += x[r * x_so + t * x_si + c];
+    float* d = y + r * ldy + c;
+    *d = accumulate ? (*d + s) : s;
+}
+
+extern "C" int gpe_reduce_inner(const float* x, long x_so, long x_si, int T, int R, int C, float* y, int ldy,
+                                int accumulate, void* stream)
+{
+    if (!x || !y || T <= 0 || R <= 0 || C <= 0) return GPE_EINVAL;
+    hipLaunchKernelGGL(gpe_reduce_inner_kernel, dim3(gpe_cdiv((long)R * C, 256)), dim3(256), 0, (hipStream_t)stream,
+                       x, x_so, x_si, T, R, C, y, ldy, accumulate);
+    GPE_CHECK_LAUNCH();
+    return GPE_OK;
+}
+
+__global__ void gpe_w1_split_kernel(const float* __restrict__ w1, int ldw1, const float* __restrict__ b1, int H,
+                                    int C, float* __restrict__ wpq, int ldwpq, float* __restrict__ bias_pq)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < H * C) {
+        const int h = e / C, c = e - h * C;
+        const float wa = w1[(size_t)h * ldw1 + c], wb = w1[(size_t)h * ldw1 + C + c];
+        wpq[(size_t)h * ldwpq + c] = wa - wb;
+        wpq[(size_t)(H + h) * ldwpq + c] = wb;
+    }
+    if (e < 2 * H) bias_pq[e] = (e < H) ? b1[e] : 0.f;
+}
+
+extern "C" int gpe_w1_split(const float* w1, int ldw1, const float* b1, int H, int C, float* wpq, int ldwpq,
+                            float* bias_pq, void* stream)
+{
+    if (!w1 || !b1 || !wpq || !bias_pq || H <= 0 || C <= 0 || ldw1 < 2 * C || ldwpq < C) return GPE_EINVAL;
+    const int total = (H * C > 2 * H) ? H * C : 2 * H;
+    hipLaunchKernelGGL(gpe_w1_split_kernel, dim3(gpe_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, w1, ldw1,
+                       b1, H, C, wpq, ldwpq, bias_pq);
+    GPE_CHECK_LAUNCH();
+    return GPE_OK;
+}
+
+__global__ void gpe_w1_grad_kernel(const float* __restrict__ dwpq, int ld, int H, int C, float* __restrict__ dw1,
+                                   int lddw1)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= H * C) return;
+    const int h = e / C, c = e - h * C;
+    const float dp = dwpq[(size_t)h * ld + c], dq = dwpq[(size_t)(H + h) * ld + c];
+    dw1[(size_t)h * lddw1 + c] = dp;
+    dw1[(size_t)h * lddw1 + C + c] = dq - dp;
+}
+
+extern "C" int gpe_w1_grad_from_pq(const float* dwpq, int ld, int H, int C, float* dw1, int lddw1, void* stream)
+{
+    if (!dwpq || !dw1 || H <= 0 || C <= 0 || ld < C || lddw1 < 2 * C) return GPE_EINVAL;
+    hipLaunchKernelGGL(gpe_w1_grad_kernel, dim3(gpe_cdiv(H * C, 256)), dim3(256), 0, (hipStream_t)stream, dwpq, ld,
+                       H, C, dw1, lddw1);
+    GPE_CHECK_LAUNCH();
+    return GPE_OK;
+}
+
+__global__ void gpe_add_kernel(const float* a, const float* b, float* out, long n)
+{
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < n) out[e] = a[e] + b[e];
+}
+
+extern "C" int gpe_add(const float* a, const float* b, float* out, long n, void* stream)
+{
+    if (!a || !b || !out || n < 0) return GPE_EINVAL;
+    if (n == 0) return GPE_OK;
+    hipLaunchKernelGGL(gpe_add_kernel, dim3(gpe_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, a, b, out, n);
+    GPE_CHECK_LAUNCH();
+    return GPE_OK;
+}

@@ -1,0 +1,475 @@
+// Row-tile GEMM family for gfx950:  Y[rows, N] = f(A[rows, K]) . W[N, K]^T  with fused producers / epilogues.
+//
+//   * nn.Linear / LSTM gate projections                  (/root/reference/nn/net_blocks.py:45,158,373-376,397)
+//   * the per-edge MLP of DynamicEdgeConv, forward       (nn/net_blocks.py:43-47,124-135)
+//   * its backward (input-gradient half; the weight-gradient half is gpe_redgemm.hip)
+//
+// Structure (one 256-thread workgroup = 4 waves, one per SIMD; two workgroups per CU):
+//   - a 64-row A tile is BUILT in LDS by the producer (dense copy | gather relu(P_i+Q_j) | dz3 on the fly);
+//   - the weight arrives pre-packed (gpe_pack_weight) in 16-wide K chunks that are copied to LDS with coalesced
+//     16-B loads, register-prefetched one chunk ahead;
+//   - wave w multiplies rows 16w..16w+15 of the tile against all NT 16-column tiles with
+//     v_mfma_f32_16x16x4_f32 (exact fp32, 32-cycle issue) — every operand fetch is a ds_read_b128 giving the
+//     4 k-values of 4 consecutive MFMAs, and the packed layout [k/4][n][4] makes the B reads conflict-free;
+//   - the accumulator tile goes back through LDS so that stores are whole-row coalesced and the fused
+//     epilogues (BN statistics in fp64, ReLU, max/min over the k messages of a point, BN/ReLU backward,
+//     per-point sums) see complete rows.
+// fp32 MFMA runs at the fp32 vector rate (157 TF chip peak), so these kernels are MFMA-issue bound by design;
+// everything else (LDS traffic, gathers from L2/MALL, stores) hides underneath.
+#include "gpe_common.h"
+
+#define RG_BM 64
+#define RG_KSLAB 256
+
+enum { A_DENSE = 0, A_GATHER = 1, A_DZ3 = 2 };
+enum { E_LINEAR = 0, E_EDGE_FWD = 1, E_BWD_INPLACE = 2, E_BWD_GATHER = 3 };
+
+struct RgParams {
+    // problem
+    long M;                 // logical rows (E for edge kernels)
+    int N, K;               // output cols / reduction dim
+    int R;                  // rows per tile (<= 64); edge kernels: whole points, R = (64/k)*k
+    int num_tiles;
+    // A producers
+    GpeRows a;              // A_DENSE
+    const float* pq; int ldpq; int H;           // A_GATHER / E_BWD_GATHER : P = pq[:, 0:H], Q = pq[:, H:2H]
+    const int32_t* idx; int npts; int k;        // kNN graph (local indices), points per cloud, neighbours
+    const float* a3; int lda3;                  // A_DZ3: stored activation
+    const float* g; int ldg;                    //        upstream gradient per point
+    const uint8_t* amx; const uint8_t* amn; int ldagg;
+    const float* coef_in;                       //        [3][K] = {s, k1, k2}
+    // weight
+    const float* wp; int Npad;
+    const float* bias;
+    // epilogue
+    GpeRows addend;         // E_LINEAR (base may be NULL)
+    float* y; long y_so, y_si; int y_inner; int act;
+    float* out; int ldo;    // edge kernels: activation / dz rows
+    double* stats_part;     // E_EDGE_FWD: [gridDim.x][2][N]
+    int agg; float* mx; float* mn; uint8_t* oamx; uint8_t* oamn; int oldagg;
+    const float* coef_out;  // E_BWD_*: [3][N]
+    float* dP; int lddp;    // E_BWD_GATHER
+};
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+
+// guarded load of 4 consecutive floats p[0..3] of which `nvalid` exist; vec => p is 16-B aligned
+__device__ __forceinline__ float4 ld4_guard(const float* p, int nvalid, bool vec)
+{
+    if (nvalid >= 4 && vec) return ld4(p);
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (nvalid > 0) v.x = p[0];
+    if (nvalid > 1) v.y = p[1];
+    if (nvalid > 2) v.z = p[2];
+    if (nvalid > 3) v.w = p[3];
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// A-tile producers: fill As[64][lda] columns [0, kp) for the K slab [ks, ks+kslab)
+// ---------------------------------------------------------------------------------------------------------
+template <int AMODE>
+__device__ __forceinline__ void rg_build_a(const RgParams& p, float* As, int lda, long row0, int rv, int ks,
+                                           int kslab, int kp)
+{
+    const int tid = threadIdx.x;
+    const int q4 = kp >> 2;                       // float4 columns per row
+    for (int e = tid; e < RG_BM * q4; e += 256) {
+        const int r = e / q4;
+        const int c = (e - r * q4) << 2;          // column inside the slab
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r < rv && c < kslab) {
+            const long gr = row0 + r;
+            const int nvalid = kslab - c;
+            if (AMODE == A_DENSE) {
+                const float* src = gpe_row_ptr(p.a, gr) + ks + c;
+                v = ld4_guard(src, nvalid, gpe_aligned16(src));
+            } else if (AMODE == A_GATHER) {
+                const long i = gr / p.k;                                    // global point
+                const long cloud0 = (i / p.npts) * (long)p.npts;
+                const long j = cloud0 + p.idx[gr];
+                const float* pp = p.pq + i * p.ldpq + ks + c;
+                const float* qq = p.pq + j * p.ldpq + p.H + ks + c;
+                float4 a = ld4_guard(pp, nvalid, gpe_aligned16(pp));
+                float4 b = ld4_guard(qq, nvalid, gpe_aligned16(qq));
+                v.x = fmaxf(a.x + b.x, 0.f); v.y = fmaxf(a.y + b.y, 0.f);
+                v.z = fmaxf(a.z + b.z, 0.f); v.w = fmaxf(a.w + b.w, 0.f);
+            } else {   // A_DZ3: dz3 = (a3>0) ? [slot==argsel]*s*g - k1 - a3*k2 : 0
+                const long i = gr / p.k;
+                const int slot = (int)(gr - i * p.k);
+                const float* ap = p.a3 + gr * p.lda3 + ks + c;
+                const float* gp = p.g + i * p.ldg + ks + c;
+                float4 a = ld4_guard(ap, nvalid, gpe_aligned16(ap));
+                float4 gg = ld4_guard(gp, nvalid, gpe_aligned16(gp));
+                const float av[4] = {a.x, a.y, a.z, a.w};
+                const float gv[4] = {gg.x, gg.y, gg.z, gg.w};
+                float o[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    o[t] = 0.f;
+                    if (t < nvalid) {
+                        const int cc = ks + c + t;
+                        const float s = p.coef_in[cc];
+                        const float k1 = p.coef_in[p.K + cc];
+                        const float k2 = p.coef_in[2 * p.K + cc];
+                        const uint8_t sel = (s >= 0.f) ? p.amx[i * p.ldagg + cc] : p.amn[i * p.ldagg + cc];
+                        const float hit = (sel == slot) ? s * gv[t] : 0.f;
+                        o[t] = (av[t] > 0.f) ? (hit - k1 - av[t] * k2) : 0.f;
+                    }
+                }
+                v = make_float4(o[0], o[1], o[2], o[3]);
+            }
+        }
+        st4(&As[r * lda + c], v);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// MFMA over one K slab held in As
+// ---------------------------------------------------------------------------------------------------------
+template <int NT>
+__device__ __forceinline__ void rg_mma_slab(const RgParams& p, const float* As, int lda, int kp, int chunk0,
+                                            int n0, float* Wl, f32x4 (&acc)[NT])
+{
+    constexpr int NQ = 64 * NT;                 // float4 per packed chunk of this N block
+    constexpr int PRE = (NQ + 255) / 256;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 15, g = lane >> 4;
+    const int nchunks = kp >> 4;
+    float4 pre[PRE];
+
+    auto gload = [&](int kc) {
+#pragma unroll
+        for (int q = 0; q < PRE; ++q) {
+            const int e = tid + 256 * q;
+            pre[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (e < NQ) {
+                const int plane = e / (16 * NT), n = e - plane * (16 * NT);
+                if (n0 + n < p.Npad)
+                    pre[q] = ld4(p.wp + ((((long)(chunk0 + kc) << 2) + plane) * p.Npad + n0 + n) * 4);
+            }
+        }
+    };
+    gload(0);
+    for (int kc = 0; kc < nchunks; ++kc) {
+        __syncthreads();                        // Wl free again; on kc==0 also: A slab complete
+#pragma unroll
+        for (int q = 0; q < PRE; ++q) {
+            const int e = tid + 256 * q;
+            if (e < NQ) st4(&Wl[e * 4], pre[q]);
+        }
+        __syncthreads();
+        if (kc + 1 < nchunks) gload(kc + 1);
+
+        const float4 a4 = ld4(&As[(16 * wave + j) * lda + kc * 16 + 4 * g]);
+        const float av[4] = {a4.x, a4.y, a4.z, a4.w};
+        float4 b4[NT];
+#pragma unroll
+        for (int n = 0; n < NT; ++n) b4[n] = ld4(&Wl[((g * 16 * NT) + 16 * n + j) * 4]);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                const float bv = (t == 0) ? b4[n].x : (t == 1) ? b4[n].y : (t == 2) ? b4[n].z : b4[n].w;
+                acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t], bv, acc[n], 0, 0, 0);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+template <int NT, int AMODE, int EMODE>
+__global__ __launch_bounds__(256, 2) void gpe_rowgemm_kernel(RgParams p)
+{
+    extern __shared__ __align__(16) float smem[];
+    const int kp_max = ((p.K < RG_KSLAB ? p.K : RG_KSLAB) + 15) & ~15;
+    const int lda = kp_max + 4;
+    constexpr int ldc = 16 * NT + 4;
+    const int a_floats = RG_BM * (lda > ldc ? lda : ldc);
+    float* As = smem;
+    float* Cs = smem;                    // aliases As after the MFMA loop
+    float* Wl = smem + a_floats;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 15, g = lane >> 4;
+    const int n0 = blockIdx.y * (16 * NT);
+    const int ncols = (p.N - n0 < 16 * NT) ? (p.N - n0) : 16 * NT;      // valid output cols of this block
+
+    // fp64 running BN statistics of column `tid` across all tiles of this workgroup (E_EDGE_FWD)
+    double st_sum = 0.0, st_sq = 0.0;
+
+    for (int tile = blockIdx.x; tile < p.num_tiles; tile += gridDim.x) {
+        const long row0 = (long)tile * p.R;
+        const int rv = (int)((p.M - row0 < p.R) ? (p.M - row0) : p.R);
+
+        f32x4 acc[NT];
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+        for (int ks = 0; ks < p.K; ks += RG_KSLAB) {
+            const int kslab = (p.K - ks < RG_KSLAB) ? (p.K - ks) : RG_KSLAB;
+            const int kp = (kslab + 15) & ~15;
+            __syncthreads();             // previous slab / previous tile's epilogue done with the A region
+            rg_build_a<AMODE>(p, As, lda, row0, rv, ks, kslab, kp);
+            rg_mma_slab<NT>(p, As, lda, kp, ks >> 4, n0, Wl, acc);   // begins with a barrier
+        }
+        __syncthreads();                 // all waves done reading As -> reuse as Cs
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Cs[(16 * wave + 4 * g + r) * ldc + 16 * n + j] = acc[n][r];
+        __syncthreads();
+
+        // ------------------------------------------------------------------------------------------------
+        if (EMODE == E_LINEAR) {
+            const int q4 = (ncols + 3) >> 2;
+            for (int e = tid; e < rv * q4; e += 256) {
+                const int r = e / q4, c = (e - r * q4) << 2;
+                const long gr = row0 + r;
+                float4 v = ld4(&Cs[r * ldc + c]);
+                float o[4] = {v.x, v.y, v.z, v.w};
+                const int nvalid = ncols - c;
+                const float* ad = nullptr;
+                if (p.addend.base) ad = gpe_row_ptr(p.addend, gr) + n0 + c;
+                float* dst;
+                if (p.y_inner <= 0) dst = p.y + gr * p.y_so + n0 + c;
+                else { long oo = gr / p.y_inner; dst = p.y + oo * p.y_so + (gr - oo * p.y_inner) * p.y_si + n0 + c; }
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    if (t < nvalid) {
+                        float x = o[t];
+                        if (p.bias) x += p.bias[n0 + c + t];
+                        if (ad) x += ad[t];
+                        if (p.act == 1) x = fmaxf(x, 0.f);
+                        o[t] = x;
+                    }
+                }
+                if (nvalid >= 4 && gpe_aligned16(dst)) st4(dst, make_float4(o[0], o[1], o[2], o[3]));
+                else {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) if (t < nvalid) dst[t] = o[t];
+                }
+            }
+        } else if (EMODE == E_EDGE_FWD) {
+            // bias + ReLU in place in LDS; BN statistics per column in fp64
+            if (tid < ncols) {
+                const float bz = p.bias ? p.bias[n0 + tid] : 0.f;
+                for (int r = 0; r < rv; ++r) {
+                    float v = fmaxf(Cs[r * ldc + tid] + bz, 0.f);
+                    Cs[r * ldc + tid] = v;
+                    st_sum += (double)v;
+                    st_sq += (double)v * (double)v;
+                }
+            }
+            __syncthreads();
+            // coalesced row stores (ldo is a multiple of 4; pad columns hold relu(0) = 0)
+            const int q4 = (ncols + 3) >> 2;
+            for (int e = tid; e < rv * q4; e += 256) {
+                const int r = e / q4, c = (e - r * q4) << 2;
+                st4(p.out + (row0 + r) * p.ldo + n0 + c, ld4(&Cs[r * ldc + c]));
+            }
+            if (p.agg) {
+                const int pts = rv / p.k;
+                const long pt0 = row0 / p.k;
+                for (int e = tid; e < pts * ncols; e += 256) {
+                    const int pt = e / ncols, c = e - pt * ncols;
+                    const float* col = &Cs[(pt * p.k) * ldc + c];
+                    float vmx = col[0], vmn = col[0];
+                    int imx = 0, imn = 0;
+                    for (int s = 1; s < p.k; ++s) {
+                        const float v = col[s * ldc];
+                        if (v > vmx) { vmx = v; imx = s; }
+                        if (v < vmn) { vmn = v; imn = s; }
+                    }
+                    const long o = (pt0 + pt) * p.oldagg + n0 + c;
+                    p.mx[o] = vmx; p.mn[o] = vmn;
+                    p.oamx[o] = (uint8_t)imx; p.oamn[o] = (uint8_t)imn;
+                }
+            }
+        } else {   // E_BWD_INPLACE / E_BWD_GATHER : dz = (act>0) ? s*u - k1 - act*k2 : 0  (coef_out = {s,k1,k2})
+            const int q4 = (ncols + 3) >> 2;
+            for (int e = tid; e < rv * q4; e += 256) {
+                const int r = e / q4, c = (e - r * q4) << 2;
+                const long gr = row0 + r;
+                const float4 u4 = ld4(&Cs[r * ldc + c]);
+                float* dst = p.out + gr * p.ldo + n0 + c;
+                float4 act;
+                if (EMODE == E_BWD_INPLACE) {
+                    act = ld4(dst);
+                } else {
+                    const long i = gr / p.k;
+                    const long cloud0 = (i / p.npts) * (long)p.npts;
+                    const long jj = cloud0 + p.idx[gr];
+                    const float4 a = ld4(p.pq + i * p.ldpq + n0 + c);
+                    const float4 b = ld4(p.pq + jj * p.ldpq + p.H + n0 + c);
+                    act = make_float4(fmaxf(a.x + b.x, 0.f), fmaxf(a.y + b.y, 0.f), fmaxf(a.z + b.z, 0.f),
+                                      fmaxf(a.w + b.w, 0.f));
+                }
+                const float uv[4] = {u4.x, u4.y, u4.z, u4.w};
+                const float av[4] = {act.x, act.y, act.z, act.w};
+                float o[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int cc = n0 + c + t;
+                    o[t] = 0.f;
+                    if (cc < p.N && av[t] > 0.f)
+                        o[t] = uv[t] * p.coef_out[cc] - p.coef_out[p.N + cc] - av[t] * p.coef_out[2 * p.N + cc];
+                }
+                const float4 o4 = make_float4(o[0], o[1], o[2], o[3]);
+                st4(dst, o4);
+                if (EMODE == E_BWD_GATHER) st4(&Cs[r * ldc + c], o4);
+            }
+            if (EMODE == E_BWD_GATHER) {
+                __syncthreads();
+                const int pts = rv / p.k;
+                const long pt0 = row0 / p.k;
+                for (int e = tid; e < pts * ncols; e += 256) {
+                    const int pt = e / ncols, c = e - pt * ncols;
+                    const float* col = &Cs[(pt * p.k) * ldc + c];
+                    float s = 0.f;
+                    for (int t = 0; t < p.k; ++t) s += col[t * ldc];
+                    p.dP[(pt0 + pt) * p.lddp + n0 + c] = s;
+                }
+            }
+        }
+    }
+
+    if (EMODE == E_EDGE_FWD && p.stats_part && tid < ncols) {
+        double* dst = p.stats_part + (size_t)blockIdx.x * 2 * p.N;
+        dst[n0 + tid] = st_sum;
+        dst[p.N + n0 + tid] = st_sq;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------------
+static size_t rg_lds_bytes(int NT, int K)
+{
+    const int kp_max = gpe_round_up(K < RG_KSLAB ? K : RG_KSLAB, 16);
+    const int lda = kp_max + 4, ldc = 16 * NT + 4;
+    return ((size_t)RG_BM * (lda > ldc ? lda : ldc) + (size_t)64 * NT * 4) * sizeof(float);
+}
+
+template <int NT, int AMODE, int EMODE>
+static int rg_launch(const RgParams& p, dim3 grid, hipStream_t stream)
+{
+    const size_t lds = rg_lds_bytes(NT, p.K);
+    if (lds > 160 * 1024) return GPE_EINVAL;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gpe_rowgemm_kernel<NT, AMODE, EMODE>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            return GPE_ELAUNCH;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gpe_rowgemm_kernel<NT, AMODE, EMODE>), grid, dim3(256), lds, stream, p);
+    GPE_CHECK_LAUNCH();
+    return GPE_OK;
+}
+
+template <int AMODE, int EMODE>
+static int rg_dispatch_nt(int NT, const RgParams& p, dim3 grid, hipStream_t stream)
+{
+    switch (NT) {
+        case 4: return rg_launch<4, AMODE, EMODE>(p, grid, stream);
+        case 7: return rg_launch<7, AMODE, EMODE>(p, grid, stream);
+        case 10: return rg_launch<10, AMODE, EMODE>(p, grid, stream);
+        case 13: return rg_launch<13, AMODE, EMODE>(p, grid, stream);
+        case 16: return rg_launch<16, AMODE, EMODE>(p, grid, stream);
+    }
+    return GPE_EINVAL;
+}
+
+static int rg_pick_nt_single(int N)   // smallest instantiated NT whose block covers all N columns
+{
+    const int need = gpe_cdiv(N, 16);
+    const int opts[5] = {4, 7, 10, 13, 16};
+    for (int i = 0; i < 5; ++i) if (opts[i] >= need) return opts[i];
+    return -1;
+}
+
+#define GPE_STATS_BLOCKS 512
+extern "C" int gpe_stats_blocks(void) { return GPE_STATS_BLOCKS; }
+
+extern "C" int gpe_linear(const float* a, long a_so, long a_si, int a_inner, const float* wp, const float* bias,
+                          const float* addend, long ad_so, long ad_si, int ad_inner, float* y, long y_so,
+                          long y_si, int y_inner, int M, int N, int K, int act, void* stream)
+{
+    if (!a || !wp || !y || M < 0 || N <= 0 || K <= 0 || (act != 0 && act != 1)) return GPE_EINVAL;
+    if (M == 0) return GPE_OK;
+    RgParams p = {};
+    p.M = M; p.N = N; p.K = K; p.R = RG_BM; p.num_tiles = gpe_cdiv(M, RG_BM);
+    p.a = GpeRows{a, a_so, a_si, a_inner};
+    p.wp = wp; p.Npad = gpe_round_up(N, 16); p.bias = bias;
+    p.addend = GpeRows{addend, ad_so, ad_si, ad_inner};
+    p.y = y; p.y_so = y_so; p.y_si = y_si; p.y_inner = y_inner; p.act = act;
+    // widest column block that still gives the chip >= 256 workgroups, else the narrowest (latency-bound case)
+    int NT = 4;
+    const int opts[5] = {16, 13, 10, 7, 4};
+    for (int i = 0; i < 5; ++i) {
+        const int nblk = gpe_cdiv(N, 16 * opts[i]);
+        if ((long)nblk * p.num_tiles >= 256 || opts[i] == 4) { NT = opts[i]; break; }
+    }
+    // never use a block much wider than N
+    const int single = rg_pick_nt_single(N);
+    if (single > 0 && single < NT) NT = single;
+    dim3 grid(p.num_tiles, gpe_cdiv(N, 16 * NT));
+    return rg_dispatch_nt<A_DENSE, E_LINEAR>(NT, p, grid, (hipStream_t)stream);
+}
+
+extern "C" int gpe_edge_mlp_fwd(int a_mode, const float* pq, int ldpq, const int32_t* idx, const float* a_in,
+                                int lda, int B, int N, int k, int Cin, int Cout, const float* wp,
+                                const float* bias, float* out, int ldo, double* stats_part, int agg, float* mx,
+                                float* mn, uint8_t* amx, uint8_t* amn, int ldagg, void* stream)
+{
+    if (!wp || !out || B <= 0 || N <= 0 || k <= 0 || k > 64 || Cin <= 0 || Cout <= 0 || Cin > RG_KSLAB ||
+        (ldo & 3) || ldo < Cout)
+        return GPE_EINVAL;
+    if (a_mode == 0 && (!pq || !idx || (ldpq & 3) || (Cin & 3))) return GPE_EINVAL;
+    if (a_mode == 1 && (!a_in || lda < Cin)) return GPE_EINVAL;
+    if (agg && (!mx || !mn || !amx || !amn || ldagg < Cout)) return GPE_EINVAL;
+    const int NT = rg_pick_nt_single(Cout);
+    if (NT < 0) return GPE_EINVAL;
+    RgParams p = {};
+    p.M = (long)B * N * k; p.N = Cout; p.K = Cin;
+    p.R = (RG_BM / k) * k; p.num_tiles = gpe_cdiv(p.M, p.R);
+    p.a = GpeRows{a_in, lda, 0, 0};
+    p.pq = pq; p.ldpq = ldpq; p.H = Cin; p.idx = idx; p.npts = N; p.k = k;
+    p.wp = wp; p.Npad = gpe_round_up(Cout, 16); p.bias = bias;
+    p.out = out; p.ldo = ldo; p.stats_part = stats_part;
+    p.agg = agg; p.mx = mx; p.mn = mn; p.oamx = amx; p.oamn = amn; p.oldagg = ldagg;
+    dim3 grid(GPE_STATS_BLOCKS, 1);
+    if (a_mode == 0) return rg_dispatch_nt<A_GATHER, E_EDGE_FWD>(NT, p, grid, (hipStream_t)stream);
+    return rg_dispatch_nt<A_DENSE, E_EDGE_FWD>(NT, p, grid, (hipStream_t)stream);
+}
+
+extern "C" int gpe_edge_mlp_bwd(int a_mode, const float* a, int lda, const float* g, int ldg, const uint8_t* amx,
+                                const uint8_t* amn, int ldagg, const float* coef_in, int act_mode,
+                                const float* pq, int ldpq, const int32_t* idx, int B, int N, int k, int Cin,
+                                int Cout, const float* wp, const float* coef_out, float* dz_out, int ldo,
+                                float* dP, int lddp, void* stream)
+{
+    if (!a || !wp || !coef_out || !dz_out || B <= 0 || N <= 0 || k <= 0 || k > 64 || Cin <= 0 || Cout <= 0 ||
+        Cin > RG_KSLAB || (ldo & 3) || ldo < Cout || lda < Cin)
+        return GPE_EINVAL;
+    if (a_mode == 0 && (!g || !amx || !amn || !coef_in)) return GPE_EINVAL;
+    if (act_mode == 1 && (!pq || !idx || !dP || (ldpq & 3) || (Cout & 3))) return GPE_EINVAL;
+    const int NT = rg_pick_nt_single(Cout);
+    if (NT < 0) return GPE_EINVAL;
+    RgParams p = {};
+    p.M = (long)B * N * k; p.N = Cout; p.K = Cin;
+    p.R = (RG_BM / k) * k; p.num_tiles = gpe_cdiv(p.M, p.R);
+    p.a = GpeRows{a, lda, 0, 0};
+    p.a3 = a; p.lda3 = lda; p.g = g; p.ldg = ldg; p.amx = amx; p.amn = amn; p.ldagg = ldagg; p.coef_in = coef_in;
+    p.pq = pq; p.ldpq = ldpq; p.H = Cout; p.idx = idx; p.npts = N; p.k = k;
+    p.wp = wp; p.Npad = gpe_round_up(Cout, 16);
+    p.out = dz_out; p.ldo = ldo; p.coef_out = coef_out; p.dP = dP; p.lddp = lddp;
+    dim3 grid(p.num_tiles < 2048 ? p.num_tiles : 2048, 1);
+    hipStream_t s = (hipStream_t)stream;
+    if (a_mode == 0 && act_mode == 0) return rg_dispatch_nt<A_DZ3, E_BWD_INPLACE>(NT, p, grid, s);
+    if (a_mode == 1 && act_mode == 1) return rg_dispatch_nt<A_DENSE, E_BWD_GATHER>(NT, p, grid, s);
+    if (a_mode == 1 && act_mode == 0) return rg_dispatch_nt<A_DENSE, E_BWD_INPLACE>(NT, p, grid, s);
+    return GPE_EINVAL;
+}

@@ -1,0 +1,181 @@
+"""Drop-in for the reference's nn/net_blocks.py (classes resolved by name from the YAML config,
+nn/nets.py:100,106,116).  The torch modules below only HOLD parameters/buffers under the reference's names
+(`conv_layers.{i}.nn.{j}.{0,2}.*`, `lstm.weight_ih_l0`, `lin.*` ...); every forward/backward runs the HIP
+kernels through ops.py."""
+import torch
+import torch.nn as nn
+
+from . import ops
+
+
+def MLP(channels, batch_norm=True):
+    """Parameter container with the reference layout [Linear -> ReLU -> BatchNorm1d] x n, BN after ReLU and on
+    the last layer too (nn/net_blocks.py:43-47; `batch_norm` is ignored there as well)."""
+    return nn.Sequential(*[
+        nn.Sequential(nn.Linear(channels[i - 1], channels[i]), nn.ReLU(), nn.BatchNorm1d(channels[i]))
+        for i in range(1, len(channels))])
+
+
+class DynamicEdgeConv(nn.Module):
+    """Holder with PyG's attribute name `.nn` (state-dict compatibility); the arithmetic is ops.EdgeConvFn."""
+
+    def __init__(self, nn_module, k, aggr='max'):
+        super().__init__()
+        if aggr != 'max':
+            raise NotImplementedError("EConv_aggr='%s': only 'max' (all shipped configs) has kernels" % aggr)
+        if len(nn_module) != 3:
+            raise NotImplementedError('EConv_hidden_depth must be 2 (edge MLP of 3 blocks), got %d blocks'
+                                      % len(nn_module))
+        self.nn = nn_module
+        self.k = k
+        self.aggr = aggr
+        self.last_knn = None
+
+    def forward(self, x, n_clouds, n_points):
+        blocks = [self.nn[i] for i in range(3)]
+        lin = [b[0] for b in blocks]
+        bn = [b[2] for b in blocks]
+        eps, mom = bn[0].eps, bn[0].momentum
+        args = []
+        for l, b in zip(lin, bn):
+            args += [l.weight, l.bias, b.weight, b.bias]
+        for b in bn:
+            args += [b.running_mean, b.running_var, b.num_batches_tracked]
+        out, idx = ops.EdgeConvFn.apply(x, n_clouds, n_points, self.k, self.training, eps, mom, *args)
+        self.last_knn = idx
+        return out
+
+
+class EdgeConvFeatures(nn.Module):
+    """nn/net_blocks.py:93-191: defaults, 2x DynamicEdgeConv, optional skip concat, global pool, Linear.
+    forward(positions [B,N,3], global_pool=True) -> (encoding [B,out] | None, per-point [B*N,F(+3)], batch)."""
+
+    def __init__(self, out_size, config={}):
+        super().__init__()
+        self.config = {
+            'conv_depth': 2, 'k_neighbors': 5, 'EConv_hidden': 200, 'EConv_hidden_depth': 2,
+            'EConv_feature': 112, 'EConv_aggr': 'max', 'global_pool': 'mean',
+            'skip_connections': False, 'graph_pooling': False, 'pool_ratio': 0.1}
+        self.config.update(config)
+        if self.config['graph_pooling']:
+            raise NotImplementedError('graph_pooling (DynamicASAPool) is outside the accelerated path; '
+                                      'no shipped config enables it')
+        depth = self.config['conv_depth']
+        feat = [self.config['EConv_feature']] * depth
+        hid = [self.config['EConv_hidden']] * depth
+        mlp_depth = self.config['EConv_hidden_depth']
+        self.conv_layers = nn.ModuleList()
+        self.conv_layers.append(DynamicEdgeConv(
+            MLP([2 * 3] + [hid[0]] * mlp_depth + [feat[0]]),
+            k=self.config['k_neighbors'], aggr=self.config['EConv_aggr']))
+        for c in range(1, depth):
+            self.conv_layers.append(DynamicEdgeConv(
+                MLP([2 * feat[c - 1]] + [hid[c]] * mlp_depth + [feat[c]]),
+                k=self.config['k_neighbors'], aggr=self.config['EConv_aggr']))
+        if self.config['global_pool'] == 'mean':
+            self.global_pool = ops.segment_mean
+        elif self.config['global_pool'] in ('max', 'add'):
+            raise NotImplementedError("global_pool='%s': only 'mean' (all shipped configs) has kernels"
+                                      % self.config['global_pool'])
+        else:
+            raise ValueError('{} pooling is not supported'.format(self.config['global_pool']))
+        out_features = self.config['EConv_feature'] + 3 if self.config['skip_connections'] \
+            else self.config['EConv_feature']
+        self.lin = nn.Linear(out_features, out_size)
+
+    def forward(self, positions, global_pool=True):
+        B, N = positions.size(0), positions.size(1)
+        pos_flat = positions.reshape(-1, positions.size(-1))
+        if pos_flat.dtype != torch.float32:
+            pos_flat = pos_flat.float()
+        pos_flat = pos_flat.contiguous()
+        # batch vector of the reference (nn/net_blocks.py:165-167); the kernels only need (B, N)
+        batch = torch.arange(B, device=positions.device).repeat_interleave(N)
+        out = pos_flat
+        for conv in self.conv_layers:
+            out = conv(out, B, N)
+        if self.config['skip_connections']:
+            out = torch.cat([out, pos_flat], dim=-1)
+        if global_pool:
+            pooled = self.global_pool(out.contiguous() if out.stride(1) != 1 else out, B, N)
+            return ops.linear(pooled, self.lin.weight, self.lin.bias), out, batch
+        return None, out, batch
+
+
+def _init_tenzor(*shape, device='cpu', init_type=''):
+    """nn/net_blocks.py:302-315 — drawn on the CPU generator, then moved (keeps the reference's RNG stream)."""
+    if not init_type or len(shape) == 1:
+        t = torch.zeros(shape)
+    elif 'kaiming_normal' in init_type:
+        t = torch.empty(shape)
+        nn.init.kaiming_normal_(t)
+    else:
+        raise NotImplementedError('{} tenzor initialization is not implemented'.format(init_type))
+    return t.to(device)
+
+
+def _init_weights(module, init_type=''):
+    """nn/net_blocks.py:318-333."""
+    if not init_type:
+        return
+    for name, param in module.named_parameters():
+        if 'weight' in name:
+            if 'kaiming_normal' in init_type:
+                if len(param.shape) > 1:
+                    nn.init.kaiming_normal_(param)
+            else:
+                raise NotImplementedError('{} weight initialization is not implemented'.format(init_type))
+
+
+class LSTMDecoderModule(nn.Module):
+    """nn/net_blocks.py:363-402.  `self.lstm` is a torch.nn.LSTM used ONLY as the parameter container
+    (weight_ih_l*, weight_hh_l*, bias_ih_l*, bias_hh_l*); the recurrence runs in ops.LSTMDecoderFn."""
+
+    def __init__(self, encoding_size, hidden_size, out_elem_size, n_layers, dropout=0,
+                 custom_init='kaiming_normal', **kwargs):
+        super().__init__()
+        if dropout:
+            raise NotImplementedError('LSTM dropout > 0 has no kernel (shipped configs use 0)')
+        self.custom_init = custom_init
+        self.n_layers = n_layers
+        self.encoding_size = encoding_size
+        self.hidden_size = hidden_size
+        self.out_elem_size = out_elem_size
+        self.lstm = nn.LSTM(encoding_size, hidden_size, n_layers, dropout=dropout, batch_first=True)
+        self.lin = nn.Linear(hidden_size, out_elem_size)
+        _init_weights(self.lstm, init_type=custom_init)
+        self.last_states = None
+
+    def forward(self, batch_enc, out_len):
+        device = batch_enc.device
+        bs = batch_enc.size(0)
+        # hidden first, then cell: the reference's draw order (nn/net_blocks.py:391-392)
+        h0 = _init_tenzor(self.n_layers, bs, self.hidden_size, device=device, init_type=self.custom_init)
+        c0 = _init_tenzor(self.n_layers, bs, self.hidden_size, device=device, init_type=self.custom_init)
+        self.last_states = (h0, c0)
+        params = []
+        for l in range(self.n_layers):
+            params += [getattr(self.lstm, 'weight_ih_l%d' % l), getattr(self.lstm, 'weight_hh_l%d' % l),
+                       getattr(self.lstm, 'bias_ih_l%d' % l), getattr(self.lstm, 'bias_hh_l%d' % l)]
+        enc = batch_enc if batch_enc.is_contiguous() else batch_enc.contiguous()
+        return ops.LSTMDecoderFn.apply(enc, h0, c0, out_len, self.n_layers, self.lin.weight, self.lin.bias,
+                                       *params)
+
+
+def _not_accelerated(name):
+    class _Missing(nn.Module):
+        def __init__(self, *a, **kw):
+            raise NotImplementedError(
+                '%s is selectable in the reference (nn/net_blocks.py) but used by no shipped config; '
+                'it is a "next" row of the scope table (SURVEY.md §8f) and has no kernels yet' % name)
+    _Missing.__name__ = name
+    return _Missing
+
+
+PointNetPlusPlus = _not_accelerated('PointNetPlusPlus')
+EdgeConvPoolingFeatures = _not_accelerated('EdgeConvPoolingFeatures')
+DynamicASAPool = _not_accelerated('DynamicASAPool')
+MLPDecoder = _not_accelerated('MLPDecoder')
+LSTMEncoderModule = _not_accelerated('LSTMEncoderModule')
+LSTMDoubleReverseDecoderModule = _not_accelerated('LSTMDoubleReverseDecoderModule')
+GRUDecoderModule = _not_accelerated('GRUDecoderModule')

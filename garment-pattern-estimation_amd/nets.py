@@ -1,0 +1,116 @@
+"""Drop-in for the reference's nn/nets.py: same class names (resolved with getattr from the YAML, nn/train.py:120,
+nn/experiment.py:232), constructor signature `(data_config, config={}, in_loss_config={})`, merged `.config`,
+`forward(positions_batch, **kwargs) -> dict`, `.loss(preds, gt, epoch=)`, parameter/buffer names and shapes."""
+import torch
+import torch.nn as nn
+
+from . import net_blocks as blocks
+from . import ops
+from .metrics import ComposedPatternLoss
+
+
+class BaseModule(nn.Module):
+    """nn/nets.py:11-37."""
+
+    def __init__(self):
+        super().__init__()
+        self.config = {'loss': 'MSELoss', 'model': self.__class__.__name__}
+        self.regression_loss = nn.MSELoss()
+
+    def loss(self, preds, ground_truth, **kwargs):
+        ground_truth = ground_truth.to(preds.device)
+        loss = self.regression_loss(preds, ground_truth)
+        return loss, {'regression loss': loss}, False
+
+    def train(self, mode=True):
+        super().train(mode)
+        if isinstance(self.loss, object):
+            self.loss.train(mode)
+        return self
+
+    def eval(self):
+        super().eval()
+        if isinstance(self.loss, object):
+            self.loss.eval()
+        return self
+
+
+class GarmentFullPattern3D(BaseModule):
+    """nn/nets.py:41-184: EdgeConv encoder -> pattern LSTM -> panel LSTM + placement Linear."""
+
+    def __init__(self, data_config, config={}, in_loss_config={}):
+        super().__init__()
+        self.panel_elem_len = data_config['element_size']
+        self.max_panel_len = data_config['max_panel_len']
+        self.max_pattern_size = data_config['max_pattern_len']
+        self.rotation_size = data_config['rotation_size']
+        self.translation_size = data_config['translation_size']
+        self.config.update({
+            'panel_encoding_size': 250, 'panel_hidden_size': 250, 'panel_n_layers': 3,
+            'pattern_encoding_size': 250, 'pattern_hidden_size': 250, 'pattern_n_layers': 2,
+            'dropout': 0, 'lstm_init': 'kaiming_normal_', 'feature_extractor': 'EdgeConvFeatures',
+            'panel_decoder': 'LSTMDecoderModule', 'pattern_decoder': 'LSTMDecoderModule',
+            'stitch_tag_dim': 3})
+        # back-compat mutation of the CALLER's dict, as the reference does (nn/nets.py:75-78)
+        if 'panel_hidden_size' not in config:
+            config['panel_hidden_size'] = config['panel_encoding_size']
+        if 'pattern_hidden_size' not in config:
+            config['pattern_hidden_size'] = config['pattern_encoding_size']
+        self.config.update(config)
+        self.config['loss'] = {
+            'loss_components': ['shape', 'loop', 'rotation', 'translation'],
+            'quality_components': ['shape', 'discrete', 'rotation', 'translation'],
+            'loop_loss_weight': 1., 'stitch_tags_margin': 0.3, 'epoch_with_stitches': 40,
+            'stitch_supervised_weight': 0.1, 'stitch_hardnet_version': False,
+            'panel_origin_invariant_loss': True}
+        self.config['loss'].update(in_loss_config)
+        self.loss = ComposedPatternLoss(data_config, self.config['loss'])
+        self.config['loss'] = self.loss.config
+
+        feature_extractor_module = getattr(blocks, self.config['feature_extractor'])
+        self.feature_extractor = feature_extractor_module(self.config['pattern_encoding_size'], self.config)
+        if hasattr(self.feature_extractor, 'config'):
+            self.config.update(self.feature_extractor.config)
+        panel_decoder_module = getattr(blocks, self.config['panel_decoder'])
+        self.panel_decoder = panel_decoder_module(
+            encoding_size=self.config['panel_encoding_size'], hidden_size=self.config['panel_hidden_size'],
+            out_elem_size=self.panel_elem_len + self.config['stitch_tag_dim'] + 1,
+            n_layers=self.config['panel_n_layers'], out_len=self.max_panel_len,
+            dropout=self.config['dropout'], custom_init=self.config['lstm_init'])
+        pattern_decoder_module = getattr(blocks, self.config['pattern_decoder'])
+        self.pattern_decoder = pattern_decoder_module(
+            encoding_size=self.config['pattern_encoding_size'], hidden_size=self.config['pattern_hidden_size'],
+            out_elem_size=self.config['panel_encoding_size'], n_layers=self.config['pattern_n_layers'],
+            out_len=self.max_pattern_size, dropout=self.config['dropout'],
+            custom_init=self.config['lstm_init'])
+        self.placement_decoder = nn.Linear(self.config['panel_encoding_size'],
+                                           self.rotation_size + self.translation_size)
+
+    def forward_encode(self, positions_batch):
+        return self.feature_extractor(positions_batch)[0]
+
+    def forward_pattern_decode(self, garment_encodings):
+        panel_encodings = self.pattern_decoder(garment_encodings, self.max_pattern_size)
+        return panel_encodings.contiguous().view(-1, panel_encodings.shape[-1])
+
+    def forward_panel_decode(self, flat_panel_encodings, batch_size):
+        flat_panels = self.panel_decoder(flat_panel_encodings, self.max_panel_len)
+        flat_placement = ops.linear(flat_panel_encodings, self.placement_decoder.weight,
+                                    self.placement_decoder.bias)
+        flat_rotations = flat_placement[:, :self.rotation_size]
+        flat_translations = flat_placement[:, self.rotation_size:]
+        panel_predictions = flat_panels.contiguous().view(batch_size, self.max_pattern_size, self.max_panel_len, -1)
+        stitch_tags = panel_predictions[:, :, :, self.panel_elem_len:-1]
+        free_edge_class = panel_predictions[:, :, :, -1]
+        outlines = panel_predictions[:, :, :, :self.panel_elem_len]
+        rotations = flat_rotations.contiguous().view(batch_size, self.max_pattern_size, -1)
+        translations = flat_translations.contiguous().view(batch_size, self.max_pattern_size, -1)
+        return {'outlines': outlines, 'rotations': rotations, 'translations': translations,
+                'stitch_tags': stitch_tags, 'free_edges_mask': free_edge_class}
+
+    def forward_decode(self, garment_encodings):
+        flat_panel_encodings = self.forward_pattern_decode(garment_encodings)
+        return self.forward_panel_decode(flat_panel_encodings, garment_encodings.size(0))
+
+    def forward(self, positions_batch, **kwargs):
+        return self.forward_decode(self.forward_encode(positions_batch))

@@ -1,0 +1,174 @@
+/*
+ * libgpe_hip.so — C ABI of the MI355X (gfx950) encoder/decoder hot path.
+ *
+ * The reference (maria-korosteleva/Garment-Pattern-Estimation) has no FFI: its "plugin API" is class-name
+ * lookup from YAML (nn/train.py:120, nn/nets.py:100,106,116).  The Python modules in
+ * garment-pattern-estimation_amd/ keep that surface; underneath them every tensor op of the path is one of the
+ * entry points below.  Each entry point names the reference line(s) whose arithmetic it replaces.
+ *
+ * Conventions (all functions):
+ *   - plain C symbols; raw DEVICE pointers + dims + a hipStream_t passed as void*; caller owns every buffer,
+ *     no hidden allocation, no global state; work is enqueued on `stream` and the call returns immediately;
+ *   - return 0 on success, -22 (EINVAL) on bad arguments, -5 (EIO) if the launch failed;
+ *   - fp32 storage and arithmetic unless stated; matrix products run on v_mfma_f32_16x16x4_f32 (exact fp32);
+ *     BatchNorm statistics are accumulated in fp64;
+ *   - "ld" = leading dimension in elements; "packed weight" = the layout produced by gpe_pack_weight.
+ */
+#ifndef GPE_HIP_H
+#define GPE_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* version / capability probe (host only, no GPU needed) */
+int gpe_abi_version(void);
+
+/* ---- kNN graph: torch_cluster.knn as called by DynamicEdgeConv (nn/net_blocks.py:127-135,174) ------------
+ * x [B][N][ldx>=C]; idx [B][N][k] int32, LOCAL to the cloud, ascending (dist, index); self included.
+ * dist = fp32 fma chain over channels of (x_c - y_c)^2, ties -> lower index (same rules as oracle/knn_ref.c). */
+int gpe_knn(const float* x, int B, int N, int C, int ldx, int k, int32_t* idx, void* stream);
+
+/* reverse adjacency of the kNN graph (needed by the gather's backward = scatter-add into x_j rows):
+ * rev_off [B][N+1] int32 (local offsets), rev_edge [B][N*k] int32 = local edge ids (i*k+s) sorted ascending
+ * inside each bucket, so the pull-style accumulation order is deterministic. */
+int gpe_knn_reverse(const int32_t* idx, int B, int N, int k, int32_t* rev_off, int32_t* rev_edge, void* stream);
+
+/* ---- weight packing (+ BatchNorm folding) ------------------------------------------------------------------
+ * w [N][ldw] row-major (nn.Linear layout, nn/net_blocks.py:45) or, if transpose != 0, w is [K][ldw] and the packed
+ * operand is its transpose.  Optional col_scale[K]: packed(n,k) = w(n,k)*col_scale[k]  (folds the previous
+ * BatchNorm's scale s=gamma*rstd into this Linear).  wp holds gpe_packed_size(N,K) floats. */
+long gpe_packed_size(int N, int K);
+int gpe_pack_weight(const float* w, int ldw, int N, int K, int transpose, const float* col_scale,
+                    float* wp, void* stream);
+/* folded bias: out[n] = bias[n] + sum_k w[n][k]*t[k]   (t = beta - mean*s of the previous BatchNorm) */
+int gpe_fold_bias(const float* w, int ldw, int N, int K, const float* bias, const float* t, float* out,
+                  void* stream);
+
+/* ---- dense Linear: nn.Linear / LSTM gate projections (nn/net_blocks.py:45,158,373-376,397) -----------------
+ * Y[r][n] = act( sum_k A[r][k]*W[n][k] + bias[n] + addend[r][n] ),  r<M, n<N.   A rows use 2-level addressing
+ * (a_inner<=0: row r at a + r*a_so; else row r at a + (r/a_inner)*a_so + (r%a_inner)*a_si); same for Y and addend.
+ * act: 0 none, 1 relu.  bias/addend may be NULL. */
+int gpe_linear(const float* a, long a_so, long a_si, int a_inner,
+               const float* wp, const float* bias,
+               const float* addend, long ad_so, long ad_si, int ad_inner,
+               float* y, long y_so, long y_si, int y_inner,
+               int M, int N, int K, int act, void* stream);
+
+/* reduce-GEMM: G[m][n] (+)= sum_r U[r][m]*V[r][n]  (weight gradients, nn.Linear backward), colsum[m] = sum_r U[r][m].
+ * part: workspace of gpe_redgemm_ws(Mg,Ng) floats.  accumulate != 0 adds into G / colsum. */
+long gpe_redgemm_ws(int Mg, int Ng);
+int gpe_redgemm(const float* u, long u_so, long u_si, int u_inner,
+                const float* v, long v_so, long v_si, int v_inner,
+                long rows, int Mg, int Ng, float* G, int ldg, float* colsum, float* part, int accumulate,
+                void* stream);
+
+/* ---- EdgeConv block (PyG DynamicEdgeConv.message + MLP + max aggregation; nn/net_blocks.py:43-47,124-135) ---
+ * Algebra used: W1.[x_i, x_j-x_i] = (W1a-W1b).x_i + W1b.x_j = P_i + Q_j, with PQ = [P|Q] [B*N][2H] produced by
+ * gpe_linear on the per-point features; every BatchNorm is folded into the next Linear once its batch statistics
+ * are known (training mode needs the global reduction between layers; eval mode uses running stats).           */
+
+/* stats of a1 = relu(P_i + Q_j) over all E=B*N*k edges: part [nblk][2][H] fp64 partial (sum, sumsq); nblk returned
+ * by gpe_stats_blocks().  This is the EdgeConv neighbourhood gather. */
+int gpe_stats_blocks(void);
+int gpe_edge_gather_stats(const float* pq, int ldpq, int H, const int32_t* idx, int B, int N, int k,
+                          double* part, void* stream);
+
+/* BatchNorm finalisation (nn.BatchNorm1d in training mode, nn/net_blocks.py:45): from fp64 partials over `count`
+ * rows -> mean, biased var; scale s = gamma/sqrt(var+eps), shift t = beta - mean*s; running stats updated with
+ * `momentum` (unbiased var) and num_batches_tracked += 1 when running_mean != NULL.
+ * stats_out [4][C] fp32 = {mean, rstd, s, t}. */
+int gpe_bn_finalize(const double* part, int nblk, int C, double count, const float* gamma, const float* beta,
+                    float eps, float momentum, float* running_mean, float* running_var, int64_t* num_batches,
+                    float* stats_out, void* stream);
+/* eval mode: stats_out from running stats */
+int gpe_bn_from_running(const float* running_mean, const float* running_var, int C, const float* gamma,
+                        const float* beta, float eps, float* stats_out, void* stream);
+
+/* fused per-edge Linear+ReLU (+BN statistics, + max/min aggregation over the k messages of each point).
+ * a_mode 0: A rows = relu(P_i+Q_j) gathered through idx (layer 2 of the edge MLP);
+ * a_mode 1: A rows = a_in[e][*] dense (layer 3).
+ * out [E][ldo] = relu(A.Wp^T + bias');  stats_part [nblk][2][Cout] fp64 (NULL in eval mode);
+ * if agg != 0: mx,mn [B*N][ldagg] = max/min over the k rows of each point, amx/amn uint8 argmax/argmin slot. */
+int gpe_edge_mlp_fwd(int a_mode, const float* pq, int ldpq, const int32_t* idx, const float* a_in, int lda,
+                     int B, int N, int k, int Cin, int Cout, const float* wp, const float* bias,
+                     float* out, int ldo, double* stats_part,
+                     int agg, float* mx, float* mn, uint8_t* amx, uint8_t* amn, int ldagg, void* stream);
+
+/* layer output: y[i][c] = s[c]*(s[c]>=0 ? mx : mn)[i][c] + t[c]  (BN applied after the max, sign-aware) */
+int gpe_edge_finish(const float* mx, const float* mn, int ldagg, const float* stats, long rows, int C,
+                    float* y, int ldy, void* stream);
+
+/* ---- EdgeConv backward ------------------------------------------------------------------------------------ */
+/* per-channel sums for the last BN's backward from per-point data, as fp64 partials
+ * part [gpe_point_sums_blocks()][2][C]: sum_i g, sum_i g*xhat_sel */
+int gpe_point_sums_blocks(void);
+int gpe_edge_bwd_point_sums(const float* g, int ldg, const float* mx, const float* mn, int ldagg,
+                            const float* stats, long rows, int C, double* part, void* stream);
+/* coefficient vectors for "dz = (a>0) ? u - k1 - a*k2 : 0":  coef [3][C] = {s, k1, k2} from partial sums
+ * part [nblk][2][C]; also the BatchNorm parameter gradients dgamma = sum dy*xhat, dbeta = sum dy (may be NULL) */
+int gpe_bn_bwd_coef(const double* part, int nblk, const float* stats, int C, double count, float* coef,
+                    float* dgamma, float* dbeta, void* stream);
+/* sums for an inner BN from the next layer's weight-gradient: G [Cn][ldG] = dz_next^T a, db [Cn] = colsum dz_next,
+ * w_next [Cn][ldw] the UNFOLDED next Linear:  sums[0][c] = sum_f w[f][c]*db[f];
+ * sums[1][c] = rstd_c * sum_f w[f][c]*(G[f][c] - mean_c*db[f]);   also emits the true weight gradient
+ * dW_next[f][c] = G[f][c]*s_c + db[f]*t_c into dw (ld lddw). */
+int gpe_bn_bwd_from_G(const float* G, int ldG, const float* db, const float* w_next, int ldw, int Cn, int C,
+                      const float* stats, double* sums, float* dw, int lddw, void* stream);
+
+/* reduce-GEMM over edges with fused operand producers:
+ * u_mode 0: U rows = dz3 built on the fly from (a3, g, argsel, coef) ; u_mode 1: U rows dense [E][ldu]
+ * v_mode 0: V rows = relu(P_i+Q_j) gathered ; v_mode 1: V rows dense [E][ldv] */
+int gpe_edge_redgemm(int u_mode, const float* u, int ldu, const float* g, int ldg, const uint8_t* amx,
+                     const uint8_t* amn, int ldagg, const float* coef,
+                     int v_mode, const float* v, int ldv, const float* pq, int ldpq, const int32_t* idx,
+                     int B, int N, int k, int Mg, int Ng, float* G, int ldG, float* colsum, float* part,
+                     void* stream);
+
+/* propagate + BN/ReLU backward:  u = A.Wp^T ; dz = (act>0) ? s*u - k1 - act*k2 : 0 ; written to dz_out
+ * (coef_out [3][Cout] = {s,k1,k2} of the BatchNorm being crossed; Wp = packed TRANSPOSE of the unfolded Linear).
+ * a_mode 0: A rows = dz3 on the fly (as above); a_mode 1: A rows dense.
+ * act_mode 0: act = dz_out's previous contents (in place over the stored activation);
+ * act_mode 1: act = relu(P_i+Q_j) gathered, and dP[i] = sum_s dz[(i,s)] is also written (ld lddp). */
+int gpe_edge_mlp_bwd(int a_mode, const float* a, int lda, const float* g, int ldg, const uint8_t* amx,
+                     const uint8_t* amn, int ldagg, const float* coef_in,
+                     int act_mode, const float* pq, int ldpq, const int32_t* idx,
+                     int B, int N, int k, int Cin, int Cout, const float* wp, const float* coef_out,
+                     float* dz_out, int ldo, float* dP, int lddp, void* stream);
+
+/* dQ[j] = sum over incoming edges e of dz1[e]  (deterministic pull through the reverse adjacency) */
+int gpe_edge_pull_dq(const float* dz, int lddz, const int32_t* rev_off, const int32_t* rev_edge,
+                     int B, int N, int k, int H, float* dQ, int lddq, void* stream);
+
+/* ---- pooling (torch_geometric global_mean_pool, nn/net_blocks.py:148,184) --------------------------------- */
+int gpe_segment_mean_fwd(const float* x, int ldx, int B, int N, int C, float* y, int ldy, void* stream);
+int gpe_segment_mean_bwd(const float* gy, int ldgy, int B, int N, int C, float* gx, int ldgx, int accumulate,
+                         void* stream);
+
+/* ---- LSTM cell pointwise (nn.LSTM, gate order i,f,g,o; nn/net_blocks.py:373,393) --------------------------- */
+/* gates_pre [Bn][4H] (pre-activation, overwritten with activated gates), c_prev [Bn][H] (row stride ldc_prev),
+ * writes c [Bn][H] and h rows (2-level addressing via h + b*h_stride). */
+int gpe_lstm_cell_fwd(float* gates, const float* c_prev, long ldc_prev, float* c, float* h, long h_stride,
+                      int Bn, int H, void* stream);
+/* dh_total = dh_out + dh_rec; computes dgates (pre-activation grads) [Bn][4H] rows at dgates + b*dg_stride,
+ * dc_prev; inputs: activated gates, c (this step), c_prev. */
+int gpe_lstm_cell_bwd(const float* dh_out, long dho_stride, const float* dh_rec, const float* dc_next,
+                      const float* gates, const float* c, const float* c_prev, long ldc_prev,
+                      float* dgates, long dg_stride, float* dc_prev, int Bn, int H, void* stream);
+
+/* ---- small helpers --------------------------------------------------------------------------------------- */
+/* y[r][c] (+)= sum over inner index t of x[r][t][c]   (x rows: r*x_so + t*x_si) */
+int gpe_reduce_inner(const float* x, long x_so, long x_si, int T, int R, int C, float* y, int ldy,
+                     int accumulate, void* stream);
+/* dW1 [H][2C] from dWpq [2H][C]:  dW1[:, :C] = dWp ; dW1[:, C:] = dWq - dWp */
+int gpe_w1_grad_from_pq(const float* dwpq, int ld, int H, int C, float* dw1, int lddw1, void* stream);
+/* Wpq [2H][C] from W1 [H][2C]: rows 0..H-1 = W1a - W1b, rows H..2H-1 = W1b; bias_pq = [b1 | 0] */
+int gpe_w1_split(const float* w1, int ldw1, const float* b1, int H, int C, float* wpq, int ldwpq, float* bias_pq,
+                 void* stream);
+/* out = a + b (n floats) */
+int gpe_add(const float* a, const float* b, float* out, long n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GPE_HIP_H */

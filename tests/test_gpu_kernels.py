@@ -1,0 +1,259 @@
+"""-m gpu: kernel-level parity of libgpe_hip.so (through the C ABI via ops.py) against the CPU oracle.
+
+Bars: kNN indices BIT-EXACT vs oracle/knn_ref.c; fp32 tensors compared with the fp64 oracle evaluated on the
+SAME graph, tolerance written next to each check (matrix products are exact-fp32 MFMA fma chains, so the error
+budget is summation-order roundoff: ~1e-6 relative for K<=256, amplified by 1/sqrt(var+eps) through BatchNorm)."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def gpe():
+    if not torch.cuda.is_available():
+        pytest.skip('needs the MI355X')
+    import gpe_amd
+    return gpe_amd
+
+
+def relerr(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return ((a - b).abs().max() / (b.abs().max() + 1e-30)).item()
+
+
+# --------------------------------------------------------------------------------------------------
+KNN_CASES = [(2, 64, 3, 4), (3, 200, 24, 5), (2, 256, 150, 16), (1, 130, 33, 20), (2, 2048, 3, 16),
+             (1, 1024, 150, 16), (2, 70, 7, 64)]
+
+
+@pytest.mark.parametrize('B,N,C,k', KNN_CASES)
+def test_knn_bit_exact(gpe, B, N, C, k):
+    from oracle import ref_path as O
+    g = torch.Generator().manual_seed(B * 1000 + N + C + k)
+    x = torch.randn(B * N, C, generator=g)
+    ref = O.knn_local(x, B, k).to(torch.int32).view(B, N, k)
+    got = gpe.ops.knn(x.cuda(), B, N, k).cpu()
+    bad = (got != ref).any(-1).sum().item()
+    assert bad == 0, '%d / %d queries differ' % (bad, B * N)
+
+
+def test_knn_ties_lower_index_wins(gpe):
+    from oracle import ref_path as O
+    # integer lattice -> many exactly equal distances, plus duplicated points
+    g = torch.Generator().manual_seed(7)
+    x = torch.randint(0, 4, (2 * 192, 3), generator=g).float()
+    ref = O.knn_local(x, 2, 9).to(torch.int32).view(2, 192, 9)
+    got = gpe.ops.knn(x.cuda(), 2, 192, 9).cpu()
+    assert torch.equal(got, ref)
+
+
+def test_knn_strided_rows(gpe):
+    from oracle import ref_path as O
+    g = torch.Generator().manual_seed(11)
+    buf = torch.randn(2 * 128, 152, generator=g)
+    x = buf[:, :150]
+    ref = O.knn_local(x.contiguous(), 2, 16).to(torch.int32).view(2, 128, 16)
+    got = gpe.ops.knn(buf.cuda()[:, :150], 2, 128, 16).cpu()
+    assert torch.equal(got, ref)
+
+
+def test_knn_reverse(gpe):
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(3 * 200, 5, generator=g).cuda()
+    idx = gpe.ops.knn(x, 3, 200, 6)
+    off, edge = gpe.ops.knn_reverse(idx)
+    idx, off, edge = idx.cpu(), off.cpu(), edge.cpu()
+    for b in range(3):
+        flat = idx[b].reshape(-1)
+        for j in range(200):
+            exp = torch.nonzero(flat == j).view(-1).to(torch.int32)
+            got = edge[b, off[b, j]:off[b, j + 1]]
+            assert torch.equal(got, exp), (b, j)
+        assert off[b, 200].item() == 200 * 6
+
+
+# --------------------------------------------------------------------------------------------------
+LIN_CASES = [(64, 200, 200), (100, 8, 250), (736, 1000, 250), (32, 250, 1000), (33, 7, 3), (1000, 400, 150),
+             (130, 23, 153), (65, 300, 520)]
+
+
+@pytest.mark.parametrize('M,N,K', LIN_CASES)
+def test_linear_fwd_bwd(gpe, M, N, K):
+    g = torch.Generator().manual_seed(M + N + K)
+    x = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) / K ** 0.5
+    b = torch.randn(N, generator=g)
+    gy = torch.randn(M, N, generator=g)
+    xr, wr, br = x.double().requires_grad_(), w.double().requires_grad_(), b.double().requires_grad_()
+    yr = xr @ wr.t() + br
+    yr.backward(gy.double())
+    xd, wd, bd = x.cuda().requires_grad_(), w.cuda().requires_grad_(), b.cuda().requires_grad_()
+    y = gpe.ops.linear(xd, wd, bd)
+    y.backward(gy.cuda())
+    assert relerr(y, yr) < 2e-6
+    assert relerr(xd.grad, xr.grad) < 2e-6
+    assert relerr(wd.grad, wr.grad) < 2e-6
+    assert relerr(bd.grad, br.grad) < 2e-6
+
+
+def test_linear_strided_addend_act(gpe):
+    ops = gpe.ops
+    g = torch.Generator().manual_seed(5)
+    Bn, T, H = 40, 5, 36
+    hs = torch.randn(Bn, T + 1, H, generator=g).cuda()
+    w = (torch.randn(4 * H, H, generator=g) / 6).cuda()
+    add = torch.randn(Bn, T, 4 * H, generator=g).cuda()
+    out = torch.zeros(T, Bn, 4 * H).cuda()
+    wp = ops.pack_weight(w)
+    for t in range(T):
+        ops.linear_raw((hs[:, t], (T + 1) * H, 0, 0), wp, None, Bn, 4 * H, H, (out[t], 4 * H, 0, 0), 1,
+                       (add[:, t], T * 4 * H, 0, 0))
+    ref = torch.relu(torch.einsum('bth,gh->tbg', hs[:, :T].double().cpu(), w.double().cpu())
+                     + add.double().cpu().transpose(0, 1))
+    assert relerr(out, ref) < 2e-6
+    # 2-level rows + transposed pack
+    y = torch.empty(Bn * T, H).cuda()
+    ops.linear_raw(ops._rows3d(add), ops.pack_weight(w, transpose=True), None, Bn * T, H, 4 * H, (y, H, 0, 0))
+    ref2 = add.double().cpu().reshape(Bn * T, 4 * H) @ w.double().cpu()
+    assert relerr(y, ref2) < 2e-6
+
+
+@pytest.mark.parametrize('rows,Mg,Ng', [(1000, 150, 200), (77, 8, 250), (5000, 1000, 250), (4096, 400, 3),
+                                        (300, 23, 153)])
+def test_redgemm(gpe, rows, Mg, Ng):
+    ops = gpe.ops
+    g = torch.Generator().manual_seed(rows + Mg)
+    u = torch.randn(rows, Mg, generator=g)
+    v = torch.randn(rows, Ng, generator=g)
+    G, cs = ops.redgemm_raw(ops._rows2d(u.cuda()), ops._rows2d(v.cuda()), rows, Mg, Ng)
+    assert relerr(G, u.double().t() @ v.double()) < 3e-6
+    assert relerr(cs, u.double().sum(0)) < 3e-6
+
+
+# --------------------------------------------------------------------------------------------------
+def _oracle_conv(C, H, Fo, k, seed):
+    from oracle import ref_path as O
+    torch.manual_seed(seed)
+    conv = O.DynamicEdgeConv(O.MLP([2 * C, H, H, Fo]), k=k)
+    # non-trivial BN affine parameters, including a negative scale (exercises the min-tracking path)
+    with torch.no_grad():
+        for blk in conv.nn:
+            blk[2].weight.uniform_(0.5, 1.5)
+            blk[2].bias.uniform_(-0.3, 0.3)
+        conv.nn[2][2].weight[::5] *= -1
+    return conv
+
+
+def _product_conv(gpe, oconv, C, H, Fo, k):
+    pconv = gpe.net_blocks.DynamicEdgeConv(gpe.net_blocks.MLP([2 * C, H, H, Fo]), k=k)
+    pconv.load_state_dict(oconv.state_dict())
+    return pconv.cuda()
+
+
+@pytest.mark.parametrize('B,N,C,H,Fo,k', [(2, 64, 3, 32, 24, 4), (2, 96, 24, 32, 24, 5), (2, 128, 3, 200, 150, 16),
+                                          (1, 256, 150, 200, 150, 16), (3, 50, 6, 64, 30, 20)])
+def test_edgeconv_layer_fwd_bwd(gpe, B, N, C, H, Fo, k):
+    from oracle import ref_path as O
+    oconv = _oracle_conv(C, H, Fo, k, seed=B + N + C)
+    pconv = _product_conv(gpe, oconv, C, H, Fo, k)
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(B * N, C, generator=g)
+    wgt = torch.randn(B * N, Fo, generator=g)
+    batch = torch.arange(B).repeat_interleave(N)
+
+    xd = x.cuda().requires_grad_()
+    pconv.train()
+    out = pconv(xd, B, N)
+    (out * wgt.cuda()).sum().backward()
+
+    ref_idx = O.knn_local(x, B, k)
+    assert torch.equal(pconv.last_knn.cpu().view(B * N, k).long(), ref_idx)
+
+    o64 = copy.deepcopy(oconv).double().train()
+    o64.knn_override = ref_idx
+    xr = x.double().requires_grad_()
+    out_r = o64(xr, batch)
+    (out_r * wgt.double()).sum().backward()
+
+    o32 = copy.deepcopy(oconv).train()
+    o32.knn_override = ref_idx
+    out_32 = o32(x.clone(), batch)
+    err32 = relerr(out_32, out_r)
+    err = relerr(out, out_r)
+    print('edgeconv fwd relerr build=%.2e oracle-fp32=%.2e' % (err, err32))
+    assert err < max(5e-5, 20 * err32)
+    assert relerr(xd.grad, xr.grad) < 2e-4
+    pn = dict(pconv.named_parameters())
+    for n, p in o64.named_parameters():
+        e = relerr(pn[n].grad, p.grad)
+        assert e < 3e-4, (n, e)
+    # BatchNorm running statistics (momentum 0.1, unbiased variance) and the batch counter
+    pb = dict(pconv.named_buffers())
+    for n, bbuf in o64.named_buffers():
+        if 'num_batches' in n:
+            assert pb[n].item() == bbuf.item()
+        else:
+            assert relerr(pb[n], bbuf) < 1e-5, n
+
+
+def test_edgeconv_eval_mode(gpe):
+    from oracle import ref_path as O
+    B, N, C, H, Fo, k = 2, 64, 3, 32, 24, 4
+    oconv = _oracle_conv(C, H, Fo, k, seed=9)
+    with torch.no_grad():
+        for blk in oconv.nn:
+            blk[2].running_mean.uniform_(0.1, 0.4)
+            blk[2].running_var.uniform_(0.5, 1.5)
+    pconv = _product_conv(gpe, oconv, C, H, Fo, k).eval()
+    x = torch.randn(B * N, C, generator=torch.Generator().manual_seed(2))
+    with torch.no_grad():
+        out = pconv(x.cuda(), B, N)
+    o64 = copy.deepcopy(oconv).double().eval()
+    o64.knn_override = pconv.last_knn.cpu().view(B * N, k).long()
+    ref = o64(x.double(), torch.arange(B).repeat_interleave(N))
+    assert relerr(out, ref) < 1e-5
+    assert dict(pconv.named_buffers())['nn.0.2.num_batches_tracked'].item() == 0
+
+
+def test_segment_mean(gpe):
+    x = torch.randn(3 * 100, 37, generator=torch.Generator().manual_seed(4))
+    xd = x.cuda().requires_grad_()
+    y = gpe.ops.segment_mean(xd, 3, 100)
+    y.sum().backward()
+    assert relerr(y, x.double().view(3, 100, 37).mean(1)) < 1e-6
+    assert relerr(xd.grad, torch.full((300, 37), 0.01)) < 1e-6
+
+
+# --------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('Bn,In,Hh,T,L,Out', [(6, 40, 40, 5, 2, 40), (46, 40, 40, 14, 3, 8),
+                                              (32, 250, 250, 23, 2, 250), (64, 250, 250, 14, 3, 8)])
+def test_lstm_decoder_fwd_bwd(gpe, Bn, In, Hh, T, L, Out):
+    from oracle import ref_path as O
+    torch.manual_seed(Bn + T)
+    odec = O.LSTMDecoderModule(In, Hh, Out, L, custom_init='kaiming_normal_')
+    pdec = gpe.net_blocks.LSTMDecoderModule(In, Hh, Out, L, custom_init='kaiming_normal_')
+    pdec.load_state_dict(odec.state_dict())
+    pdec = pdec.cuda()
+    enc = torch.randn(Bn, In, generator=torch.Generator().manual_seed(1))
+    wgt = torch.randn(Bn, T, Out, generator=torch.Generator().manual_seed(2))
+    o64 = copy.deepcopy(odec).double()
+    er = enc.double().requires_grad_()
+    torch.manual_seed(77)
+    out_r = o64(er, T)
+    (out_r * wgt.double()).sum().backward()
+    ed = enc.cuda().requires_grad_()
+    torch.manual_seed(77)
+    out = pdec(ed, T)
+    (out * wgt.cuda()).sum().backward()
+    assert torch.equal(pdec.last_states[0].cpu(), o64.last_states[0].float())   # same RNG stream
+    assert relerr(out, out_r) < 2e-5
+    assert relerr(ed.grad, er.grad) < 1e-4
+    pn = dict(pdec.named_parameters())
+    for n, p in o64.named_parameters():
+        e = relerr(pn[n].grad, p.grad)
+        assert e < 1e-4, (n, e)
