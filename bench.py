@@ -1,0 +1,223 @@
+#!/usr/bin/env python3
+"""bench.py — garments/sec of one training step (fwd -> loss -> bwd [-> grad all-reduce] -> Adam) of the
+NeuralTailor LSTM model (GarmentFullPattern3D, reference nn/nets.py:41-184 driven as nn/trainer.py:92-99) on
+synthetic point clouds, BASELINE.json config 2 per GPU:  N=2048 points, batch 32, k=16, EdgeConv encoder + LSTM
+decoders.  fp32 storage, exact-fp32 MFMA (the parity-proven mode; BASELINE's "bf16" is a storage option not built
+yet — see DESIGN.md).
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line.  `value` = garments processed by all ranks / max-over-ranks wall time of exactly K
+steps (barrier + synchronize on both sides).  Extra objects:
+  roofline      — the dominant kernel family of the step (MFMA-bound fp32 edge-MLP GEMMs): algorithmic FLOPs per
+                  launch / average launch duration from HIP events on the launch stream, vs 157.3 TFLOP/s;
+  roofline_gather — the EdgeConv neighbourhood gather (HBM/L2-bound): algorithmic bytes / duration vs 8 TB/s;
+  cpu_baseline  — the CPU oracle (oracle/ref_path.py, kind "port") timed on this box's host cores on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+import torch  # noqa: E402
+
+PEAK_F32_TFLOPS = 157.3     # MI355X fp32 vector = fp32-input MFMA peak (MI355X_MICROARCH.md)
+PEAK_HBM_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--batch', type=int, default=32, help='garments per GPU')
+    ap.add_argument('--points', type=int, default=2048)
+    ap.add_argument('--k', type=int, default=16)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-batch', type=int, default=8)
+    ap.add_argument('--cpu-steps', type=int, default=2)
+    ap.add_argument('--no-kernel-timing', action='store_true')
+    return ap.parse_args()
+
+
+def synthetic(B, N, data_config, seed, device):
+    g = torch.Generator().manual_seed(seed)
+    P, Lp = data_config['max_pattern_len'], data_config['max_panel_len']
+    feats = torch.randn(B, N, 3, generator=g)
+    gt = {'outlines': torch.randn(B, P, Lp, 4, generator=g), 'rotations': torch.randn(B, P, 4, generator=g),
+          'translations': torch.randn(B, P, 3, generator=g),
+          'num_edges': torch.randint(3, Lp + 1, (B, P), generator=g)}
+    return feats.to(device), {k: v.to(device) for k, v in gt.items()}
+
+
+# algorithmic work per C-ABI call, from its integer arguments (see include/gpe_hip.h for the argument order)
+def call_work(name, a):
+    """-> (flops, bytes) for one launch"""
+    if name == 'gpe_edge_mlp_fwd':          # a_mode, ldpq, lda, B, N, k, Cin, Cout, ...
+        B, N, k, Cin, Cout = a[3], a[4], a[5], a[6], a[7]
+        return 2.0 * B * N * k * Cin * Cout, 0.0
+    if name == 'gpe_edge_mlp_bwd':          # a_mode, lda, ldg, ldagg, act_mode, ldpq, B, N, k, Cin, Cout
+        B, N, k, Cin, Cout = a[6], a[7], a[8], a[9], a[10]
+        return 2.0 * B * N * k * Cin * Cout, 0.0
+    if name == 'gpe_edge_redgemm':          # u_mode, ldu, ldg, ldagg, v_mode, ldv, ldpq, B, N, k, Mg, Ng
+        B, N, k, Mg, Ng = a[7], a[8], a[9], a[10], a[11]
+        return 2.0 * B * N * k * Mg * Ng, 0.0
+    if name == 'gpe_linear':                # strides..., M, N, K, act  (last four ints)
+        M, N, K = a[-4], a[-3], a[-2]
+        return 2.0 * M * N * K, 0.0
+    if name == 'gpe_redgemm':               # ..., rows, Mg, Ng, ldg, accumulate
+        rows, Mg, Ng = a[-5], a[-4], a[-3]
+        return 2.0 * rows * Mg * Ng, 0.0
+    if name == 'gpe_edge_gather_stats':     # ldpq, H, B, N, k
+        H, B, N, k = a[1], a[2], a[3], a[4]
+        return 0.0, float(B) * N * (k * (H * 4 + 4) + H * 4)
+    if name == 'gpe_edge_pull_dq':          # lddz, B, N, k, H, lddq
+        B, N, k, H = a[1], a[2], a[3], a[4]
+        return 0.0, float(B) * N * (k * (H * 4 + 4) + H * 4)
+    return 0.0, 0.0
+
+
+def cpu_baseline(args, data_config, nn_cfg):
+    """The CPU oracle (pure torch restatement of the reference path + C kNN) on this box's host cores."""
+    import copy
+    from oracle import ref_path as O
+    ncores = os.cpu_count() or 1
+    torch.set_num_threads(ncores)
+    torch.manual_seed(0)
+    model = O.GarmentFullPattern3D(data_config, copy.deepcopy(nn_cfg), copy.deepcopy(nn_cfg['loss'])).train()
+    feats, gt = O.synthetic_batch(args.cpu_batch, args.points, data_config, seed=0)
+    times = []
+    for step in range(1 + args.cpu_steps):
+        t0 = time.perf_counter()
+        model.zero_grad(set_to_none=True)
+        O.train_step(model, feats, {k: v.clone() for k, v in gt.items()}, epoch=0, seed=step)
+        times.append(time.perf_counter() - t0)
+    t = sum(times[1:]) / len(times[1:])
+    cpu_name = ''
+    try:
+        with open('/proc/cpuinfo') as f:
+            for line in f:
+                if line.startswith('model name'):
+                    cpu_name = line.split(':', 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return {'value': args.cpu_batch / t, 'unit': 'garments/s', 'cores': ncores, 'kind': 'port',
+            'sample': 'oracle/ref_path.py fwd+loss+bwd, B=%d N=%d k=%d fp32, 1 warm-up + %d timed steps, %.2f s/step'
+                      % (args.cpu_batch, args.points, args.k, args.cpu_steps, t),
+            'cpu': cpu_name}
+
+
+def main():
+    args = parse()
+    import gpe_amd
+    from gpe_amd import _lib, configs, nets, parallel
+
+    rank, local, world = parallel.init_distributed()
+    if world != args.gpus:
+        raise SystemExit('launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)' % (args.gpus, world))
+    dev = torch.device('cuda', local)
+    data_config = configs.data_config()
+    nn_cfg = configs.lstm_model_config(k_neighbors=args.k)
+
+    torch.manual_seed(0)                               # identical replicas on every rank
+    model = nets.GarmentFullPattern3D(data_config, dict(nn_cfg), dict(nn_cfg['loss'])).to(dev).train()
+    model.loss.with_quality_eval = False
+    wrapped = parallel.DistributedHotPath(model, device_ids=[dev])
+    opt = torch.optim.Adam(model.parameters(), lr=2e-3)
+    feats, gt = synthetic(args.batch, args.points, data_config, seed=1000 + rank, device=dev)
+
+    def step(i):
+        torch.manual_seed(i * 131 + rank)              # the decoder draws random LSTM states every forward
+        preds = wrapped(feats, log_step=i, epoch=0)
+        loss, _, _ = model.loss(preds, gt, epoch=0)
+        loss.backward()
+        wrapped.finish_gradient_sync()
+        opt.step()
+        opt.zero_grad(set_to_none=True)
+        return loss
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss = step(args.warmup + i)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = t.item()
+    final_loss = loss.item()
+
+    # ---- per-kernel durations: HIP events on the launch stream, same workload, right after the timed region ----
+    roof, roof_gather, breakdown = None, None, None
+    if rank == 0 and not args.no_kernel_timing:
+        nsteps = min(args.steps, 5)
+        _lib.TIMING = []
+        for i in range(nsteps):
+            step(args.warmup + args.steps + i)
+        torch.cuda.synchronize()
+        rec, _lib.TIMING = _lib.TIMING, None
+        agg = {}
+        for name, ints, e0, e1 in rec:
+            fl, by = call_work(name, ints)
+            d = agg.setdefault(name, [0, 0.0, 0.0, 0.0])
+            d[0] += 1
+            d[1] += e0.elapsed_time(e1)
+            d[2] += fl
+            d[3] += by
+        breakdown = {n: {'launches_per_step': v[0] / nsteps, 'ms_per_step': v[1] / nsteps} for n, v in
+                     sorted(agg.items(), key=lambda kv: -kv[1][1])}
+        # dominant = the fused per-edge GEMM family (forward + backward + weight-gradient kernels)
+        fam = ['gpe_edge_mlp_fwd', 'gpe_edge_mlp_bwd', 'gpe_edge_redgemm']
+        dom = max(fam, key=lambda n: agg.get(n, [0, 0, 0, 0])[1])
+        n_l, ms, fl, _ = agg[dom]
+        ach = fl / (ms * 1e-3) / 1e12
+        roof = {'kernel': dom, 'bound': 'mfma', 'achieved': ach, 'peak': PEAK_F32_TFLOPS, 'unit': 'TFLOP/s',
+                'frac': ach / PEAK_F32_TFLOPS, 'traffic': None, 'launches_per_step': n_l / nsteps,
+                'avg_launch_ms': ms / n_l, 'flops_per_launch': fl / n_l}
+        if 'gpe_edge_gather_stats' in agg:
+            n_l, ms, _, by = agg['gpe_edge_gather_stats']
+            ach = by / (ms * 1e-3) / 1e9
+            roof_gather = {'kernel': 'gpe_edge_gather_stats', 'bound': 'hbm', 'achieved': ach, 'peak': PEAK_HBM_GBS,
+                           'unit': 'GB/s', 'frac': ach / PEAK_HBM_GBS, 'traffic': None,
+                           'avg_launch_ms': ms / n_l, 'bytes_per_launch': by / n_l}
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(args, data_config, nn_cfg)
+
+    if rank == 0:
+        garments = args.batch * world * args.steps
+        out = {
+            'metric': 'garments/sec (fwd+bwd) at N=%d pts, batch %d per GPU' % (args.points, args.batch),
+            'value': garments / elapsed, 'unit': 'garments/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'BASELINE cfg 2: GarmentFullPattern3D, N=%d, batch %d/GPU, k=%d, EdgeConv encoder'
+                                   ' + LSTM decoders' % (args.points, args.batch, args.k),
+                       'global_batch': args.batch * world, 'parallelism': 'dp%d' % world,
+                       'step': 'fwd + ComposedPatternLoss + bwd' + (' + RCCL grad all-reduce' if world > 1 else '')
+                               + ' + Adam', 'final_loss': final_loss},
+            'roofline': roof, 'roofline_gather': roof_gather, 'cpu_baseline': cpu, 'kernel_ms_per_step': breakdown}
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -67,10 +67,22 @@ def _conv(a):
     return a
 
 
+# When a list, every call is bracketed by HIP events recorded on the stream the kernel is launched on (torch's
+# current stream): entries are (name, args, start_event, end_event).  Used by bench.py for per-kernel durations.
+TIMING = None
+
+
 def call(name, *args):
     """Invoke a C-ABI entry point on torch's current HIP stream (appended as the trailing `stream` argument)."""
     fn = getattr(lib(), name)
-    rc = fn(*[_conv(a) for a in args], torch.cuda.current_stream().cuda_stream)
+    stream = torch.cuda.current_stream()
+    if TIMING is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+    rc = fn(*[_conv(a) for a in args], stream.cuda_stream)
+    if TIMING is not None:
+        e1.record(stream)
+        TIMING.append((name, tuple(a for a in args if isinstance(a, (int, float))), e0, e1))
     if rc != 0:
         raise RuntimeError('%s failed with code %d' % (name, rc))
 

@@ -69,9 +69,13 @@ def redgemm_raw(u_desc, v_desc, rows, Mg, Ng, want_colsum=True, accumulate_into=
     else:
         G = torch.empty(Mg, Ng, device=dev, dtype=F32)
         cs = torch.empty(Mg, device=dev, dtype=F32) if want_colsum else None
-    ws = torch.empty(L.query('gpe_redgemm_ws', Mg, Ng), device=dev, dtype=F32)
-    L.call('gpe_redgemm', u_desc[0], u_desc[1], u_desc[2], u_desc[3], v_desc[0], v_desc[1], v_desc[2], v_desc[3],
-           rows, Mg, Ng, G, G.stride(0), cs, ws, int(accumulate_into is not None))
+    acc = int(accumulate_into is not None)
+    for n0 in range(0, Ng, 256):          # the kernel keeps <= 256 V columns resident per pass
+        nb = min(256, Ng - n0)
+        ws = torch.empty(L.query('gpe_redgemm_ws', Mg, nb), device=dev, dtype=F32)
+        L.call('gpe_redgemm', u_desc[0], u_desc[1], u_desc[2], u_desc[3],
+               v_desc[0][..., n0:], v_desc[1], v_desc[2], v_desc[3],
+               rows, Mg, nb, G[:, n0:], G.stride(0), cs if n0 == 0 else None, ws, acc)
     return G, cs
 
 
