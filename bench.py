@@ -43,6 +43,7 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-batch', type=int, default=8)
     ap.add_argument('--cpu-steps', type=int, default=2)
+    ap.add_argument('--cpu-threads', type=int, default=32)
     ap.add_argument('--no-kernel-timing', action='store_true')
     return ap.parse_args()
 
@@ -88,7 +89,9 @@ def cpu_baseline(args, data_config, nn_cfg):
     """The CPU oracle (pure torch restatement of the reference path + C kNN) on this box's host cores."""
     import copy
     from oracle import ref_path as O
-    ncores = os.cpu_count() or 1
+    # torch's intra-op pool stops scaling (and then collapses) long before a 2-socket EPYC's core count on this
+    # op mix; 32 threads is the measured sweet spot class for oneDNN/MKL at these sizes
+    ncores = min(os.cpu_count() or 1, args.cpu_threads)
     torch.set_num_threads(ncores)
     torch.manual_seed(0)
     model = O.GarmentFullPattern3D(data_config, copy.deepcopy(nn_cfg), copy.deepcopy(nn_cfg['loss'])).train()

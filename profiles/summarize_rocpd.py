@@ -1,0 +1,20 @@
+#!/usr/bin/env python3
+"""Turns a rocprofv3 (ROCm 7.2, rocpd sqlite output) kernel trace into the per-kernel stats table kept under
+profiles/.   usage: summarize_rocpd.py <results.db> <steps-in-trace> > profiles/<name>.md"""
+import re
+import sqlite3
+import sys
+
+db = sqlite3.connect(sys.argv[1])
+steps = float(sys.argv[2]) if len(sys.argv) > 2 else 1.0
+rows = db.execute('select name, count(*), sum(end-start)/1e3, avg(end-start)/1e3, min(end-start)/1e3, '
+                  'max(end-start)/1e3, max(vgpr_count), max(accum_vgpr_count), max(lds_size) from kernels '
+                  'group by name order by 3 desc').fetchall()
+tot = sum(r[2] for r in rows)
+print('total kernel time %.1f us over %g steps = %.2f ms/step\n' % (tot, steps, tot / steps / 1e3))
+print('| kernel | launches/step | total us | avg us | min us | max us | % | vgpr | agpr | lds |')
+print('|---|---|---|---|---|---|---|---|---|---|')
+for r in rows:
+    name = re.sub(r'\(.*', '', r[0]).replace('void ', '')[:80]
+    print('| %s | %.1f | %.0f | %.1f | %.1f | %.1f | %.1f | %s | %s | %s |' % (
+        name, r[1] / steps, r[2], r[3], r[4], r[5], 100 * r[2] / tot, r[6], r[7], r[8]))
