@@ -64,11 +64,11 @@ def call_work(name, a):
     if name == 'gpe_edge_mlp_fwd':          # a_mode, ldpq, lda, B, N, k, Cin, Cout, ...
         B, N, k, Cin, Cout = a[3], a[4], a[5], a[6], a[7]
         return 2.0 * B * N * k * Cin * Cout, 0.0
-    if name == 'gpe_edge_mlp_bwd':          # a_mode, lda, ldg, ldagg, act_mode, ldpq, B, N, k, Cin, Cout
-        B, N, k, Cin, Cout = a[6], a[7], a[8], a[9], a[10]
+    if name == 'gpe_edge_mlp_bwd':          # lda, act_mode, ldpq, B, N, k, Cin, Cout
+        B, N, k, Cin, Cout = a[3], a[4], a[5], a[6], a[7]
         return 2.0 * B * N * k * Cin * Cout, 0.0
-    if name == 'gpe_edge_redgemm':          # u_mode, ldu, ldg, ldagg, v_mode, ldv, ldpq, B, N, k, Mg, Ng
-        B, N, k, Mg, Ng = a[7], a[8], a[9], a[10], a[11]
+    if name == 'gpe_edge_redgemm':          # ldu, v_mode, ldv, ldpq, B, N, k, Mg, Ng
+        B, N, k, Mg, Ng = a[4], a[5], a[6], a[7], a[8]
         return 2.0 * B * N * k * Mg * Ng, 0.0
     if name == 'gpe_linear':                # strides..., M, N, K, act  (last four ints)
         M, N, K = a[-4], a[-3], a[-2]

@@ -37,3 +37,13 @@ __device__ __forceinline__ const float* gpe_row_ptr(const GpeRows& a, long r)
 }
 
 __device__ __forceinline__ bool gpe_aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
+// exact n / d for 32-bit unsigned n via fp64 reciprocal + one correction step (~8 instructions instead of the
+// ~100+ of a 64-bit integer division; matters in the 1-wave/SIMD MFMA kernels where VALU work is not hidden)
+__device__ __forceinline__ unsigned gpe_udiv(unsigned n, unsigned d, double rcp)
+{
+    unsigned q = (unsigned)__double2uint_rz((double)n * rcp);
+    if ((unsigned long long)(q + 1) * d <= n) ++q;
+    else if ((unsigned long long)q * d > n) --q;
+    return q;
+}

@@ -19,7 +19,7 @@
 #define KNN_LD 68           // row stride (floats) of channel-major LDS tiles: 16-B aligned, rows shifted by 1 slot
 
 __global__ __launch_bounds__(256) void gpe_knn_kernel(const float* __restrict__ x, int N, int C, int ldx, int k,
-                                                      int32_t* __restrict__ idx, int Cq /* C rounded up to CCH */)
+                                                      int32_t* __restrict__ idx, int32_t* __restrict__ idx_glob, int Cq /* C rounded up to CCH */)
 {
     extern __shared__ __align__(16) float smem[];
     float* qT = smem;                          // [Cq][KNN_LD]   query tile, channel-major (resident)
@@ -120,13 +120,18 @@ __global__ __launch_bounds__(256) void gpe_knn_kernel(const float* __restrict__ 
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
         const int q = q0 + 16 * wave + i;
-        if (q < N && lane < k) idx[((size_t)b * N + q) * k + lane] = li_[i];
+        if (q < N && lane < k) {
+            const size_t o = ((size_t)b * N + q) * k + lane;
+            idx[o] = li_[i];
+            if (idx_glob) idx_glob[o] = b * N + li_[i];
+        }
     }
 }
 
-extern "C" int gpe_knn(const float* x, int B, int N, int C, int ldx, int k, int32_t* idx, void* stream)
+extern "C" int gpe_knn(const float* x, int B, int N, int C, int ldx, int k, int32_t* idx, int32_t* idx_glob,
+                       void* stream)
 {
-    if (!x || !idx || B < 0 || N <= 0 || C <= 0 || ldx < C || k <= 0 || k > 64 || k > N) return GPE_EINVAL;
+    if (!x || !idx || B < 0 || N <= 0 || C <= 0 || ldx < C || k <= 0 || k > 64 || k > N || (long)B * N * k >= (1L << 31)) return GPE_EINVAL;
     if (B == 0) return GPE_OK;
     const int Cq = gpe_round_up(C, KNN_CCH);
     const size_t lds = ((size_t)Cq * KNN_LD + KNN_CCH * KNN_LD + 64 * KNN_LD) * sizeof(float);
@@ -139,7 +144,7 @@ extern "C" int gpe_knn(const float* x, int B, int N, int C, int ldx, int k, int3
         attr_set = true;
     }
     dim3 grid(gpe_cdiv(N, KNN_TQ), B);
-    hipLaunchKernelGGL(gpe_knn_kernel, grid, dim3(256), lds, (hipStream_t)stream, x, N, C, ldx, k, idx, Cq);
+    hipLaunchKernelGGL(gpe_knn_kernel, grid, dim3(256), lds, (hipStream_t)stream, x, N, C, ldx, k, idx, idx_glob, Cq);
     GPE_CHECK_LAUNCH();
     return GPE_OK;
 }

@@ -45,6 +45,37 @@ extern "C" int gpe_pack_weight(const float* w, int ldw, int N, int K, int transp
     return GPE_OK;
 }
 
+// gate-interleaved packing of an LSTM weight [4H][ldw] (rows i|f|g|o x H, torch.nn.LSTM layout): packed row
+// b*64 + gate*16 + u'  <->  original row gate*H + 16*b + u', so one 64-column block holds the four gates of 16 units.
+__global__ void gpe_pack_gates_kernel(const float* __restrict__ w, int ldw, int H, int K, float* __restrict__ wp,
+                                      int Npad, long total)
+{
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= total) return;
+    const int t = (int)(e & 3);
+    const long r = e >> 2;
+    const int n = (int)(r % Npad);
+    const long kq = r / Npad;
+    const int k = (int)(kq * 4 + t);
+    const int b = n >> 6, gate = (n >> 4) & 3, u = (b << 4) + (n & 15);
+    float v = 0.f;
+    if (u < H && k < K) v = w[(size_t)(gate * H + u) * ldw + k];
+    wp[e] = v;
+}
+
+extern "C" long gpe_packed_gates_size(int H, int K) { return 64L * gpe_cdiv(H, 16) * gpe_round_up(K, 16); }
+
+extern "C" int gpe_pack_weight_gates(const float* w, int ldw, int H, int K, float* wp, void* stream)
+{
+    if (!w || !wp || H <= 0 || K <= 0 || ldw < K) return GPE_EINVAL;
+    const int Npad = 64 * gpe_cdiv(H, 16);
+    const long total = (long)Npad * gpe_round_up(K, 16);
+    hipLaunchKernelGGL(gpe_pack_gates_kernel, dim3(gpe_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, w, ldw, H,
+                       K, wp, Npad, total);
+    GPE_CHECK_LAUNCH();
+    return GPE_OK;
+}
+
 __global__ void gpe_fold_bias_kernel(const float* __restrict__ w, int ldw, int N, int K,
                                      const float* __restrict__ bias, const float* __restrict__ t, float* out)
 {
@@ -73,7 +104,7 @@ extern "C" int gpe_fold_bias(const float* w, int ldw, int N, int K, const float*
 #define GS_BLOCKS 512
 template <int KU>
 __global__ __launch_bounds__(256) void gpe_gather_stats_kernel(const float* __restrict__ pq, int ldpq, int H,
-                                                               const int32_t* __restrict__ idx, int npts, int k,
+                                                               const int32_t* __restrict__ jg, int k,
                                                                long total_pts, double* __restrict__ part)
 {
     __shared__ double red[4][2][256];
@@ -83,8 +114,7 @@ __global__ __launch_bounds__(256) void gpe_gather_stats_kernel(const float* __re
     double s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
     const long nw = (long)gridDim.x * 4;
     for (long i = (long)blockIdx.x * 4 + wave; i < total_pts; i += nw) {
-        const long cloud0 = (i / npts) * (long)npts;
-        const int myidx = (lane < k) ? idx[i * k + lane] : 0;
+        const int myidx = (lane < k) ? jg[i * k + lane] : 0;
         float4 p4 = make_float4(0.f, 0.f, 0.f, 0.f);
         if (active) p4 = pw_ld4(pq + i * ldpq + c);
         for (int s0 = 0; s0 < k; s0 += KU) {
@@ -93,7 +123,7 @@ __global__ __launch_bounds__(256) void gpe_gather_stats_kernel(const float* __re
             for (int u = 0; u < KU; ++u) {
                 nb[u] = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (s0 + u < k) {
-                    const long jrow = cloud0 + __shfl(myidx, s0 + u);
+                    const long jrow = __shfl(myidx, s0 + u);
                     if (active) nb[u] = pw_ld4(pq + jrow * ldpq + H + c);
                 }
             }
@@ -121,14 +151,14 @@ __global__ __launch_bounds__(256) void gpe_gather_stats_kernel(const float* __re
     }
 }
 
-extern "C" int gpe_edge_gather_stats(const float* pq, int ldpq, int H, const int32_t* idx, int B, int N, int k,
+extern "C" int gpe_edge_gather_stats(const float* pq, int ldpq, int H, const int32_t* jg, int B, int N, int k,
                                      double* part, void* stream)
 {
-    if (!pq || !idx || !part || B <= 0 || N <= 0 || k <= 0 || k > 64 || H <= 0 || H > 256 || (H & 3) || (ldpq & 3) ||
+    if (!pq || !jg || !part || B <= 0 || N <= 0 || k <= 0 || k > 64 || H <= 0 || H > 256 || (H & 3) || (ldpq & 3) ||
         ldpq < 2 * H)
         return GPE_EINVAL;
     hipLaunchKernelGGL(gpe_gather_stats_kernel<8>, dim3(GS_BLOCKS), dim3(256), 0, (hipStream_t)stream, pq, ldpq, H,
-                       idx, N, k, (long)B * N, part);
+                       jg, k, (long)B * N, part);
     GPE_CHECK_LAUNCH();
     return GPE_OK;
 }
@@ -136,19 +166,31 @@ extern "C" int gpe_edge_gather_stats(const float* pq, int ldpq, int H, const int
 // ---------------------------------------------------------------------------------------------------------
 // BatchNorm finalisation
 // ---------------------------------------------------------------------------------------------------------
-__global__ void gpe_bn_finalize_kernel(const double* __restrict__ part, int nblk, int C, double count,
-                                       const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
-                                       float momentum, float* running_mean, float* running_var,
-                                       int64_t* num_batches, float* __restrict__ stats)
+__global__ __launch_bounds__(256) void gpe_bn_finalize_kernel(const double* __restrict__ part, int nblk, int C,
+                                                              double count, const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, float eps,
+                                                              float momentum, float* running_mean,
+                                                              float* running_var, int64_t* num_batches,
+                                                              float* __restrict__ stats)
 {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c == 0 && num_batches) *num_batches += 1;
-    if (c >= C) return;
+    // one workgroup per 64 channels; the 4 waves split the partial blocks, combined in a fixed order
+    __shared__ double red[4][2][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && num_batches) *num_batches += 1;
     double s = 0, q = 0;
-    for (int b = 0; b < nblk; ++b) {
-        s += part[(size_t)b * 2 * C + c];
-        q += part[(size_t)b * 2 * C + C + c];
+    if (c < C) {
+        for (int b = wave; b < nblk; b += 4) {
+            s += part[(size_t)b * 2 * C + c];
+            q += part[(size_t)b * 2 * C + C + c];
+        }
     }
+    red[wave][0][lane] = s;
+    red[wave][1][lane] = q;
+    __syncthreads();
+    if (wave != 0 || c >= C) return;
+    s = (red[0][0][lane] + red[1][0][lane]) + (red[2][0][lane] + red[3][0][lane]);
+    q = (red[0][1][lane] + red[1][1][lane]) + (red[2][1][lane] + red[3][1][lane]);
     const double mean = s / count;
     double var = q / count - mean * mean;
     if (var < 0) var = 0;
@@ -170,7 +212,7 @@ extern "C" int gpe_bn_finalize(const double* part, int nblk, int C, double count
                                float* running_var, int64_t* num_batches, float* stats_out, void* stream)
 {
     if (!part || !gamma || !beta || !stats_out || nblk <= 0 || C <= 0 || count <= 0) return GPE_EINVAL;
-    hipLaunchKernelGGL(gpe_bn_finalize_kernel, dim3(gpe_cdiv(C, 64)), dim3(64), 0, (hipStream_t)stream, part, nblk,
+    hipLaunchKernelGGL(gpe_bn_finalize_kernel, dim3(gpe_cdiv(C, 64)), dim3(256), 0, (hipStream_t)stream, part, nblk,
                        C, count, gamma, beta, eps, momentum, running_mean, running_var, num_batches, stats_out);
     GPE_CHECK_LAUNCH();
     return GPE_OK;
@@ -276,10 +318,10 @@ __global__ void gpe_bn_bwd_coef_kernel(const double* __restrict__ part, int nblk
     const double mean = stats[c], rstd = stats[C + c], s = stats[2 * C + c];
     const double m1 = s1 / count, m2 = s2 / count;
     const double k2 = s * rstd * m2;
-    const double k1 = s * m1 - mean * k2;
     coef[c] = (float)s;
-    coef[C + c] = (float)k1;
+    coef[C + c] = (float)(s * m1);
     coef[2 * C + c] = (float)k2;
+    coef[3 * C + c] = (float)mean;
     if (dgamma) dgamma[c] = (float)s2;
     if (dbeta) dbeta[c] = (float)s1;
 }
@@ -294,7 +336,69 @@ extern "C" int gpe_bn_bwd_coef(const double* part, int nblk, const float* stats,
     return GPE_OK;
 }
 
-// sums for an inner BN + true weight gradient of the next Linear, from G = dz_next^T a and db = colsum(dz_next)
+// dz3 = (a3>0) ? [slot==argsel]*s*g - c1 - (a3-mean)*k2 : 0, written IN PLACE over the stored activation
+// a3 [E][lda3].  One wave per edge row (lanes = column quads), point/slot indices wave-uniform: no divisions.
+__global__ __launch_bounds__(256) void gpe_dz3_kernel(float* __restrict__ a3, int lda3, const float* __restrict__ g,
+                                                      int ldg, const uint8_t* __restrict__ amx,
+                                                      const uint8_t* __restrict__ amn, int ldagg,
+                                                      const float* __restrict__ coef, long E, int k, double rcp_k,
+                                                      int F)
+{
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int c = lane << 2;
+    if (c >= F) return;
+    float cs_[4], c1_[4], k2_[4], mu_[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int cc = (c + t < F) ? c + t : c;
+        cs_[t] = coef[cc]; c1_[t] = coef[F + cc]; k2_[t] = coef[2 * F + cc]; mu_[t] = coef[3 * F + cc];
+    }
+    const long nw = (long)gridDim.x * 4;
+    for (long row = (long)blockIdx.x * 4 + wave; row < E; row += nw) {
+        const long i = (long)gpe_udiv((unsigned)row, (unsigned)k, rcp_k);
+        const int slot = (int)(row - i * k);
+        float* ap = a3 + row * lda3 + c;
+        const float4 a = pw_ld4(ap);
+        const uchar4 smx = *reinterpret_cast<const uchar4*>(amx + i * ldagg + c);
+        const uchar4 smn = *reinterpret_cast<const uchar4*>(amn + i * ldagg + c);
+        const float av[4] = {a.x, a.y, a.z, a.w};
+        const uint8_t mxv[4] = {smx.x, smx.y, smx.z, smx.w};
+        const uint8_t mnv[4] = {smn.x, smn.y, smn.z, smn.w};
+        float o[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            o[t] = 0.f;
+            if (c + t < F && av[t] > 0.f) {
+                const uint8_t sel = (cs_[t] >= 0.f) ? mxv[t] : mnv[t];
+                const float hit = (sel == slot) ? cs_[t] * g[i * ldg + c + t] : 0.f;
+                o[t] = hit - c1_[t] - (av[t] - mu_[t]) * k2_[t];
+            }
+        }
+        pw_st4(ap, make_float4(o[0], o[1], o[2], o[3]));
+    }
+}
+
+extern "C" int gpe_edge_dz3(float* a3, int lda3, const float* g, int ldg, const uint8_t* amx, const uint8_t* amn,
+                            int ldagg, const float* coef, int B, int N, int k, int F, void* stream)
+{
+    if (!a3 || !g || !amx || !amn || !coef || B <= 0 || N <= 0 || k <= 0 || F <= 0 || (lda3 & 3) || (ldagg & 3) ||
+        lda3 < F || ldagg < F)
+        return GPE_EINVAL;
+    const long E = (long)B * N * k;
+    if (F > 256 || E >= (1L << 31)) return GPE_EINVAL;
+    const int blocks = (int)((E + 3) / 4 < 4096 ? (E + 3) / 4 : 4096);
+    hipLaunchKernelGGL(gpe_dz3_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a3, lda3, g, ldg, amx, amn,
+                       ldagg, coef, E, k, 1.0 / k, F);
+    GPE_CHECK_LAUNCH();
+    return GPE_OK;
+}
+
+// sums for an inner BN + true weight gradient of the next Linear, from the CENTRED product
+// Gc = dz_next^T (a - mean)  (accumulated without cancellation by the reduce-GEMM) and db = colsum(dz_next):
+//   sum dy     = sum_f w[f][c] * db[f]
+//   sum dy*xhat = rstd_c * sum_f w[f][c] * Gc[f][c]
+//   dW_next[f][c] = Gc[f][c]*s_c + db[f]*beta_c          (since mean*s + t = beta)
 __global__ void gpe_bn_bwd_from_G_kernel(const float* __restrict__ G, int ldG, const float* __restrict__ db,
                                          const float* __restrict__ w, int ldw, int Cn, int C,
                                          const float* __restrict__ stats, double* __restrict__ sums,
@@ -303,15 +407,16 @@ __global__ void gpe_bn_bwd_from_G_kernel(const float* __restrict__ G, int ldG, c
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
     const double mean = stats[c], rstd = stats[C + c];
-    const float s = stats[2 * C + c], t = stats[3 * C + c];
+    const double s = stats[2 * C + c], t = stats[3 * C + c];
+    const double beta = t + mean * s;
     double a = 0, b = 0;
     for (int f = 0; f < Cn; ++f) {
         const double wf = w[(size_t)f * ldw + c];
         const double gf = G[(size_t)f * ldG + c];
         const double dbf = db[f];
         a += wf * dbf;
-        b += wf * (gf - mean * dbf);
-        if (dw) dw[(size_t)f * lddw + c] = (float)(gf * (double)s + dbf * (double)t);
+        b += wf * gf;
+        if (dw) dw[(size_t)f * lddw + c] = (float)(gf * s + dbf * beta);
     }
     sums[c] = a;
     sums[C + c] = b * rstd;

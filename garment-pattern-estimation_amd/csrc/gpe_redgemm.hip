@@ -1,31 +1,34 @@
 // Reduce-GEMM family for gfx950:  G[Mg, Ng] = sum over rows r of U[r, :]^T V[r, :]   (+ colsum of U)
 //
 // This is the weight-gradient half of every Linear on the path (nn.Linear backward under
-// /root/reference/nn/trainer.py:97 `loss.backward()`), with the row operands produced on the fly:
-//   U: dense rows | dz3 rebuilt from (a3, g, argsel, coef)        V: dense rows | relu(P_i+Q_j) gathered
-// Because BatchNorm's backward reductions are linear in the same products, G and colsum(U) are also all that
-// the BN backward of the previous block needs (gpe_bn_bwd_from_G) — no extra pass over the E edges.
+// /root/reference/nn/trainer.py:97 `loss.backward()`).  V rows are either dense or the EdgeConv gather
+// relu(P_i + Q_j) rebuilt on the fly.  Because BatchNorm's backward reductions are linear in the same products,
+// G and colsum(U) are also all that the BN backward of the previous block needs (gpe_bn_bwd_from_G) — no extra
+// pass over the E edges.
 //
-// Structure: persistent workgroups (grid.x ~ 2 per CU) walk 32-row tiles; both operand tiles are staged in
-// LDS; wave w keeps the accumulators of M-tiles {w, w+4, ...} x all N-tiles in registers across ALL its row
-// tiles (v_mfma_f32_16x16x4_f32, reduction dim = rows) and writes ONE partial per workgroup at the end; a
-// second kernel sums the partials in a fixed order (fp64) so results are run-to-run deterministic.
+// Structure: ONE persistent 256-thread workgroup per CU (grid = #CUs), 512-VGPR budget per wave.
+//   * 32-row operand tiles are fetched global -> registers one tile AHEAD (the dependent idx -> Q-row gather
+//     included), written to a double-buffered LDS image after the current tile's MFMAs: one barrier per tile, HBM/L2
+//     latency fully under the matrix pipe;
+//   * the 4 waves tile G 2x2: wave (wm, wn) keeps the accumulators of M-tiles [wm*MH, ..) x N-tiles [wn*NH, ..)
+//     in registers across ALL its row tiles (v_mfma_f32_16x16x4_f32, reduction dim = rows); 13 x 13 tiles split
+//     7/6 x 7/6 instead of 4/3/3/3 rows of 13 (86 % vs 81 % balance, half the operand reads);
+//   * one partial per workgroup at the end; a second kernel sums the partials in a fixed order (fp64), so results
+//     are run-to-run deterministic.
 #include "gpe_common.h"
 
 #define RD_RT 32
 
-enum { U_DENSE = 1, U_DZ3 = 0 };
-enum { V_DENSE = 1, V_GATHER = 0 };
+enum { V_GATHER = 0, V_DENSE = 1 };
 
 struct RdParams {
     long rows;
     int Mg, Ng, MgPad, NgPad;
     int num_tiles;
-    GpeRows u;                                   // U_DENSE
-    const float* a3; int lda3; const float* g; int ldg; const uint8_t* amx; const uint8_t* amn; int ldagg;
-    const float* coef;                           // U_DZ3: [3][Mg]
+    GpeRows u;
     GpeRows v;                                   // V_DENSE
-    const float* pq; int ldpq; int H; const int32_t* idx; int npts; int k;   // V_GATHER
+    const float* pq; int ldpq; int H; const int32_t* jg; int k; double rcp_k;   // V_GATHER (global neighbour rows)
+    const float* v_shift;                        // optional [Ng]: V := V - shift on valid rows (BN centring)
     float* part;                                 // [gridDim.x][MgPad][NgPad]
     double* part_cs;                             // [gridDim.x][MgPad]
 };
@@ -43,140 +46,208 @@ __device__ __forceinline__ float4 rd_ld4_guard(const float* p, int nvalid, bool 
     return v;
 }
 
-template <int MTW, int NT, int UMODE, int VMODE>
-__global__ __launch_bounds__(256, (MTW * NT * 4 > 200) ? 1 : 2) void gpe_redgemm_kernel(RdParams p)
+// MFMA body over one 32-row tile for a compile-time (MC x NC) block of 16x16 tiles — no branches
+template <int MH, int NH, int MC, int NC>
+__device__ __forceinline__ void rd_mma(const float* ub, const float* vb, int LDU, int LDV, int mt0, int nt0, int j,
+                                       int g, f32x4 (&acc)[MH][NH])
 {
-    constexpr int UC = 64 * MTW;                                  // U columns handled by this block
-    constexpr int LDU = (UC % 32 == 0) ? UC + 16 : UC;            // stride == 16 (mod 32): conflict-free b32 reads
-    constexpr int VC = 16 * NT;
-    constexpr int LDV = (VC % 32 == 0) ? VC + 16 : VC;
-    __shared__ __align__(16) float Us[RD_RT * LDU];
-    __shared__ __align__(16) float Vs[RD_RT * LDV];
+#pragma unroll
+    for (int r0 = 0; r0 < RD_RT; r0 += 4) {
+        float a[MC], b[NC];
+#pragma unroll
+        for (int q = 0; q < MC; ++q) a[q] = ub[(r0 + g) * LDU + 16 * (mt0 + q) + j];
+#pragma unroll
+        for (int n = 0; n < NC; ++n) b[n] = vb[(r0 + g) * LDV + 16 * (nt0 + n) + j];
+#pragma unroll
+        for (int q = 0; q < MC; ++q)
+#pragma unroll
+            for (int n = 0; n < NC; ++n)
+                acc[q][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q], b[n], acc[q][n], 0, 0, 0);
+    }
+}
+
+template <int MH, int NH, int VMODE>
+__global__ __launch_bounds__(256, 1) void gpe_redgemm_kernel(RdParams p)
+{
+    constexpr int UC = 32 * MH;                    // U columns of this block (2*MH tiles of 16)
+    constexpr int LDU = UC + 16;                   // stride == 16 (mod 32): conflict-free b32 operand reads
+    constexpr int VC = 32 * NH;
+    constexpr int LDV = VC + 16;
+    extern __shared__ __align__(16) float smem[];
+    float* Us = smem;                              // [2][RD_RT * LDU]
+    float* Vs = smem + 2 * RD_RT * LDU;            // [2][RD_RT * LDV]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 15, g = lane >> 4;
+    const int wm = wave & 1, wn = wave >> 1;
     const int m0 = blockIdx.y * UC;
     const int ucols = (p.Mg - m0 < UC) ? (p.Mg - m0) : UC;
+    const int mt_blk = (ucols + 15) >> 4, nt_all = (p.Ng + 15) >> 4;
+    const int mt0 = wm * MH, nt0 = wn * NH;
+    const int mc = (mt_blk - mt0 < MH) ? (mt_blk - mt0) : MH;     // may be <= 0
+    const int nc = (nt_all - nt0 < NH) ? (nt_all - nt0) : NH;
 
-    f32x4 acc[MTW][NT];
+    f32x4 acc[MH][NH];
 #pragma unroll
-    for (int q = 0; q < MTW; ++q)
+    for (int q = 0; q < MH; ++q)
 #pragma unroll
-        for (int n = 0; n < NT; ++n) acc[q][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int n = 0; n < NH; ++n) acc[q][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
     double cs = 0.0;
 
-    for (int tile = blockIdx.x; tile < p.num_tiles; tile += gridDim.x) {
+    // operand staging: lane = column quad, rows = wave + 4*q (wave-uniform: row scalars computed once per wave),
+    // fetched global -> registers one tile ahead of the MFMAs that consume them
+    constexpr int RQ = RD_RT / 4;
+    const int uwave = __builtin_amdgcn_readfirstlane(wave);
+    const int cq = lane << 2;
+    const bool u_on = cq < UC && cq < ucols;
+    const bool v_on = cq < VC && cq < p.Ng;
+    float4 ur[RQ], vr[RQ], vr2[VMODE == V_GATHER ? RQ : 1];
+    unsigned rmask = 0;
+    float sh[4] = {0.f, 0.f, 0.f, 0.f};
+    if (p.v_shift && v_on) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) if (cq + t < p.Ng) sh[t] = p.v_shift[cq + t];
+    }
+
+    auto fetch = [&](int tile) {
         const long row0 = (long)tile * RD_RT;
         const int rv = (int)((p.rows - row0 < RD_RT) ? (p.rows - row0) : RD_RT);
-        __syncthreads();
-        // ---- stage U columns [m0, m0+UC) --------------------------------------------------------------
-        for (int e = tid; e < RD_RT * (UC / 4); e += 256) {
-            const int r = e / (UC / 4), c = (e - r * (UC / 4)) << 2;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (r < rv && c < ucols) {
-                const long gr = row0 + r;
-                const int nvalid = ucols - c;
-                if (UMODE == U_DENSE) {
-                    const float* src = gpe_row_ptr(p.u, gr) + m0 + c;
-                    v = rd_ld4_guard(src, nvalid, gpe_aligned16(src));
-                } else {
-                    const long i = gr / p.k;
-                    const int slot = (int)(gr - i * p.k);
-                    const float* ap = p.a3 + gr * p.lda3 + m0 + c;
-                    const float* gp = p.g + i * p.ldg + m0 + c;
-                    const float4 a = rd_ld4_guard(ap, nvalid, gpe_aligned16(ap));
-                    const float4 gg = rd_ld4_guard(gp, nvalid, gpe_aligned16(gp));
-                    const float av[4] = {a.x, a.y, a.z, a.w};
-                    const float gv[4] = {gg.x, gg.y, gg.z, gg.w};
-                    float o[4];
+        rmask = 0;
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        o[t] = 0.f;
-                        if (t < nvalid) {
-                            const int cc = m0 + c + t;
-                            const float s = p.coef[cc];
-                            const float k1 = p.coef[p.Mg + cc];
-                            const float k2 = p.coef[2 * p.Mg + cc];
-                            const uint8_t sel = (s >= 0.f) ? p.amx[i * p.ldagg + cc] : p.amn[i * p.ldagg + cc];
-                            const float hit = (sel == slot) ? s * gv[t] : 0.f;
-                            o[t] = (av[t] > 0.f) ? (hit - k1 - av[t] * k2) : 0.f;
-                        }
+        for (int q = 0; q < RQ; ++q) {
+            const int r = uwave + 4 * q;
+            ur[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+            vr[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (VMODE == V_GATHER) vr2[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (r < rv) {
+                rmask |= 1u << q;
+                const long gr = row0 + r;
+                if (u_on) {
+                    const float* src = gpe_row_ptr(p.u, gr) + m0 + cq;
+                    ur[q] = rd_ld4_guard(src, ucols - cq, gpe_aligned16(src));
+                }
+                if (v_on) {
+                    if (VMODE == V_DENSE) {
+                        const float* src = gpe_row_ptr(p.v, gr) + cq;
+                        vr[q] = rd_ld4_guard(src, p.Ng - cq, gpe_aligned16(src));
+                    } else {
+                        const long i = (long)gpe_udiv((unsigned)gr, (unsigned)p.k, p.rcp_k);
+                        const long jj = p.jg[gr];
+                        vr[q] = rd_ld4(p.pq + i * p.ldpq + cq);               // H % 4 == 0, ldpq % 4 == 0
+                        vr2[q] = rd_ld4(p.pq + jj * p.ldpq + p.H + cq);
                     }
-                    v = make_float4(o[0], o[1], o[2], o[3]);
                 }
             }
-            *reinterpret_cast<float4*>(&Us[r * LDU + c]) = v;
         }
-        // ---- stage V columns [0, Ng) --------------------------------------------------------------------
-        for (int e = tid; e < RD_RT * (VC / 4); e += 256) {
-            const int r = e / (VC / 4), c = (e - r * (VC / 4)) << 2;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (r < rv && c < p.Ng) {
-                const long gr = row0 + r;
-                const int nvalid = p.Ng - c;
-                if (VMODE == V_DENSE) {
-                    const float* src = gpe_row_ptr(p.v, gr) + c;
-                    v = rd_ld4_guard(src, nvalid, gpe_aligned16(src));
-                } else {
-                    const long i = gr / p.k;
-                    const long cloud0 = (i / p.npts) * (long)p.npts;
-                    const long jj = cloud0 + p.idx[gr];
-                    const float* pp = p.pq + i * p.ldpq + c;
-                    const float* qq = p.pq + jj * p.ldpq + p.H + c;
-                    const float4 a = rd_ld4_guard(pp, nvalid, gpe_aligned16(pp));
-                    const float4 b = rd_ld4_guard(qq, nvalid, gpe_aligned16(qq));
-                    v = make_float4(fmaxf(a.x + b.x, 0.f), fmaxf(a.y + b.y, 0.f), fmaxf(a.z + b.z, 0.f),
-                                    fmaxf(a.w + b.w, 0.f));
+    };
+    auto commit = [&](int buf) {
+        float* ub = Us + buf * RD_RT * LDU;
+        float* vb = Vs + buf * RD_RT * LDV;
+#pragma unroll
+        for (int q = 0; q < RQ; ++q) {
+            const int r = uwave + 4 * q;
+            if (cq < UC) *reinterpret_cast<float4*>(&ub[r * LDU + cq]) = ur[q];
+            if (cq < VC) {
+                float4 v = vr[q];
+                if (VMODE == V_GATHER) {
+                    v.x = fmaxf(v.x + vr2[q].x, 0.f); v.y = fmaxf(v.y + vr2[q].y, 0.f);
+                    v.z = fmaxf(v.z + vr2[q].z, 0.f); v.w = fmaxf(v.w + vr2[q].w, 0.f);
                 }
+                if ((rmask >> q) & 1u) {
+                    if (cq < p.Ng) v.x -= sh[0];
+                    if (cq + 1 < p.Ng) v.y -= sh[1];
+                    if (cq + 2 < p.Ng) v.z -= sh[2];
+                    if (cq + 3 < p.Ng) v.w -= sh[3];
+                }
+                *reinterpret_cast<float4*>(&vb[r * LDV + cq]) = v;
             }
-            *reinterpret_cast<float4*>(&Vs[r * LDV + c]) = v;
         }
-        __syncthreads();
+    };
+
+    int tile = blockIdx.x;
+    if (tile < p.num_tiles) fetch(tile);
+    int buf = 0;
+    for (; tile < p.num_tiles; tile += gridDim.x) {
+        commit(buf);
+        __syncthreads();            // tile visible; every wave is past the MFMAs that read buffer buf^1
+        if (tile + (int)gridDim.x < p.num_tiles) fetch(tile + gridDim.x);    // in flight under the MFMAs below
+        const float* ub = Us + buf * RD_RT * LDU;
+        const float* vb = Vs + buf * RD_RT * LDV;
         if (tid < ucols) {
-            for (int r = 0; r < rv; ++r) cs += (double)Us[r * LDU + tid];
+            float c32[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int r = 0; r < RD_RT; r += 4) {
+                c32[0] += ub[r * LDU + tid]; c32[1] += ub[(r + 1) * LDU + tid];
+                c32[2] += ub[(r + 2) * LDU + tid]; c32[3] += ub[(r + 3) * LDU + tid];
+            }
+            cs += ((double)c32[0] + (double)c32[1]) + ((double)c32[2] + (double)c32[3]);
         }
+        // the wave's block is (mc x nc) tiles with mc in {MH, MH-1}, nc in {NH, NH-1} in every shipped shape: four
+        // branch-free specialisations; anything else takes the guarded generic body
+        if (mc == MH && nc == NH) rd_mma<MH, NH, MH, NH>(ub, vb, LDU, LDV, mt0, nt0, j, g, acc);
+        else if (mc == MH && nc == NH - 1) rd_mma<MH, NH, MH, (NH > 1 ? NH - 1 : 1)>(ub, vb, LDU, LDV, mt0, nt0, j, g, acc);
+        else if (mc == MH - 1 && nc == NH) rd_mma<MH, NH, (MH > 1 ? MH - 1 : 1), NH>(ub, vb, LDU, LDV, mt0, nt0, j, g, acc);
+        else if (mc == MH - 1 && nc == NH - 1)
+            rd_mma<MH, NH, (MH > 1 ? MH - 1 : 1), (NH > 1 ? NH - 1 : 1)>(ub, vb, LDU, LDV, mt0, nt0, j, g, acc);
+        else if (mc > 0 && nc > 0) {
 #pragma unroll
-        for (int r0 = 0; r0 < RD_RT; r0 += 4) {
-            float a[MTW], b[NT];
+            for (int r0 = 0; r0 < RD_RT; r0 += 4) {
+                float a[MH], b[NH];
 #pragma unroll
-            for (int q = 0; q < MTW; ++q) a[q] = Us[(r0 + g) * LDU + 16 * (wave + 4 * q) + j];
+                for (int q = 0; q < MH; ++q) a[q] = ub[(r0 + g) * LDU + 16 * (mt0 + q) + j];
 #pragma unroll
-            for (int n = 0; n < NT; ++n) b[n] = Vs[(r0 + g) * LDV + 16 * n + j];
+                for (int n = 0; n < NH; ++n) b[n] = vb[(r0 + g) * LDV + 16 * (nt0 + n) + j];
 #pragma unroll
-            for (int q = 0; q < MTW; ++q)
+                for (int q = 0; q < MH; ++q) {
+                    if (q < mc) {
 #pragma unroll
-                for (int n = 0; n < NT; ++n)
-                    acc[q][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q], b[n], acc[q][n], 0, 0, 0);
+                        for (int n = 0; n < NH; ++n)
+                            if (n < nc)
+                                acc[q][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q], b[n], acc[q][n], 0, 0, 0);
+                    }
+                }
+            }
         }
+        buf ^= 1;
     }
 
     // ---- one partial per workgroup ---------------------------------------------------------------------
     float* dst = p.part + (size_t)blockIdx.x * p.MgPad * p.NgPad;
 #pragma unroll
-    for (int q = 0; q < MTW; ++q) {
-        const int mrow0 = m0 + 16 * (wave + 4 * q);
+    for (int q = 0; q < MH; ++q) {
 #pragma unroll
-        for (int n = 0; n < NT; ++n)
+        for (int n = 0; n < NH; ++n)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int m = mrow0 + 4 * g + r, nn = 16 * n + j;
-                if (m < p.MgPad && nn < p.NgPad) dst[(size_t)m * p.NgPad + nn] = acc[q][n][r];
+                const int m = m0 + 16 * (mt0 + q) + 4 * g + r, nn = 16 * (nt0 + n) + j;
+                if (q < MH && m < p.MgPad && nn < p.NgPad) dst[(size_t)m * p.NgPad + nn] = acc[q][n][r];
             }
     }
-    if (UC >= 256 ? (tid < ucols) : (tid < UC && tid < ucols))
-        p.part_cs[(size_t)blockIdx.x * p.MgPad + m0 + tid] = cs;
+    if (tid < ucols) p.part_cs[(size_t)blockIdx.x * p.MgPad + m0 + tid] = cs;
 }
 
-__global__ void gpe_redgemm_finish(const float* part, const double* part_cs, int nblk, int Mg, int Ng, int MgPad,
-                                   int NgPad, float* G, int ldg, float* colsum, int accumulate)
+// fixed-order (deterministic) reduction of the per-workgroup partials; 4 independent fp64 chains for load ILP
+__global__ void gpe_redgemm_finish(const float* __restrict__ part, const double* __restrict__ part_cs, int nblk,
+                                   int Mg, int Ng, int MgPad, int NgPad, float* G, int ldg, float* colsum,
+                                   int accumulate)
 {
     const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (e < (long)Mg * Ng) {
         const int m = (int)(e / Ng), n = (int)(e - (long)m * Ng);
-        double s = 0.0;
-        for (int b = 0; b < nblk; ++b) s += (double)part[((size_t)b * MgPad + m) * NgPad + n];
+        const size_t stride = (size_t)MgPad * NgPad;
+        const float* src = part + (size_t)m * NgPad + n;
+        double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+        int b = 0;
+        for (; b + 3 < nblk; b += 4) {
+            s0 += (double)src[(size_t)b * stride];
+            s1 += (double)src[(size_t)(b + 1) * stride];
+            s2 += (double)src[(size_t)(b + 2) * stride];
+            s3 += (double)src[(size_t)(b + 3) * stride];
+        }
+        for (; b < nblk; ++b) s0 += (double)src[(size_t)b * stride];
+        const float s = (float)((s0 + s1) + (s2 + s3));
         float* d = G + (size_t)m * ldg + n;
-        *d = accumulate ? (*d + (float)s) : (float)s;
+        *d = accumulate ? (*d + s) : s;
     }
     if (colsum && e < Mg) {
         double s = 0.0;
@@ -186,74 +257,96 @@ __global__ void gpe_redgemm_finish(const float* part, const double* part_cs, int
 }
 
 // ---------------------------------------------------------------------------------------------------------
-static int rd_pick_nt(int Ng)
+static int rd_pick(int need, const int* opts, int n)
 {
-    const int need = gpe_cdiv(Ng, 16);
-    const int opts[5] = {1, 4, 10, 13, 16};
-    for (int i = 0; i < 5; ++i) if (opts[i] >= need) return opts[i];
+    for (int i = 0; i < n; ++i) if (opts[i] >= need) return opts[i];
     return -1;
 }
+static const int RD_MH_OPTS[3] = {2, 5, 7};
+static const int RD_NH_OPTS[4] = {1, 5, 7, 8};
 
-static void rd_geometry(int Mg, int Ng, long rows, int* MTW, int* gy, int* gx, int* MgPad, int* NgPad)
+static int rd_num_cus()
 {
-    const int mt = gpe_cdiv(Mg, 16);
-    *MTW = (mt <= 8) ? 2 : 4;
-    *gy = gpe_cdiv(Mg, 64 * (*MTW));
-    *MgPad = (*gy) * 64 * (*MTW);
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+            cus = prop.multiProcessorCount;
+        if (cus <= 0) cus = 256;
+    }
+    return cus;
+}
+
+// geometry shared by the workspace query and the launcher (no device query here: the ws size must be computable on a
+// CPU-only box, so it is sized for the largest grid we ever launch)
+#define RD_MAX_GX 256
+static void rd_geometry(int Mg, int Ng, int* MH, int* NH, int* gy, int* MgPad, int* NgPad)
+{
+    const int mt = gpe_cdiv(Mg, 16), nt = gpe_cdiv(Ng, 16);
+    const int mtb = mt < 14 ? mt : 14;
+    *MH = rd_pick(gpe_cdiv(mtb, 2), RD_MH_OPTS, 3);
+    *NH = rd_pick(gpe_cdiv(nt, 2), RD_NH_OPTS, 4);
+    *gy = gpe_cdiv(mt, 2 * (*MH));
+    *MgPad = (*gy) * 32 * (*MH);
     *NgPad = gpe_round_up(Ng, 16);
-    long cap = (1L << 24) / ((long)(*MgPad) * (*NgPad));
-    if (cap < 8) cap = 8;
-    long g = 512 / (*gy);
-    if (g < 1) g = 1;
-    if (g > cap) g = cap;
-    *gx = (int)g;
 }
 
 extern "C" long gpe_redgemm_ws(int Mg, int Ng)
 {
-    int MTW, gy, gx, MgPad, NgPad;
-    rd_geometry(Mg, Ng, 0, &MTW, &gy, &gx, &MgPad, &NgPad);
-    // floats: partial G + fp64 colsum partials (2 floats each), 16-B aligned sections
-    return (long)gx * MgPad * NgPad + 2L * gx * MgPad + 8;
+    int MH, NH, gy, MgPad, NgPad;
+    rd_geometry(Mg, Ng, &MH, &NH, &gy, &MgPad, &NgPad);
+    if (NH < 0) return -1;
+    const long gx = RD_MAX_GX / gy > 0 ? RD_MAX_GX / gy : 1;
+    return gx * MgPad * NgPad + 2L * gx * MgPad + 8;
 }
 
-template <int MTW, int NT, int UMODE, int VMODE>
+template <int MH, int NH, int VMODE>
 static int rd_launch(const RdParams& p, dim3 grid, hipStream_t s)
 {
-    hipLaunchKernelGGL((gpe_redgemm_kernel<MTW, NT, UMODE, VMODE>), grid, dim3(256), 0, s, p);
+    const size_t lds = (size_t)2 * RD_RT * ((32 * MH + 16) + (32 * NH + 16)) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gpe_redgemm_kernel<MH, NH, VMODE>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            return GPE_ELAUNCH;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gpe_redgemm_kernel<MH, NH, VMODE>), grid, dim3(256), lds, s, p);
     GPE_CHECK_LAUNCH();
     return GPE_OK;
 }
 
-template <int UMODE, int VMODE>
-static int rd_dispatch(int MTW, int NT, const RdParams& p, dim3 grid, hipStream_t s)
+template <int VMODE>
+static int rd_dispatch(int MH, int NH, const RdParams& p, dim3 grid, hipStream_t s)
 {
-#define RD_CASE(M_, N_) if (MTW == M_ && NT == N_) return rd_launch<M_, N_, UMODE, VMODE>(p, grid, s)
-    RD_CASE(2, 1); RD_CASE(2, 4); RD_CASE(2, 10); RD_CASE(2, 13); RD_CASE(2, 16);
-    RD_CASE(4, 1); RD_CASE(4, 4); RD_CASE(4, 10); RD_CASE(4, 13); RD_CASE(4, 16);
+#define RD_CASE(M_, N_) if (MH == M_ && NH == N_) return rd_launch<M_, N_, VMODE>(p, grid, s)
+    RD_CASE(2, 1); RD_CASE(2, 5); RD_CASE(2, 7); RD_CASE(2, 8);
+    RD_CASE(5, 1); RD_CASE(5, 5); RD_CASE(5, 7); RD_CASE(5, 8);
+    RD_CASE(7, 1); RD_CASE(7, 5); RD_CASE(7, 7); RD_CASE(7, 8);
 #undef RD_CASE
     return GPE_EINVAL;
 }
 
-static int rd_run(RdParams& p, int umode, int vmode, float* G, int ldG, float* colsum, float* part,
-                  int accumulate, hipStream_t s)
+static int rd_run(RdParams& p, int vmode, float* G, int ldG, float* colsum, float* part, int accumulate,
+                  hipStream_t s)
 {
-    int MTW, gy, gx, MgPad, NgPad;
-    rd_geometry(p.Mg, p.Ng, p.rows, &MTW, &gy, &gx, &MgPad, &NgPad);
-    const int NT = rd_pick_nt(p.Ng);
-    if (NT < 0) return GPE_EINVAL;
+    int MH, NH, gy, MgPad, NgPad;
+    rd_geometry(p.Mg, p.Ng, &MH, &NH, &gy, &MgPad, &NgPad);
+    if (MH < 0 || NH < 0) return GPE_EINVAL;
     p.MgPad = MgPad; p.NgPad = NgPad;
     p.num_tiles = gpe_cdiv(p.rows, RD_RT);
+    int cus = rd_num_cus();
+    if (cus > RD_MAX_GX) cus = RD_MAX_GX;
+    int gx = cus / gy;
+    if (gx < 1) gx = 1;
+    if (gx > p.num_tiles) gx = p.num_tiles > 0 ? p.num_tiles : 1;
     p.part = part;
     size_t off = (size_t)gx * MgPad * NgPad;
     off = (off + 1) & ~(size_t)1;                                  // 8-B align the fp64 section
     p.part_cs = reinterpret_cast<double*>(part + off);
     dim3 grid(gx, gy);
-    int rc;
-    if (umode == U_DENSE && vmode == V_DENSE) rc = rd_dispatch<U_DENSE, V_DENSE>(MTW, NT, p, grid, s);
-    else if (umode == U_DZ3 && vmode == V_DENSE) rc = rd_dispatch<U_DZ3, V_DENSE>(MTW, NT, p, grid, s);
-    else if (umode == U_DENSE && vmode == V_GATHER) rc = rd_dispatch<U_DENSE, V_GATHER>(MTW, NT, p, grid, s);
-    else return GPE_EINVAL;
+    int rc = (vmode == V_DENSE) ? rd_dispatch<V_DENSE>(MH, NH, p, grid, s) : rd_dispatch<V_GATHER>(MH, NH, p, grid, s);
     if (rc != GPE_OK) return rc;
     const long total = (long)p.Mg * p.Ng;
     hipLaunchKernelGGL(gpe_redgemm_finish, dim3(gpe_cdiv(total, 256)), dim3(256), 0, s, p.part, p.part_cs, gx,
@@ -263,33 +356,31 @@ static int rd_run(RdParams& p, int umode, int vmode, float* G, int ldG, float* c
 }
 
 extern "C" int gpe_redgemm(const float* u, long u_so, long u_si, int u_inner, const float* v, long v_so,
-                           long v_si, int v_inner, long rows, int Mg, int Ng, float* G, int ldg, float* colsum,
-                           float* part, int accumulate, void* stream)
+                           long v_si, int v_inner, const float* v_shift, long rows, int Mg, int Ng, float* G,
+                           int ldg, float* colsum, float* part, int accumulate, void* stream)
 {
     if (!u || !v || !G || !part || rows < 0 || Mg <= 0 || Ng <= 0 || Ng > 256 || ldg < Ng) return GPE_EINVAL;
     RdParams p = {};
     p.rows = rows; p.Mg = Mg; p.Ng = Ng;
     p.u = GpeRows{u, u_so, u_si, u_inner};
     p.v = GpeRows{v, v_so, v_si, v_inner};
-    return rd_run(p, U_DENSE, V_DENSE, G, ldg, colsum, part, accumulate, (hipStream_t)stream);
+    p.v_shift = v_shift;
+    return rd_run(p, V_DENSE, G, ldg, colsum, part, accumulate, (hipStream_t)stream);
 }
 
-extern "C" int gpe_edge_redgemm(int u_mode, const float* u, int ldu, const float* g, int ldg, const uint8_t* amx,
-                                const uint8_t* amn, int ldagg, const float* coef, int v_mode, const float* v,
-                                int ldv, const float* pq, int ldpq, const int32_t* idx, int B, int N, int k,
-                                int Mg, int Ng, float* G, int ldG, float* colsum, float* part, void* stream)
+extern "C" int gpe_edge_redgemm(const float* u, int ldu, int v_mode, const float* v, int ldv, const float* pq,
+                                int ldpq, const int32_t* jg, const float* v_shift, int B, int N, int k, int Mg,
+                                int Ng, float* G, int ldG, float* colsum, float* part, void* stream)
 {
-    if (!u || !G || !part || B <= 0 || N <= 0 || k <= 0 || Mg <= 0 || Ng <= 0 || Ng > 256 || ldG < Ng)
+    if (!u || !G || !part || B <= 0 || N <= 0 || k <= 0 || Mg <= 0 || Ng <= 0 || Ng > 256 || ldG < Ng || ldu < Mg)
         return GPE_EINVAL;
-    if (u_mode == 0 && (!g || !amx || !amn || !coef)) return GPE_EINVAL;
-    if (v_mode == 0 && (!pq || !idx)) return GPE_EINVAL;
-    if (v_mode == 1 && !v) return GPE_EINVAL;
+    if (v_mode == 0 && (!pq || !jg || (Ng & 3) || (ldpq & 3))) return GPE_EINVAL;
+    if ((long)B * N * k >= (1L << 31)) return GPE_EINVAL;
+    if (v_mode == 1 && (!v || ldv < Ng)) return GPE_EINVAL;
     RdParams p = {};
     p.rows = (long)B * N * k; p.Mg = Mg; p.Ng = Ng;
     p.u = GpeRows{u, ldu, 0, 0};
-    p.a3 = u; p.lda3 = ldu; p.g = g; p.ldg = ldg; p.amx = amx; p.amn = amn; p.ldagg = ldagg; p.coef = coef;
     p.v = GpeRows{v, ldv, 0, 0};
-    p.pq = pq; p.ldpq = ldpq; p.H = Ng; p.idx = idx; p.npts = N; p.k = k;
-    return rd_run(p, u_mode == 0 ? U_DZ3 : U_DENSE, v_mode == 0 ? V_GATHER : V_DENSE, G, ldG, colsum, part, 0,
-                  (hipStream_t)stream);
+    p.pq = pq; p.ldpq = ldpq; p.H = Ng; p.jg = jg; p.k = k; p.rcp_k = 1.0 / k; p.v_shift = v_shift;
+    return rd_run(p, v_mode == 0 ? V_GATHER : V_DENSE, G, ldG, colsum, part, 0, (hipStream_t)stream);
 }

@@ -18,53 +18,7 @@
 // everything else (LDS traffic, gathers from L2/MALL, stores) hides underneath.
 #include "gpe_common.h"
 
-#define RG_BM 64
-#define RG_KSLAB 256
-
-enum { A_DENSE = 0, A_GATHER = 1, A_DZ3 = 2 };
-enum { E_LINEAR = 0, E_EDGE_FWD = 1, E_BWD_INPLACE = 2, E_BWD_GATHER = 3 };
-
-struct RgParams {
-    // problem
-    long M;                 // logical rows (E for edge kernels)
-    int N, K;               // output cols / reduction dim
-    int R;                  // rows per tile (<= 64); edge kernels: whole points, R = (64/k)*k
-    int num_tiles;
-    // A producers
-    GpeRows a;              // A_DENSE
-    const float* pq; int ldpq; int H;           // A_GATHER / E_BWD_GATHER : P = pq[:, 0:H], Q = pq[:, H:2H]
-    const int32_t* idx; int npts; int k;        // kNN graph (local indices), points per cloud, neighbours
-    const float* a3; int lda3;                  // A_DZ3: stored activation
-    const float* g; int ldg;                    //        upstream gradient per point
-    const uint8_t* amx; const uint8_t* amn; int ldagg;
-    const float* coef_in;                       //        [3][K] = {s, k1, k2}
-    // weight
-    const float* wp; int Npad;
-    const float* bias;
-    // epilogue
-    GpeRows addend;         // E_LINEAR (base may be NULL)
-    float* y; long y_so, y_si; int y_inner; int act;
-    float* out; int ldo;    // edge kernels: activation / dz rows
-    double* stats_part;     // E_EDGE_FWD: [gridDim.x][2][N]
-    int agg; float* mx; float* mn; uint8_t* oamx; uint8_t* oamn; int oldagg;
-    const float* coef_out;  // E_BWD_*: [3][N]
-    float* dP; int lddp;    // E_BWD_GATHER
-};
-
-__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
-__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
-
-// guarded load of 4 consecutive floats p[0..3] of which `nvalid` exist; vec => p is 16-B aligned
-__device__ __forceinline__ float4 ld4_guard(const float* p, int nvalid, bool vec)
-{
-    if (nvalid >= 4 && vec) return ld4(p);
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (nvalid > 0) v.x = p[0];
-    if (nvalid > 1) v.y = p[1];
-    if (nvalid > 2) v.z = p[2];
-    if (nvalid > 3) v.w = p[3];
-    return v;
-}
+#include "gpe_rowgemm.h"
 
 // ---------------------------------------------------------------------------------------------------------
 // A-tile producers: fill As[64][lda] columns [0, kp) for the K slab [ks, ks+kslab)
@@ -74,51 +28,25 @@ __device__ __forceinline__ void rg_build_a(const RgParams& p, float* As, int lda
                                            int kslab, int kp)
 {
     const int tid = threadIdx.x;
-    const int q4 = kp >> 2;                       // float4 columns per row
-    for (int e = tid; e < RG_BM * q4; e += 256) {
-        const int r = e / q4;
-        const int c = (e - r * q4) << 2;          // column inside the slab
+    const int c = (tid & 63) << 2;                // column quad inside the slab (kp <= 256)
+    if (c >= kp) return;
+    const int nvalid = kslab - c;
+    for (int r = tid >> 6; r < RG_BM; r += 4) {   // wave-uniform row
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (r < rv && c < kslab) {
+        if (r < rv && nvalid > 0) {
             const long gr = row0 + r;
-            const int nvalid = kslab - c;
             if (AMODE == A_DENSE) {
                 const float* src = gpe_row_ptr(p.a, gr) + ks + c;
                 v = ld4_guard(src, nvalid, gpe_aligned16(src));
-            } else if (AMODE == A_GATHER) {
-                const long i = gr / p.k;                                    // global point
-                const long cloud0 = (i / p.npts) * (long)p.npts;
-                const long j = cloud0 + p.idx[gr];
+            } else {   // A_GATHER: relu(P_i + Q_j)
+                const long i = (long)gpe_udiv((unsigned)gr, (unsigned)p.k, p.rcp_k);
+                const long j = p.jg[gr];
                 const float* pp = p.pq + i * p.ldpq + ks + c;
                 const float* qq = p.pq + j * p.ldpq + p.H + ks + c;
-                float4 a = ld4_guard(pp, nvalid, gpe_aligned16(pp));
-                float4 b = ld4_guard(qq, nvalid, gpe_aligned16(qq));
+                const float4 a = ld4_guard(pp, nvalid, gpe_aligned16(pp));
+                const float4 b = ld4_guard(qq, nvalid, gpe_aligned16(qq));
                 v.x = fmaxf(a.x + b.x, 0.f); v.y = fmaxf(a.y + b.y, 0.f);
                 v.z = fmaxf(a.z + b.z, 0.f); v.w = fmaxf(a.w + b.w, 0.f);
-            } else {   // A_DZ3: dz3 = (a3>0) ? [slot==argsel]*s*g - k1 - a3*k2 : 0
-                const long i = gr / p.k;
-                const int slot = (int)(gr - i * p.k);
-                const float* ap = p.a3 + gr * p.lda3 + ks + c;
-                const float* gp = p.g + i * p.ldg + ks + c;
-                float4 a = ld4_guard(ap, nvalid, gpe_aligned16(ap));
-                float4 gg = ld4_guard(gp, nvalid, gpe_aligned16(gp));
-                const float av[4] = {a.x, a.y, a.z, a.w};
-                const float gv[4] = {gg.x, gg.y, gg.z, gg.w};
-                float o[4];
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    o[t] = 0.f;
-                    if (t < nvalid) {
-                        const int cc = ks + c + t;
-                        const float s = p.coef_in[cc];
-                        const float k1 = p.coef_in[p.K + cc];
-                        const float k2 = p.coef_in[2 * p.K + cc];
-                        const uint8_t sel = (s >= 0.f) ? p.amx[i * p.ldagg + cc] : p.amn[i * p.ldagg + cc];
-                        const float hit = (sel == slot) ? s * gv[t] : 0.f;
-                        o[t] = (av[t] > 0.f) ? (hit - k1 - av[t] * k2) : 0.f;
-                    }
-                }
-                v = make_float4(o[0], o[1], o[2], o[3]);
             }
         }
         st4(&As[r * lda + c], v);
@@ -221,118 +149,7 @@ __global__ __launch_bounds__(256, 2) void gpe_rowgemm_kernel(RgParams p)
             for (int r = 0; r < 4; ++r) Cs[(16 * wave + 4 * g + r) * ldc + 16 * n + j] = acc[n][r];
         __syncthreads();
 
-        // ------------------------------------------------------------------------------------------------
-        if (EMODE == E_LINEAR) {
-            const int q4 = (ncols + 3) >> 2;
-            for (int e = tid; e < rv * q4; e += 256) {
-                const int r = e / q4, c = (e - r * q4) << 2;
-                const long gr = row0 + r;
-                float4 v = ld4(&Cs[r * ldc + c]);
-                float o[4] = {v.x, v.y, v.z, v.w};
-                const int nvalid = ncols - c;
-                const float* ad = nullptr;
-                if (p.addend.base) ad = gpe_row_ptr(p.addend, gr) + n0 + c;
-                float* dst;
-                if (p.y_inner <= 0) dst = p.y + gr * p.y_so + n0 + c;
-                else { long oo = gr / p.y_inner; dst = p.y + oo * p.y_so + (gr - oo * p.y_inner) * p.y_si + n0 + c; }
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    if (t < nvalid) {
-                        float x = o[t];
-                        if (p.bias) x += p.bias[n0 + c + t];
-                        if (ad) x += ad[t];
-                        if (p.act == 1) x = fmaxf(x, 0.f);
-                        o[t] = x;
-                    }
-                }
-                if (nvalid >= 4 && gpe_aligned16(dst)) st4(dst, make_float4(o[0], o[1], o[2], o[3]));
-                else {
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) if (t < nvalid) dst[t] = o[t];
-                }
-            }
-        } else if (EMODE == E_EDGE_FWD) {
-            // bias + ReLU in place in LDS; BN statistics per column in fp64
-            if (tid < ncols) {
-                const float bz = p.bias ? p.bias[n0 + tid] : 0.f;
-                for (int r = 0; r < rv; ++r) {
-                    float v = fmaxf(Cs[r * ldc + tid] + bz, 0.f);
-                    Cs[r * ldc + tid] = v;
-                    st_sum += (double)v;
-                    st_sq += (double)v * (double)v;
-                }
-            }
-            __syncthreads();
-            // coalesced row stores (ldo is a multiple of 4; pad columns hold relu(0) = 0)
-            const int q4 = (ncols + 3) >> 2;
-            for (int e = tid; e < rv * q4; e += 256) {
-                const int r = e / q4, c = (e - r * q4) << 2;
-                st4(p.out + (row0 + r) * p.ldo + n0 + c, ld4(&Cs[r * ldc + c]));
-            }
-            if (p.agg) {
-                const int pts = rv / p.k;
-                const long pt0 = row0 / p.k;
-                for (int e = tid; e < pts * ncols; e += 256) {
-                    const int pt = e / ncols, c = e - pt * ncols;
-                    const float* col = &Cs[(pt * p.k) * ldc + c];
-                    float vmx = col[0], vmn = col[0];
-                    int imx = 0, imn = 0;
-                    for (int s = 1; s < p.k; ++s) {
-                        const float v = col[s * ldc];
-                        if (v > vmx) { vmx = v; imx = s; }
-                        if (v < vmn) { vmn = v; imn = s; }
-                    }
-                    const long o = (pt0 + pt) * p.oldagg + n0 + c;
-                    p.mx[o] = vmx; p.mn[o] = vmn;
-                    p.oamx[o] = (uint8_t)imx; p.oamn[o] = (uint8_t)imn;
-                }
-            }
-        } else {   // E_BWD_INPLACE / E_BWD_GATHER : dz = (act>0) ? s*u - k1 - act*k2 : 0  (coef_out = {s,k1,k2})
-            const int q4 = (ncols + 3) >> 2;
-            for (int e = tid; e < rv * q4; e += 256) {
-                const int r = e / q4, c = (e - r * q4) << 2;
-                const long gr = row0 + r;
-                const float4 u4 = ld4(&Cs[r * ldc + c]);
-                float* dst = p.out + gr * p.ldo + n0 + c;
-                float4 act;
-                if (EMODE == E_BWD_INPLACE) {
-                    act = ld4(dst);
-                } else {
-                    const long i = gr / p.k;
-                    const long cloud0 = (i / p.npts) * (long)p.npts;
-                    const long jj = cloud0 + p.idx[gr];
-                    const float4 a = ld4(p.pq + i * p.ldpq + n0 + c);
-                    const float4 b = ld4(p.pq + jj * p.ldpq + p.H + n0 + c);
-                    act = make_float4(fmaxf(a.x + b.x, 0.f), fmaxf(a.y + b.y, 0.f), fmaxf(a.z + b.z, 0.f),
-                                      fmaxf(a.w + b.w, 0.f));
-                }
-                const float uv[4] = {u4.x, u4.y, u4.z, u4.w};
-                const float av[4] = {act.x, act.y, act.z, act.w};
-                float o[4];
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const int cc = n0 + c + t;
-                    o[t] = 0.f;
-                    if (cc < p.N && av[t] > 0.f)
-                        o[t] = uv[t] * p.coef_out[cc] - p.coef_out[p.N + cc] - av[t] * p.coef_out[2 * p.N + cc];
-                }
-                const float4 o4 = make_float4(o[0], o[1], o[2], o[3]);
-                st4(dst, o4);
-                if (EMODE == E_BWD_GATHER) st4(&Cs[r * ldc + c], o4);
-            }
-            if (EMODE == E_BWD_GATHER) {
-                __syncthreads();
-                const int pts = rv / p.k;
-                const long pt0 = row0 / p.k;
-                for (int e = tid; e < pts * ncols; e += 256) {
-                    const int pt = e / ncols, c = e - pt * ncols;
-                    const float* col = &Cs[(pt * p.k) * ldc + c];
-                    float s = 0.f;
-                    for (int t = 0; t < p.k; ++t) s += col[t * ldc];
-                    p.dP[(pt0 + pt) * p.lddp + n0 + c] = s;
-                }
-            }
-        }
+        rg_epilogue<EMODE>(p, Cs, ldc, row0, rv, n0, ncols, st_sum, st_sq);
     }
 
     if (EMODE == E_EDGE_FWD && p.stats_part && tid < ncols) {
@@ -390,6 +207,14 @@ static int rg_pick_nt_single(int N)   // smallest instantiated NT whose block co
     return -1;
 }
 
+// single-stage kernel for latency-bound shapes (gpe_smallgemm.hip)
+int gpe_smallgemm_linear(const RgParams& r, hipStream_t s);
+// register-stationary fast path for the shipped edge-MLP sizes (gpe_edgegemm.hip): 1 launched, 0 not on its menu
+int gpe_edgegemm_try(const RgParams& p, int amode, int emode, int stats_nblk, hipStream_t s);
+
+static int g_gpe_dbg = 0;
+extern "C" int gpe_debug_set(int flags) { g_gpe_dbg = flags; return 0; }
+
 #define GPE_STATS_BLOCKS 512
 extern "C" int gpe_stats_blocks(void) { return GPE_STATS_BLOCKS; }
 
@@ -405,7 +230,9 @@ extern "C" int gpe_linear(const float* a, long a_so, long a_si, int a_inner, con
     p.wp = wp; p.Npad = gpe_round_up(N, 16); p.bias = bias;
     p.addend = GpeRows{addend, ad_so, ad_si, ad_inner};
     p.y = y; p.y_so = y_so; p.y_si = y_si; p.y_inner = y_inner; p.act = act;
-    // widest column block that still gives the chip >= 256 workgroups, else the narrowest (latency-bound case)
+    // latency-bound regime (the streaming kernel could not even put one workgroup on half the CUs): single-stage kernel
+    if ((long)p.num_tiles * gpe_cdiv(N, 208) < 128) return gpe_smallgemm_linear(p, (hipStream_t)stream);
+    // widest column block that still gives the chip >= 256 workgroups, else the narrowest
     int NT = 4;
     const int opts[5] = {16, 13, 10, 7, 4};
     for (int i = 0; i < 5; ++i) {
@@ -419,7 +246,7 @@ extern "C" int gpe_linear(const float* a, long a_so, long a_si, int a_inner, con
     return rg_dispatch_nt<A_DENSE, E_LINEAR>(NT, p, grid, (hipStream_t)stream);
 }
 
-extern "C" int gpe_edge_mlp_fwd(int a_mode, const float* pq, int ldpq, const int32_t* idx, const float* a_in,
+extern "C" int gpe_edge_mlp_fwd(int a_mode, const float* pq, int ldpq, const int32_t* jg, const float* a_in,
                                 int lda, int B, int N, int k, int Cin, int Cout, const float* wp,
                                 const float* bias, float* out, int ldo, double* stats_part, int agg, float* mx,
                                 float* mn, uint8_t* amx, uint8_t* amn, int ldagg, void* stream)
@@ -427,7 +254,7 @@ extern "C" int gpe_edge_mlp_fwd(int a_mode, const float* pq, int ldpq, const int
     if (!wp || !out || B <= 0 || N <= 0 || k <= 0 || k > 64 || Cin <= 0 || Cout <= 0 || Cin > RG_KSLAB ||
         (ldo & 3) || ldo < Cout)
         return GPE_EINVAL;
-    if (a_mode == 0 && (!pq || !idx || (ldpq & 3) || (Cin & 3))) return GPE_EINVAL;
+    if (a_mode == 0 && (!pq || !jg || (ldpq & 3) || (Cin & 3))) return GPE_EINVAL;
     if (a_mode == 1 && (!a_in || lda < Cin)) return GPE_EINVAL;
     if (agg && (!mx || !mn || !amx || !amn || ldagg < Cout)) return GPE_EINVAL;
     const int NT = rg_pick_nt_single(Cout);
@@ -436,40 +263,41 @@ extern "C" int gpe_edge_mlp_fwd(int a_mode, const float* pq, int ldpq, const int
     p.M = (long)B * N * k; p.N = Cout; p.K = Cin;
     p.R = (RG_BM / k) * k; p.num_tiles = gpe_cdiv(p.M, p.R);
     p.a = GpeRows{a_in, lda, 0, 0};
-    p.pq = pq; p.ldpq = ldpq; p.H = Cin; p.idx = idx; p.npts = N; p.k = k;
+    p.pq = pq; p.ldpq = ldpq; p.H = Cin; p.jg = jg; p.k = k; p.rcp_k = 1.0 / k;
     p.wp = wp; p.Npad = gpe_round_up(Cout, 16); p.bias = bias;
     p.out = out; p.ldo = ldo; p.stats_part = stats_part;
     p.agg = agg; p.mx = mx; p.mn = mn; p.oamx = amx; p.oamn = amn; p.oldagg = ldagg;
+    p.dbg = g_gpe_dbg;
+    const int fast = gpe_edgegemm_try(p, a_mode == 0 ? A_GATHER : A_DENSE, E_EDGE_FWD,
+                                      stats_part ? GPE_STATS_BLOCKS : 0, (hipStream_t)stream);
+    if (fast != 0) return fast == 1 ? GPE_OK : fast;
     dim3 grid(GPE_STATS_BLOCKS, 1);
     if (a_mode == 0) return rg_dispatch_nt<A_GATHER, E_EDGE_FWD>(NT, p, grid, (hipStream_t)stream);
     return rg_dispatch_nt<A_DENSE, E_EDGE_FWD>(NT, p, grid, (hipStream_t)stream);
 }
 
-extern "C" int gpe_edge_mlp_bwd(int a_mode, const float* a, int lda, const float* g, int ldg, const uint8_t* amx,
-                                const uint8_t* amn, int ldagg, const float* coef_in, int act_mode,
-                                const float* pq, int ldpq, const int32_t* idx, int B, int N, int k, int Cin,
-                                int Cout, const float* wp, const float* coef_out, float* dz_out, int ldo,
-                                float* dP, int lddp, void* stream)
+extern "C" int gpe_edge_mlp_bwd(const float* a, int lda, int act_mode, const float* pq, int ldpq,
+                                const int32_t* jg, int B, int N, int k, int Cin, int Cout, const float* wp,
+                                const float* coef_out, float* dz_out, int ldo, float* dP, int lddp, void* stream)
 {
     if (!a || !wp || !coef_out || !dz_out || B <= 0 || N <= 0 || k <= 0 || k > 64 || Cin <= 0 || Cout <= 0 ||
         Cin > RG_KSLAB || (ldo & 3) || ldo < Cout || lda < Cin)
         return GPE_EINVAL;
-    if (a_mode == 0 && (!g || !amx || !amn || !coef_in)) return GPE_EINVAL;
-    if (act_mode == 1 && (!pq || !idx || !dP || (ldpq & 3) || (Cout & 3))) return GPE_EINVAL;
+    if (act_mode == 1 && (!pq || !jg || !dP || (ldpq & 3) || (Cout & 3))) return GPE_EINVAL;
     const int NT = rg_pick_nt_single(Cout);
     if (NT < 0) return GPE_EINVAL;
     RgParams p = {};
     p.M = (long)B * N * k; p.N = Cout; p.K = Cin;
     p.R = (RG_BM / k) * k; p.num_tiles = gpe_cdiv(p.M, p.R);
     p.a = GpeRows{a, lda, 0, 0};
-    p.a3 = a; p.lda3 = lda; p.g = g; p.ldg = ldg; p.amx = amx; p.amn = amn; p.ldagg = ldagg; p.coef_in = coef_in;
-    p.pq = pq; p.ldpq = ldpq; p.H = Cout; p.idx = idx; p.npts = N; p.k = k;
+    p.pq = pq; p.ldpq = ldpq; p.H = Cout; p.jg = jg; p.k = k; p.rcp_k = 1.0 / k;
     p.wp = wp; p.Npad = gpe_round_up(Cout, 16);
     p.out = dz_out; p.ldo = ldo; p.coef_out = coef_out; p.dP = dP; p.lddp = lddp;
-    dim3 grid(p.num_tiles < 2048 ? p.num_tiles : 2048, 1);
     hipStream_t s = (hipStream_t)stream;
-    if (a_mode == 0 && act_mode == 0) return rg_dispatch_nt<A_DZ3, E_BWD_INPLACE>(NT, p, grid, s);
-    if (a_mode == 1 && act_mode == 1) return rg_dispatch_nt<A_DENSE, E_BWD_GATHER>(NT, p, grid, s);
-    if (a_mode == 1 && act_mode == 0) return rg_dispatch_nt<A_DENSE, E_BWD_INPLACE>(NT, p, grid, s);
-    return GPE_EINVAL;
+    p.dbg = g_gpe_dbg;
+    const int fast = gpe_edgegemm_try(p, A_DENSE, act_mode == 1 ? E_BWD_GATHER : E_BWD_INPLACE, 0, s);
+    if (fast != 0) return fast == 1 ? GPE_OK : fast;
+    dim3 grid(p.num_tiles < 2048 ? p.num_tiles : 2048, 1);
+    if (act_mode == 1) return rg_dispatch_nt<A_DENSE, E_BWD_GATHER>(NT, p, grid, s);
+    return rg_dispatch_nt<A_DENSE, E_BWD_INPLACE>(NT, p, grid, s);
 }

@@ -74,18 +74,20 @@ def redgemm_raw(u_desc, v_desc, rows, Mg, Ng, want_colsum=True, accumulate_into=
         nb = min(256, Ng - n0)
         ws = torch.empty(L.query('gpe_redgemm_ws', Mg, nb), device=dev, dtype=F32)
         L.call('gpe_redgemm', u_desc[0], u_desc[1], u_desc[2], u_desc[3],
-               v_desc[0][..., n0:], v_desc[1], v_desc[2], v_desc[3],
+               v_desc[0][..., n0:], v_desc[1], v_desc[2], v_desc[3], None,
                rows, Mg, nb, G[:, n0:], G.stride(0), cs if n0 == 0 else None, ws, acc)
     return G, cs
 
 
-def knn(x, B, N, k):
-    """x: [B*N, C] rows (ld = x.stride(0)).  -> int32 [B, N, k] local neighbour indices.
+def knn(x, B, N, k, want_global=False):
+    """x: [B*N, C] rows (ld = x.stride(0)).  -> int32 [B, N, k] local neighbour indices (and, optionally, the same
+    graph as global row numbers b*N + idx, the form the gather kernels consume).
     Replaces torch_cluster.knn under DynamicEdgeConv (nn/net_blocks.py:127-135)."""
     _dev_check(x)
     idx = torch.empty(B, N, k, device=x.device, dtype=torch.int32)
-    L.call('gpe_knn', x, B, N, x.shape[1], x.stride(0), k, idx)
-    return idx
+    jg = torch.empty(B, N, k, device=x.device, dtype=torch.int32) if want_global else None
+    L.call('gpe_knn', x, B, N, x.shape[1], x.stride(0), k, idx, jg)
+    return (idx, jg) if want_global else idx
 
 
 def knn_reverse(idx):
@@ -112,7 +114,7 @@ def bn_from_running(rm, rv, gamma, beta, eps):
 
 def bn_bwd_coef(part, nblk, stats, C, count, want_param_grads=True):
     dev = stats.device
-    coef = torch.empty(3, C, device=dev, dtype=F32)
+    coef = torch.empty(4, C, device=dev, dtype=F32)
     dg = torch.empty(C, device=dev, dtype=F32) if want_param_grads else None
     db = torch.empty(C, device=dev, dtype=F32) if want_param_grads else None
     L.call('gpe_bn_bwd_coef', part, nblk, stats, C, float(count), coef, dg, db)
@@ -213,7 +215,7 @@ class EdgeConvFn(torch.autograd.Function):
         ldF = round_up(Fo, 4)
         nblk = L.query('gpe_stats_blocks')
 
-        idx = knn(x, B, N, k)
+        idx, jg = knn(x, B, N, k, want_global=True)
         # per-point projection: [P|Q] = x [W1a-W1b | W1b]^T + [b1|0]
         wpq = torch.empty(2 * H, C, device=dev, dtype=F32)
         bpq = torch.empty(2 * H, device=dev, dtype=F32)
@@ -228,11 +230,11 @@ class EdgeConvFn(torch.autograd.Function):
 
         part = torch.empty(nblk, 2, H, device=dev, dtype=torch.float64) if training else None
         if training:
-            L.call('gpe_edge_gather_stats', PQ, 2 * H, H, idx, B, N, k, part)
+            L.call('gpe_edge_gather_stats', PQ, 2 * H, H, jg, B, N, k, part)
         st1 = stats_of(part, H, g1, be1, rm1, rv1, nb1)
 
         a2 = torch.empty(E, H, device=dev, dtype=F32)
-        L.call('gpe_edge_mlp_fwd', 0, PQ, 2 * H, idx, None, 0, B, N, k, H, H,
+        L.call('gpe_edge_mlp_fwd', 0, PQ, 2 * H, jg, None, 0, B, N, k, H, H,
                pack_weight(W2, col_scale=st1[2]), fold_bias(W2, b2, st1[3]), a2, H, part,
                0, None, None, None, None, 0)
         st2 = stats_of(part, H, g2, be2, rm2, rv2, nb2)
@@ -252,13 +254,13 @@ class EdgeConvFn(torch.autograd.Function):
         L.call('gpe_edge_finish', mx, mn, ldF, st3, BN, Fo, out, ldF)
 
         ctx.dims = (B, N, k, C, H, Fo, ldF)
-        ctx.save_for_backward(x, idx, PQ, a2, a3, mx, mn, amx, amn, st1, st2, st3, W1, W2, W3, wpq)
+        ctx.save_for_backward(x, idx, jg, PQ, a2, a3, mx, mn, amx, amn, st1, st2, st3, W1, W2, W3, wpq)
         ctx.mark_non_differentiable(idx)
         return out, idx
 
     @staticmethod
     def backward(ctx, g_out, _g_idx):
-        (x, idx, PQ, a2, a3, mx, mn, amx, amn, st1, st2, st3, W1, W2, W3, wpq) = ctx.saved_tensors
+        (x, idx, jg, PQ, a2, a3, mx, mn, amx, amn, st1, st2, st3, W1, W2, W3, wpq) = ctx.saved_tensors
         B, N, k, C, H, Fo, ldF = ctx.dims
         dev = x.device
         BN, E = B * N, B * N * k
@@ -271,33 +273,33 @@ class EdgeConvFn(torch.autograd.Function):
         part = torch.empty(psb, 2, Fo, device=dev, dtype=torch.float64)
         L.call('gpe_edge_bwd_point_sums', g_out, ldg, mx, mn, ldF, st3, BN, Fo, part)
         coef3, dg3, dbe3 = bn_bwd_coef(part, psb, st3, Fo, E)
+        # dz3 in place over a3 (one coalesced pass), then everything downstream reads dense rows
+        L.call('gpe_edge_dz3', a3, ldF, g_out, ldg, amx, amn, ldF, coef3, B, N, k, Fo)
         G3 = torch.empty(Fo, H, device=dev, dtype=F32)
         db3 = torch.empty(Fo, device=dev, dtype=F32)
         ws = torch.empty(max(L.query('gpe_redgemm_ws', Fo, H), L.query('gpe_redgemm_ws', H, H)), device=dev,
                          dtype=F32)
-        L.call('gpe_edge_redgemm', 0, a3, ldF, g_out, ldg, amx, amn, ldF, coef3, 1, a2, H, None, 0, None,
-               B, N, k, Fo, H, G3, H, db3, ws)
+        L.call('gpe_edge_redgemm', a3, ldF, 1, a2, H, None, 0, None, st2[0], B, N, k, Fo, H, G3, H, db3, ws)
         sums = torch.empty(1, 2, H, device=dev, dtype=torch.float64)
         dW3 = torch.empty(Fo, H, device=dev, dtype=F32)
         L.call('gpe_bn_bwd_from_G', G3, H, db3, W3, W3.stride(0), Fo, H, st2, sums, dW3, H)
         coef2, dg2, dbe2 = bn_bwd_coef(sums, 1, st2, H, E)
         # dz2 = (a2>0) ? s2*(dz3 W3) - k1 - a2*k2 : 0, in place over a2
-        L.call('gpe_edge_mlp_bwd', 0, a3, ldF, g_out, ldg, amx, amn, ldF, coef3, 0, None, 0, None,
-               B, N, k, Fo, H, pack_weight(W3, transpose=True), coef2, a2, H, None, 0)
+        L.call('gpe_edge_mlp_bwd', a3, ldF, 0, None, 0, None, B, N, k, Fo, H,
+               pack_weight(W3, transpose=True), coef2, a2, H, None, 0)
 
         # ---- block 2 -----------------------------------------------------------------------------------
         G2 = torch.empty(H, H, device=dev, dtype=F32)
         db2 = torch.empty(H, device=dev, dtype=F32)
-        L.call('gpe_edge_redgemm', 1, a2, H, None, 0, None, None, 0, None, 0, None, 0, PQ, 2 * H, idx,
-               B, N, k, H, H, G2, H, db2, ws)
+        L.call('gpe_edge_redgemm', a2, H, 0, None, 0, PQ, 2 * H, jg, st1[0], B, N, k, H, H, G2, H, db2, ws)
         sums1 = torch.empty(1, 2, H, device=dev, dtype=torch.float64)
         dW2 = torch.empty(H, H, device=dev, dtype=F32)
         L.call('gpe_bn_bwd_from_G', G2, H, db2, W2, W2.stride(0), H, H, st1, sums1, dW2, H)
         coef1, dg1, dbe1 = bn_bwd_coef(sums1, 1, st1, H, E)
         # dz1 = (a1>0) ? s1*(dz2 W2) - k1 - a1*k2 : 0 (a1 re-gathered), in place over a2; dP = sum over slots
         dPQ = torch.empty(BN, 2 * H, device=dev, dtype=F32)
-        L.call('gpe_edge_mlp_bwd', 1, a2, H, None, 0, None, None, 0, None, 1, PQ, 2 * H, idx,
-               B, N, k, H, H, pack_weight(W2, transpose=True), coef1, a2, H, dPQ, 2 * H)
+        L.call('gpe_edge_mlp_bwd', a2, H, 1, PQ, 2 * H, jg, B, N, k, H, H,
+               pack_weight(W2, transpose=True), coef1, a2, H, dPQ, 2 * H)
 
         # ---- block 1: gather backward = deterministic pull through the transposed graph -----------------
         rev_off, rev_edge = knn_reverse(idx)
@@ -349,12 +351,13 @@ class LSTMDecoderFn(torch.autograd.Function):
                 xproj = torch.empty(Bn, T, 4 * Hh, device=dev, dtype=F32)
                 linear_raw(_rows3d(prev_hs[:, 1:]), pack_weight(w_ih), bias, Bn * T, 4 * Hh, Hh,
                            (xproj, 4 * Hh, 0, 0))
-            whh_p = pack_weight(w_hh)
+            whh_p = torch.empty(L.query('gpe_packed_gates_size', Hh, Hh), device=dev, dtype=F32)
+            L.call('gpe_pack_weight_gates', w_hh, w_hh.stride(0), Hh, Hh, whh_p)
             for t in range(T):
-                add = (xproj, 4 * Hh, 0, 0) if l == 0 else (xproj[:, t], T * 4 * Hh, 0, 0)
-                linear_raw((hs[:, t], (T + 1) * Hh, 0, 0), whh_p, None, Bn, 4 * Hh, Hh,
-                           (gates[t], 4 * Hh, 0, 0), 0, add)
-                L.call('gpe_lstm_cell_fwd', gates[t], cs[t], Hh, cs[t + 1], hs[:, t + 1], (T + 1) * Hh, Bn, Hh)
+                xp, xps = (xproj, 4 * Hh) if l == 0 else (xproj[:, t], T * 4 * Hh)
+                # gates = h_{t-1} W_hh^T + xproj_t, cell update, h_t / c_t / activated gates: one launch
+                L.call('gpe_lstm_step_fwd', hs[:, t], (T + 1) * Hh, whh_p, xp, xps, cs[t], Hh,
+                       gates[t], cs[t + 1], hs[:, t + 1], (T + 1) * Hh, Bn, Hh)
             saved_layers += [hs, cs, gates]
             prev_hs = hs
         out_sz = lin_w.shape[0]

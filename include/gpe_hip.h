@@ -23,11 +23,15 @@ extern "C" {
 
 /* version / capability probe (host only, no GPU needed) */
 int gpe_abi_version(void);
+/* profiling aid: ablation switches for the fused edge kernels (0 = production behaviour; results are WRONG otherwise) */
+int gpe_debug_set(int flags);
 
 /* ---- kNN graph: torch_cluster.knn as called by DynamicEdgeConv (nn/net_blocks.py:127-135,174) ------------
  * x [B][N][ldx>=C]; idx [B][N][k] int32, LOCAL to the cloud, ascending (dist, index); self included.
  * dist = fp32 fma chain over channels of (x_c - y_c)^2, ties -> lower index (same rules as oracle/knn_ref.c). */
-int gpe_knn(const float* x, int B, int N, int C, int ldx, int k, int32_t* idx, void* stream);
+int gpe_knn(const float* x, int B, int N, int C, int ldx, int k, int32_t* idx, int32_t* idx_glob, void* stream);
+/* idx_glob (may be NULL) [B][N][k] = b*N + idx: the GLOBAL row of each neighbour, which is what the gather kernels
+ * below take as `jg` (B*N*k must be < 2^31). */
 
 /* reverse adjacency of the kNN graph (needed by the gather's backward = scatter-add into x_j rows):
  * rev_off [B][N+1] int32 (local offsets), rev_edge [B][N*k] int32 = local edge ids (i*k+s) sorted ascending
@@ -59,9 +63,11 @@ int gpe_linear(const float* a, long a_so, long a_si, int a_inner,
  * part: workspace of gpe_redgemm_ws(Mg,Ng) floats.  accumulate != 0 adds into G / colsum. */
 long gpe_redgemm_ws(int Mg, int Ng);
 int gpe_redgemm(const float* u, long u_so, long u_si, int u_inner,
-                const float* v, long v_so, long v_si, int v_inner,
+                const float* v, long v_so, long v_si, int v_inner, const float* v_shift,
                 long rows, int Mg, int Ng, float* G, int ldg, float* colsum, float* part, int accumulate,
                 void* stream);
+/* v_shift (may be NULL) [Ng]: V rows are centred on the fly, G = sum_r U^T (V - shift) — used with shift = BatchNorm
+ * batch mean so the BN-backward covariance term is accumulated without cancellation. */
 
 /* ---- EdgeConv block (PyG DynamicEdgeConv.message + MLP + max aggregation; nn/net_blocks.py:43-47,124-135) ---
  * Algebra used: W1.[x_i, x_j-x_i] = (W1a-W1b).x_i + W1b.x_j = P_i + Q_j, with PQ = [P|Q] [B*N][2H] produced by
@@ -71,7 +77,7 @@ int gpe_redgemm(const float* u, long u_so, long u_si, int u_inner,
 /* stats of a1 = relu(P_i + Q_j) over all E=B*N*k edges: part [nblk][2][H] fp64 partial (sum, sumsq); nblk returned
  * by gpe_stats_blocks().  This is the EdgeConv neighbourhood gather. */
 int gpe_stats_blocks(void);
-int gpe_edge_gather_stats(const float* pq, int ldpq, int H, const int32_t* idx, int B, int N, int k,
+int gpe_edge_gather_stats(const float* pq, int ldpq, int H, const int32_t* jg, int B, int N, int k,
                           double* part, void* stream);
 
 /* BatchNorm finalisation (nn.BatchNorm1d in training mode, nn/net_blocks.py:45): from fp64 partials over `count`
@@ -86,11 +92,11 @@ int gpe_bn_from_running(const float* running_mean, const float* running_var, int
                         const float* beta, float eps, float* stats_out, void* stream);
 
 /* fused per-edge Linear+ReLU (+BN statistics, + max/min aggregation over the k messages of each point).
- * a_mode 0: A rows = relu(P_i+Q_j) gathered through idx (layer 2 of the edge MLP);
+ * a_mode 0: A rows = relu(P_i+Q_j) gathered through the global neighbour rows jg (layer 2 of the edge MLP);
  * a_mode 1: A rows = a_in[e][*] dense (layer 3).
  * out [E][ldo] = relu(A.Wp^T + bias');  stats_part [nblk][2][Cout] fp64 (NULL in eval mode);
  * if agg != 0: mx,mn [B*N][ldagg] = max/min over the k rows of each point, amx/amn uint8 argmax/argmin slot. */
-int gpe_edge_mlp_fwd(int a_mode, const float* pq, int ldpq, const int32_t* idx, const float* a_in, int lda,
+int gpe_edge_mlp_fwd(int a_mode, const float* pq, int ldpq, const int32_t* jg, const float* a_in, int lda,
                      int B, int N, int k, int Cin, int Cout, const float* wp, const float* bias,
                      float* out, int ldo, double* stats_part,
                      int agg, float* mx, float* mn, uint8_t* amx, uint8_t* amn, int ldagg, void* stream);
@@ -105,34 +111,37 @@ int gpe_edge_finish(const float* mx, const float* mn, int ldagg, const float* st
 int gpe_point_sums_blocks(void);
 int gpe_edge_bwd_point_sums(const float* g, int ldg, const float* mx, const float* mn, int ldagg,
                             const float* stats, long rows, int C, double* part, void* stream);
-/* coefficient vectors for "dz = (a>0) ? u - k1 - a*k2 : 0":  coef [3][C] = {s, k1, k2} from partial sums
- * part [nblk][2][C]; also the BatchNorm parameter gradients dgamma = sum dy*xhat, dbeta = sum dy (may be NULL) */
+/* coefficient vectors for "dz = (a>0) ? s*dy - c1 - (a-mean)*k2 : 0":  coef [4][C] = {s, c1 = s*mean(dy),
+ * k2 = s*rstd*mean(dy*xhat), mean} from partial sums part [nblk][2][C]; also the BatchNorm parameter gradients
+ * dgamma = sum dy*xhat, dbeta = sum dy (may be NULL) */
 int gpe_bn_bwd_coef(const double* part, int nblk, const float* stats, int C, double count, float* coef,
                     float* dgamma, float* dbeta, void* stream);
-/* sums for an inner BN from the next layer's weight-gradient: G [Cn][ldG] = dz_next^T a, db [Cn] = colsum dz_next,
- * w_next [Cn][ldw] the UNFOLDED next Linear:  sums[0][c] = sum_f w[f][c]*db[f];
- * sums[1][c] = rstd_c * sum_f w[f][c]*(G[f][c] - mean_c*db[f]);   also emits the true weight gradient
- * dW_next[f][c] = G[f][c]*s_c + db[f]*t_c into dw (ld lddw). */
+/* sums for an inner BN from the next layer's CENTRED weight-gradient product: G [Cn][ldG] = dz_next^T (a - mean)
+ * (gpe_edge_redgemm with v_shift = mean), db [Cn] = colsum dz_next, w_next [Cn][ldw] the UNFOLDED next Linear:
+ *   sums[0][c] = sum_f w[f][c]*db[f];   sums[1][c] = rstd_c * sum_f w[f][c]*G[f][c];
+ * also emits the true weight gradient dW_next[f][c] = G[f][c]*s_c + db[f]*beta_c into dw (ld lddw). */
 int gpe_bn_bwd_from_G(const float* G, int ldG, const float* db, const float* w_next, int ldw, int Cn, int C,
                       const float* stats, double* sums, float* dw, int lddw, void* stream);
 
-/* reduce-GEMM over edges with fused operand producers:
- * u_mode 0: U rows = dz3 built on the fly from (a3, g, argsel, coef) ; u_mode 1: U rows dense [E][ldu]
- * v_mode 0: V rows = relu(P_i+Q_j) gathered ; v_mode 1: V rows dense [E][ldv] */
-int gpe_edge_redgemm(int u_mode, const float* u, int ldu, const float* g, int ldg, const uint8_t* amx,
-                     const uint8_t* amn, int ldagg, const float* coef,
-                     int v_mode, const float* v, int ldv, const float* pq, int ldpq, const int32_t* idx,
-                     int B, int N, int k, int Mg, int Ng, float* G, int ldG, float* colsum, float* part,
-                     void* stream);
+/* dz3 = (a3>0) ? [slot==argsel]*s*g - k1 - a3*k2 : 0 written IN PLACE over the stored activation a3 [E][lda3]
+ * (BN-after-max backward + ReLU backward of the last edge-MLP block; g [B*N][ldg] is the layer-output gradient,
+ * amx/amn the argmax/argmin slots saved by gpe_edge_mlp_fwd, coef [4][F] from gpe_bn_bwd_coef). */
+int gpe_edge_dz3(float* a3, int lda3, const float* g, int ldg, const uint8_t* amx, const uint8_t* amn, int ldagg,
+                 const float* coef, int B, int N, int k, int F, void* stream);
 
-/* propagate + BN/ReLU backward:  u = A.Wp^T ; dz = (act>0) ? s*u - k1 - act*k2 : 0 ; written to dz_out
- * (coef_out [3][Cout] = {s,k1,k2} of the BatchNorm being crossed; Wp = packed TRANSPOSE of the unfolded Linear).
- * a_mode 0: A rows = dz3 on the fly (as above); a_mode 1: A rows dense.
+/* reduce-GEMM over the E edges: G[Mg][Ng] = sum_e U[e][:]^T (V[e][:] - v_shift), colsum[Mg] = sum_e U[e][:];
+ * U dense [E][ldu]; v_mode 0: V rows = relu(P_i+Q_j) gathered through jg (Ng = H) ; v_mode 1: V rows dense [E][ldv];
+ * v_shift [Ng] may be NULL */
+int gpe_edge_redgemm(const float* u, int ldu, int v_mode, const float* v, int ldv, const float* pq, int ldpq,
+                     const int32_t* jg, const float* v_shift, int B, int N, int k, int Mg, int Ng, float* G, int ldG,
+                     float* colsum, float* part, void* stream);
+
+/* propagate + BN/ReLU backward:  u = A.Wp^T ; dz = (act>0) ? s*u - c1 - (act-mean)*k2 : 0 ; written to dz_out
+ * (A dense [E][lda]; coef_out [4][Cout] = {s,c1,k2,mean} of the BatchNorm being crossed; Wp = packed TRANSPOSE of the
+ * unfolded Linear).
  * act_mode 0: act = dz_out's previous contents (in place over the stored activation);
  * act_mode 1: act = relu(P_i+Q_j) gathered, and dP[i] = sum_s dz[(i,s)] is also written (ld lddp). */
-int gpe_edge_mlp_bwd(int a_mode, const float* a, int lda, const float* g, int ldg, const uint8_t* amx,
-                     const uint8_t* amn, int ldagg, const float* coef_in,
-                     int act_mode, const float* pq, int ldpq, const int32_t* idx,
+int gpe_edge_mlp_bwd(const float* a, int lda, int act_mode, const float* pq, int ldpq, const int32_t* jg,
                      int B, int N, int k, int Cin, int Cout, const float* wp, const float* coef_out,
                      float* dz_out, int ldo, float* dP, int lddp, void* stream);
 
@@ -155,6 +164,16 @@ int gpe_lstm_cell_fwd(float* gates, const float* c_prev, long ldc_prev, float* c
 int gpe_lstm_cell_bwd(const float* dh_out, long dho_stride, const float* dh_rec, const float* dc_next,
                       const float* gates, const float* c, const float* c_prev, long ldc_prev,
                       float* dgates, long dg_stride, float* dc_prev, int Bn, int H, void* stream);
+
+/* fused LSTM step (nn.LSTM recurrence, gate order i,f,g,o): gates = h_prev . W_hh^T + xproj (xproj = x_t . W_ih^T + b_ih
+ * + b_hh, rows at xproj + b*xp_stride), then the cell update, in ONE launch.  W_hh must be packed gate-interleaved by
+ * gpe_pack_weight_gates (gpe_packed_gates_size(H, K) floats).  Writes the ACTIVATED gates [Bn][4H] (for backward),
+ * c_out [Bn][H] and h rows at h_out + b*h_stride. */
+long gpe_packed_gates_size(int H, int K);
+int gpe_pack_weight_gates(const float* w, int ldw, int H, int K, float* wp, void* stream);
+int gpe_lstm_step_fwd(const float* h_prev, long hp_stride, const float* whh_gates_packed, const float* xproj,
+                      long xp_stride, const float* c_prev, long ldc_prev, float* gates, float* c_out, float* h_out,
+                      long h_stride, int Bn, int H, void* stream);
 
 /* ---- small helpers --------------------------------------------------------------------------------------- */
 /* y[r][c] (+)= sum over inner index t of x[r][t][c]   (x rows: r*x_so + t*x_si) */
