@@ -1,0 +1,108 @@
+"""not-gpu: the drop-in surface — constructors, config merging, state-dict layout, error types — mirrors the reference
+(SURVEY.md §8b), checked without touching the GPU."""
+import copy
+import os
+
+import pytest
+import torch
+
+import gpe_amd
+from gpe_amd import configs, net_blocks, nets
+
+
+def _full(**over):
+    nn_cfg = configs.lstm_model_config(**over)
+    return nets.GarmentFullPattern3D(configs.data_config(), nn_cfg, copy.deepcopy(nn_cfg['loss'])), nn_cfg
+
+
+def test_state_dict_layout_and_param_count():
+    model, _ = _full()
+    sd = model.state_dict()
+    assert len(sd) == 70
+    assert sum(p.numel() for p in model.parameters()) == 2818765         # SURVEY.md §2.2 [probe]
+    assert sd['feature_extractor.conv_layers.0.nn.0.0.weight'].shape == (200, 6)
+    assert sd['feature_extractor.conv_layers.1.nn.0.0.weight'].shape == (200, 300)
+    assert sd['feature_extractor.conv_layers.1.nn.2.2.running_var'].shape == (150,)
+    assert sd['feature_extractor.conv_layers.0.nn.1.2.num_batches_tracked'].dtype == torch.int64
+    assert sd['panel_decoder.lstm.weight_hh_l2'].shape == (1000, 250)
+    assert sd['panel_decoder.lin.weight'].shape == (8, 250)
+    assert sd['pattern_decoder.lin.weight'].shape == (250, 250)
+    assert sd['placement_decoder.weight'].shape == (7, 250)
+
+
+def test_fixture_state_keys_match(golden_dir):
+    fx = torch.load(os.path.join(golden_dir, 'full3d_shipped.pt'), weights_only=False)
+    torch.manual_seed(fx['seed'])
+    model = nets.GarmentFullPattern3D(fx['data_config'], copy.deepcopy(fx['nn_config']),
+                                      copy.deepcopy(fx['loss_config']))
+    assert [(k, tuple(v.shape)) for k, v in model.state_dict().items()] == [tuple(x) for x in fx['state_keys']]
+    assert sorted(model.config.keys()) == fx['merged_config_keys']
+
+
+def test_config_merge_and_caller_mutation():
+    cfg = {'panel_encoding_size': 64, 'pattern_encoding_size': 48, 'EConv_hidden': 32, 'EConv_feature': 24}
+    loss_cfg = {'panel_origin_invariant_loss': False, 'panel_order_inariant_loss': False}
+    model = nets.GarmentFullPattern3D(configs.data_config(), cfg, loss_cfg)
+    # back-compat: the CALLER's dict gains the hidden sizes (nn/nets.py:75-78)
+    assert cfg['panel_hidden_size'] == 64 and cfg['pattern_hidden_size'] == 48
+    assert model.config['k_neighbors'] == 5 and model.config['EConv_aggr'] == 'max'      # extractor defaults merged
+    assert model.config['loss'] is model.loss.config
+    assert model.config['model'] == 'GarmentFullPattern3D'
+    assert model.panel_decoder.lstm.weight_ih_l0.shape == (256, 64)
+
+
+def test_error_types_match_reference():
+    with pytest.raises(ValueError):
+        net_blocks.EdgeConvFeatures(16, {'global_pool': 'median'})
+    with pytest.raises(NotImplementedError):
+        net_blocks._init_tenzor(2, 3, 4, init_type='xavier')
+    with pytest.raises(AttributeError):
+        _full(feature_extractor='NoSuchExtractor')
+    with pytest.raises(NotImplementedError):        # selectable in the reference, no kernels yet: loud, not silent
+        _full(panel_decoder='GRUDecoderModule')
+
+
+def test_train_eval_forward_to_loss():
+    model, _ = _full()
+    model.eval()
+    assert model.loss.training is False and not model.feature_extractor.conv_layers[0].nn[0][2].training
+    model.train()
+    assert model.loss.training is True
+
+
+def test_vectorised_loss_equals_reference_loop_form():
+    """metrics.PanelLoopLoss (batched) == the oracle's per-panel loop (nn/metrics/losses.py:19-51), value and grad."""
+    from oracle import ref_path as O
+    dc = configs.data_config()
+    nn_cfg = configs.lstm_model_config()
+    ours = gpe_amd.metrics.ComposedPatternLoss(dc, copy.deepcopy(nn_cfg['loss']))
+    theirs = O.ComposedPatternLoss(dc, copy.deepcopy(nn_cfg['loss']))
+    g = torch.Generator().manual_seed(0)
+    B, P, Lp = 3, 23, 14
+    preds = {'outlines': torch.randn(B, P, Lp, 4, generator=g, requires_grad=True),
+             'rotations': torch.randn(B, P, 4, generator=g, requires_grad=True),
+             'translations': torch.randn(B, P, 3, generator=g, requires_grad=True)}
+    gt = {'outlines': torch.randn(B, P, Lp, 4, generator=g), 'rotations': torch.randn(B, P, 4, generator=g),
+          'translations': torch.randn(B, P, 3, generator=g), 'num_edges': torch.randint(0, Lp + 1, (B, P), generator=g)}
+    la, da, _ = ours(preds, {k: v.clone() for k, v in gt.items()}, epoch=0)
+    ga = torch.autograd.grad(la, list(preds.values()))
+    lb, db, _ = theirs(preds, {k: v.clone() for k, v in gt.items()}, epoch=0)
+    gb = torch.autograd.grad(lb, list(preds.values()))
+    assert set(da.keys()) == set(db.keys()) == {'pattern_loss', 'loop_loss', 'rotation_loss', 'translation_loss'}
+    torch.testing.assert_close(la, lb, rtol=1e-6, atol=1e-7)
+    for a, b in zip(ga, gb):
+        torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-8)
+
+
+@pytest.mark.skipif(not os.path.exists('/root/reference/models'), reason='reference tree only exists in the build box')
+def test_configs_equal_shipped_yamls():
+    import yaml
+    for rel, fn in [('models/baseline/lstm_stitch_tags.yaml', configs.lstm_model_config),
+                    ('models/att/att.yaml', configs.att_model_config)]:
+        y = yaml.safe_load(open('/root/reference/' + rel))
+        ref_nn = y['NN']
+        ref_nn.pop('pre-trained')
+        assert fn() == ref_nn
+        for k, v in configs.data_config().items():
+            if k in y['dataset'] and k != 'max_pattern_len':
+                assert y['dataset'][k] == v, k
