@@ -421,6 +421,7 @@ static int eg_dispatch(int NT, int KCH, const RgParams& p, int stats_nblk, hipSt
 int gpe_edgegemm_try(const RgParams& p, int amode, int emode, int stats_nblk, hipStream_t s)
 {
     if (p.N <= 96 || p.N > 208 || p.K <= 96 || p.K > 208) return 0;
+    if (emode != E_EDGE_FWD && (p.N & 3)) return 0;      // the backward epilogues use aligned 16-B coefficient loads
     const int NT = (p.N <= 160) ? 10 : 13;
     const int KCH = (p.K <= 160) ? 10 : 13;
     int rc = GPE_EINVAL;

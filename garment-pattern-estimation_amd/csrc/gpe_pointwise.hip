@@ -680,6 +680,95 @@ extern "C" int gpe_lstm_cell_bwd(const float* dh_out, long dho_stride, const flo
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// sparsemax over rows of width W <= 32 (sparsemax.Sparsemax(dim=1), /root/reference/nn/nets.py:225; Martins &
+// Astudillo 2016): out = max(z - tau, 0), tau from the sorted-cumsum support rule; backward nz*(g - mean_nz(g)).
+// One row per lane, the row sorted in registers by a fully unrolled odd-even transposition network.
+// ---------------------------------------------------------------------------------------------------------
+#define SPX_W 32
+__global__ __launch_bounds__(256) void gpe_sparsemax_fwd_kernel(const float* __restrict__ z, int ldz, long rows, int W,
+                                                                float* __restrict__ out, int ldo)
+{
+    const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    float v[SPX_W];
+#pragma unroll
+    for (int i = 0; i < SPX_W; ++i) v[i] = (i < W) ? z[r * ldz + i] : -INFINITY;
+#pragma unroll
+    for (int pass = 0; pass < SPX_W; ++pass) {
+#pragma unroll
+        for (int i = (pass & 1); i + 1 < SPX_W; i += 2) {
+            const float a = v[i], b = v[i + 1];
+            v[i] = fmaxf(a, b); v[i + 1] = fminf(a, b);          // descending
+        }
+    }
+    float cs = 0.f, tau = 0.f;
+#pragma unroll
+    for (int i = 0; i < SPX_W; ++i) {
+        if (i < W) {
+            cs += v[i];
+            if (1.f + (float)(i + 1) * v[i] > cs) tau = (cs - 1.f) / (float)(i + 1);   // support grows monotonically
+        }
+    }
+    for (int i = 0; i < W; ++i) out[r * ldo + i] = fmaxf(z[r * ldz + i] - tau, 0.f);
+}
+
+__global__ __launch_bounds__(256) void gpe_sparsemax_bwd_kernel(const float* __restrict__ out, int ldo,
+                                                                const float* __restrict__ g, int ldg, long rows, int W,
+                                                                float* __restrict__ gz, int ldgz)
+{
+    const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    float s = 0.f, n = 0.f;
+    for (int i = 0; i < W; ++i)
+        if (out[r * ldo + i] > 0.f) { s += g[r * ldg + i]; n += 1.f; }
+    const float m = (n > 0.f) ? s / n : 0.f;
+    for (int i = 0; i < W; ++i) gz[r * ldgz + i] = (out[r * ldo + i] > 0.f) ? g[r * ldg + i] - m : 0.f;
+}
+
+extern "C" int gpe_sparsemax_fwd(const float* z, int ldz, long rows, int W, float* out, int ldo, void* stream)
+{
+    if (!z || !out || rows < 0 || W <= 0 || W > SPX_W || ldz < W || ldo < W) return GPE_EINVAL;
+    if (rows == 0) return GPE_OK;
+    hipLaunchKernelGGL(gpe_sparsemax_fwd_kernel, dim3(gpe_cdiv(rows, 256)), dim3(256), 0, (hipStream_t)stream, z, ldz,
+                       rows, W, out, ldo);
+    GPE_CHECK_LAUNCH();
+    return GPE_OK;
+}
+
+extern "C" int gpe_sparsemax_bwd(const float* out, int ldo, const float* g, int ldg, long rows, int W, float* gz,
+                                 int ldgz, void* stream)
+{
+    if (!out || !g || !gz || rows < 0 || W <= 0 || ldo < W || ldg < W || ldgz < W) return GPE_EINVAL;
+    if (rows == 0) return GPE_OK;
+    hipLaunchKernelGGL(gpe_sparsemax_bwd_kernel, dim3(gpe_cdiv(rows, 256)), dim3(256), 0, (hipStream_t)stream, out,
+                       ldo, g, ldg, rows, W, gz, ldgz);
+    GPE_CHECK_LAUNCH();
+    return GPE_OK;
+}
+
+// y[r][c] = s[c]*a[r][c] + t[c]   (BatchNorm applied to a stored post-ReLU activation; dense-MLP last layer)
+__global__ void gpe_bn_apply_kernel(const float* __restrict__ a, int lda, const float* __restrict__ stats, long rows,
+                                    int C, float* __restrict__ y, int ldy)
+{
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= rows * C) return;
+    const long r = e / C;
+    const int c = (int)(e - r * C);
+    y[r * ldy + c] = stats[2 * C + c] * a[r * lda + c] + stats[3 * C + c];
+}
+
+extern "C" int gpe_bn_apply(const float* a, int lda, const float* stats, long rows, int C, float* y, int ldy,
+                            void* stream)
+{
+    if (!a || !stats || !y || rows < 0 || C <= 0 || lda < C || ldy < C) return GPE_EINVAL;
+    if (rows == 0) return GPE_OK;
+    hipLaunchKernelGGL(gpe_bn_apply_kernel, dim3(gpe_cdiv(rows * C, 256)), dim3(256), 0, (hipStream_t)stream, a, lda,
+                       stats, rows, C, y, ldy);
+    GPE_CHECK_LAUNCH();
+    return GPE_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // small helpers
 // ---------------------------------------------------------------------------------------------------------
 __global__ void gpe_reduce_inner_kernel(const float* __restrict__ x, long x_so, long x_si, int T, int R, int C,
@@ -753,6 +842,21 @@ __global__ void gpe_add_kernel(const float* a, const float* b, float* out, long 
 {
     const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (e < n) out[e] = a[e] + b[e];
+}
+
+__global__ void gpe_scale_kernel(const float* x, float alpha, float* out, long n)
+{
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < n) out[e] = alpha * x[e];
+}
+
+extern "C" int gpe_scale(const float* x, float alpha, float* out, long n, void* stream)
+{
+    if (!x || !out || n < 0) return GPE_EINVAL;
+    if (n == 0) return GPE_OK;
+    hipLaunchKernelGGL(gpe_scale_kernel, dim3(gpe_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, x, alpha, out, n);
+    GPE_CHECK_LAUNCH();
+    return GPE_OK;
 }
 
 extern "C" int gpe_add(const float* a, const float* b, float* out, long n, void* stream)

@@ -114,3 +114,61 @@ class GarmentFullPattern3D(BaseModule):
 
     def forward(self, positions_batch, **kwargs):
         return self.forward_decode(self.forward_encode(positions_batch))
+
+
+class GarmentSegmentPattern3D(GarmentFullPattern3D):
+    """nn/nets.py:187-299: per-point sparsemax attention over the EdgeConv features -> per-panel pooled encodings ->
+    panel LSTM.  The per-panel Python loop of the reference is one reduce-GEMM per cloud here."""
+
+    def __init__(self, data_config, config={}, in_loss_config={}):
+        if 'loss_components' not in in_loss_config:     # mutates the caller's dict like the reference (:194-199)
+            in_loss_config.update(loss_components=['shape', 'loop', 'rotation', 'translation'],
+                                  quality_components=['shape', 'discrete', 'rotation', 'translation'])
+        super().__init__(data_config, config, in_loss_config)
+        self.save_att_weights = 'segmentation' in self.loss.config['loss_components']
+        if 'local_attention' not in self.config:
+            self.config['local_attention'] = False
+        attention_input_size = self.feature_extractor.config['EConv_feature']
+        if not self.config['local_attention']:
+            attention_input_size += self.config['pattern_encoding_size']
+        if self.config['skip_connections']:
+            attention_input_size += 3
+        # parameter container with the reference's key layout: point_segment_mlp.0.{i}.{0,2}.* ; index 1 is the
+        # parameter-free Sparsemax of the reference's Sequential
+        self.point_segment_mlp = nn.Sequential(
+            blocks.MLP([attention_input_size, attention_input_size, attention_input_size, self.max_pattern_size]),
+            nn.Identity())
+        panel_att_out_size = self.feature_extractor.config['EConv_feature']
+        if self.config['skip_connections']:
+            panel_att_out_size += 3
+        self.panel_dec_lin = nn.Linear(panel_att_out_size, self.feature_extractor.config['panel_encoding_size'])
+        del self.pattern_decoder
+
+    def forward_panel_enc_from_3d(self, positions_batch):
+        batch_size = positions_batch.shape[0]
+        init_pattern_encodings, point_features_flat, batch = self.feature_extractor(
+            positions_batch, not self.config['local_attention'])
+        num_points = point_features_flat.shape[0] // batch_size
+        point_features_flat = point_features_flat.contiguous()
+        if self.config['local_attention']:
+            att_in = point_features_flat
+        else:
+            glob = init_pattern_encodings.unsqueeze(1).repeat(1, num_points, 1).view(
+                [-1, init_pattern_encodings.shape[-1]])
+            att_in = torch.cat([glob, point_features_flat], dim=-1)
+        logits = ops.dense_mlp(att_in, self.point_segment_mlp[0], self.training)
+        points_weights = ops.SparsemaxFn.apply(logits)
+        pooled = ops.AttentionPoolFn.apply(points_weights, point_features_flat, batch_size, num_points)
+        panel_encodings = ops.linear(pooled, self.panel_dec_lin.weight, self.panel_dec_lin.bias)
+        panel_encodings = panel_encodings.view(batch_size, -1, panel_encodings.shape[-1])
+        points_weights = points_weights.view(batch_size, -1, points_weights.shape[-1]) \
+            if self.save_att_weights else []
+        return panel_encodings, points_weights
+
+    def forward(self, positions_batch, **kwargs):
+        batch_size = positions_batch.shape[0]
+        panel_encodings, att_weights = self.forward_panel_enc_from_3d(positions_batch)
+        panels = self.forward_panel_decode(panel_encodings.view(-1, panel_encodings.shape[-1]), batch_size)
+        if len(att_weights) > 0:
+            panels.update(att_weights=att_weights)
+        return panels

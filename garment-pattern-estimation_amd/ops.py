@@ -414,3 +414,170 @@ class LSTMDecoderFn(torch.autograd.Function):
                 linear_raw(dG_rows, pack_weight(w_ih, transpose=True), None, Bn * T, Hh, 4 * Hh, (dH, Hh, 0, 0))
             grads[4 * l: 4 * l + 4] = [d_wih, d_whh, d_b, d_b.clone()]
         return (d_enc, None, None, None, None, d_lin_w, d_lin_b, *grads)
+
+
+# -------------------------------------------------------------------------------------------------
+# attention variant (GarmentSegmentPattern3D)
+# -------------------------------------------------------------------------------------------------
+class DenseMLPFn(torch.autograd.Function):
+    """MLP(channels) = [Linear -> ReLU -> BatchNorm1d] x n on dense rows (nn/net_blocks.py:43-47 as used by
+    point_segment_mlp, nn/nets.py:223-226).  Same kernels as the edge MLP with one "message" per row (k = 1):
+    fused Linear+ReLU(+fp64 BN statistics), every BatchNorm folded into the next Linear, the last one applied
+    explicitly; backward = the edge MLP's chain (centred reduce-GEMM -> BN coefficients -> propagate in place)."""
+
+    @staticmethod
+    def forward(ctx, x, training, eps, momentum, n_blocks, *tensors):
+        _dev_check(x)
+        dev = x.device
+        M = x.shape[0]
+        nblk = L.query('gpe_stats_blocks')
+        params = tensors[:4 * n_blocks]
+        bufs = tensors[4 * n_blocks:]
+        acts, stats = [], []
+        a_in, Cin = x, x.shape[1]
+        scale = tvec = None
+        for l in range(n_blocks):
+            W, b, g, be = params[4 * l: 4 * l + 4]
+            rm, rv, nb = bufs[3 * l: 3 * l + 3]
+            Cout = W.shape[0]
+            ldo = round_up(Cout, 4)
+            a = torch.empty(M, ldo, device=dev, dtype=F32)
+            part = torch.empty(nblk, 2, Cout, device=dev, dtype=torch.float64) if training else None
+            L.call('gpe_edge_mlp_fwd', 1, None, 0, None, a_in, a_in.stride(0), 1, M, 1, Cin, Cout,
+                   pack_weight(W, col_scale=scale), b if tvec is None else fold_bias(W, b, tvec), a, ldo, part,
+                   0, None, None, None, None, 0)
+            st = bn_finalize(part, nblk, Cout, M, g, be, eps, momentum, rm, rv, nb) if training \
+                else bn_from_running(rm, rv, g, be, eps)
+            acts.append(a)
+            stats.append(st)
+            scale, tvec = st[2], st[3]
+            a_in, Cin = a, Cout
+        y = torch.empty(M, Cin, device=dev, dtype=F32)
+        L.call('gpe_bn_apply', a_in, a_in.stride(0), stats[-1], M, Cin, y, Cin)
+        ctx.n_blocks = n_blocks
+        ctx.save_for_backward(x, *params, *acts, *stats)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        n = ctx.n_blocks
+        sv = ctx.saved_tensors
+        x, params, acts, stats = sv[0], sv[1:1 + 4 * n], sv[1 + 4 * n:1 + 5 * n], sv[1 + 5 * n:1 + 6 * n]
+        dev = x.device
+        M = x.shape[0]
+        gy = gy.contiguous()
+        grads = [None] * (4 * n)
+        # last block: BN applied explicitly -> same algebra as the edge layer's BN-after-max with one slot per row
+        a, st = acts[-1], stats[-1]
+        C = params[4 * (n - 1)].shape[0]
+        psb = L.query('gpe_point_sums_blocks')
+        part = torch.empty(psb, 2, C, device=dev, dtype=torch.float64)
+        L.call('gpe_edge_bwd_point_sums', gy, C, a, a, a.stride(0), st, M, C, part)
+        coef, dgam, dbet = bn_bwd_coef(part, psb, st, C, M)
+        slot0 = torch.zeros(M, a.stride(0), device=dev, dtype=torch.uint8)
+        L.call('gpe_edge_dz3', a, a.stride(0), gy, C, slot0, slot0, a.stride(0), coef, 1, M, 1, C)
+        grads[4 * (n - 1) + 2], grads[4 * (n - 1) + 3] = dgam, dbet
+        for l in reversed(range(n)):
+            W = params[4 * l]
+            dz = acts[l]                          # holds dz_l now
+            C = W.shape[0]
+            if l > 0:
+                prev, stp = acts[l - 1], stats[l - 1]
+                Cp = params[4 * (l - 1)].shape[0]
+                G = torch.empty(C, Cp, device=dev, dtype=F32)
+                db = torch.empty(C, device=dev, dtype=F32)
+                ws = torch.empty(L.query('gpe_redgemm_ws', C, Cp), device=dev, dtype=F32)
+                L.call('gpe_edge_redgemm', dz, dz.stride(0), 1, prev, prev.stride(0), None, 0, None, stp[0],
+                       1, M, 1, C, Cp, G, Cp, db, ws)
+                sums = torch.empty(1, 2, Cp, device=dev, dtype=torch.float64)
+                dW = torch.empty(C, Cp, device=dev, dtype=F32)
+                L.call('gpe_bn_bwd_from_G', G, Cp, db, W, W.stride(0), C, Cp, stp, sums, dW, Cp)
+                coef_p, dgam_p, dbet_p = bn_bwd_coef(sums, 1, stp, Cp, M)
+                L.call('gpe_edge_mlp_bwd', dz, dz.stride(0), 0, None, 0, None, 1, M, 1, C, Cp,
+                       pack_weight(W, transpose=True), coef_p, prev, prev.stride(0), None, 0)
+                grads[4 * l], grads[4 * l + 1] = dW, db
+                grads[4 * (l - 1) + 2], grads[4 * (l - 1) + 3] = dgam_p, dbet_p
+            else:
+                K0 = x.shape[1]
+                dW, db = redgemm_raw((dz, dz.stride(0), 0, 0), _rows2d(x), M, C, K0)
+                grads[0], grads[1] = dW, db
+        gx = None
+        if ctx.needs_input_grad[0]:
+            dz0, W0 = acts[0], params[0]
+            gx = torch.empty(M, x.shape[1], device=dev, dtype=F32)
+            linear_raw((dz0, dz0.stride(0), 0, 0), pack_weight(W0, transpose=True), None, M, x.shape[1],
+                       W0.shape[0], _rows2d(gx))
+        return (gx, None, None, None, None, *grads, *([None] * (3 * n)))
+
+
+def dense_mlp(x, mlp, training):
+    """mlp: the nn.Sequential parameter container built by net_blocks.MLP."""
+    blocks = [mlp[i] for i in range(len(mlp))]
+    params, bufs = [], []
+    for blk in blocks:
+        params += [blk[0].weight, blk[0].bias, blk[2].weight, blk[2].bias]
+        bufs += [blk[2].running_mean, blk[2].running_var, blk[2].num_batches_tracked]
+    x = x if x.stride(1) == 1 else x.contiguous()
+    return DenseMLPFn.apply(x, training, blocks[0][2].eps, blocks[0][2].momentum, len(blocks), *params, *bufs)
+
+
+class SparsemaxFn(torch.autograd.Function):
+    """sparsemax.Sparsemax(dim=1) (nn/nets.py:225)."""
+
+    @staticmethod
+    def forward(ctx, z):
+        _dev_check(z)
+        z = z.contiguous()
+        M, W = z.shape
+        out = torch.empty_like(z)
+        L.call('gpe_sparsemax_fwd', z, W, M, W, out, W)
+        ctx.save_for_backward(out)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        out, = ctx.saved_tensors
+        g = g.contiguous()
+        M, W = out.shape
+        gz = torch.empty_like(out)
+        L.call('gpe_sparsemax_bwd', out, W, g, W, M, W, gz, W)
+        return gz
+
+
+class AttentionPoolFn(torch.autograd.Function):
+    """pooled[b, p, :] = mean_n w[b, n, p] * feat[b, n, :]  — the reference's 23-iteration loop of
+    `w[:, p] * features -> global_mean_pool` (nn/nets.py:263-276) as one reduce-GEMM [P x N].[N x C] per cloud."""
+
+    @staticmethod
+    def forward(ctx, w, feat, B, N):
+        _dev_check(w)
+        dev = w.device
+        P, C = w.shape[1], feat.shape[1]
+        pooled = torch.empty(B, P, C, device=dev, dtype=F32)
+        for b in range(B):
+            G = pooled[b]
+            ws = torch.empty(L.query('gpe_redgemm_ws', P, C), device=dev, dtype=F32)
+            L.call('gpe_redgemm', w[b * N:(b + 1) * N], w.stride(0), 0, 0, feat[b * N:(b + 1) * N], feat.stride(0),
+                   0, 0, None, N, P, C, G, C, None, ws, 0)
+        L.call('gpe_scale', pooled, 1.0 / N, pooled, pooled.numel())
+        ctx.dims = (B, N, P, C)
+        ctx.save_for_backward(w, feat)
+        return pooled.view(B * P, C)
+
+    @staticmethod
+    def backward(ctx, g):
+        w, feat = ctx.saved_tensors
+        B, N, P, C = ctx.dims
+        dev = w.device
+        g = g.contiguous().view(B, P, C)
+        gs = torch.empty_like(g)
+        L.call('gpe_scale', g, 1.0 / N, gs, g.numel())
+        gw = torch.empty(B * N, P, device=dev, dtype=F32)
+        gf = torch.empty(B * N, C, device=dev, dtype=F32)
+        for b in range(B):
+            sl = slice(b * N, (b + 1) * N)
+            # dw[n, p] = sum_c feat[n, c] * gs[b, p, c]
+            linear_raw(_rows2d(feat[sl]), pack_weight(gs[b]), None, N, P, C, _rows2d(gw[sl]))
+            # dfeat[n, c] = sum_p w[n, p] * gs[b, p, c]
+            linear_raw(_rows2d(w[sl]), pack_weight(gs[b], transpose=True), None, N, C, P, _rows2d(gf[sl]))
+        return gw, gf, None, None

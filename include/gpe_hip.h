@@ -175,6 +175,14 @@ int gpe_lstm_step_fwd(const float* h_prev, long hp_stride, const float* whh_gate
                       long xp_stride, const float* c_prev, long ldc_prev, float* gates, float* c_out, float* h_out,
                       long h_stride, int Bn, int H, void* stream);
 
+/* ---- attention variant (GarmentSegmentPattern3D, nn/nets.py:187-299) ------------------------------------------ */
+/* sparsemax.Sparsemax(dim=1) over rows of width W <= 32 (nn/nets.py:225): forward and backward */
+int gpe_sparsemax_fwd(const float* z, int ldz, long rows, int W, float* out, int ldo, void* stream);
+int gpe_sparsemax_bwd(const float* out, int ldo, const float* g, int ldg, long rows, int W, float* gz, int ldgz,
+                      void* stream);
+/* y = s*a + t with {s,t} = stats rows 2,3: BatchNorm of a stored post-ReLU activation (last block of a dense MLP) */
+int gpe_bn_apply(const float* a, int lda, const float* stats, long rows, int C, float* y, int ldy, void* stream);
+
 /* ---- small helpers --------------------------------------------------------------------------------------- */
 /* y[r][c] (+)= sum over inner index t of x[r][t][c]   (x rows: r*x_so + t*x_si) */
 int gpe_reduce_inner(const float* x, long x_so, long x_si, int T, int R, int C, float* y, int ldy,
@@ -184,6 +192,8 @@ int gpe_w1_grad_from_pq(const float* dwpq, int ld, int H, int C, float* dw1, int
 /* Wpq [2H][C] from W1 [H][2C]: rows 0..H-1 = W1a - W1b, rows H..2H-1 = W1b; bias_pq = [b1 | 0] */
 int gpe_w1_split(const float* w1, int ldw1, const float* b1, int H, int C, float* wpq, int ldwpq, float* bias_pq,
                  void* stream);
+/* out = alpha * x (n floats; out may alias x) */
+int gpe_scale(const float* x, float alpha, float* out, long n, void* stream);
 /* out = a + b (n floats) */
 int gpe_add(const float* a, const float* b, float* out, long n, void* stream);
 

@@ -257,3 +257,75 @@ def test_lstm_decoder_fwd_bwd(gpe, Bn, In, Hh, T, L, Out):
     for n, p in o64.named_parameters():
         e = relerr(pn[n].grad, p.grad)
         assert e < 1e-4, (n, e)
+
+
+# --------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('M,chans', [(300, [27, 27, 27, 23]), (1000, [153, 153, 153, 23]), (130, [16, 200, 200, 200, 1])])
+def test_dense_mlp_fwd_bwd(gpe, M, chans):
+    from oracle import ref_path as O
+    torch.manual_seed(M)
+    omlp = O.MLP(chans)
+    with torch.no_grad():
+        for blk in omlp:
+            blk[2].weight.uniform_(0.5, 1.5)
+            blk[2].bias.uniform_(-0.3, 0.3)
+        omlp[-1][2].weight[::3] *= -1
+    pmlp = gpe.net_blocks.MLP(chans)
+    pmlp.load_state_dict(omlp.state_dict())
+    pmlp = pmlp.cuda().train()
+    x = torch.randn(M, chans[0], generator=torch.Generator().manual_seed(1))
+    wgt = torch.randn(M, chans[-1], generator=torch.Generator().manual_seed(2))
+    o64 = copy.deepcopy(omlp).double().train()
+    xr = x.double().requires_grad_()
+    yr = o64(xr)
+    (yr * wgt.double()).sum().backward()
+    xd = x.cuda().requires_grad_()
+    y = gpe.ops.dense_mlp(xd, pmlp, True)
+    (y * wgt.cuda()).sum().backward()
+    o32 = copy.deepcopy(omlp).train()
+    e32 = relerr(o32(x), yr)
+    assert relerr(y, yr) < max(5e-5, 20 * e32)
+    assert relerr(xd.grad, xr.grad) < 3e-4
+    pn = dict(pmlp.named_parameters())
+    for n, p in o64.named_parameters():
+        e = relerr(pn[n].grad, p.grad)
+        assert e < (5e-3 if p.grad.dim() == 1 else 5e-4), (n, e)
+    pb = dict(pmlp.named_buffers())
+    for n, b in o64.named_buffers():
+        if 'num_batches' in n:
+            assert pb[n].item() == b.item()
+        else:
+            assert relerr(pb[n], b) < 1e-5, n
+
+
+def test_sparsemax_fwd_bwd(gpe):
+    from oracle import ref_path as O
+    g = torch.Generator().manual_seed(3)
+    z = torch.randn(5000, 23, generator=g) * 2
+    gy = torch.randn(5000, 23, generator=g)
+    zr = z.double().requires_grad_()
+    pr = O.Sparsemax(dim=1)(zr)
+    pr.backward(gy.double())
+    zd = z.cuda().requires_grad_()
+    pd = gpe.ops.SparsemaxFn.apply(zd)
+    pd.backward(gy.cuda())
+    assert relerr(pd, pr) < 2e-6
+    assert torch.equal(pd.cpu() > 0, pr > 0)                     # identical support
+    assert relerr(zd.grad, zr.grad) < 2e-6
+
+
+def test_attention_pool_fwd_bwd(gpe):
+    B, N, P, C = 3, 200, 23, 27
+    g = torch.Generator().manual_seed(4)
+    w = torch.rand(B * N, P, generator=g)
+    f = torch.randn(B * N, C, generator=g)
+    gy = torch.randn(B * P, C, generator=g)
+    wr, fr = w.double().requires_grad_(), f.double().requires_grad_()
+    ref = torch.einsum('bnp,bnc->bpc', wr.view(B, N, P), fr.view(B, N, C)) / N
+    ref.reshape(B * P, C).backward(gy.double())
+    wd, fd = w.cuda().requires_grad_(), f.cuda().requires_grad_()
+    out = gpe.ops.AttentionPoolFn.apply(wd, fd, B, N)
+    out.backward(gy.cuda())
+    assert relerr(out, ref.reshape(B * P, C)) < 3e-6
+    assert relerr(wd.grad, wr.grad) < 3e-6
+    assert relerr(fd.grad, fr.grad) < 3e-6
