@@ -29,6 +29,7 @@ struct RdParams {
     GpeRows v;                                   // V_DENSE
     const float* pq; int ldpq; int H; const int32_t* jg; int k; double rcp_k;   // V_GATHER (global neighbour rows)
     const float* v_shift;                        // optional [Ng]: V := V - shift on valid rows (BN centring)
+    int vec;                                     // rows aligned to 16 B and padded to 4 columns: plain 16-B loads
     float* part;                                 // [gridDim.x][MgPad][NgPad]
     double* part_cs;                             // [gridDim.x][MgPad]
 };
@@ -94,8 +95,10 @@ __global__ __launch_bounds__(256, 1) void gpe_redgemm_kernel(RdParams p)
         for (int n = 0; n < NH; ++n) acc[q][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
     double cs = 0.0;
 
-    // operand staging: lane = column quad, rows = wave + 4*q (wave-uniform: row scalars computed once per wave),
-    // fetched global -> registers one tile ahead of the MFMAs that consume them
+    // operand staging: lane = column quad, rows = wave + 4*q (wave-uniform), fetched global -> registers one tile
+    // ahead of the MFMAs that consume them.  With p.vec (aligned, padded rows: every internal edge buffer) each row is
+    // ONE plain 16-B load per lane, unconditional with a clamped row, so all RQ loads stay in flight; the guarded
+    // scalar-tail loader (whose two paths force a wait between loads) is only for ragged external tensors.
     constexpr int RQ = RD_RT / 4;
     const int uwave = __builtin_amdgcn_readfirstlane(wave);
     const int cq = lane << 2;
@@ -113,6 +116,25 @@ __global__ __launch_bounds__(256, 1) void gpe_redgemm_kernel(RdParams p)
         const long row0 = (long)tile * RD_RT;
         const int rv = (int)((p.rows - row0 < RD_RT) ? (p.rows - row0) : RD_RT);
         rmask = 0;
+        if (p.vec) {
+#pragma unroll
+            for (int q = 0; q < RQ; ++q) {
+                const int r = uwave + 4 * q;
+                if (r < rv) rmask |= 1u << q;
+                const long gr = row0 + ((r < rv) ? r : rv - 1);          // clamped: the load is unconditional
+                if (u_on) ur[q] = rd_ld4(p.u.base + gr * p.u.stride_outer + m0 + cq);
+                if (v_on) {
+                    if (VMODE == V_DENSE) vr[q] = rd_ld4(p.v.base + gr * p.v.stride_outer + cq);
+                    else {
+                        const long i = (long)gpe_udiv((unsigned)gr, (unsigned)p.k, p.rcp_k);
+                        const long jj = p.jg[gr];
+                        vr[q] = rd_ld4(p.pq + i * p.ldpq + cq);
+                        vr2[q] = rd_ld4(p.pq + jj * p.ldpq + p.H + cq);
+                    }
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int q = 0; q < RQ; ++q) {
             const int r = uwave + 4 * q;
@@ -146,18 +168,29 @@ __global__ __launch_bounds__(256, 1) void gpe_redgemm_kernel(RdParams p)
 #pragma unroll
         for (int q = 0; q < RQ; ++q) {
             const int r = uwave + 4 * q;
-            if (cq < UC) *reinterpret_cast<float4*>(&ub[r * LDU + cq]) = ur[q];
+            const bool ok = (rmask >> q) & 1u;
+            if (cq < UC) {
+                float4 u = ur[q];
+                if (!(ok && u_on)) u = make_float4(0.f, 0.f, 0.f, 0.f);
+                else {                                              // ragged last quad (padded columns are not data)
+                    if (cq + 1 >= ucols) u.y = 0.f;
+                    if (cq + 2 >= ucols) u.z = 0.f;
+                    if (cq + 3 >= ucols) u.w = 0.f;
+                }
+                *reinterpret_cast<float4*>(&ub[r * LDU + cq]) = u;
+            }
             if (cq < VC) {
                 float4 v = vr[q];
                 if (VMODE == V_GATHER) {
                     v.x = fmaxf(v.x + vr2[q].x, 0.f); v.y = fmaxf(v.y + vr2[q].y, 0.f);
                     v.z = fmaxf(v.z + vr2[q].z, 0.f); v.w = fmaxf(v.w + vr2[q].w, 0.f);
                 }
-                if ((rmask >> q) & 1u) {
-                    if (cq < p.Ng) v.x -= sh[0];
-                    if (cq + 1 < p.Ng) v.y -= sh[1];
-                    if (cq + 2 < p.Ng) v.z -= sh[2];
-                    if (cq + 3 < p.Ng) v.w -= sh[3];
+                v.x -= sh[0]; v.y -= sh[1]; v.z -= sh[2]; v.w -= sh[3];
+                if (!(ok && v_on)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                else {
+                    if (cq + 1 >= p.Ng) v.y = 0.f;
+                    if (cq + 2 >= p.Ng) v.z = 0.f;
+                    if (cq + 3 >= p.Ng) v.w = 0.f;
                 }
                 *reinterpret_cast<float4*>(&vb[r * LDV + cq]) = v;
             }
@@ -328,9 +361,17 @@ static int rd_dispatch(int MH, int NH, const RdParams& p, dim3 grid, hipStream_t
     return GPE_EINVAL;
 }
 
+static bool rd_rows_vec(const GpeRows& r, int cols)
+{
+    return r.inner <= 0 && !(r.stride_outer & 3) && r.stride_outer >= ((cols + 3) & ~3) && !(((uintptr_t)r.base) & 15);
+}
+
 static int rd_run(RdParams& p, int vmode, float* G, int ldG, float* colsum, float* part, int accumulate,
                   hipStream_t s)
 {
+    // measured (scripts/ablate_edge.py): in this single-role kernel the burst of unconditional loads stalls the MFMA
+    // stream more than the guarded loader does; kept off until the kernel is split into producer/consumer waves
+    p.vec = 0 && rd_rows_vec(p.u, p.Mg) && (vmode == V_GATHER || rd_rows_vec(p.v, p.Ng));
     int MH, NH, gy, MgPad, NgPad;
     rd_geometry(p.Mg, p.Ng, &MH, &NH, &gy, &MgPad, &NgPad);
     if (MH < 0 || NH < 0) return GPE_EINVAL;
