@@ -93,6 +93,7 @@ def cpu_baseline(args, data_config, nn_cfg):
     # op mix; 32 threads is the measured sweet spot class for oneDNN/MKL at these sizes
     ncores = min(os.cpu_count() or 1, args.cpu_threads)
     torch.set_num_threads(ncores)
+    O.KNN_IMPL = 'torch'          # cdist+topk: a fair CPU kNN (the parity oracle's scalar C loop is a definition, not a baseline)
     torch.manual_seed(0)
     model = O.GarmentFullPattern3D(data_config, copy.deepcopy(nn_cfg), copy.deepcopy(nn_cfg['loss'])).train()
     feats, gt = O.synthetic_batch(args.cpu_batch, args.points, data_config, seed=0)
@@ -112,8 +113,9 @@ def cpu_baseline(args, data_config, nn_cfg):
                     break
     except OSError:
         pass
+    O.KNN_IMPL = 'c'
     return {'value': args.cpu_batch / t, 'unit': 'garments/s', 'cores': ncores, 'kind': 'port',
-            'sample': 'oracle/ref_path.py fwd+loss+bwd, B=%d N=%d k=%d fp32, 1 warm-up + %d timed steps, %.2f s/step'
+            'sample': 'oracle/ref_path.py (kNN by cdist+topk) fwd+loss+bwd, B=%d N=%d k=%d fp32, 1 warm-up + %d timed steps, %.2f s/step'
                       % (args.cpu_batch, args.points, args.k, args.cpu_steps, t),
             'cpu': cpu_name}
 

@@ -61,10 +61,26 @@ def _oracle_lib():
 # ---------------------------------------------------------------------------------------------
 # third-party ops restated (parity unpinned, see module docstring)
 # ---------------------------------------------------------------------------------------------
+# 'c'     : oracle/knn_ref.c — THE definition (fp32 fmaf chain, ties -> lower index); what every parity test uses.
+# 'torch' : cdist + topk in torch — same neighbours except at fp32 near-ties; used ONLY by bench.py's cpu_baseline leg,
+#           where the naive scalar C loop (O(N^2 C), one thread) would misrepresent what a CPU can do.
+KNN_IMPL = 'c'
+
+
+def _knn_torch(x, n_clouds, k):
+    total, C = x.shape
+    N = total // n_clouds
+    xb = x.detach().to(torch.float32).view(n_clouds, N, C)
+    d = torch.cdist(xb, xb)
+    return d.topk(k, dim=-1, largest=False, sorted=True).indices.reshape(total, k)
+
+
 def knn_local(x, n_clouds, k):
     """Per-cloud exact kNN incl. self; x: [B*N, C] (any float dtype, evaluated in fp32).
     Returns LongTensor [B*N, k] of indices LOCAL to each cloud, ascending distance, ties -> lower index.
     Restates torch_cluster.knn as used by DynamicEdgeConv (call sites nn/net_blocks.py:127-135)."""
+    if KNN_IMPL == 'torch':
+        return _knn_torch(x, n_clouds, k)
     total, C = x.shape
     N = total // n_clouds
     xf = np.ascontiguousarray(x.detach().to(torch.float32).cpu().numpy())
