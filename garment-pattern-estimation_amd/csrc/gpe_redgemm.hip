@@ -259,6 +259,208 @@ __global__ __launch_bounds__(256, 1) void gpe_redgemm_kernel(RdParams p)
     if (tid < ucols) p.part_cs[(size_t)blockIdx.x * p.MgPad + m0 + tid] = cs;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Producer/consumer variant for the two edge shapes (tile grids 13x13 and 10x13): one persistent 512-thread workgroup
+// per CU, two waves per SIMD.
+//   consumers (waves 0-3): 2x2 blocks of (MT/2) x (NT/2) accumulator tiles, nothing but ds_read_b32 operands + MFMAs;
+//   producers (waves 4-7): fetch the next 32-row tile (plain 16-B loads of aligned rows; gather = P_i + Q_j), commit it
+//                          to the other LDS buffer, keep the fp64 column sums of U from their staging registers, and
+//                          compute the left-over tile row / column (MT or NT odd) so each SIMD carries ~MT*NT/4 tiles.
+// One barrier per tile.  Requires p.vec (aligned, 4-padded rows) — true for every internal edge buffer.
+// ---------------------------------------------------------------------------------------------------------
+template <int MT, int NT, int VMODE>
+__global__ __launch_bounds__(512, 2) void gpe_redgemm_pc_kernel(RdParams p)
+{
+    constexpr int MB = MT / 2, NB = NT / 2;
+    constexpr int LEFT = (MT & 1) * NT + (NT & 1) * (MT - (MT & 1));     // left-over tiles
+    constexpr int PMAX = (LEFT + 3) / 4;
+    constexpr int UC = 16 * MT, VC = 16 * NT;
+    constexpr int LDU = (UC % 32 == 16) ? UC : UC + 16;
+    constexpr int LDV = (VC % 32 == 16) ? VC : VC + 16;
+    constexpr int RQ = RD_RT / 4;
+    extern __shared__ __align__(16) float smem[];
+    float* Us = smem;                              // [2][RD_RT * LDU]
+    float* Vs = smem + 2 * RD_RT * LDU;            // [2][RD_RT * LDV]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int w4 = wave & 3;
+    const int j = lane & 15, g = lane >> 4;
+    float* dst = p.part + (size_t)blockIdx.x * p.MgPad * p.NgPad;
+
+    if (wave < 4) {
+        // ================================ consumers ================================
+        const int mt0 = (w4 & 1) * MB, nt0 = (w4 >> 1) * NB;
+        f32x4 acc[MB][NB];
+#pragma unroll
+        for (int q = 0; q < MB; ++q)
+#pragma unroll
+            for (int n = 0; n < NB; ++n) acc[q][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        __syncthreads();                           // prologue: tile 0 staged
+        int buf = 0;
+        for (int tile = blockIdx.x; tile < p.num_tiles; tile += gridDim.x) {
+            const float* ub = Us + buf * RD_RT * LDU;
+            const float* vb = Vs + buf * RD_RT * LDV;
+#pragma unroll
+            for (int r0 = 0; r0 < RD_RT; r0 += 4) {
+                float a[MB], b[NB];
+#pragma unroll
+                for (int q = 0; q < MB; ++q) a[q] = ub[(r0 + g) * LDU + 16 * (mt0 + q) + j];
+#pragma unroll
+                for (int n = 0; n < NB; ++n) b[n] = vb[(r0 + g) * LDV + 16 * (nt0 + n) + j];
+#pragma unroll
+                for (int q = 0; q < MB; ++q)
+#pragma unroll
+                    for (int n = 0; n < NB; ++n)
+                        acc[q][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q], b[n], acc[q][n], 0, 0, 0);
+            }
+            __syncthreads();
+            buf ^= 1;
+        }
+#pragma unroll
+        for (int q = 0; q < MB; ++q)
+#pragma unroll
+            for (int n = 0; n < NB; ++n)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    dst[(size_t)(16 * (mt0 + q) + 4 * g + r) * p.NgPad + 16 * (nt0 + n) + j] = acc[q][n][r];
+        __syncthreads();                           // tail: producers' column sums in LDS
+    } else {
+        // ================================ producers ================================
+        const int cq = lane << 2;
+        const bool u_on = cq < p.Mg, v_on = cq < p.Ng;
+        const int cu = u_on ? cq : 0, cv = v_on ? cq : 0;
+        float sh[4] = {0.f, 0.f, 0.f, 0.f};
+        if (p.v_shift && v_on) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) if (cq + t < p.Ng) sh[t] = p.v_shift[cq + t];
+        }
+        // my left-over tiles: list index t = w4, w4+4, ...  ->  (m, n)
+        int offU[PMAX > 0 ? PMAX : 1], offV[PMAX > 0 ? PMAX : 1];
+        int my_count = 0;
+#pragma unroll
+        for (int s_ = 0; s_ < PMAX; ++s_) {
+            const int t = w4 + 4 * s_;
+            int m = 0, n = 0;
+            if (t < LEFT) {
+                ++my_count;
+                if ((MT & 1) && t < NT) { m = MT - 1; n = t; }
+                else { const int t2 = t - (MT & 1) * NT; m = t2; n = NT - 1; }
+            }
+            offU[s_] = 16 * m; offV[s_] = 16 * n;
+        }
+        f32x4 accP[PMAX > 0 ? PMAX : 1];
+#pragma unroll
+        for (int s_ = 0; s_ < (PMAX > 0 ? PMAX : 1); ++s_) accP[s_] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        double csd[4] = {0, 0, 0, 0};
+        float4 ur[RQ], vr[RQ], vr2[VMODE == V_GATHER ? RQ : 1];
+
+        auto fetch = [&](int tile) {
+            const long row0 = (long)tile * RD_RT;
+            const int rv = (int)((p.rows - row0 < RD_RT) ? (p.rows - row0) : RD_RT);
+#pragma unroll
+            for (int q = 0; q < RQ; ++q) {
+                const int r = w4 + 4 * q;
+                const long gr = row0 + ((r < rv) ? r : rv - 1);
+                ur[q] = rd_ld4(p.u.base + gr * p.u.stride_outer + cu);
+                if (VMODE == V_DENSE) vr[q] = rd_ld4(p.v.base + gr * p.v.stride_outer + cv);
+                else {
+                    const long i = (long)gpe_udiv((unsigned)gr, (unsigned)p.k, p.rcp_k);
+                    const long jj = p.jg[gr];
+                    vr[q] = rd_ld4(p.pq + i * p.ldpq + cv);
+                    vr2[q] = rd_ld4(p.pq + jj * p.ldpq + p.H + cv);
+                }
+            }
+        };
+        auto commit = [&](int buf, int tile) {
+            float* ub = Us + buf * RD_RT * LDU;
+            float* vb = Vs + buf * RD_RT * LDV;
+            const long row0 = (long)tile * RD_RT;
+            const int rv = (int)((p.rows - row0 < RD_RT) ? (p.rows - row0) : RD_RT);
+            float c32[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int q = 0; q < RQ; ++q) {
+                const int r = w4 + 4 * q;
+                const bool ok = r < rv;
+                if (cq < UC) {
+                    float4 u = ur[q];
+                    if (!(ok && u_on)) u = make_float4(0.f, 0.f, 0.f, 0.f);
+                    else {
+                        if (cq + 1 >= p.Mg) u.y = 0.f;
+                        if (cq + 2 >= p.Mg) u.z = 0.f;
+                        if (cq + 3 >= p.Mg) u.w = 0.f;
+                    }
+                    c32[0] += u.x; c32[1] += u.y; c32[2] += u.z; c32[3] += u.w;
+                    *reinterpret_cast<float4*>(&ub[r * LDU + cq]) = u;
+                }
+                if (cq < VC) {
+                    float4 v = vr[q];
+                    if (VMODE == V_GATHER) {
+                        v.x = fmaxf(v.x + vr2[q].x, 0.f); v.y = fmaxf(v.y + vr2[q].y, 0.f);
+                        v.z = fmaxf(v.z + vr2[q].z, 0.f); v.w = fmaxf(v.w + vr2[q].w, 0.f);
+                    }
+                    v.x -= sh[0]; v.y -= sh[1]; v.z -= sh[2]; v.w -= sh[3];
+                    if (!(ok && v_on)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    else {
+                        if (cq + 1 >= p.Ng) v.y = 0.f;
+                        if (cq + 2 >= p.Ng) v.z = 0.f;
+                        if (cq + 3 >= p.Ng) v.w = 0.f;
+                    }
+                    *reinterpret_cast<float4*>(&vb[r * LDV + cq]) = v;
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) csd[t] += (double)c32[t];
+        };
+
+        int tile = blockIdx.x;
+        if (tile < p.num_tiles) { fetch(tile); commit(0, tile); }
+        __syncthreads();                           // prologue
+        int buf = 0;
+        for (; tile < p.num_tiles; tile += gridDim.x) {
+            const int next = tile + gridDim.x;
+            if (next < p.num_tiles) fetch(next);
+            if (PMAX > 0) {
+                const float* ub = Us + buf * RD_RT * LDU;
+                const float* vb = Vs + buf * RD_RT * LDV;
+#pragma unroll
+                for (int r0 = 0; r0 < RD_RT; r0 += 4) {
+#pragma unroll
+                    for (int s_ = 0; s_ < PMAX; ++s_) {
+                        if (s_ < my_count) {
+                            const float a = ub[(r0 + g) * LDU + offU[s_] + j];
+                            const float b = vb[(r0 + g) * LDV + offV[s_] + j];
+                            accP[s_] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, accP[s_], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+            if (next < p.num_tiles) commit(buf ^ 1, next);
+            __syncthreads();
+            buf ^= 1;
+        }
+#pragma unroll
+        for (int s_ = 0; s_ < PMAX; ++s_) {
+            if (s_ < my_count) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    dst[(size_t)(offU[s_] + 4 * g + r) * p.NgPad + offV[s_] + j] = accP[s_][r];
+            }
+        }
+        double* red = reinterpret_cast<double*>(smem);          // [4][UC]
+        if (cq < UC) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) red[w4 * UC + cq + t] = csd[t];
+        }
+        __syncthreads();                           // tail
+    }
+    if (tid < p.Mg) {
+        const double* red = reinterpret_cast<const double*>(smem);
+        p.part_cs[(size_t)blockIdx.x * p.MgPad + tid] =
+            (red[tid] + red[UC + tid]) + (red[2 * UC + tid] + red[3 * UC + tid]);
+    }
+}
+
 // fixed-order (deterministic) reduction of the per-workgroup partials; 4 independent fp64 chains for load ILP
 __global__ void gpe_redgemm_finish(const float* __restrict__ part, const double* __restrict__ part_cs, int nblk,
                                    int Mg, int Ng, int MgPad, int NgPad, float* G, int ldg, float* colsum,
@@ -350,6 +552,25 @@ static int rd_launch(const RdParams& p, dim3 grid, hipStream_t s)
     return GPE_OK;
 }
 
+template <int MT, int NT, int VMODE>
+static int rd_pc_launch(const RdParams& p, int gx, hipStream_t s)
+{
+    constexpr int UC = 16 * MT, VC = 16 * NT;
+    constexpr int LDU = (UC % 32 == 16) ? UC : UC + 16;
+    constexpr int LDV = (VC % 32 == 16) ? VC : VC + 16;
+    const size_t lds = (size_t)2 * RD_RT * (LDU + LDV) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gpe_redgemm_pc_kernel<MT, NT, VMODE>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            return GPE_ELAUNCH;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gpe_redgemm_pc_kernel<MT, NT, VMODE>), dim3(gx), dim3(512), lds, s, p);
+    GPE_CHECK_LAUNCH();
+    return GPE_OK;
+}
+
 template <int VMODE>
 static int rd_dispatch(int MH, int NH, const RdParams& p, dim3 grid, hipStream_t s)
 {
@@ -387,7 +608,17 @@ static int rd_run(RdParams& p, int vmode, float* G, int ldG, float* colsum, floa
     off = (off + 1) & ~(size_t)1;                                  // 8-B align the fp64 section
     p.part_cs = reinterpret_cast<double*>(part + off);
     dim3 grid(gx, gy);
-    int rc = (vmode == V_DENSE) ? rd_dispatch<V_DENSE>(MH, NH, p, grid, s) : rd_dispatch<V_GATHER>(MH, NH, p, grid, s);
+    int rc = GPE_EINVAL;
+    const int mt_all = gpe_cdiv(p.Mg, 16), nt_all = gpe_cdiv(p.Ng, 16);
+    const bool pc_ok = gy == 1 && nt_all == 13 && (mt_all == 13 || mt_all == 10) && rd_rows_vec(p.u, p.Mg) &&
+                       (vmode == V_GATHER || rd_rows_vec(p.v, p.Ng)) && p.num_tiles >= 4 * gx;
+    if (pc_ok) {
+        if (mt_all == 13 && vmode == V_DENSE) rc = rd_pc_launch<13, 13, V_DENSE>(p, gx, s);
+        else if (mt_all == 13) rc = rd_pc_launch<13, 13, V_GATHER>(p, gx, s);
+        else if (vmode == V_DENSE) rc = rd_pc_launch<10, 13, V_DENSE>(p, gx, s);
+        else rc = rd_pc_launch<10, 13, V_GATHER>(p, gx, s);
+    } else
+        rc = (vmode == V_DENSE) ? rd_dispatch<V_DENSE>(MH, NH, p, grid, s) : rd_dispatch<V_GATHER>(MH, NH, p, grid, s);
     if (rc != GPE_OK) return rc;
     const long total = (long)p.Mg * p.Ng;
     hipLaunchKernelGGL(gpe_redgemm_finish, dim3(gpe_cdiv(total, 256)), dim3(256), 0, s, p.part, p.part_cs, gx,
