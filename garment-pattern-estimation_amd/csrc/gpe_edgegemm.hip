@@ -63,14 +63,24 @@ __global__ __launch_bounds__(512, 2) void gpe_edgegemm_kernel(RgParams p, int st
             for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
                 for (int i = 0; i < AQ; ++i) acc[mt][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            // A fragments are read ONE CHUNK AHEAD of the MFMAs that use them: LDS latency (inflated by the producers'
+            // staging/epilogue traffic) then sits under 48 MFMAs instead of stalling the matrix pipe 13x per tile
+            float4 an[4];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) an[mt] = ld4(&As[(16 * mt + j) * LDA + 4 * g]);
+            if (!(p.dbg & 16))
 #pragma unroll
             for (int kc = 0; kc < KCH; ++kc) {
                 float a[4][4];
 #pragma unroll
                 for (int mt = 0; mt < 4; ++mt) {
-                    const float4 t4 = ld4(&As[(16 * mt + j) * LDA + 16 * kc + 4 * g]);
-                    a[mt][0] = t4.x; a[mt][1] = t4.y; a[mt][2] = t4.z; a[mt][3] = t4.w;
+                    a[mt][0] = an[mt].x; a[mt][1] = an[mt].y; a[mt][2] = an[mt].z; a[mt][3] = an[mt].w;
                 }
+                if (kc + 1 < KCH) {
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt) an[mt] = ld4(&As[(16 * mt + j) * LDA + 16 * (kc + 1) + 4 * g]);
+                }
+                __builtin_amdgcn_sched_barrier(0);       // keep the prefetch ahead of this chunk's MFMAs
 #pragma unroll
                 for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -106,6 +116,9 @@ __global__ __launch_bounds__(512, 2) void gpe_edgegemm_kernel(RgParams p, int st
                 wB[b][kc] = (col < p.Npad) ? ld4(p.wp + (((long)(kc * 4 + g)) * p.Npad + col) * 4)
                                            : make_float4(0.f, 0.f, 0.f, 0.f);
         }
+        // producers issue few, latency-critical memory instructions: let them win issue arbitration against the
+        // MFMA-issuing consumer wave on the same SIMD (MI355X_MICROARCH.md "Two waves per SIMD")
+        __builtin_amdgcn_s_setprio(3);
         const int c = lane << 2;                         // this lane's column quad
         const bool k_on = c < p.K;                       // staging lanes
         const bool n_on = c < p.N;                       // epilogue lanes
@@ -272,7 +285,7 @@ __global__ __launch_bounds__(512, 2) void gpe_edgegemm_kernel(RgParams p, int st
             f32x4 accB[BQ > 0 ? BQ : 1];
 #pragma unroll
             for (int b = 0; b < (BQ > 0 ? BQ : 1); ++b) accB[b] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (BQ > 0) {
+            if (BQ > 0 && !(p.dbg & 32)) {
 #pragma unroll
                 for (int kc = 0; kc < KCH; ++kc) {
                     const float4 t4 = ld4(&As[(16 * w4 + j) * LDA + 16 * kc + 4 * g]);

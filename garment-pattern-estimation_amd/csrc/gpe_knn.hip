@@ -51,37 +51,64 @@ __global__ __launch_bounds__(256) void gpe_knn_kernel(const float* __restrict__ 
     const int tq = tid & 15;        // query micro-row: queries 4*tq .. 4*tq+3
     const int tc = tid >> 4;        // candidate micro-col: candidates 4*tc .. 4*tc+3
 
-    for (int c0 = 0; c0 < N; c0 += KNN_TC) {
-        float acc[4][4];
+    // candidate chunks are register-prefetched one (tile, channel-chunk) step ahead, so the global-load latency sits
+    // under the previous chunk's arithmetic instead of between two barriers
+    const int nchunk = Cq / KNN_CCH;
+    const int nsteps = ((N + KNN_TC - 1) / KNN_TC) * nchunk;
+    float pre[(KNN_TC * KNN_CCH) / 256];
+    auto prefetch = [&](int step) {
+        const int c0n = (step / nchunk) * KNN_TC, chn = (step % nchunk) * KNN_CCH;
 #pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-            for (int bb = 0; bb < 4; ++bb) acc[a][bb] = 0.f;
+        for (int i = 0; i < (KNN_TC * KNN_CCH) / 256; ++i) {
+            const int e = tid + 256 * i;
+            const int p = e / KNN_CCH, c = e - p * KNN_CCH;
+            const int pr = (c0n + p < N) ? c0n + p : N - 1;           // clamped (unconditional load); masked below
+            const int cr = (chn + c < C) ? chn + c : C - 1;
+            const float v = cloud[(size_t)pr * ldx + cr];
+            pre[i] = (c0n + p < N && chn + c < C) ? v : 0.f;
+        }
+    };
+    prefetch(0);
+    int step = 0;
 
-        for (int ch = 0; ch < Cq; ch += KNN_CCH) {
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    for (int c0 = 0; c0 < N; c0 += KNN_TC) {
+        // packed accumulators: acc2[a][h] = {acc[a][2h], acc[a][2h+1]}  (v_pk_fma_f32: per-element IEEE fma, so the
+        // chain is bit-identical to the scalar fmaf of oracle/knn_ref.c)
+        f32x2 acc2[4][2];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) { acc2[a][0] = (f32x2){0.f, 0.f}; acc2[a][1] = (f32x2){0.f, 0.f}; }
+
+        for (int ch = 0; ch < Cq; ch += KNN_CCH, ++step) {
             __syncthreads();   // previous chunk (and, on the first pass, the previous tile's dist reads) done
-            for (int e = tid; e < KNN_TC * KNN_CCH; e += 256) {
-                int p = e / KNN_CCH, c = e - p * KNN_CCH;
-                float v = 0.f;
-                if (c0 + p < N && ch + c < C) v = cloud[(size_t)(c0 + p) * ldx + ch + c];
-                cT[c * KNN_LD + p] = v;
+#pragma unroll
+            for (int i = 0; i < (KNN_TC * KNN_CCH) / 256; ++i) {
+                const int e = tid + 256 * i;
+                const int p = e / KNN_CCH, c = e - p * KNN_CCH;
+                cT[c * KNN_LD + p] = pre[i];
             }
             __syncthreads();
+            if (step + 1 < nsteps) prefetch(step + 1);
             const int cend = (C - ch < KNN_CCH) ? (C - ch) : KNN_CCH;   // skip the zero-padded channels
 #pragma unroll 4
             for (int c = 0; c < cend; ++c) {
                 const float4 qv = *reinterpret_cast<const float4*>(&qT[(ch + c) * KNN_LD + 4 * tq]);
                 const float4 pv = *reinterpret_cast<const float4*>(&cT[c * KNN_LD + 4 * tc]);
                 const float qa[4] = {qv.x, qv.y, qv.z, qv.w};
-                const float pa[4] = {pv.x, pv.y, pv.z, pv.w};
+                const f32x2 p01 = (f32x2){pv.x, pv.y}, p23 = (f32x2){pv.z, pv.w};
 #pragma unroll
-                for (int a = 0; a < 4; ++a)
-#pragma unroll
-                    for (int bb = 0; bb < 4; ++bb) {
-                        float d = qa[a] - pa[bb];
-                        acc[a][bb] = __builtin_fmaf(d, d, acc[a][bb]);
-                    }
+                for (int a = 0; a < 4; ++a) {
+                    const f32x2 qq = (f32x2){qa[a], qa[a]};
+                    const f32x2 d0 = qq - p01, d1 = qq - p23;
+                    acc2[a][0] = __builtin_elementwise_fma(d0, d0, acc2[a][0]);
+                    acc2[a][1] = __builtin_elementwise_fma(d1, d1, acc2[a][1]);
+                }
             }
+        }
+        float acc[4][4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            acc[a][0] = acc2[a][0].x; acc[a][1] = acc2[a][0].y; acc[a][2] = acc2[a][1].x; acc[a][3] = acc2[a][1].y;
         }
         // padded channels contribute fmaf(0,0,acc) = acc exactly, so chunking does not change the chain
 
@@ -102,16 +129,18 @@ __global__ __launch_bounds__(256) void gpe_knn_kernel(const float* __restrict__ 
             while (m) {
                 const int src = __builtin_ctzll(m);
                 m &= m - 1;
-                const float dn = __shfl(d, src);
+                // all cross-lane traffic below is v_readlane / DPP wave_shr (VALU latency), not ds_bpermute
+                const float dn = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d), src));
                 if (!(dn < thr[i])) continue;               // the threshold may have tightened meanwhile
                 const int jn = c0 + src;
                 // number of list entries that stay in front: all with dist <= dn (they have lower indices)
                 const int pos = __builtin_popcountll(__ballot(ld_[i] <= dn));
-                const float upd = __shfl_up(ld_[i], 1);
-                const int upi = __shfl_up(li_[i], 1);
+                const int ldb = __float_as_int(ld_[i]);
+                const int updb = __builtin_amdgcn_update_dpp(ldb, ldb, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+                const int upi = __builtin_amdgcn_update_dpp(li_[i], li_[i], 0x138, 0xf, 0xf, false);
                 if (lane == pos) { ld_[i] = dn; li_[i] = jn; }
-                else if (lane > pos) { ld_[i] = upd; li_[i] = upi; }
-                thr[i] = __shfl(ld_[i], k - 1);
+                else if (lane > pos) { ld_[i] = __int_as_float(updb); li_[i] = upi; }
+                thr[i] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ld_[i]), k - 1));
             }
         }
     }

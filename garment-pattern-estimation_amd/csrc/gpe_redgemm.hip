@@ -327,6 +327,7 @@ __global__ __launch_bounds__(512, 2) void gpe_redgemm_pc_kernel(RdParams p)
         __syncthreads();                           // tail: producers' column sums in LDS
     } else {
         // ================================ producers ================================
+        __builtin_amdgcn_s_setprio(3);             // memory-issuing waves win arbitration against the MFMA stream
         const int cq = lane << 2;
         const bool u_on = cq < p.Mg, v_on = cq < p.Ng;
         const int cu = u_on ? cq : 0, cv = v_on ? cq : 0;

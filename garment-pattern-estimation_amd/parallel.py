@@ -90,8 +90,13 @@ def init_distributed(backend=None):
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
     if torch.cuda.is_available():
+        # GPE_SHARE_DEVICE=1 (testing only): all ranks use cuda:0, for exercising the N>1 code path on a 1-GPU box
+        # together with backend gloo (RCCL rejects two ranks on one device)
+        if os.environ.get('GPE_SHARE_DEVICE') == '1':
+            local = 0
         torch.cuda.set_device(local)
     if world > 1 and not dist.is_initialized():
+        backend = backend or os.environ.get('GPE_DIST_BACKEND')
         dist.init_process_group(backend or ('nccl' if torch.cuda.is_available() else 'gloo'),
                                 rank=rank, world_size=world)
     return rank, local, world

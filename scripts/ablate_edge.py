@@ -47,7 +47,7 @@ def rd(): L.call('gpe_edge_redgemm', a3, 152, 1, a2, H, None, 0, None, shift, B,
 
 flops = {'f2': 2.0 * E * H * H, 'f3': 2.0 * E * H * Fo, 'b2a': 2.0 * E * H * Fo, 'rg': 2.0 * E * H * H, 'rd': 2.0 * E * H * Fo}
 for flags, label in [(0, 'production'), (1, 'no staging'), (2, 'no epilogue'), (3, 'no staging, no epilogue'),
-                     (7, 'MFMA only + barriers'), (15, 'MFMA only, no barriers'), (4, 'no LDS frag reads')]:
+                     (7, 'MFMA only + barriers'), (15, 'MFMA only, no barriers'), (32, 'no producer MFMAs'), (16, 'producers only (no consumer MFMA)')]:
     L.query('gpe_debug_set', flags)
     out = []
     for name, fn in [('f2', f2), ('f3', f3), ('b2a', b2a)]:
