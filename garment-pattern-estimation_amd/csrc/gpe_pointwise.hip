@@ -642,7 +642,8 @@ extern "C" int gpe_lstm_cell_fwd(float* gates, const float* c_prev, long ldc_pre
 }
 
 __global__ void gpe_lstm_cell_bwd_kernel(const float* __restrict__ dh_out, long dho_stride,
-                                         const float* __restrict__ dh_rec, const float* __restrict__ dc_next,
+                                         const float* __restrict__ dh_rec, int n_rec,
+                                         const float* __restrict__ dc_next,
                                          const float* __restrict__ gates, const float* __restrict__ c,
                                          const float* __restrict__ c_prev, long ldc_prev,
                                          float* __restrict__ dgates, long dg_stride, float* __restrict__ dc_prev,
@@ -655,7 +656,8 @@ __global__ void gpe_lstm_cell_bwd_kernel(const float* __restrict__ dh_out, long 
     const float* gr = gates + b * 4 * H;
     const float ig = gr[u], fg = gr[H + u], gg = gr[2 * H + u], og = gr[3 * H + u];
     float dh = dh_out ? dh_out[b * dho_stride + u] : 0.f;
-    if (dh_rec) dh += dh_rec[b * H + u];
+    if (dh_rec)
+        for (int z = 0; z < n_rec; ++z) dh += dh_rec[(long)z * Bn * H + b * H + u];   // split-K partials
     const float tc = tanhf(c[b * H + u]);
     float dc = dh * og * (1.f - tc * tc);
     if (dc_next) dc += dc_next[b * H + u];
@@ -667,13 +669,14 @@ __global__ void gpe_lstm_cell_bwd_kernel(const float* __restrict__ dh_out, long 
     dc_prev[b * H + u] = dc * fg;
 }
 
-extern "C" int gpe_lstm_cell_bwd(const float* dh_out, long dho_stride, const float* dh_rec, const float* dc_next,
+extern "C" int gpe_lstm_cell_bwd(const float* dh_out, long dho_stride, const float* dh_rec, int n_rec,
+                                 const float* dc_next,
                                  const float* gates, const float* c, const float* c_prev, long ldc_prev,
                                  float* dgates, long dg_stride, float* dc_prev, int Bn, int H, void* stream)
 {
     if (!gates || !c || !c_prev || !dgates || !dc_prev || Bn <= 0 || H <= 0) return GPE_EINVAL;
     hipLaunchKernelGGL(gpe_lstm_cell_bwd_kernel, dim3(gpe_cdiv((long)Bn * H, 256)), dim3(256), 0,
-                       (hipStream_t)stream, dh_out, dho_stride, dh_rec, dc_next, gates, c, c_prev, ldc_prev, dgates,
+                       (hipStream_t)stream, dh_out, dho_stride, dh_rec, n_rec, dc_next, gates, c, c_prev, ldc_prev, dgates,
                        dg_stride, dc_prev, Bn, H);
     GPE_CHECK_LAUNCH();
     return GPE_OK;

@@ -26,6 +26,9 @@ struct SgParams {
     const float* xproj; long xp_stride;          // [M][4H] rows (b_ih + b_hh already folded in)
     const float* c_prev; long ldc_prev;
     float* gates; float* c_out; float* h_out; long h_stride;
+    int a_padded;                // A rows may be read up to round4(K) (finite pad): enables plain 16-B staging loads
+    // split-K (gridDim.z > 1): block z handles K slab z only and writes its partial product to y + z * y_zstride
+    long y_zstride;
 };
 
 __device__ __forceinline__ float sg_sigmoid(float x) { return 1.f / (1.f + expf(-x)); }
@@ -52,22 +55,48 @@ __global__ __launch_bounds__(256) void gpe_smallgemm_kernel(SgParams p)
 #pragma unroll
     for (int n = 0; n < NT; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    for (int ks = 0; ks < p.K; ks += RG_KSLAB) {
+    const int ks_begin = (gridDim.z > 1) ? (int)blockIdx.z * RG_KSLAB : 0;
+    const int ks_end = (gridDim.z > 1) ? ((ks_begin + RG_KSLAB < p.K) ? ks_begin + RG_KSLAB : p.K) : p.K;
+    for (int ks = ks_begin; ks < ks_end; ks += RG_KSLAB) {
         const int kslab = (p.K - ks < RG_KSLAB) ? (p.K - ks) : RG_KSLAB;
         const int kp = (kslab + 15) & ~15;
         __syncthreads();                            // previous slab's reads finished
         // ---- stage A slab: lane = column quad, rows = wave + 4*it ------------------------------------------
         {
             const int c = lane << 2;
+            const bool vec = p.a_padded && p.a.inner <= 0 && !(p.a.stride_outer & 3) && gpe_aligned16(p.a.base);
             if (c < kp) {
                 const int nvalid = kslab - c;
-                for (int r = wave; r < RG_BM; r += 4) {
-                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (r < rv && nvalid > 0) {
-                        const float* src = gpe_row_ptr(p.a, row0 + r) + ks + c;
-                        v = ld4_guard(src, nvalid, gpe_aligned16(src));
+                if (vec) {
+                    // aligned rows: one plain 16-B load per row, unconditional (row clamped), all 16 in flight
+                    const int cc = (nvalid > 0) ? c : 0;
+                    float4 v[RG_BM / 4];
+#pragma unroll
+                    for (int q = 0; q < RG_BM / 4; ++q) {
+                        const int r = wave + 4 * q;
+                        v[q] = ld4(p.a.base + (long)(row0 + (r < rv ? r : rv - 1)) * p.a.stride_outer + ks + cc);
                     }
-                    st4(&As[r * lda + c], v);
+#pragma unroll
+                    for (int q = 0; q < RG_BM / 4; ++q) {
+                        const int r = wave + 4 * q;
+                        float4 o = v[q];
+                        if (r >= rv || nvalid <= 0) o = make_float4(0.f, 0.f, 0.f, 0.f);
+                        else {
+                            if (nvalid < 2) o.y = 0.f;
+                            if (nvalid < 3) o.z = 0.f;
+                            if (nvalid < 4) o.w = 0.f;
+                        }
+                        st4(&As[r * lda + c], o);
+                    }
+                } else {
+                    for (int r = wave; r < RG_BM; r += 4) {
+                        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (r < rv && nvalid > 0) {
+                            const float* src = gpe_row_ptr(p.a, row0 + r) + ks + c;
+                            v = ld4_guard(src, nvalid, gpe_aligned16(src));
+                        }
+                        st4(&As[r * lda + c], v);
+                    }
                 }
             }
         }
@@ -120,7 +149,7 @@ __global__ __launch_bounds__(256) void gpe_smallgemm_kernel(SgParams p)
                 const float* ad = nullptr;
                 if (p.addend.base) ad = gpe_row_ptr(p.addend, gr) + n0 + c;
                 float* dst;
-                if (p.y_inner <= 0) dst = p.y + gr * p.y_so + n0 + c;
+                if (p.y_inner <= 0) dst = p.y + (long)blockIdx.z * p.y_zstride + gr * p.y_so + n0 + c;
                 else { long oo = gr / p.y_inner; dst = p.y + oo * p.y_so + (gr - oo * p.y_inner) * p.y_si + n0 + c; }
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
@@ -194,6 +223,7 @@ int gpe_smallgemm_linear(const RgParams& r, hipStream_t s)
     p.M = (int)r.M; p.N = r.N; p.K = r.K;
     p.a = r.a; p.wp = r.wp; p.Npad = r.Npad; p.bias = r.bias; p.addend = r.addend;
     p.y = r.y; p.y_so = r.y_so; p.y_si = r.y_si; p.y_inner = r.y_inner; p.act = r.act;
+    p.a_padded = !(p.K & 3);
     const int tiles = gpe_cdiv(p.M, RG_BM);
     // 64-column blocks unless that leaves most CUs idle, then 16-column blocks
     if ((long)tiles * gpe_cdiv(p.N, 64) >= 128 || p.N <= 16) {
@@ -213,8 +243,26 @@ extern "C" int gpe_lstm_step_fwd(const float* h_prev, long hp_stride, const floa
     SgParams p = {};
     p.M = Bn; p.N = 4 * H; p.K = H;
     p.a = GpeRows{h_prev, hp_stride, 0, 0};
+    p.a_padded = !(hp_stride & 3);              // contract: h rows are padded to a multiple of 4 floats (finite pad)
     p.wp = whh_gates_packed; p.Npad = 64 * gpe_cdiv(H, 16);
     p.H = H; p.xproj = xproj; p.xp_stride = xp_stride; p.c_prev = c_prev; p.ldc_prev = ldc_prev;
     p.gates = gates; p.c_out = c_out; p.h_out = h_out; p.h_stride = h_stride;
     return sg_launch<4, EPI_LSTM>(p, dim3(gpe_cdiv(Bn, RG_BM), gpe_cdiv(H, 16)), (hipStream_t)stream);
+}
+
+// split-K product for long-K, small-M shapes (the LSTM backward recurrence dh = dG . W_hh, K = 4H): one K slab per
+// workgroup so every load of the launch is in flight at once; the ceil(K/256) partial products land in
+// y[z][M][N] and are summed by their consumer (gpe_lstm_cell_bwd's n_rec).  Returns the number of partials via *nz.
+extern "C" int gpe_linear_splitk(const float* a, long a_so, const float* wp, float* y, int M, int N, int K,
+                                 void* stream)
+{
+    if (!a || !wp || !y || M <= 0 || N <= 0 || K <= 0) return GPE_EINVAL;
+    SgParams p = {};
+    p.M = M; p.N = N; p.K = K;
+    p.a = GpeRows{a, a_so, 0, 0};
+    p.wp = wp; p.Npad = gpe_round_up(N, 16);
+    p.y = y; p.y_so = N; p.y_zstride = (long)M * N;
+    p.a_padded = !(K & 3);
+    const int nz = gpe_cdiv(K, RG_KSLAB);
+    return sg_launch<4, EPI_LINEAR>(p, dim3(gpe_cdiv(M, RG_BM), gpe_cdiv(N, 64), nz), (hipStream_t)stream);
 }

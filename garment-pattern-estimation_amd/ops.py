@@ -339,7 +339,9 @@ class LSTMDecoderFn(torch.autograd.Function):
             w_ih, w_hh, b_ih, b_hh = lstm_params[4 * l: 4 * l + 4]
             bias = torch.empty(4 * Hh, device=dev, dtype=F32)
             L.call('gpe_add', b_ih, b_hh, bias, 4 * Hh)
-            hs = torch.empty(Bn, T + 1, Hh, device=dev, dtype=F32)
+            # row pitch padded to 16 B (zero pad) so the recurrence's A operand is staged with plain aligned loads
+            Hp = round_up(Hh, 4)
+            hs = torch.zeros(Bn, T + 1, Hp, device=dev, dtype=F32)[:, :, :Hh]
             hs[:, 0].copy_(h0[l])
             cs = torch.empty(T + 1, Bn, Hh, device=dev, dtype=F32)
             cs[0].copy_(c0[l])
@@ -356,8 +358,8 @@ class LSTMDecoderFn(torch.autograd.Function):
             for t in range(T):
                 xp, xps = (xproj, 4 * Hh) if l == 0 else (xproj[:, t], T * 4 * Hh)
                 # gates = h_{t-1} W_hh^T + xproj_t, cell update, h_t / c_t / activated gates: one launch
-                L.call('gpe_lstm_step_fwd', hs[:, t], (T + 1) * Hh, whh_p, xp, xps, cs[t], Hh,
-                       gates[t], cs[t + 1], hs[:, t + 1], (T + 1) * Hh, Bn, Hh)
+                L.call('gpe_lstm_step_fwd', hs[:, t], hs.stride(0), whh_p, xp, xps, cs[t], Hh,
+                       gates[t], cs[t + 1], hs[:, t + 1], hs.stride(0), Bn, Hh)
             saved_layers += [hs, cs, gates]
             prev_hs = hs
         out_sz = lin_w.shape[0]
@@ -387,16 +389,17 @@ class LSTMDecoderFn(torch.autograd.Function):
             w_ih, w_hh = lstm_params[4 * l], lstm_params[4 * l + 1]
             hs, cs, gates = saved_layers[3 * l: 3 * l + 3]
             dG = torch.empty(Bn, T, 4 * Hh, device=dev, dtype=F32)
-            dh_rec = torch.empty(Bn, Hh, device=dev, dtype=F32)
+            nz = (4 * Hh + 255) // 256                     # split-K partials of dh_rec = dG_t . W_hh
+            dh_rec = torch.empty(nz, Bn, Hh, device=dev, dtype=F32)
             dc = [torch.empty(Bn, Hh, device=dev, dtype=F32) for _ in range(2)]
             whh_t = pack_weight(w_hh, transpose=True)
             for t in reversed(range(T)):
                 last = t == T - 1
-                L.call('gpe_lstm_cell_bwd', dH[:, t], T * Hh, None if last else dh_rec,
+                L.call('gpe_lstm_cell_bwd', dH[:, t], T * Hh, None if last else dh_rec, nz,
                        None if last else dc[(t + 1) & 1], gates[t], cs[t + 1], cs[t], Hh,
                        dG[:, t], T * 4 * Hh, dc[t & 1], Bn, Hh)
                 if t > 0:
-                    linear_raw((dG[:, t], T * 4 * Hh, 0, 0), whh_t, None, Bn, Hh, 4 * Hh, (dh_rec, Hh, 0, 0))
+                    L.call('gpe_linear_splitk', dG[:, t], T * 4 * Hh, whh_t, dh_rec, Bn, Hh, 4 * Hh)
             dG_rows = (dG, 4 * Hh, 0, 0)
             d_whh, d_b = redgemm_raw(dG_rows, _rows3d(hs[:, :T]), Bn * T, 4 * Hh, Hh)
             if l == 0:

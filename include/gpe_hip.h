@@ -159,9 +159,9 @@ int gpe_segment_mean_bwd(const float* gy, int ldgy, int B, int N, int C, float* 
  * writes c [Bn][H] and h rows (2-level addressing via h + b*h_stride). */
 int gpe_lstm_cell_fwd(float* gates, const float* c_prev, long ldc_prev, float* c, float* h, long h_stride,
                       int Bn, int H, void* stream);
-/* dh_total = dh_out + dh_rec; computes dgates (pre-activation grads) [Bn][4H] rows at dgates + b*dg_stride,
+/* dh_total = dh_out + sum of the n_rec partials dh_rec[z][Bn][H] (gpe_linear_splitk); computes dgates (pre-activation grads) [Bn][4H] rows at dgates + b*dg_stride,
  * dc_prev; inputs: activated gates, c (this step), c_prev. */
-int gpe_lstm_cell_bwd(const float* dh_out, long dho_stride, const float* dh_rec, const float* dc_next,
+int gpe_lstm_cell_bwd(const float* dh_out, long dho_stride, const float* dh_rec, int n_rec, const float* dc_next,
                       const float* gates, const float* c, const float* c_prev, long ldc_prev,
                       float* dgates, long dg_stride, float* dc_prev, int Bn, int H, void* stream);
 
@@ -182,6 +182,10 @@ int gpe_sparsemax_bwd(const float* out, int ldo, const float* g, int ldg, long r
                       void* stream);
 /* y = s*a + t with {s,t} = stats rows 2,3: BatchNorm of a stored post-ReLU activation (last block of a dense MLP) */
 int gpe_bn_apply(const float* a, int lda, const float* stats, long rows, int C, float* y, int ldy, void* stream);
+
+/* split-K product y[z][M][N] = A[:, z*256:(z+1)*256] . W[:, z*256:...]^T for z < ceil(K/256): one K slab per workgroup
+ * (latency-bound long-K shapes: the LSTM backward recurrence).  The partials are summed by the consumer. */
+int gpe_linear_splitk(const float* a, long a_so, const float* wp, float* y, int M, int N, int K, void* stream);
 
 /* ---- small helpers --------------------------------------------------------------------------------------- */
 /* y[r][c] (+)= sum over inner index t of x[r][t][c]   (x rows: r*x_so + t*x_si) */
