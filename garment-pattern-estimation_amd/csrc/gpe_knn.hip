@@ -22,8 +22,10 @@ __global__ __launch_bounds__(256) void gpe_knn_kernel(const float* __restrict__ 
                                                       int32_t* __restrict__ idx, int32_t* __restrict__ idx_glob, int Cq /* C rounded up to CCH */)
 {
     extern __shared__ __align__(16) float smem[];
-    float* qT = smem;                          // [Cq][KNN_LD]   query tile, channel-major (resident)
-    float* cT = qT + (size_t)Cq * KNN_LD;      // [CCH][KNN_LD]  candidate chunk
+    // both operand tiles are staged per 32-channel chunk (35 KB of LDS per workgroup -> 4 workgroups per CU; a resident
+    // 150-channel query tile cost 43 KB and left the barrier-heavy loop with 2 waves per SIMD, 44 % of wave time parked)
+    float* qT = smem;                          // [CCH][KNN_LD]  query chunk, channel-major
+    float* cT = qT + KNN_CCH * KNN_LD;         // [CCH][KNN_LD]  candidate chunk
     float* dist = cT + KNN_CCH * KNN_LD;       // [64][KNN_LD]   distance tile (query-major)
 
     const int tid = threadIdx.x;
@@ -32,14 +34,6 @@ __global__ __launch_bounds__(256) void gpe_knn_kernel(const float* __restrict__ 
     const int b = blockIdx.y;
     const int q0 = blockIdx.x * KNN_TQ;
     const float* cloud = x + (size_t)b * N * ldx;
-
-    // ---- stage the query tile, transposed to channel-major -------------------------------------------------
-    for (int e = tid; e < KNN_TQ * Cq; e += 256) {
-        int q = e / Cq, c = e - q * Cq;        // consecutive threads walk the channels of one row: coalesced
-        float v = 0.f;
-        if (q0 + q < N && c < C) v = cloud[(size_t)(q0 + q) * ldx + c];
-        qT[c * KNN_LD + q] = v;
-    }
 
     // lane-distributed top-k lists for the 16 queries this wave selects for
     float ld_[16];
@@ -55,17 +49,20 @@ __global__ __launch_bounds__(256) void gpe_knn_kernel(const float* __restrict__ 
     // under the previous chunk's arithmetic instead of between two barriers
     const int nchunk = Cq / KNN_CCH;
     const int nsteps = ((N + KNN_TC - 1) / KNN_TC) * nchunk;
-    float pre[(KNN_TC * KNN_CCH) / 256];
+    float pre[(KNN_TC * KNN_CCH) / 256], preq[(KNN_TQ * KNN_CCH) / 256];
     auto prefetch = [&](int step) {
         const int c0n = (step / nchunk) * KNN_TC, chn = (step % nchunk) * KNN_CCH;
 #pragma unroll
         for (int i = 0; i < (KNN_TC * KNN_CCH) / 256; ++i) {
             const int e = tid + 256 * i;
             const int p = e / KNN_CCH, c = e - p * KNN_CCH;
-            const int pr = (c0n + p < N) ? c0n + p : N - 1;           // clamped (unconditional load); masked below
             const int cr = (chn + c < C) ? chn + c : C - 1;
+            const int pr = (c0n + p < N) ? c0n + p : N - 1;           // clamped (unconditional load); masked below
+            const int qr = (q0 + p < N) ? q0 + p : N - 1;
             const float v = cloud[(size_t)pr * ldx + cr];
+            const float w = cloud[(size_t)qr * ldx + cr];
             pre[i] = (c0n + p < N && chn + c < C) ? v : 0.f;
+            preq[i] = (q0 + p < N && chn + c < C) ? w : 0.f;
         }
     };
     prefetch(0);
@@ -86,13 +83,14 @@ __global__ __launch_bounds__(256) void gpe_knn_kernel(const float* __restrict__ 
                 const int e = tid + 256 * i;
                 const int p = e / KNN_CCH, c = e - p * KNN_CCH;
                 cT[c * KNN_LD + p] = pre[i];
+                qT[c * KNN_LD + p] = preq[i];
             }
             __syncthreads();
             if (step + 1 < nsteps) prefetch(step + 1);
             const int cend = (C - ch < KNN_CCH) ? (C - ch) : KNN_CCH;   // skip the zero-padded channels
 #pragma unroll 4
             for (int c = 0; c < cend; ++c) {
-                const float4 qv = *reinterpret_cast<const float4*>(&qT[(ch + c) * KNN_LD + 4 * tq]);
+                const float4 qv = *reinterpret_cast<const float4*>(&qT[c * KNN_LD + 4 * tq]);
                 const float4 pv = *reinterpret_cast<const float4*>(&cT[c * KNN_LD + 4 * tc]);
                 const float qa[4] = {qv.x, qv.y, qv.z, qv.w};
                 const f32x2 p01 = (f32x2){pv.x, pv.y}, p23 = (f32x2){pv.z, pv.w};
@@ -125,6 +123,24 @@ __global__ __launch_bounds__(256) void gpe_knn_kernel(const float* __restrict__ 
         for (int i = 0; i < 16; ++i) {
             float d = dist[(16 * wave + i) * KNN_LD + lane];
             if (cand >= N) d = INFINITY;
+            if (c0 == 0) {
+                // first tile: the list is empty, so instead of 64 one-at-a-time insertions rank all 64 candidates at
+                // once — rank = #candidates that precede this one in (dist, index) order — and scatter the k best to
+                // their list lanes with one ds_permute each
+                const int db = __float_as_int(d);
+                int rank = 0;
+#pragma unroll
+                for (int s2 = 0; s2 < 64; ++s2) {
+                    const float ds = __int_as_float(__builtin_amdgcn_readlane(db, s2));
+                    rank += (ds < d || (ds == d && s2 < lane)) ? 1 : 0;
+                }
+                const int dperm = __builtin_amdgcn_ds_permute(rank << 2, db);
+                const int iperm = __builtin_amdgcn_ds_permute(rank << 2, lane);
+                ld_[i] = (lane < k) ? __int_as_float(dperm) : INFINITY;
+                li_[i] = (lane < k) ? iperm : -1;
+                thr[i] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ld_[i]), k - 1));
+                continue;
+            }
             unsigned long long m = __ballot(d < thr[i]);
             while (m) {
                 const int src = __builtin_ctzll(m);
@@ -163,8 +179,7 @@ extern "C" int gpe_knn(const float* x, int B, int N, int C, int ldx, int k, int3
     if (!x || !idx || B < 0 || N <= 0 || C <= 0 || ldx < C || k <= 0 || k > 64 || k > N || (long)B * N * k >= (1L << 31)) return GPE_EINVAL;
     if (B == 0) return GPE_OK;
     const int Cq = gpe_round_up(C, KNN_CCH);
-    const size_t lds = ((size_t)Cq * KNN_LD + KNN_CCH * KNN_LD + 64 * KNN_LD) * sizeof(float);
-    if (lds > 160 * 1024) return GPE_EINVAL;   // C up to ~500 channels
+    const size_t lds = ((size_t)2 * KNN_CCH * KNN_LD + 64 * KNN_LD) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(gpe_knn_kernel),
