@@ -76,13 +76,38 @@ def call_work(name, a):
     if name == 'gpe_redgemm':               # ..., rows, Mg, Ng, ldg, accumulate
         rows, Mg, Ng = a[-5], a[-4], a[-3]
         return 2.0 * rows * Mg * Ng, 0.0
-    if name == 'gpe_edge_gather_stats':     # ldpq, H, B, N, k
-        H, B, N, k = a[1], a[2], a[3], a[4]
-        return 0.0, float(B) * N * (k * (H * 4 + 4) + H * 4)
-    if name == 'gpe_edge_pull_dq':          # lddz, B, N, k, H, lddq
+    if name == 'gpe_edge_gather_stats':     # ldpq, H, B, N, k : compulsory bytes = PQ once + the kNN graph once
+        H, B, N, k = a[1], a[2], a[3], a[4]  # (the k-fold neighbour re-reads are L2/MALL hits, not HBM work)
+        return 0.0, float(B) * N * (2 * H * 4 + k * 4)
+    if name == 'gpe_edge_pull_dq':          # lddz, B, N, k, H, lddq : dz rows read once through the reversed graph
         B, N, k, H = a[1], a[2], a[3], a[4]
         return 0.0, float(B) * N * (k * (H * 4 + 4) + H * 4)
     return 0.0, 0.0
+
+
+# HBM traffic per launch from the committed PMC passes (profiles/*_hbm_traffic.json, made by scripts/collect_profiles.sh
+# from two `rocprofv3 --pmc` runs of this same command); C-ABI entry -> device kernels it launches
+_TRAFFIC_KERNELS = {
+    'gpe_edge_mlp_fwd': r'gpe_(edgegemm|rowgemm)_kernel<.*, 1>$',
+    'gpe_edge_mlp_bwd': r'gpe_(edgegemm|rowgemm)_kernel<.*, [23]>$',
+    'gpe_edge_redgemm': r'gpe_redgemm_pc_kernel<',
+    'gpe_edge_gather_stats': r'gpe_gather_stats_kernel',
+}
+
+
+def pmc_traffic(entry):
+    import glob
+    import re
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', '*_hbm_traffic.json')))
+    if not files or entry not in _TRAFFIC_KERNELS:
+        return None, None
+    kern = json.load(open(files[-1]))['kernels']
+    n = b = 0.0
+    for name, v in kern.items():
+        if re.search(_TRAFFIC_KERNELS[entry], name):
+            n += v['launches']
+            b += v['launches'] * v['hbm_bytes']
+    return (b / n, 'profiles/' + os.path.basename(files[-1])) if n else (None, None)
 
 
 def cpu_baseline(args, data_config, nn_cfg):
@@ -192,14 +217,17 @@ def main():
         dom = max(fam, key=lambda n: agg.get(n, [0, 0, 0, 0])[1])
         n_l, ms, fl, _ = agg[dom]
         ach = fl / (ms * 1e-3) / 1e12
+        traffic, tsrc = pmc_traffic(dom)
         roof = {'kernel': dom, 'bound': 'mfma', 'achieved': ach, 'peak': PEAK_F32_TFLOPS, 'unit': 'TFLOP/s',
-                'frac': ach / PEAK_F32_TFLOPS, 'traffic': None, 'launches_per_step': n_l / nsteps,
+                'frac': ach / PEAK_F32_TFLOPS, 'traffic': traffic, 'traffic_unit': 'HBM bytes/launch',
+                'traffic_source': tsrc, 'launches_per_step': n_l / nsteps,
                 'avg_launch_ms': ms / n_l, 'flops_per_launch': fl / n_l}
         if 'gpe_edge_gather_stats' in agg:
             n_l, ms, _, by = agg['gpe_edge_gather_stats']
             ach = by / (ms * 1e-3) / 1e9
             roof_gather = {'kernel': 'gpe_edge_gather_stats', 'bound': 'hbm', 'achieved': ach, 'peak': PEAK_HBM_GBS,
-                           'unit': 'GB/s', 'frac': ach / PEAK_HBM_GBS, 'traffic': None,
+                           'unit': 'GB/s', 'frac': ach / PEAK_HBM_GBS,
+                           'traffic': pmc_traffic('gpe_edge_gather_stats')[0],
                            'avg_launch_ms': ms / n_l, 'bytes_per_launch': by / n_l}
 
     cpu = None

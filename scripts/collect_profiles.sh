@@ -1,0 +1,30 @@
+#!/bin/bash
+# Round-end measurement artefacts (run on the GPU box through gpurun):  scripts/collect_profiles.sh <tag>
+#   1. the default bench line (with cpu_baseline)            -> gpurun_out/<tag>_bench.json
+#   2. rocprofv3 --kernel-trace --stats of the same workload -> gpurun_out/<tag>_kernel_trace.md
+#   3. two PMC passes (FETCH_SIZE, WRITE_SIZE; own runs)     -> gpurun_out/<tag>_hbm_traffic.json
+TAG=${1:-r01_x}
+ROOT=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=$ROOT/gpurun_out
+mkdir -p $OUT
+cd $ROOT
+if [ -z "$SKIP_BENCH" ]; then
+  timeout 600 python bench.py > $OUT/${TAG}_bench.log 2>&1
+  grep '^{' $OUT/${TAG}_bench.log | tail -1 > $OUT/${TAG}_bench.json
+fi
+cd /tmp && export TMPDIR=/tmp
+STEPS=10
+rm -rf $OUT/prof_kt $OUT/prof_fetch $OUT/prof_write
+timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/prof_kt -- python $ROOT/bench.py --steps $STEPS --warmup 3 \
+    --no-cpu-baseline --no-kernel-timing > $OUT/${TAG}_kt.log 2>&1
+DB=$(find $OUT/prof_kt -name '*.db' | head -1)
+python $ROOT/profiles/summarize_rocpd.py $DB $((STEPS + 3)) > $OUT/${TAG}_kernel_trace.md
+for C in FETCH_SIZE WRITE_SIZE; do
+  D=$OUT/prof_$(echo $C | tr A-Z a-z | sed s/_size//)
+  timeout 600 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $D -- python $ROOT/bench.py --steps 2 --warmup 1 \
+      --no-cpu-baseline --no-kernel-timing > $OUT/${TAG}_pmc_$C.log 2>&1
+done
+python $ROOT/profiles/summarize_pmc.py $OUT/prof_fetch $OUT/prof_write > $OUT/${TAG}_hbm_traffic.json
+# keep the merge-back small: raw traces stay on the box
+rm -rf $OUT/prof_kt $OUT/prof_fetch $OUT/prof_write
+head -c 600 $OUT/${TAG}_bench.json; echo; head -12 $OUT/${TAG}_kernel_trace.md; head -c 1500 $OUT/${TAG}_hbm_traffic.json
