@@ -56,7 +56,29 @@ def lib():
             fn.restype = _CT[res]
             fn.argtypes = [_CT[a] for a in args]
         _lib = l
+        env = os.environ.get('GPE_MATH')
+        if env:
+            set_math(env)
     return _lib
+
+
+MATH_MODES = {'f32': 0, 'bf16x3': 1}
+
+
+def set_math(mode):
+    """Arithmetic of the fused per-edge GEMMs: 'f32' (exact fp32 MFMA) or 'bf16x3' (split-bf16 on the bf16 matrix
+    pipe, fp32 accumulate) — include/gpe_hip.h gpe_math_set.  Returns the previous mode's name.  The environment
+    variable GPE_MATH selects the mode at library load."""
+    if mode not in MATH_MODES:
+        raise ValueError('unknown math mode %r (choose from %s)' % (mode, sorted(MATH_MODES)))
+    prev = lib().gpe_math_set(MATH_MODES[mode])
+    if prev < 0:
+        raise RuntimeError('gpe_math_set failed with code %d' % prev)
+    return {v: k for k, v in MATH_MODES.items()}[prev]
+
+
+def get_math():
+    return {v: k for k, v in MATH_MODES.items()}[lib().gpe_math_get()]
 
 
 def _conv(a):

@@ -21,7 +21,73 @@
 #include "gpe_rowgemm.h"
 #include <math.h>
 
-template <int AQ, int BQ, int KCH, int AMODE, int EMODE>
+// ---- split-bf16 ("bf16x3") arithmetic ------------------------------------------------------------------------------
+// x = hi + lo + O(2^-18 |x|) with hi = bf16(x), lo = bf16(x - hi);  a*b ~= ah*bh + ah*bl + al*bh on the bf16 matrix pipe
+// (v_mfma_f32_16x16x32_bf16, fp32 accumulate): three MFMAs at 16x the fp32-MFMA rate each, AND a bf16 stream leaves the
+// SIMD's other wave free to issue (see the header).  LDS/VGPR footprint is unchanged: 2 x 2 bytes per element.
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef short s16x4_t __attribute__((ext_vector_type(4)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void eg_split4(const float4 v, uint2& hi, uint2& lo)
+{
+    const f32x2_t a = {v.x, v.y}, b = {v.z, v.w};
+    const unsigned h0 = __builtin_bit_cast(unsigned, __builtin_convertvector(a, bf16x2_t));   // v_cvt_pk_bf16_f32 (RNE)
+    const unsigned h1 = __builtin_bit_cast(unsigned, __builtin_convertvector(b, bf16x2_t));
+    const f32x2_t ra = {v.x - __uint_as_float(h0 << 16), v.y - __uint_as_float(h0 & 0xffff0000u)};
+    const f32x2_t rb = {v.z - __uint_as_float(h1 << 16), v.w - __uint_as_float(h1 & 0xffff0000u)};
+    hi = make_uint2(h0, h1);
+    lo = make_uint2(__builtin_bit_cast(unsigned, __builtin_convertvector(ra, bf16x2_t)),
+                    __builtin_bit_cast(unsigned, __builtin_convertvector(rb, bf16x2_t)));
+}
+
+// One N-tile of the packed weight as bf16x3 B fragments: KCH/2 slabs of 32 k (+ a 16-k tail when KCH is odd).  Slab s of
+// lane (j, g) holds k = 32s + 4g + {0..3} and 32s + 16 + 4g + {0..3} (packed chunks 2s and 2s+1); the A tile is laid
+// out in LDS with the same k order (eg_kpos), so any consistent order is as good as the natural one.
+template <int KCH>
+struct EgWFrag {
+    uint4 h[KCH / 2 > 0 ? KCH / 2 : 1], l[KCH / 2 > 0 ? KCH / 2 : 1];
+    uint2 ht, lt;
+    __device__ __forceinline__ void load(const float* wp, int Npad, int col, int g)
+    {
+        const bool on = col < Npad;
+#pragma unroll
+        for (int sl = 0; sl < KCH / 2; ++sl) {
+            const float4 f0 = on ? ld4(wp + (((long)((2 * sl) * 4 + g)) * Npad + col) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 f1 = on ? ld4(wp + (((long)((2 * sl + 1) * 4 + g)) * Npad + col) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            uint2 h0, l0, h1, l1;
+            eg_split4(f0, h0, l0); eg_split4(f1, h1, l1);
+            h[sl] = make_uint4(h0.x, h0.y, h1.x, h1.y);
+            l[sl] = make_uint4(l0.x, l0.y, l1.x, l1.y);
+        }
+        ht = lt = make_uint2(0u, 0u);
+        if (KCH & 1) {
+            const float4 ft = on ? ld4(wp + (((long)((KCH - 1) * 4 + g)) * Npad + col) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            eg_split4(ft, ht, lt);
+        }
+    }
+};
+
+// bf16 index inside a row of the LDS A tile of column quad c (c % 4 == 0): 32-slabs are stored so that lane group g of
+// the MFMA finds its 8 k-values in 16 contiguous bytes
+template <int KCH>
+__device__ __forceinline__ int eg_kpos(int c)
+{
+    if (c >= 32 * (KCH / 2)) return c;                                   // 16-k tail: natural order
+    return (c & ~31) + 8 * ((c >> 2) & 3) + 4 * ((c >> 4) & 1);
+}
+
+__device__ __forceinline__ f32x4 eg_mfma32(const uint4 a, const uint4 b, const f32x4 c)
+{
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 eg_mfma16(const uint2 a, const uint2 b, const f32x4 c)
+{
+    return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4_t, a), __builtin_bit_cast(s16x4_t, b), c, 0, 0, 0);
+}
+
+template <int AQ, int BQ, int KCH, int AMODE, int EMODE, int MATH>
 __global__ __launch_bounds__(512, 2) void gpe_edgegemm_kernel(RgParams p, int stats_nblk)
 {
     constexpr int NT = 4 * AQ + BQ;
@@ -45,14 +111,19 @@ __global__ __launch_bounds__(512, 2) void gpe_edgegemm_kernel(RgParams p, int st
 
     if (consumer) {
         // =================================================================================================
-        float4 wA[AQ][KCH];
+        float4 wA[MATH == 0 ? AQ : 1][MATH == 0 ? KCH : 1];
+        EgWFrag<KCH> wF[MATH == 1 ? AQ : 1];
 #pragma unroll
         for (int i = 0; i < AQ; ++i) {
             const int col = 16 * (AQ * w4 + i) + j;
+            if constexpr (MATH == 0) {
 #pragma unroll
-            for (int kc = 0; kc < KCH; ++kc)
-                wA[i][kc] = (col < p.Npad) ? ld4(p.wp + (((long)(kc * 4 + g)) * p.Npad + col) * 4)
-                                           : make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int kc = 0; kc < KCH; ++kc)
+                    wA[i][kc] = (col < p.Npad) ? ld4(p.wp + (((long)(kc * 4 + g)) * p.Npad + col) * 4)
+                                               : make_float4(0.f, 0.f, 0.f, 0.f);
+            } else {
+                wF[i].load(p.wp, p.Npad, col, g);
+            }
         }
         __syncthreads();                                 // prologue: tile 0 staged by the producers
         int buf = 0;
@@ -63,34 +134,90 @@ __global__ __launch_bounds__(512, 2) void gpe_edgegemm_kernel(RgParams p, int st
             for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
                 for (int i = 0; i < AQ; ++i) acc[mt][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            // A fragments are read ONE CHUNK AHEAD of the MFMAs that use them: LDS latency (inflated by the producers'
-            // staging/epilogue traffic) then sits under 48 MFMAs instead of stalling the matrix pipe 13x per tile
-            float4 an[4];
+            if constexpr (MATH == 0) {
+                // A fragments are read ONE CHUNK AHEAD of the MFMAs that use them: LDS latency (inflated by the
+                // producers' staging/epilogue traffic) then sits under 48 MFMAs instead of stalling the matrix pipe
+                float4 an[4];
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) an[mt] = ld4(&As[(16 * mt + j) * LDA + 4 * g]);
-            if (!(p.dbg & 16))
+                for (int mt = 0; mt < 4; ++mt) an[mt] = ld4(&As[(16 * mt + j) * LDA + 4 * g]);
+                if (!(p.dbg & 16))
 #pragma unroll
-            for (int kc = 0; kc < KCH; ++kc) {
-                float a[4][4];
+                for (int kc = 0; kc < KCH; ++kc) {
+                    float a[4][4];
 #pragma unroll
-                for (int mt = 0; mt < 4; ++mt) {
-                    a[mt][0] = an[mt].x; a[mt][1] = an[mt].y; a[mt][2] = an[mt].z; a[mt][3] = an[mt].w;
-                }
-                if (kc + 1 < KCH) {
-#pragma unroll
-                    for (int mt = 0; mt < 4; ++mt) an[mt] = ld4(&As[(16 * mt + j) * LDA + 16 * (kc + 1) + 4 * g]);
-                }
-                __builtin_amdgcn_sched_barrier(0);       // keep the prefetch ahead of this chunk's MFMAs
-#pragma unroll
-                for (int t = 0; t < 4; ++t)
-#pragma unroll
-                    for (int i = 0; i < AQ; ++i) {
-                        const float bv = (t == 0) ? wA[i][kc].x : (t == 1) ? wA[i][kc].y : (t == 2) ? wA[i][kc].z
-                                                                                                   : wA[i][kc].w;
-#pragma unroll
-                        for (int mt = 0; mt < 4; ++mt)
-                            acc[mt][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt][t], bv, acc[mt][i], 0, 0, 0);
+                    for (int mt = 0; mt < 4; ++mt) {
+                        a[mt][0] = an[mt].x; a[mt][1] = an[mt].y; a[mt][2] = an[mt].z; a[mt][3] = an[mt].w;
                     }
+                    if (kc + 1 < KCH) {
+#pragma unroll
+                        for (int mt = 0; mt < 4; ++mt) an[mt] = ld4(&As[(16 * mt + j) * LDA + 16 * (kc + 1) + 4 * g]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);   // keep the prefetch ahead of this chunk's MFMAs
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+#pragma unroll
+                        for (int i = 0; i < AQ; ++i) {
+                            const float bv = (t == 0) ? wA[i][kc].x : (t == 1) ? wA[i][kc].y : (t == 2) ? wA[i][kc].z
+                                                                                                       : wA[i][kc].w;
+#pragma unroll
+                            for (int mt = 0; mt < 4; ++mt)
+                                acc[mt][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt][t], bv, acc[mt][i], 0, 0, 0);
+                        }
+                }
+            } else {
+                // bf16x3: row (16 mt + j), hi plane at byte 0 and lo plane at byte 32 KCH of the row
+                constexpr int S32 = KCH / 2;
+                const char* rowp = reinterpret_cast<const char*>(As) + (size_t)j * (4 * LDA) + 16 * g;
+                if (!(p.dbg & 16)) {
+#pragma unroll
+                    for (int sl = 0; sl < S32; ++sl) {
+                        // no software prefetch here: the bf16 stream is short next to the producers' work, and the 32
+                        // extra VGPRs would spill at AQ = 3, KCH = 13
+                        uint4 ah[4], al[4];
+#pragma unroll
+                        for (int mt = 0; mt < 4; ++mt) {
+                            ah[mt] = *reinterpret_cast<const uint4*>(rowp + (size_t)mt * (64 * LDA) + 64 * sl);
+                            al[mt] = *reinterpret_cast<const uint4*>(rowp + (size_t)mt * (64 * LDA) + 32 * KCH + 64 * sl);
+                        }
+                        // small terms first; consecutive MFMAs always hit different accumulators
+#pragma unroll
+                        for (int i = 0; i < AQ; ++i)
+#pragma unroll
+                            for (int mt = 0; mt < 4; ++mt) acc[mt][i] = eg_mfma32(al[mt], wF[i].h[sl], acc[mt][i]);
+#pragma unroll
+                        for (int i = 0; i < AQ; ++i)
+#pragma unroll
+                            for (int mt = 0; mt < 4; ++mt) acc[mt][i] = eg_mfma32(ah[mt], wF[i].l[sl], acc[mt][i]);
+#pragma unroll
+                        for (int i = 0; i < AQ; ++i)
+#pragma unroll
+                            for (int mt = 0; mt < 4; ++mt) acc[mt][i] = eg_mfma32(ah[mt], wF[i].h[sl], acc[mt][i]);
+                    }
+                    if (KCH & 1) {
+                        const char* tp = reinterpret_cast<const char*>(As) + (size_t)j * (4 * LDA) + 64 * S32 + 8 * g;
+                        uint2 th[4], tl[4];
+#pragma unroll
+                        for (int mt = 0; mt < 4; ++mt) {
+                            th[mt] = *reinterpret_cast<const uint2*>(tp + (size_t)mt * (64 * LDA));
+                            tl[mt] = *reinterpret_cast<const uint2*>(tp + (size_t)mt * (64 * LDA) + 32 * KCH);
+                        }
+                        // Shape change on the same accumulator: safe HERE because 4*AQ-1 >= 7 other MFMAs (>= 100
+                        // cycles) sit between the last 16x16x32 and the first 16x16x16 that touch a given accumulator —
+                        // issued back to back the narrower one reads stale registers (see the producers' left-over tile)
+#pragma unroll
+                        for (int i = 0; i < AQ; ++i)
+#pragma unroll
+                            for (int mt = 0; mt < 4; ++mt) acc[mt][i] = eg_mfma16(tl[mt], wF[i].ht, acc[mt][i]);
+#pragma unroll
+                        for (int i = 0; i < AQ; ++i)
+#pragma unroll
+                            for (int mt = 0; mt < 4; ++mt) acc[mt][i] = eg_mfma16(th[mt], wF[i].lt, acc[mt][i]);
+#pragma unroll
+                        for (int i = 0; i < AQ; ++i)
+#pragma unroll
+                            for (int mt = 0; mt < 4; ++mt) acc[mt][i] = eg_mfma16(th[mt], wF[i].ht, acc[mt][i]);
+                    }
+                }
             }
             __syncthreads();                             // (1) producers are done with C (epilogue of tile-1)
 #pragma unroll
@@ -107,19 +234,25 @@ __global__ __launch_bounds__(512, 2) void gpe_edgegemm_kernel(RgParams p, int st
         __syncthreads();                                 // tail (T2): statistics combined in LDS
     } else {
         // =================================================================================================
-        float4 wB[BQ > 0 ? BQ : 1][KCH];
+        float4 wB[(MATH == 0 && BQ > 0) ? BQ : 1][MATH == 0 ? KCH : 1];
+        EgWFrag<KCH> wG[(MATH == 1 && BQ > 0) ? BQ : 1];
 #pragma unroll
         for (int b = 0; b < BQ; ++b) {
             const int col = 16 * (4 * AQ + b) + j;
+            if constexpr (MATH == 0) {
 #pragma unroll
-            for (int kc = 0; kc < KCH; ++kc)
-                wB[b][kc] = (col < p.Npad) ? ld4(p.wp + (((long)(kc * 4 + g)) * p.Npad + col) * 4)
-                                           : make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int kc = 0; kc < KCH; ++kc)
+                    wB[b][kc] = (col < p.Npad) ? ld4(p.wp + (((long)(kc * 4 + g)) * p.Npad + col) * 4)
+                                               : make_float4(0.f, 0.f, 0.f, 0.f);
+            } else {
+                wG[b].load(p.wp, p.Npad, col, g);
+            }
         }
         // producers issue few, latency-critical memory instructions: let them win issue arbitration against the
         // MFMA-issuing consumer wave on the same SIMD (MI355X_MICROARCH.md "Two waves per SIMD")
         __builtin_amdgcn_s_setprio(3);
         const int c = lane << 2;                         // this lane's column quad
+        const int kpos = eg_kpos<KCH>(c);                // bf16x3: where that quad sits in an LDS A row
         const bool k_on = c < p.K;                       // staging lanes
         const bool n_on = c < p.N;                       // epilogue lanes
         double stS[4] = {0, 0, 0, 0}, stQ[4] = {0, 0, 0, 0};
@@ -171,7 +304,15 @@ __global__ __launch_bounds__(512, 2) void gpe_edgegemm_kernel(RgParams p, int st
                                     o.x = fmaxf(o.x + pv.x, 0.f); o.y = fmaxf(o.y + pv.y, 0.f);
                                     o.z = fmaxf(o.z + pv.z, 0.f); o.w = fmaxf(o.w + pv.w, 0.f);
                                 }
-                                st4(&As[(pt * p.k + s0 + u) * LDA + c], o);
+                                if constexpr (MATH == 0) {
+                                    st4(&As[(pt * p.k + s0 + u) * LDA + c], o);
+                                } else {
+                                    uint2 hi, lo;
+                                    eg_split4(o, hi, lo);
+                                    char* rp = reinterpret_cast<char*>(As) + (size_t)(pt * p.k + s0 + u) * (4 * LDA) + 2 * kpos;
+                                    *reinterpret_cast<uint2*>(rp) = hi;
+                                    *reinterpret_cast<uint2*>(rp + 32 * KCH) = lo;
+                                }
                             }
                         }
                     }
@@ -286,18 +427,51 @@ __global__ __launch_bounds__(512, 2) void gpe_edgegemm_kernel(RgParams p, int st
 #pragma unroll
             for (int b = 0; b < (BQ > 0 ? BQ : 1); ++b) accB[b] = (f32x4){0.f, 0.f, 0.f, 0.f};
             if (BQ > 0 && !(p.dbg & 32)) {
+                if constexpr (MATH == 0) {
 #pragma unroll
-                for (int kc = 0; kc < KCH; ++kc) {
-                    const float4 t4 = ld4(&As[(16 * w4 + j) * LDA + 16 * kc + 4 * g]);
-                    const float aw[4] = {t4.x, t4.y, t4.z, t4.w};
+                    for (int kc = 0; kc < KCH; ++kc) {
+                        const float4 t4 = ld4(&As[(16 * w4 + j) * LDA + 16 * kc + 4 * g]);
+                        const float aw[4] = {t4.x, t4.y, t4.z, t4.w};
 #pragma unroll
-                    for (int t = 0; t < 4; ++t)
+                        for (int t = 0; t < 4; ++t)
 #pragma unroll
-                        for (int b = 0; b < BQ; ++b) {
-                            const float bv = (t == 0) ? wB[b][kc].x : (t == 1) ? wB[b][kc].y : (t == 2) ? wB[b][kc].z
-                                                                                                       : wB[b][kc].w;
-                            accB[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[t], bv, accB[b], 0, 0, 0);
-                        }
+                            for (int b = 0; b < BQ; ++b) {
+                                const float bv = (t == 0) ? wB[b][kc].x : (t == 1) ? wB[b][kc].y : (t == 2) ? wB[b][kc].z
+                                                                                                           : wB[b][kc].w;
+                                accB[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[t], bv, accB[b], 0, 0, 0);
+                            }
+                    }
+                } else {
+                    constexpr int S32 = KCH / 2;
+                    const char* rowp = reinterpret_cast<const char*>(As) + (size_t)(16 * w4 + j) * (4 * LDA);
+#pragma unroll
+                    for (int sl = 0; sl < S32; ++sl) {
+                        const uint4 ah = *reinterpret_cast<const uint4*>(rowp + 64 * sl + 16 * g);
+                        const uint4 al = *reinterpret_cast<const uint4*>(rowp + 32 * KCH + 64 * sl + 16 * g);
+#pragma unroll
+                        for (int b = 0; b < BQ; ++b) accB[b] = eg_mfma32(al, wG[b].h[sl], accB[b]);
+#pragma unroll
+                        for (int b = 0; b < BQ; ++b) accB[b] = eg_mfma32(ah, wG[b].l[sl], accB[b]);
+#pragma unroll
+                        for (int b = 0; b < BQ; ++b) accB[b] = eg_mfma32(ah, wG[b].h[sl], accB[b]);
+                    }
+                    if (KCH & 1) {
+                        // The 16-k tail gets its OWN accumulators: a v_mfma_f32_16x16x16_bf16 issued right behind a
+                        // v_mfma_f32_16x16x32_bf16 with the same vDst as SrcC intermittently picks up two of the four
+                        // accumulator registers before the wider instruction has written them (seen as rows 4g+{0,1}
+                        // of this tile losing one product whenever the LDS wait in between happened to be short).
+                        const uint2 th = *reinterpret_cast<const uint2*>(rowp + 64 * S32 + 8 * g);
+                        const uint2 tl = *reinterpret_cast<const uint2*>(rowp + 32 * KCH + 64 * S32 + 8 * g);
+                        f32x4 accT[BQ > 0 ? BQ : 1];
+#pragma unroll
+                        for (int b = 0; b < BQ; ++b) accT[b] = eg_mfma16(tl, wG[b].ht, (f32x4){0.f, 0.f, 0.f, 0.f});
+#pragma unroll
+                        for (int b = 0; b < BQ; ++b) accT[b] = eg_mfma16(th, wG[b].lt, accT[b]);
+#pragma unroll
+                        for (int b = 0; b < BQ; ++b) accT[b] = eg_mfma16(th, wG[b].ht, accT[b]);
+#pragma unroll
+                        for (int b = 0; b < BQ; ++b) accB[b] += accT[b];
+                    }
                 }
             }
             if (prev >= 0 && !(p.dbg & 2)) epilogue(prev, jg_prev);      // overlaps the consumers' MFMAs of `tile`
@@ -351,7 +525,7 @@ static int eg_num_cus()
     return cus;
 }
 
-template <int AQ, int BQ, int KCH, int AMODE, int EMODE>
+template <int AQ, int BQ, int KCH, int AMODE, int EMODE, int MATH>
 static int eg_launch(const RgParams& p, int stats_nblk, hipStream_t s)
 {
     constexpr int NT = 4 * AQ + BQ;
@@ -359,7 +533,7 @@ static int eg_launch(const RgParams& p, int stats_nblk, hipStream_t s)
     const size_t lds = (size_t)RG_BM * (2 * LDA + LDC) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gpe_edgegemm_kernel<AQ, BQ, KCH, AMODE, EMODE>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gpe_edgegemm_kernel<AQ, BQ, KCH, AMODE, EMODE, MATH>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             return GPE_ELAUNCH;
         attr_set = true;
@@ -367,19 +541,29 @@ static int eg_launch(const RgParams& p, int stats_nblk, hipStream_t s)
     int gx = eg_num_cus();
     if (gx > p.num_tiles) gx = p.num_tiles;
     if (stats_nblk > 0 && gx > stats_nblk) gx = stats_nblk;
-    hipLaunchKernelGGL((gpe_edgegemm_kernel<AQ, BQ, KCH, AMODE, EMODE>), dim3(gx), dim3(512), lds, s, p, stats_nblk);
+    hipLaunchKernelGGL((gpe_edgegemm_kernel<AQ, BQ, KCH, AMODE, EMODE, MATH>), dim3(gx), dim3(512), lds, s, p, stats_nblk);
     GPE_CHECK_LAUNCH();
     return GPE_OK;
 }
 
+template <int AMODE, int EMODE, int MATH>
+static int eg_dispatch_m(int NT, int KCH, const RgParams& p, int stats_nblk, hipStream_t s)
+{
+    if (NT == 13 && KCH == 13) return eg_launch<3, 1, 13, AMODE, EMODE, MATH>(p, stats_nblk, s);
+    if (NT == 13 && KCH == 10) return eg_launch<3, 1, 10, AMODE, EMODE, MATH>(p, stats_nblk, s);
+    if (NT == 10 && KCH == 13) return eg_launch<2, 2, 13, AMODE, EMODE, MATH>(p, stats_nblk, s);
+    if (NT == 10 && KCH == 10) return eg_launch<2, 2, 10, AMODE, EMODE, MATH>(p, stats_nblk, s);
+    return GPE_EINVAL;
+}
+
+static int g_eg_math = 0;            // 0: exact fp32 MFMA, 1: bf16x3 (gpe_math_set)
+void gpe_edgegemm_set_math(int m) { g_eg_math = m; }
+
 template <int AMODE, int EMODE>
 static int eg_dispatch(int NT, int KCH, const RgParams& p, int stats_nblk, hipStream_t s)
 {
-    if (NT == 13 && KCH == 13) return eg_launch<3, 1, 13, AMODE, EMODE>(p, stats_nblk, s);
-    if (NT == 13 && KCH == 10) return eg_launch<3, 1, 10, AMODE, EMODE>(p, stats_nblk, s);
-    if (NT == 10 && KCH == 13) return eg_launch<2, 2, 13, AMODE, EMODE>(p, stats_nblk, s);
-    if (NT == 10 && KCH == 10) return eg_launch<2, 2, 10, AMODE, EMODE>(p, stats_nblk, s);
-    return GPE_EINVAL;
+    return g_eg_math == 1 ? eg_dispatch_m<AMODE, EMODE, 1>(NT, KCH, p, stats_nblk, s)
+                          : eg_dispatch_m<AMODE, EMODE, 0>(NT, KCH, p, stats_nblk, s);
 }
 
 // Returns 1 and launches when the shape is on the register-stationary menu, 0 when the caller should use the generic

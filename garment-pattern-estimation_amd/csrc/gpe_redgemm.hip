@@ -17,6 +17,9 @@
 //     are run-to-run deterministic.
 #include "gpe_common.h"
 
+static int g_rd_math = 0;            // 0: exact fp32 MFMA, 1: bf16x3 (gpe_math_set)
+void gpe_redgemm_set_math(int m) { g_rd_math = m; }
+
 #define RD_RT 32
 
 enum { V_GATHER = 0, V_DENSE = 1 };

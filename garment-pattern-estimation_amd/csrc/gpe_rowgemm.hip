@@ -212,8 +212,22 @@ int gpe_smallgemm_linear(const RgParams& r, hipStream_t s);
 // register-stationary fast path for the shipped edge-MLP sizes (gpe_edgegemm.hip): 1 launched, 0 not on its menu
 int gpe_edgegemm_try(const RgParams& p, int amode, int emode, int stats_nblk, hipStream_t s);
 
+void gpe_edgegemm_set_math(int m);
+void gpe_redgemm_set_math(int m);
+
 static int g_gpe_dbg = 0;
 extern "C" int gpe_debug_set(int flags) { g_gpe_dbg = flags; return 0; }
+static int g_gpe_math = 0;
+extern "C" int gpe_math_get(void) { return g_gpe_math; }
+extern "C" int gpe_math_set(int mode)
+{
+    if (mode != 0 && mode != 1) return GPE_EINVAL;
+    const int prev = g_gpe_math;
+    g_gpe_math = mode;
+    gpe_edgegemm_set_math(mode);
+    gpe_redgemm_set_math(mode);
+    return prev;
+}
 
 #define GPE_STATS_BLOCKS 512
 extern "C" int gpe_stats_blocks(void) { return GPE_STATS_BLOCKS; }

@@ -25,6 +25,14 @@ extern "C" {
 int gpe_abi_version(void);
 /* profiling aid: ablation switches for the fused edge kernels (0 = production behaviour; results are WRONG otherwise) */
 int gpe_debug_set(int flags);
+/* arithmetic of the fused per-edge GEMMs (gpe_edge_mlp_fwd / gpe_edge_mlp_bwd / gpe_edge_redgemm):
+ *   0 = "f32"    exact fp32 matrix instruction (v_mfma_f32_16x16x4_f32)
+ *   1 = "bf16x3" split-bf16: every fp32 operand x = hi + lo (two bf16), a*b ~= ah*bh + ah*bl + al*bh on the bf16 matrix
+ *                pipe with fp32 accumulation (relative error ~1e-5 per product instead of ~1e-7).
+ * Returns the previous mode, or -22 for an unknown one.  kNN, BatchNorm statistics, the LSTM decoder and every
+ * elementwise op are fp32 (fp64 for reductions) in both modes. */
+int gpe_math_set(int mode);
+int gpe_math_get(void);
 
 /* ---- kNN graph: torch_cluster.knn as called by DynamicEdgeConv (nn/net_blocks.py:127-135,174) ------------
  * x [B][N][ldx>=C]; idx [B][N][k] int32, LOCAL to the cloud, ascending (dist, index); self included.

@@ -19,7 +19,7 @@ def test_header_declares_expected_surface():
     # every compute entry point ends with the stream argument (a pointer) and returns int
     for name, (res, args) in sigs.items():
         if name in ('gpe_abi_version', 'gpe_packed_size', 'gpe_packed_gates_size', 'gpe_redgemm_ws',
-                    'gpe_stats_blocks', 'gpe_point_sums_blocks', 'gpe_debug_set'):
+                    'gpe_stats_blocks', 'gpe_point_sums_blocks', 'gpe_debug_set', 'gpe_math_set', 'gpe_math_get'):
             continue
         assert res == 'i' and args[-1] == 'p', name
 
@@ -30,6 +30,13 @@ def test_library_exports_every_declared_symbol():
     for name in _lib.parse_header():
         assert hasattr(raw, name), 'libgpe_hip.so does not export %s' % name
     _lib.lib()      # binds argtypes for all of them
+
+
+def test_math_mode_switch_is_host_only():
+    assert _lib.get_math() in _lib.MATH_MODES
+    prev = _lib.set_math('bf16x3')
+    assert _lib.get_math() == 'bf16x3' and _lib.lib().gpe_math_set(7) == -22
+    assert _lib.set_math(prev) == 'bf16x3' and _lib.get_math() == prev
 
 
 def test_host_only_queries():
