@@ -45,6 +45,9 @@ def parse():
     ap.add_argument('--cpu-steps', type=int, default=2)
     ap.add_argument('--cpu-threads', type=int, default=32)
     ap.add_argument('--no-kernel-timing', action='store_true')
+    ap.add_argument('--math', choices=['f32', 'bf16x3'], default='f32',
+                    help="arithmetic of the fused edge GEMMs for the timed region (gpe_math_set); 'f32' = exact")
+    ap.add_argument('--no-fast-math-line', action='store_true', help='skip the extra bf16x3 measurement')
     return ap.parse_args()
 
 
@@ -157,6 +160,7 @@ def main():
     data_config = configs.data_config()
     nn_cfg = configs.lstm_model_config(k_neighbors=args.k)
 
+    gpe_amd.set_math(args.math)
     torch.manual_seed(0)                               # identical replicas on every rank
     model = nets.GarmentFullPattern3D(data_config, dict(nn_cfg), dict(nn_cfg['loss'])).to(dev).train()
     model.loss.with_quality_eval = False
@@ -230,6 +234,26 @@ def main():
                            'traffic': pmc_traffic('gpe_edge_gather_stats')[0],
                            'avg_launch_ms': ms / n_l, 'bytes_per_launch': by / n_l}
 
+    # the opt-in fast mode, measured the same way on the same workload (reported beside `value`, never as `value`)
+    fast = None
+    if world == 1 and args.math == 'f32' and not args.no_fast_math_line:
+        gpe_amd.set_math('bf16x3')
+        n_f = max(3, min(args.steps, 10))
+        for i in range(2):
+            step(10_000 + i)
+        barrier()
+        t1 = time.perf_counter()
+        for i in range(n_f):
+            step(10_002 + i)
+        barrier()
+        dt = time.perf_counter() - t1
+        gpe_amd.set_math('f32')
+        fast = {'math': 'bf16x3', 'value': args.batch * n_f / dt, 'unit': 'garments/s', 'steps': n_f,
+                'ms_per_step': dt / n_f * 1e3,
+                'note': 'split-bf16 edge GEMMs on the bf16 matrix pipe, fp32 accumulate: forward within 1e-4 of the '
+                        'reference, encoder gradients within ~1e-2 (tests/test_gpu_kernels.py TOL); opt-in via '
+                        'gpe_math_set(1) / GPE_MATH=bf16x3'}
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args, data_config, nn_cfg)
@@ -240,13 +264,14 @@ def main():
             'metric': 'garments/sec (fwd+bwd) at N=%d pts, batch %d per GPU' % (args.points, args.batch),
             'value': garments / elapsed, 'unit': 'garments/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True,
-            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': args.math, 'data': 'synthetic',
             'config': {'workload': 'BASELINE cfg 2: GarmentFullPattern3D, N=%d, batch %d/GPU, k=%d, EdgeConv encoder'
                                    ' + LSTM decoders' % (args.points, args.batch, args.k),
                        'global_batch': args.batch * world, 'parallelism': 'dp%d' % world,
                        'step': 'fwd + ComposedPatternLoss + bwd' + (' + RCCL grad all-reduce' if world > 1 else '')
                                + ' + Adam', 'final_loss': final_loss},
-            'roofline': roof, 'roofline_gather': roof_gather, 'cpu_baseline': cpu, 'kernel_ms_per_step': breakdown}
+            'roofline': roof, 'roofline_gather': roof_gather, 'cpu_baseline': cpu, 'fast_math': fast,
+            'kernel_ms_per_step': breakdown}
         print(json.dumps(out))
     if world > 1:
         torch.distributed.destroy_process_group()

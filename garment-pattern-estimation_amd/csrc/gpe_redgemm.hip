@@ -465,6 +465,261 @@ __global__ __launch_bounds__(512, 2) void gpe_redgemm_pc_kernel(RdParams p)
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// bf16x3 variant of the producer/consumer kernel (gpe_math_set(1)): same roles, same partial/colsum outputs, but the
+// products run on the bf16 matrix pipe — u = uh + ul, v = vh + vl (two bf16 each), u*v ~= ul*vh + uh*vl + uh*vh with
+// fp32 accumulation (v_mfma_f32_16x16x32_bf16; the reduction dim of ONE instruction is a whole 32-row tile).  A bf16
+// MFMA stream leaves the SIMD's other wave free to issue, so the producers' loads really do hide under it
+// (profiles/r01_d_coissue_ubench.md).
+//
+// The MFMA wants, per lane, 8 consecutive reduction indices (= ROWS) of one operand column, so the LDS image is the
+// TRANSPOSE of the row tile: entry (plane, g, col) = 16 bytes = bf16 of rows 8g..8g+7 of column `col`, stored at
+//     ((plane*4 + g)*4 + (col & 3)) * S + (col >> 2)            [16-byte units],  S = cols/4 + pad,  S % 8 == 2
+// A producer lane owns columns 4l..4l+3 of rows 8*w4..8*w4+7, so its four ds_write_b128 per plane land on consecutive
+// 16-byte slots across lanes (conflict-free), and a consumer's 16 lanes (i = 0..15, same g) hit 8 distinct 16-byte bank
+// groups per 8 lanes because S % 8 == 2.
+typedef __bf16 rd_bf16x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 rd_bf16x8_t __attribute__((ext_vector_type(8)));
+typedef float rd_f32x2_t __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void rd_split_pair(float x0, float x1, unsigned& hw, unsigned& lw)
+{
+    const rd_f32x2_t x = {x0, x1};
+    hw = __builtin_bit_cast(unsigned, __builtin_convertvector(x, rd_bf16x2_t));          // v_cvt_pk_bf16_f32 (RNE)
+    const rd_f32x2_t r = {x0 - __uint_as_float(hw << 16), x1 - __uint_as_float(hw & 0xffff0000u)};
+    lw = __builtin_bit_cast(unsigned, __builtin_convertvector(r, rd_bf16x2_t));
+}
+__device__ __forceinline__ f32x4 rd_mfma32(const uint4 a, const uint4 b, const f32x4 c)
+{
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(rd_bf16x8_t, a), __builtin_bit_cast(rd_bf16x8_t, b),
+                                                   c, 0, 0, 0);
+}
+__device__ __forceinline__ float rd_comp(const float4& v, int t) { return t == 0 ? v.x : t == 1 ? v.y : t == 2 ? v.z : v.w; }
+
+template <int CT> struct RdB3Layout {                 // CT = number of 16-column tiles of the operand
+    static constexpr int Q = 4 * CT;                  // column quads
+    static constexpr int S = Q + ((10 - (Q % 8)) % 8);        // S % 8 == 2
+    static constexpr int BYTES = 32 * S * 16;         // 2 planes x 4 row blocks x 4 (col & 3) x S slots x 16 B
+    __device__ static __forceinline__ int slot(int plane, int g, int col)
+    {
+        return (((plane * 4 + g) * 4 + (col & 3)) * S + (col >> 2)) * 16;
+    }
+};
+
+template <int MT, int NT, int VMODE>
+__global__ __launch_bounds__(512, 2) void gpe_redgemm_b3_kernel(RdParams p)
+{
+    static_assert(RD_RT == 32, "one v_mfma_f32_16x16x32_bf16 reduces exactly one row tile");
+    constexpr int MB = MT / 2, NB = NT / 2;
+    constexpr int LEFT = (MT & 1) * NT + (NT & 1) * (MT - (MT & 1));     // left-over tiles
+    constexpr int PMAX = (LEFT + 3) / 4;
+    constexpr int UC = 16 * MT, VC = 16 * NT;
+    using LU = RdB3Layout<MT>;
+    using LV = RdB3Layout<NT>;
+    constexpr int RQ = RD_RT / 4;                     // 8 consecutive rows per producer wave
+    extern __shared__ __align__(16) char smem_b3[];
+    char* const Ub = smem_b3;                         // [2][LU::BYTES]
+    char* const Vb = smem_b3 + 2 * LU::BYTES;         // [2][LV::BYTES]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int w4 = wave & 3;
+    const int j = lane & 15, g = lane >> 4;
+    float* dst = p.part + (size_t)blockIdx.x * p.MgPad * p.NgPad;
+
+    if (wave < 4) {
+        // ================================ consumers ================================
+        const int mt0 = (w4 & 1) * MB, nt0 = (w4 >> 1) * NB;
+        f32x4 acc[MB][NB];
+#pragma unroll
+        for (int q = 0; q < MB; ++q)
+#pragma unroll
+            for (int n = 0; n < NB; ++n) acc[q][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        __syncthreads();                           // prologue: tile 0 staged
+        int buf = 0;
+        for (int tile = blockIdx.x; tile < p.num_tiles; tile += gridDim.x) {
+            const char* ub = Ub + buf * LU::BYTES;
+            const char* vb = Vb + buf * LV::BYTES;
+            uint4 bh[NB], bl[NB];
+#pragma unroll
+            for (int n = 0; n < NB; ++n) {
+                bh[n] = *reinterpret_cast<const uint4*>(vb + LV::slot(0, g, 16 * (nt0 + n) + j));
+                bl[n] = *reinterpret_cast<const uint4*>(vb + LV::slot(1, g, 16 * (nt0 + n) + j));
+            }
+#pragma unroll
+            for (int q = 0; q < MB; ++q) {
+                const uint4 ah = *reinterpret_cast<const uint4*>(ub + LU::slot(0, g, 16 * (mt0 + q) + j));
+                const uint4 al = *reinterpret_cast<const uint4*>(ub + LU::slot(1, g, 16 * (mt0 + q) + j));
+#pragma unroll
+                for (int n = 0; n < NB; ++n) acc[q][n] = rd_mfma32(al, bh[n], acc[q][n]);
+#pragma unroll
+                for (int n = 0; n < NB; ++n) acc[q][n] = rd_mfma32(ah, bl[n], acc[q][n]);
+#pragma unroll
+                for (int n = 0; n < NB; ++n) acc[q][n] = rd_mfma32(ah, bh[n], acc[q][n]);
+            }
+            __syncthreads();
+            buf ^= 1;
+        }
+#pragma unroll
+        for (int q = 0; q < MB; ++q)
+#pragma unroll
+            for (int n = 0; n < NB; ++n)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    dst[(size_t)(16 * (mt0 + q) + 4 * g + r) * p.NgPad + 16 * (nt0 + n) + j] = acc[q][n][r];
+        __syncthreads();                           // tail: producers' column sums in LDS
+    } else {
+        // ================================ producers ================================
+        const int cq = lane << 2;
+        const bool u_on = cq < p.Mg, v_on = cq < p.Ng;
+        const int cu = u_on ? cq : 0, cv = v_on ? cq : 0;
+        float sh[4] = {0.f, 0.f, 0.f, 0.f};
+        if (p.v_shift && v_on) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) if (cq + t < p.Ng) sh[t] = p.v_shift[cq + t];
+        }
+        // my left-over tiles: list index t = w4, w4+4, ...  ->  (m, n)
+        int offU[PMAX > 0 ? PMAX : 1], offV[PMAX > 0 ? PMAX : 1];
+        int my_count = 0;
+#pragma unroll
+        for (int s_ = 0; s_ < PMAX; ++s_) {
+            const int t = w4 + 4 * s_;
+            int m = 0, n = 0;
+            if (t < LEFT) {
+                ++my_count;
+                if ((MT & 1) && t < NT) { m = MT - 1; n = t; }
+                else { const int t2 = t - (MT & 1) * NT; m = t2; n = NT - 1; }
+            }
+            offU[s_] = 16 * m; offV[s_] = 16 * n;
+        }
+        f32x4 accP[PMAX > 0 ? PMAX : 1];
+#pragma unroll
+        for (int s_ = 0; s_ < (PMAX > 0 ? PMAX : 1); ++s_) accP[s_] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        double csd[4] = {0, 0, 0, 0};
+        float4 ur[RQ], vr[RQ], vr2[VMODE == V_GATHER ? RQ : 1];
+
+        auto fetch = [&](int tile) {
+            const long row0 = (long)tile * RD_RT;
+            const int rv = (int)((p.rows - row0 < RD_RT) ? (p.rows - row0) : RD_RT);
+#pragma unroll
+            for (int q = 0; q < RQ; ++q) {
+                const int r = RQ * w4 + q;                                  // 8 CONSECUTIVE rows per wave
+                const long gr = row0 + ((r < rv) ? r : rv - 1);
+                ur[q] = rd_ld4(p.u.base + gr * p.u.stride_outer + cu);
+                if (VMODE == V_DENSE) vr[q] = rd_ld4(p.v.base + gr * p.v.stride_outer + cv);
+                else {
+                    const long i = (long)gpe_udiv((unsigned)gr, (unsigned)p.k, p.rcp_k);
+                    const long jj = p.jg[gr];
+                    vr[q] = rd_ld4(p.pq + i * p.ldpq + cv);
+                    vr2[q] = rd_ld4(p.pq + jj * p.ldpq + p.H + cv);
+                }
+            }
+        };
+        auto commit = [&](int buf, int tile) {
+            char* ub = Ub + buf * LU::BYTES;
+            char* vb = Vb + buf * LV::BYTES;
+            const long row0 = (long)tile * RD_RT;
+            const int rv = (int)((p.rows - row0 < RD_RT) ? (p.rows - row0) : RD_RT);
+            float c32[4] = {0.f, 0.f, 0.f, 0.f};
+            if (cq < UC) {
+#pragma unroll
+                for (int q = 0; q < RQ; ++q) {
+                    if (!(RQ * w4 + q < rv && u_on)) ur[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    else {
+                        if (cq + 1 >= p.Mg) ur[q].y = 0.f;
+                        if (cq + 2 >= p.Mg) ur[q].z = 0.f;
+                        if (cq + 3 >= p.Mg) ur[q].w = 0.f;
+                    }
+                    c32[0] += ur[q].x; c32[1] += ur[q].y; c32[2] += ur[q].z; c32[3] += ur[q].w;
+                }
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    unsigned hw[4], lw[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) rd_split_pair(rd_comp(ur[2 * e], t), rd_comp(ur[2 * e + 1], t), hw[e], lw[e]);
+                    *reinterpret_cast<uint4*>(ub + LU::slot(0, w4, cq + t)) = make_uint4(hw[0], hw[1], hw[2], hw[3]);
+                    *reinterpret_cast<uint4*>(ub + LU::slot(1, w4, cq + t)) = make_uint4(lw[0], lw[1], lw[2], lw[3]);
+                }
+            }
+            if (cq < VC) {
+#pragma unroll
+                for (int q = 0; q < RQ; ++q) {
+                    float4 v = vr[q];
+                    if (VMODE == V_GATHER) {
+                        v.x = fmaxf(v.x + vr2[q].x, 0.f); v.y = fmaxf(v.y + vr2[q].y, 0.f);
+                        v.z = fmaxf(v.z + vr2[q].z, 0.f); v.w = fmaxf(v.w + vr2[q].w, 0.f);
+                    }
+                    v.x -= sh[0]; v.y -= sh[1]; v.z -= sh[2]; v.w -= sh[3];
+                    if (!(RQ * w4 + q < rv && v_on)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    else {
+                        if (cq + 1 >= p.Ng) v.y = 0.f;
+                        if (cq + 2 >= p.Ng) v.z = 0.f;
+                        if (cq + 3 >= p.Ng) v.w = 0.f;
+                    }
+                    vr[q] = v;
+                }
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    unsigned hw[4], lw[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) rd_split_pair(rd_comp(vr[2 * e], t), rd_comp(vr[2 * e + 1], t), hw[e], lw[e]);
+                    *reinterpret_cast<uint4*>(vb + LV::slot(0, w4, cq + t)) = make_uint4(hw[0], hw[1], hw[2], hw[3]);
+                    *reinterpret_cast<uint4*>(vb + LV::slot(1, w4, cq + t)) = make_uint4(lw[0], lw[1], lw[2], lw[3]);
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) csd[t] += (double)c32[t];
+        };
+
+        int tile = blockIdx.x;
+        if (tile < p.num_tiles) { fetch(tile); commit(0, tile); }
+        __syncthreads();                           // prologue
+        int buf = 0;
+        for (; tile < p.num_tiles; tile += gridDim.x) {
+            const int next = tile + gridDim.x;
+            if (next < p.num_tiles) fetch(next);
+            if (PMAX > 0) {
+                const char* ub = Ub + buf * LU::BYTES;
+                const char* vb = Vb + buf * LV::BYTES;
+#pragma unroll
+                for (int s_ = 0; s_ < PMAX; ++s_) {
+                    if (s_ < my_count) {
+                        const uint4 ah = *reinterpret_cast<const uint4*>(ub + LU::slot(0, g, offU[s_] + j));
+                        const uint4 al = *reinterpret_cast<const uint4*>(ub + LU::slot(1, g, offU[s_] + j));
+                        const uint4 bh = *reinterpret_cast<const uint4*>(vb + LV::slot(0, g, offV[s_] + j));
+                        const uint4 bl = *reinterpret_cast<const uint4*>(vb + LV::slot(1, g, offV[s_] + j));
+                        f32x4 a3 = rd_mfma32(al, bh, accP[s_]);   // same shape back to back: accumulator forwarding is fine
+                        a3 = rd_mfma32(ah, bl, a3);
+                        accP[s_] = rd_mfma32(ah, bh, a3);
+                    }
+                }
+            }
+            if (next < p.num_tiles) commit(buf ^ 1, next);
+            __syncthreads();
+            buf ^= 1;
+        }
+#pragma unroll
+        for (int s_ = 0; s_ < PMAX; ++s_) {
+            if (s_ < my_count) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    dst[(size_t)(offU[s_] + 4 * g + r) * p.NgPad + offV[s_] + j] = accP[s_][r];
+            }
+        }
+        double* red = reinterpret_cast<double*>(smem_b3);       // [4][UC]
+        if (cq < UC) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) red[w4 * UC + cq + t] = csd[t];
+        }
+        __syncthreads();                           // tail
+    }
+    if (tid < p.Mg) {
+        const double* red = reinterpret_cast<const double*>(smem_b3);
+        p.part_cs[(size_t)blockIdx.x * p.MgPad + tid] =
+            (red[tid] + red[UC + tid]) + (red[2 * UC + tid] + red[3 * UC + tid]);
+    }
+}
+
 // fixed-order (deterministic) reduction of the per-workgroup partials; 4 independent fp64 chains for load ILP
 __global__ void gpe_redgemm_finish(const float* __restrict__ part, const double* __restrict__ part_cs, int nblk,
                                    int Mg, int Ng, int MgPad, int NgPad, float* G, int ldg, float* colsum,
@@ -575,6 +830,22 @@ static int rd_pc_launch(const RdParams& p, int gx, hipStream_t s)
     return GPE_OK;
 }
 
+template <int MT, int NT, int VMODE>
+static int rd_b3_launch(const RdParams& p, int gx, hipStream_t s)
+{
+    const size_t lds = (size_t)2 * (RdB3Layout<MT>::BYTES + RdB3Layout<NT>::BYTES);
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gpe_redgemm_b3_kernel<MT, NT, VMODE>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            return GPE_ELAUNCH;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gpe_redgemm_b3_kernel<MT, NT, VMODE>), dim3(gx), dim3(512), lds, s, p);
+    GPE_CHECK_LAUNCH();
+    return GPE_OK;
+}
+
 template <int VMODE>
 static int rd_dispatch(int MH, int NH, const RdParams& p, dim3 grid, hipStream_t s)
 {
@@ -616,7 +887,12 @@ static int rd_run(RdParams& p, int vmode, float* G, int ldG, float* colsum, floa
     const int mt_all = gpe_cdiv(p.Mg, 16), nt_all = gpe_cdiv(p.Ng, 16);
     const bool pc_ok = gy == 1 && nt_all == 13 && (mt_all == 13 || mt_all == 10) && rd_rows_vec(p.u, p.Mg) &&
                        (vmode == V_GATHER || rd_rows_vec(p.v, p.Ng)) && p.num_tiles >= 4 * gx;
-    if (pc_ok) {
+    if (pc_ok && g_rd_math == 1) {
+        if (mt_all == 13 && vmode == V_DENSE) rc = rd_b3_launch<13, 13, V_DENSE>(p, gx, s);
+        else if (mt_all == 13) rc = rd_b3_launch<13, 13, V_GATHER>(p, gx, s);
+        else if (vmode == V_DENSE) rc = rd_b3_launch<10, 13, V_DENSE>(p, gx, s);
+        else rc = rd_b3_launch<10, 13, V_GATHER>(p, gx, s);
+    } else if (pc_ok) {
         if (mt_all == 13 && vmode == V_DENSE) rc = rd_pc_launch<13, 13, V_DENSE>(p, gx, s);
         else if (mt_all == 13) rc = rd_pc_launch<13, 13, V_GATHER>(p, gx, s);
         else if (vmode == V_DENSE) rc = rd_pc_launch<10, 13, V_DENSE>(p, gx, s);

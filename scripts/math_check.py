@@ -75,3 +75,33 @@ for mode in ['f32', 'bf16x3']:
     r1 = run(); r2 = run()
     print(mode, 'bit-identical reruns:', [bool(torch.equal(a, b)) for a, b in zip(r1, r2)],
           [(a != b).sum().item() for a, b in zip(r1, r2)])
+
+# ---- reduce-GEMM (weight gradients) ----------------------------------------------------------------------------------
+G = torch.empty(H, H, device=dev); cs = torch.empty(H, device=dev)
+ws = torch.empty(L.query('gpe_redgemm_ws', H, H), device=dev)
+shift = torch.randn(H, device=dev)
+a2r = torch.randn(E, H, device=dev); a3r = torch.randn(E, 152, device=dev); a3r[:, 150:] = 0
+def rg(): L.call('gpe_edge_redgemm', a2r, H, 0, None, 0, PQ, 2 * H, jg, shift, B, N, k, H, H, G, H, cs, ws)
+def rd(): L.call('gpe_edge_redgemm', a3r, 152, 1, a2r, H, None, 0, None, shift, B, N, k, Fo, H, G[:Fo], H, cs, ws)
+res = {}
+for mode in ['f32', 'bf16x3']:
+    gpe_amd.set_math(mode)
+    out = []
+    for name, fn, rows in [('rg(gather)', rg, H), ('rd(dense)', rd, Fo)]:
+        fn(); torch.cuda.synchronize()
+        g1, c1 = G[:rows].clone(), cs[:rows].clone()
+        fn(); torch.cuda.synchronize()
+        assert torch.equal(g1, G[:rows]) and torch.equal(c1, cs[:rows]), 'non-deterministic ' + name
+        res[(mode, name)] = (g1.double(), c1.double())
+        out.append('%s %.3f ms' % (name, timeit(fn)))
+    print(mode, ' '.join(out))
+for name in ['rg(gather)', 'rd(dense)']:
+    r, g_ = res[('f32', name)], res[('bf16x3', name)]
+    print(name, 'G scale %.3e max abs diff %.3e (rel %.2e); colsum max diff %.3e' % (
+        r[0].abs().max().item(), (r[0] - g_[0]).abs().max().item(), ((r[0] - g_[0]).abs().max() / r[0].abs().max()).item(),
+        (r[1] - g_[1]).abs().max().item()))
+# exact check of the gather variant against fp64 torch on a subset of columns
+vfull = (torch.relu(PQ[:, :H].repeat_interleave(k, 0) + PQ[jg.view(-1).long(), H:]) - shift).double()
+Gref = a2r.double().t() @ vfull
+for mode in ['f32', 'bf16x3']:
+    print(mode, 'rg vs fp64: max abs err %.3e of scale %.3e' % ((res[(mode, 'rg(gather)')][0] - Gref).abs().max().item(), Gref.abs().max().item()))

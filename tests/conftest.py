@@ -19,3 +19,13 @@ def pytest_configure(config):
 @pytest.fixture(scope='session')
 def golden_dir():
     return os.path.join(REPO, 'tests', 'golden')
+
+
+@pytest.fixture(params=['f32', 'bf16x3'])
+def math_mode(request):
+    """Runs a GPU test once per arithmetic of the fused edge GEMMs (include/gpe_hip.h gpe_math_set) and restores the
+    library default afterwards."""
+    import gpe_amd
+    prev = gpe_amd.set_math(request.param)
+    yield request.param
+    gpe_amd.set_math(prev)

@@ -26,6 +26,24 @@ def relerr(a, b):
     return ((a - b).abs().max() / (b.abs().max() + 1e-30)).item()
 
 
+def relerr_fro(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return ((a - b).norm() / (b.norm() + 1e-30)).item()
+
+
+# Tolerances per arithmetic of the fused edge GEMMs.  'f32' = exact-fp32 MFMA (summation-order roundoff only): this is
+# the library default and the mode every parity claim is made in.  'bf16x3' = opt-in fast mode, split-bf16 products
+# (~1e-5 relative per GEMM): the forward still meets the north-star 1e-4 bar, but gradients do not inherit it — the
+# BatchNorm backward coefficients are residuals of large sums (taken from the weight-gradient product G),
+# which turns the 1e-5 product error into a coherent ~1e-2 relative error of the encoder gradients, and a forward
+# perturbation of 1e-5 flips a handful of ReLU masks per 1e5 activations (each flip moves ONE row of a per-row gradient
+# by its full value, hence the Frobenius norm).  Measured worst cases: 1.3e-2 (layer dx), 6.5e-3 (dense MLP dx).
+TOL = {
+    'f32': dict(fwd=5e-5, dx=2e-4, dparam=3e-4, mlp_dx=3e-4, mlp_dw=5e-4, mlp_db=5e-3, norm=relerr),
+    'bf16x3': dict(fwd=1e-4, dx=5e-2, dparam=5e-2, mlp_dx=5e-2, mlp_dw=5e-2, mlp_db=5e-2, norm=relerr_fro),
+}
+
+
 # --------------------------------------------------------------------------------------------------
 KNN_CASES = [(2, 64, 3, 4), (3, 200, 24, 5), (2, 256, 150, 16), (1, 130, 33, 20), (2, 2048, 3, 16),
              (1, 1024, 150, 16), (2, 70, 7, 64)]
@@ -157,8 +175,9 @@ def _product_conv(gpe, oconv, C, H, Fo, k):
 
 @pytest.mark.parametrize('B,N,C,H,Fo,k', [(2, 64, 3, 32, 24, 4), (2, 96, 24, 32, 24, 5), (2, 128, 3, 200, 150, 16),
                                           (1, 256, 150, 200, 150, 16), (3, 50, 6, 64, 30, 20)])
-def test_edgeconv_layer_fwd_bwd(gpe, B, N, C, H, Fo, k):
+def test_edgeconv_layer_fwd_bwd(gpe, math_mode, B, N, C, H, Fo, k):
     from oracle import ref_path as O
+    tol = TOL[math_mode]
     oconv = _oracle_conv(C, H, Fo, k, seed=B + N + C)
     pconv = _product_conv(gpe, oconv, C, H, Fo, k)
     g = torch.Generator().manual_seed(1)
@@ -186,12 +205,15 @@ def test_edgeconv_layer_fwd_bwd(gpe, B, N, C, H, Fo, k):
     err32 = relerr(out_32, out_r)
     err = relerr(out, out_r)
     print('edgeconv fwd relerr build=%.2e oracle-fp32=%.2e' % (err, err32))
-    assert err < max(5e-5, 20 * err32)
-    assert relerr(xd.grad, xr.grad) < 2e-4
+    assert err < max(tol['fwd'], 20 * err32)
+    e = tol['norm'](xd.grad, xr.grad)
+    print('edgeconv %s dx err %.2e' % (math_mode, e))
+    assert e < tol['dx']
     pn = dict(pconv.named_parameters())
     for n, p in o64.named_parameters():
-        e = relerr(pn[n].grad, p.grad)
-        assert e < 3e-4, (n, e)
+        e = tol['norm'](pn[n].grad, p.grad)
+        print('edgeconv %s %s err %.2e' % (math_mode, n, e))
+        assert e < tol['dparam'], (n, e)
     # BatchNorm running statistics (momentum 0.1, unbiased variance) and the batch counter
     pb = dict(pconv.named_buffers())
     for n, bbuf in o64.named_buffers():
@@ -261,8 +283,9 @@ def test_lstm_decoder_fwd_bwd(gpe, Bn, In, Hh, T, L, Out):
 
 # --------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize('M,chans', [(300, [27, 27, 27, 23]), (1000, [153, 153, 153, 23]), (130, [16, 200, 200, 200, 1])])
-def test_dense_mlp_fwd_bwd(gpe, M, chans):
+def test_dense_mlp_fwd_bwd(gpe, math_mode, M, chans):
     from oracle import ref_path as O
+    tol = TOL[math_mode]
     torch.manual_seed(M)
     omlp = O.MLP(chans)
     with torch.no_grad():
@@ -284,12 +307,15 @@ def test_dense_mlp_fwd_bwd(gpe, M, chans):
     (y * wgt.cuda()).sum().backward()
     o32 = copy.deepcopy(omlp).train()
     e32 = relerr(o32(x), yr)
-    assert relerr(y, yr) < max(5e-5, 20 * e32)
-    assert relerr(xd.grad, xr.grad) < 3e-4
+    assert relerr(y, yr) < max(tol['fwd'], 20 * e32)
+    e = tol['norm'](xd.grad, xr.grad)
+    print('dense mlp %s dx err %.2e' % (math_mode, e))
+    assert e < tol['mlp_dx']
     pn = dict(pmlp.named_parameters())
     for n, p in o64.named_parameters():
-        e = relerr(pn[n].grad, p.grad)
-        assert e < (5e-3 if p.grad.dim() == 1 else 5e-4), (n, e)
+        e = tol['norm'](pn[n].grad, p.grad)
+        print('dense mlp %s %s err %.2e' % (math_mode, n, e))
+        assert e < (tol['mlp_db'] if p.grad.dim() == 1 else tol['mlp_dw']), (n, e)
     pb = dict(pmlp.named_buffers())
     for n, b in o64.named_buffers():
         if 'num_batches' in n:
