@@ -720,33 +720,57 @@ __global__ __launch_bounds__(512, 2) void gpe_redgemm_b3_kernel(RdParams p)
     }
 }
 
-// fixed-order (deterministic) reduction of the per-workgroup partials; 4 independent fp64 chains for load ILP
-__global__ void gpe_redgemm_finish(const float* __restrict__ part, const double* __restrict__ part_cs, int nblk,
-                                   int Mg, int Ng, int MgPad, int NgPad, float* G, int ldg, float* colsum,
-                                   int accumulate)
+// Fixed-order (deterministic) reduction of the per-workgroup partials.  256 threads = 32 consecutive output elements x 8
+// partial groups: group q sums partials q, q+8, ... in fp64 (2 chains), the 8 group sums are combined through LDS in
+// index order.  8x the threads of a one-thread-per-element loop: with 256 partials of a 208 x 208 product (44 MB) the
+// serial version was latency-bound at ~0.4 TB/s.
+#define RD_FIN_E 32
+#define RD_FIN_Q 8
+__global__ __launch_bounds__(RD_FIN_E * RD_FIN_Q) void gpe_redgemm_finish(
+    const float* __restrict__ part, const double* __restrict__ part_cs, int nblk, int Mg, int Ng, int MgPad, int NgPad,
+    float* G, int ldg, float* colsum, int accumulate)
 {
-    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e < (long)Mg * Ng) {
-        const int m = (int)(e / Ng), n = (int)(e - (long)m * Ng);
-        const size_t stride = (size_t)MgPad * NgPad;
-        const float* src = part + (size_t)m * NgPad + n;
-        double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-        int b = 0;
-        for (; b + 3 < nblk; b += 4) {
-            s0 += (double)src[(size_t)b * stride];
-            s1 += (double)src[(size_t)(b + 1) * stride];
-            s2 += (double)src[(size_t)(b + 2) * stride];
-            s3 += (double)src[(size_t)(b + 3) * stride];
+    __shared__ double red[RD_FIN_Q][RD_FIN_E];
+    const int el = threadIdx.x & (RD_FIN_E - 1), q = threadIdx.x / RD_FIN_E;
+    const long total = (long)Mg * Ng;
+    const long e = (long)blockIdx.x * RD_FIN_E + el;
+    // blocks [0, ceil(total/32)) reduce G; the blocks after them reduce the column sums
+    const long g_blocks = (total + RD_FIN_E - 1) / RD_FIN_E;
+    const bool is_cs = (long)blockIdx.x >= g_blocks;
+    double s0 = 0, s1 = 0;
+    if (!is_cs) {
+        if (e < total) {
+            const int m = (int)(e / Ng), n = (int)(e - (long)m * Ng);
+            const size_t stride = (size_t)MgPad * NgPad;
+            const float* src = part + (size_t)m * NgPad + n;
+            int b = q;
+            for (; b + RD_FIN_Q < nblk; b += 2 * RD_FIN_Q) {
+                s0 += (double)src[(size_t)b * stride];
+                s1 += (double)src[(size_t)(b + RD_FIN_Q) * stride];
+            }
+            if (b < nblk) s0 += (double)src[(size_t)b * stride];
         }
-        for (; b < nblk; ++b) s0 += (double)src[(size_t)b * stride];
-        const float s = (float)((s0 + s1) + (s2 + s3));
-        float* d = G + (size_t)m * ldg + n;
-        *d = accumulate ? (*d + s) : s;
+    } else {
+        const long c = ((long)blockIdx.x - g_blocks) * RD_FIN_E + el;
+        if (c < Mg)
+            for (int b = q; b < nblk; b += RD_FIN_Q) s0 += part_cs[(size_t)b * MgPad + c];
     }
-    if (colsum && e < Mg) {
-        double s = 0.0;
-        for (int b = 0; b < nblk; ++b) s += part_cs[(size_t)b * MgPad + e];
-        colsum[e] = accumulate ? (colsum[e] + (float)s) : (float)s;
+    red[q][el] = s0 + s1;
+    __syncthreads();
+    if (q == 0) {
+        double s = red[0][el];
+#pragma unroll
+        for (int i = 1; i < RD_FIN_Q; ++i) s += red[i][el];
+        if (!is_cs) {
+            if (e < total) {
+                const int m = (int)(e / Ng), n = (int)(e - (long)m * Ng);
+                float* d = G + (size_t)m * ldg + n;
+                *d = accumulate ? (*d + (float)s) : (float)s;
+            }
+        } else {
+            const long c = ((long)blockIdx.x - g_blocks) * RD_FIN_E + el;
+            if (c < Mg) colsum[c] = accumulate ? (colsum[c] + (float)s) : (float)s;
+        }
     }
 }
 
@@ -777,6 +801,8 @@ static int rd_num_cus()
 #define RD_MAX_GX 256
 static void rd_geometry(int Mg, int Ng, int* MH, int* NH, int* gy, int* MgPad, int* NgPad)
 {
+    // (64-row output blocks for the row-poor LSTM weight gradients were tried and measured slower: 2.43 vs 1.95 ms per
+    // step — only 16 of 64 staging lanes carry U columns)
     const int mt = gpe_cdiv(Mg, 16), nt = gpe_cdiv(Ng, 16);
     const int mtb = mt < 14 ? mt : 14;
     *MH = rd_pick(gpe_cdiv(mtb, 2), RD_MH_OPTS, 3);
@@ -901,7 +927,8 @@ static int rd_run(RdParams& p, int vmode, float* G, int ldG, float* colsum, floa
         rc = (vmode == V_DENSE) ? rd_dispatch<V_DENSE>(MH, NH, p, grid, s) : rd_dispatch<V_GATHER>(MH, NH, p, grid, s);
     if (rc != GPE_OK) return rc;
     const long total = (long)p.Mg * p.Ng;
-    hipLaunchKernelGGL(gpe_redgemm_finish, dim3(gpe_cdiv(total, 256)), dim3(256), 0, s, p.part, p.part_cs, gx,
+    const long fin_blocks = gpe_cdiv(total, RD_FIN_E) + (colsum ? gpe_cdiv(p.Mg, RD_FIN_E) : 0);
+    hipLaunchKernelGGL(gpe_redgemm_finish, dim3(fin_blocks), dim3(RD_FIN_E * RD_FIN_Q), 0, s, p.part, p.part_cs, gx,
                        p.Mg, p.Ng, MgPad, NgPad, G, ldG, colsum, accumulate);
     GPE_CHECK_LAUNCH();
     return GPE_OK;

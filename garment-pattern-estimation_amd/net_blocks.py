@@ -102,16 +102,61 @@ class EdgeConvFeatures(nn.Module):
         return None, out, batch
 
 
+class _StateUploader:
+    """Host-drawn tensors reach the GPU without draining the compute stream.
+
+    The reference draws the LSTM start states on the CPU generator inside forward() (nn/net_blocks.py:391-392) and
+    moves them with `.to(device)`.  From pageable memory that copy is stream-ordered AND blocks the host until it has
+    run, i.e. until the whole encoder queued in front of it has finished — the GPU then idles while the host catches
+    up (measured: 0.85 ms in front of each decoder, profiles/r01_e_gap_trace.md).  Here the draw lands in a pinned
+    staging buffer, the copy runs on a side stream, and the compute stream only waits on its event."""
+    _per_device = {}
+
+    def __init__(self, device):
+        self.stream = torch.cuda.Stream(device=device)
+        self.slots = {}          # shape -> (pinned buffer, event of the last copy out of it)
+
+    @classmethod
+    def get(cls, device):
+        key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+        if key not in cls._per_device:
+            cls._per_device[key] = cls(device)
+        return cls._per_device[key]
+
+    def staging(self, shape):
+        if shape not in self.slots:
+            self.slots[shape] = (torch.empty(shape, pin_memory=True), torch.cuda.Event())
+        buf, ev = self.slots[shape]
+        ev.synchronize()         # the previous copy out of this buffer is long done; makes the reuse safe
+        return buf, ev
+
+    def upload(self, buf, ev, device):
+        compute = torch.cuda.current_stream(device)
+        with torch.cuda.stream(self.stream):
+            out = torch.empty(buf.shape, device=device)      # owned by the side stream's pool
+            out.copy_(buf, non_blocking=True)
+            ev.record(self.stream)
+        compute.wait_event(ev)
+        out.record_stream(compute)
+        return out
+
+
 def _init_tenzor(*shape, device='cpu', init_type=''):
     """nn/net_blocks.py:302-315 — drawn on the CPU generator, then moved (keeps the reference's RNG stream)."""
-    if not init_type or len(shape) == 1:
-        t = torch.zeros(shape)
-    elif 'kaiming_normal' in init_type:
+    device = torch.device(device)
+    zeros = not init_type or len(shape) == 1
+    if not zeros and 'kaiming_normal' not in init_type:
+        raise NotImplementedError('{} tenzor initialization is not implemented'.format(init_type))
+    if zeros:
+        return torch.zeros(shape, device=device)
+    if device.type != 'cuda':
         t = torch.empty(shape)
         nn.init.kaiming_normal_(t)
-    else:
-        raise NotImplementedError('{} tenzor initialization is not implemented'.format(init_type))
-    return t.to(device)
+        return t.to(device)
+    up = _StateUploader.get(device)
+    buf, ev = up.staging(tuple(shape))
+    nn.init.kaiming_normal_(buf)                             # same generator, same element order as torch.empty(shape)
+    return up.upload(buf, ev, device)
 
 
 def _init_weights(module, init_type=''):

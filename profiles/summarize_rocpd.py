@@ -18,3 +18,23 @@ for r in rows:
     name = re.sub(r'\(.*', '', r[0]).replace('void ', '')[:80]
     print('| %s | %.1f | %.0f | %.1f | %.1f | %.1f | %.1f | %s | %s | %s |' % (
         name, r[1] / steps, r[2], r[3], r[4], r[5], 100 * r[2] / tot, r[6], r[7], r[8]))
+
+# ---- idle gaps between consecutive kernels (where the GPU waits for the host) ------------------------------------
+if len(sys.argv) > 3 and sys.argv[3] == 'gaps':
+    ks = db.execute('select name, start, end from kernels order by start').fetchall()
+    gaps = {}
+    tot_gap = 0.0
+    for (n0, s0, e0), (n1, s1, e1) in zip(ks[:-1], ks[1:]):
+        g = (s1 - e0) / 1e3
+        if g <= 0 or g > 5000:          # overlap, or a step boundary / sync
+            continue
+        key = re.sub(r'\(.*', '', n1).replace('void ', '')[:60]
+        d = gaps.setdefault(key, [0, 0.0])
+        d[0] += 1
+        d[1] += g
+        tot_gap += g
+    print('\nidle time in front of each kernel (gaps < 5 ms): %.2f ms/step\n' % (tot_gap / steps / 1e3))
+    print('| next kernel | gaps/step | idle us/step | avg us |')
+    print('|---|---|---|---|')
+    for k, (n, g) in sorted(gaps.items(), key=lambda kv: -kv[1][1])[:25]:
+        print('| %s | %.1f | %.0f | %.1f |' % (k, n / steps, g / steps, g / n))
