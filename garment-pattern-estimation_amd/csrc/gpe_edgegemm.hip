@@ -568,8 +568,14 @@ static int eg_dispatch(int NT, int KCH, const RgParams& p, int stats_nblk, hipSt
 
 // Returns 1 and launches when the shape is on the register-stationary menu, 0 when the caller should use the generic
 // LDS-streamed kernel, < 0 on a launch error.
+int gpe_edgegemm_sr_try(const RgParams& p, int amode, int emode, int stats_nblk, hipStream_t s);   // gpe_edgegemm_sr.hip
+
 int gpe_edgegemm_try(const RgParams& p, int amode, int emode, int stats_nblk, hipStream_t s)
 {
+    if (g_eg_math == 0 && !(p.dbg & 64)) {               // exact fp32: the single-role software-pipelined kernel first
+        const int r = gpe_edgegemm_sr_try(p, amode, emode, stats_nblk, s);
+        if (r != 0) return r;
+    }
     if (p.N <= 96 || p.N > 208 || p.K <= 96 || p.K > 208) return 0;
     if (emode != E_EDGE_FWD && (p.N & 3)) return 0;      // the backward epilogues use aligned 16-B coefficient loads
     if (amode == A_GATHER && (p.K & 3)) return 0;

@@ -1,0 +1,527 @@
+// Single-role, software-pipelined fused row GEMM for the per-edge MLP of DynamicEdgeConv on gfx950 — the EXACT-fp32 path
+// (/root/reference/nn/net_blocks.py:43-47,124-135 forward; its input-gradient half in backward).
+//
+// Why this shape (profiles/r01_d_coissue_ubench.md): a wave that streams v_mfma_f32_16x16x4_f32 owns its SIMD — a second
+// wave on the same SIMD gets no issue slots, so a producer/consumer pair runs at T_consumer + T_producer.  What a wave CAN
+// do is issue its OWN memory instructions between its MFMAs: they cost a few issue cycles each (~10 % of the MFMA time in
+// total) and their latency hides under the following MFMAs.  So: ONE persistent 256-thread workgroup per CU, one wave per
+// SIMD (512 VGPRs each), every wave does everything for its share, and the K loop is hand-pipelined in chunks of 16 k:
+//
+//   chunk 0        issue ALL global loads of this iteration: the activation rows the epilogue of the PREVIOUS tile needs
+//                  (backward) and the <= 16 rows this wave stages for the NEXT tile (dense rows or gathered Q rows)
+//   chunks 1..     epilogue of the previous tile, a few rows per chunk, from the C buffer in LDS (bias+ReLU, fp64 BN
+//                  statistics, whole-row stores, max/min over each point's messages; or BN/ReLU backward with the stored
+//                  activation and per-point sums)
+//   last chunks    commit the staged rows to the other A buffer in LDS (ReLU(P_i+Q_j) applied here for the gather)
+//   every chunk    prefetch the next chunk's A fragments (ds_read_b128), then 4*AQ*4 + 4*BQ MFMAs
+//
+// Wave w owns N-tiles [AQ*w, AQ*w+AQ) for all 64 rows plus rows 16w..16w+15 of the BQ left-over N-tiles (so all four
+// SIMDs issue the same number of MFMAs), with its weights resident in VGPRs as MFMA B fragments for the whole kernel.
+// It stages and finishes rows [w*R/4, (w+1)*R/4) of every tile: R = 4*npw*k rows = whole points, npw*k <= 16.
+// LDS: A[2] + C (159 KB at the shipped sizes), two barriers per tile.
+#include "gpe_rowgemm.h"
+#include <math.h>
+
+#define SR_PB 16          // rows a wave stages / finishes per tile
+#define SR_NPW 4          // max points per wave per tile (gather / aggregation paths)
+#define GPE_ENOTSUP_SHAPE 12345
+
+// A wave has 256 architectural VGPRs + 256 accumulation VGPRs; MFMA takes its B operand from either file.  The resident
+// weights (208 registers) are pinned in AGPRs by hand: left to itself the allocator keeps them architectural and, in the
+// gather variants, spills them to scratch memory — reloaded every chunk behind an s_waitcnt vmcnt(0).
+__device__ __forceinline__ float sr_pin_agpr(float x)
+{
+    float a;
+    asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(a) : "v"(x));
+    return a;
+}
+__device__ __forceinline__ float4 sr_pin_agpr4(const float4 v)
+{
+    return make_float4(sr_pin_agpr(v.x), sr_pin_agpr(v.y), sr_pin_agpr(v.z), sr_pin_agpr(v.w));
+}
+
+// Wave-uniform choice among the (<= SR_NPW) P rows of a wave's points.  Arguments BY VALUE and selects on values: written
+// as `if (idx == q) dst = arr_q` the compiler turns the phi of loads into a load through a phi of pointers into the lambda
+// closure, which pins the closure AND every captured local (v[], act[], ...) in scratch memory — each access then drags
+// an s_waitcnt vmcnt(0) through the load pipeline.
+__device__ __forceinline__ float4 sr_sel4(const float4 a0, const float4 a1, const float4 a2, const float4 a3, int idx)
+{
+    float4 r = a0;
+    r.x = (idx == 1) ? a1.x : r.x; r.y = (idx == 1) ? a1.y : r.y; r.z = (idx == 1) ? a1.z : r.z; r.w = (idx == 1) ? a1.w : r.w;
+    r.x = (idx == 2) ? a2.x : r.x; r.y = (idx == 2) ? a2.y : r.y; r.z = (idx == 2) ? a2.z : r.z; r.w = (idx == 2) ? a2.w : r.w;
+    r.x = (idx == 3) ? a3.x : r.x; r.y = (idx == 3) ? a3.y : r.y; r.z = (idx == 3) ? a3.z : r.z; r.w = (idx == 3) ? a3.w : r.w;
+    return r;
+}
+
+template <int AQ, int BQ, int KCH, int AMODE, int EMODE>
+__global__ __launch_bounds__(256, 1) void gpe_edgegemm_sr_kernel(RgParams p, int stats_nblk)
+{
+    constexpr int NT = 4 * AQ + BQ;
+    constexpr int LDA = 16 * KCH + 4, LDC = 16 * NT + 4;
+    // chunk schedule.  Chunk 0 issues every global load of the iteration.  The staged rows are committed to LDS FIRST
+    // (chunks CM_START.., CMC rows each) and the epilogue runs in the LAST chunks (EPC rows each): the other way round the
+    // commit's s_waitcnt vmcnt(N) would also wait for the epilogue's just-issued global stores (vmcnt counts stores too
+    // and retires in order), ~1-2 us of HBM write latency per tile.
+    constexpr int CM_START = 2;
+    constexpr int CM_CH = (KCH >= 13) ? 4 : 3;
+    constexpr int CMC = (SR_PB + CM_CH - 1) / CM_CH;
+    constexpr int EPC = (KCH >= 13) ? 2 : 3;
+    constexpr int EP_CH = (SR_PB + EPC - 1) / EPC;
+    constexpr int EP_START = KCH - EP_CH;
+    static_assert(EP_START >= 2, "K too short for the chunk schedule");
+    constexpr bool GATHER_ACT = (EMODE == E_BWD_GATHER);
+
+    extern __shared__ __align__(16) float smem[];
+    float* const Abuf0 = smem;
+    float* const Abuf1 = smem + RG_BM * LDA;
+    float* const Cs = smem + 2 * RG_BM * LDA;            // [64][LDC]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 15, g = lane >> 4;
+    const int rows_w = p.R >> 2;                         // rows of a tile this wave stages / finishes (<= SR_PB)
+    const int rb = wave * rows_w;
+    const int rk16 = (65536 + p.k - 1) / p.k;            // u / k == (u * rk16) >> 16 for u < 64
+    const int PT = p.R / p.k, npw = PT >> 2;             // points per tile / per wave: first point of this wave's
+                                                         // share of tile t is t*PT + wave*npw — no per-tile division
+    const int c = lane << 2;                             // this lane's column quad
+    const bool k_on = c < p.K, n_on = c < p.N;
+    const int ck = k_on ? c : 0, cn = n_on ? c : 0;      // clamped quads for the unconditional loads
+
+    for (int e = tid; e < 2 * RG_BM * LDA; e += 256) smem[e] = 0.f;
+
+    // ---- weights: resident MFMA B fragments -------------------------------------------------------------------------
+    float4 wA[AQ][KCH], wL[BQ > 0 ? BQ : 1][KCH];
+    {
+        // all KCH fragment loads of an N-tile are issued before the first one is pinned (the pin is an asm statement that
+        // needs its operand, so load-pin-load-pin would serialise ~200 dependent round trips in the prologue)
+        auto load_tile = [&](int col, float4 (&dst)[KCH]) {
+            const int cc = (col < p.Npad) ? col : p.Npad - 1;
+            float4 t[KCH];
+#pragma unroll
+            for (int kc = 0; kc < KCH; ++kc) t[kc] = ld4(p.wp + (((long)(kc * 4 + g)) * p.Npad + cc) * 4);
+#pragma unroll
+            for (int kc = 0; kc < KCH; ++kc)
+                dst[kc] = sr_pin_agpr4((col < p.Npad) ? t[kc] : make_float4(0.f, 0.f, 0.f, 0.f));
+        };
+#pragma unroll
+        for (int i = 0; i < AQ; ++i) load_tile(16 * (AQ * wave + i) + j, wA[i]);
+#pragma unroll
+        for (int b = 0; b < BQ; ++b) load_tile(16 * (4 * AQ + b) + j, wL[b]);
+    }
+
+    // ---- epilogue constants + running state ---------------------------------------------------------------------------
+    double stS[4] = {0, 0, 0, 0}, stQ[4] = {0, 0, 0, 0};
+    float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 cs4 = bias4, c14 = bias4, k24 = bias4, mu4 = bias4;
+    if (n_on) {
+        if (EMODE == E_EDGE_FWD) {
+            if (p.bias) {
+                bias4.x = p.bias[c];
+                if (c + 1 < p.N) bias4.y = p.bias[c + 1];
+                if (c + 2 < p.N) bias4.z = p.bias[c + 2];
+                if (c + 3 < p.N) bias4.w = p.bias[c + 3];
+            }
+        } else {                                         // N % 4 == 0 guaranteed by the dispatcher
+            cs4 = ld4(p.coef_out + c); c14 = ld4(p.coef_out + p.N + c);
+            k24 = ld4(p.coef_out + 2 * p.N + c); mu4 = ld4(p.coef_out + 3 * p.N + c);
+        }
+    }
+    float s32[4], q32[4], vmx[4], vmn[4];
+    int imx[4], imn[4];
+    float4 dp;
+    int es = 0, ept = 0;                                 // row inside the current point, point inside this wave's share
+    long e_row0 = 0, e_pt0 = 0; int e_rv = 0;            // tile being finished
+
+    float4 v[SR_PB];                                     // rows staged for the next tile
+    float4 pvs0, pvs1, pvs2, pvs3;                       // P rows of the points being staged (gather)
+    pvs0 = pvs1 = pvs2 = pvs3 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 act[(EMODE != E_EDGE_FWD) ? SR_PB : 1];       // stored activations of the tile being finished (backward)
+    float4 pve0, pve1, pve2, pve3;                       // P rows of the points being finished (E_BWD_GATHER)
+    pve0 = pve1 = pve2 = pve3 = make_float4(0.f, 0.f, 0.f, 0.f);
+    int s_rv = 0;                                        // valid rows of the tile being staged
+
+    // Row addressing of the gathers stays in VGPRs: 16 rows x 64-bit scalar addresses (plus their clamps) do not fit the
+    // SGPR file next to this kernel's ~60 live scalars, and SGPR spills go to scratch memory (every reload is a
+    // scratch_load + s_waitcnt vmcnt(0) in the middle of the load pipeline).  So a tile's neighbour rows are loaded
+    // lane-distributed ONE ITERATION AHEAD (lane L <-> row rb + min(L, rows_w-1)), a row's value is broadcast with
+    // ds_bpermute, and `vz` (an opaque zero) keeps the point indices per-lane as well.
+    int vz;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(vz));
+    // LICM would hoist ~250 per-row scalars (row numbers, LDS offsets, point indices — all functions of rb, rows_w and
+    // rk16) out of the persistent tile loop and the register allocator would then spill them to scratch; re-deriving them
+    // from an opaque per-iteration zero keeps them transient.
+    int rbl = rb, rwl = rows_w, rkl = rk16;
+#define SR_REFRESH_SCALARS()                                   \
+    {                                                          \
+        int sz_;                                               \
+        asm volatile("s_mov_b32 %0, 0" : "=s"(sz_));           \
+        rbl = rb + sz_; rwl = rows_w + sz_; rkl = rk16 + sz_;  \
+    }
+    auto load_jgv = [&](int tile) -> int {
+        const long row0 = (long)tile * p.R;
+        const int rv = (int)((p.M - row0 < p.R) ? (p.M - row0) : p.R);
+        int r = rbl + ((lane < rwl) ? lane : rwl - 1);
+        r = (r < rv - 1) ? r : rv - 1;
+        return p.jg[row0 + r];
+    };
+    int jgv_s = 0, jgv_e = 0;            // neighbour rows for the NEXT stage (A_GATHER) / the NEXT epilogue (E_BWD_GATHER)
+
+    // ---- VMEM issue: everything this iteration will need --------------------------------------------------------------
+    auto issue_epi_loads = [&](int tile) {
+        e_row0 = (long)tile * p.R;
+        e_pt0 = (long)tile * PT + wave * npw;
+        e_rv = (int)((p.M - e_row0 < p.R) ? (p.M - e_row0) : p.R);
+        es = 0; ept = 0;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { s32[t] = 0.f; q32[t] = 0.f; vmx[t] = -INFINITY; vmn[t] = INFINITY; imx[t] = 0; imn[t] = 0; }
+        dp = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (EMODE == E_EDGE_FWD) return;
+        // NOTE: every load below is unconditional (clamped rows, clamped column quad): a register that is loaded under a
+        // branch needs a copy at the join, and that copy waits for the load right there — no pipelining left
+        const int last = e_rv - 1;
+#pragma unroll
+        for (int u = 0; u < SR_PB; ++u) {
+            int r = rbl + ((u < rwl) ? u : rwl - 1);
+            r = (r < last) ? r : last;                                  // clamp: unconditional loads
+            if (EMODE == E_BWD_INPLACE) act[u] = ld4(p.out + (e_row0 + r) * p.ldo + cn);
+            else {
+                const int jj = __builtin_amdgcn_ds_bpermute(u << 2, jgv_e);
+                act[u] = ld4(p.pq + (long)jj * p.ldpq + p.H + cn);
+            }
+        }
+        if (GATHER_ACT) {
+            const int pt0 = tile * PT + wave * npw + vz, ptl = tile * PT + ((last * rkl) >> 16);
+            pve0 = ld4(p.pq + (long)((pt0 + 0 < ptl) ? pt0 + 0 : ptl) * p.ldpq + cn);
+            pve1 = ld4(p.pq + (long)((pt0 + 1 < ptl) ? pt0 + 1 : ptl) * p.ldpq + cn);
+            pve2 = ld4(p.pq + (long)((pt0 + 2 < ptl) ? pt0 + 2 : ptl) * p.ldpq + cn);
+            pve3 = ld4(p.pq + (long)((pt0 + 3 < ptl) ? pt0 + 3 : ptl) * p.ldpq + cn);
+        }
+    };
+    auto issue_stage_loads = [&](int tile) {
+        const long row0 = (long)tile * p.R;
+        s_rv = (int)((p.M - row0 < p.R) ? (p.M - row0) : p.R);
+        const int last = s_rv - 1;
+#pragma unroll
+        for (int u = 0; u < SR_PB; ++u) {
+            int r = rbl + ((u < rwl) ? u : rwl - 1);
+            r = (r < last) ? r : last;
+            if (AMODE == A_GATHER) {
+                const int jj = __builtin_amdgcn_ds_bpermute(u << 2, jgv_s);
+                v[u] = ld4(p.pq + (long)jj * p.ldpq + p.H + ck);
+            } else {
+                // rows are 16-B aligned and padded to a multiple of 4 columns (checked by the dispatcher)
+                v[u] = ld4(p.a.base + (row0 + r) * p.a.stride_outer + ck);
+            }
+        }
+        if (AMODE == A_GATHER) {
+            const int pt0 = tile * PT + wave * npw + vz, ptl = tile * PT + ((last * rkl) >> 16);
+            pvs0 = ld4(p.pq + (long)((pt0 + 0 < ptl) ? pt0 + 0 : ptl) * p.ldpq + ck);
+            pvs1 = ld4(p.pq + (long)((pt0 + 1 < ptl) ? pt0 + 1 : ptl) * p.ldpq + ck);
+            pvs2 = ld4(p.pq + (long)((pt0 + 2 < ptl) ? pt0 + 2 : ptl) * p.ldpq + ck);
+            pvs3 = ld4(p.pq + (long)((pt0 + 3 < ptl) ? pt0 + 3 : ptl) * p.ldpq + ck);
+        }
+    };
+    // ---- LDS commit of staged row u (compile-time u) ------------------------------------------------------------------
+    auto commit_row = [&](float* An, int u) {
+        if (u >= rwl || !k_on) return;
+        const int r = rbl + u;
+        float4 o = v[u];
+        if (AMODE == A_GATHER) {
+            const float4 pv = sr_sel4(pvs0, pvs1, pvs2, pvs3, (u * rkl) >> 16);
+            o.x = fmaxf(o.x + pv.x, 0.f); o.y = fmaxf(o.y + pv.y, 0.f);
+            o.z = fmaxf(o.z + pv.z, 0.f); o.w = fmaxf(o.w + pv.w, 0.f);
+        }
+        if (r >= s_rv) o = make_float4(0.f, 0.f, 0.f, 0.f);      // rows past the end of a partial last tile
+        st4(&An[r * LDA + c], o);
+    };
+    // ---- epilogue of row u (compile-time u) of the tile being finished ------------------------------------------------
+    auto epi_row = [&](int u, const float4 z) {
+        if (u >= rwl) return;
+        const int r = rbl + u;
+        if (r >= e_rv) return;
+        if (n_on) {
+            if (EMODE == E_EDGE_FWD) {
+                const float vv[4] = {fmaxf(z.x + bias4.x, 0.f), fmaxf(z.y + bias4.y, 0.f), fmaxf(z.z + bias4.z, 0.f),
+                                     fmaxf(z.w + bias4.w, 0.f)};
+                st4(p.out + (e_row0 + r) * p.ldo + c, make_float4(vv[0], vv[1], vv[2], vv[3]));
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    s32[t] += vv[t];
+                    q32[t] = __builtin_fmaf(vv[t], vv[t], q32[t]);
+                    if (vv[t] > vmx[t]) { vmx[t] = vv[t]; imx[t] = es; }
+                    if (vv[t] < vmn[t]) { vmn[t] = vv[t]; imn[t] = es; }
+                }
+            } else {
+                float4 av = act[u];
+                if (GATHER_ACT) {
+                    const float4 pv = sr_sel4(pve0, pve1, pve2, pve3, (u * rkl) >> 16);
+                    av.x = fmaxf(av.x + pv.x, 0.f); av.y = fmaxf(av.y + pv.y, 0.f);
+                    av.z = fmaxf(av.z + pv.z, 0.f); av.w = fmaxf(av.w + pv.w, 0.f);
+                }
+                float4 o;
+                o.x = (av.x > 0.f) ? z.x * cs4.x - c14.x - (av.x - mu4.x) * k24.x : 0.f;
+                o.y = (av.y > 0.f) ? z.y * cs4.y - c14.y - (av.y - mu4.y) * k24.y : 0.f;
+                o.z = (av.z > 0.f) ? z.z * cs4.z - c14.z - (av.z - mu4.z) * k24.z : 0.f;
+                o.w = (av.w > 0.f) ? z.w * cs4.w - c14.w - (av.w - mu4.w) * k24.w : 0.f;
+                st4(p.out + (e_row0 + r) * p.ldo + c, o);
+                dp.x += o.x; dp.y += o.y; dp.z += o.z; dp.w += o.w;
+            }
+        }
+        if (++es == p.k) {                                   // a point is complete (wave-uniform)
+            if (n_on) {
+                const long gpt = e_pt0 + ept;
+                if (EMODE == E_EDGE_FWD && p.agg) {
+                    const long o = gpt * p.oldagg + c;
+                    st4(p.mx + o, make_float4(vmx[0], vmx[1], vmx[2], vmx[3]));
+                    st4(p.mn + o, make_float4(vmn[0], vmn[1], vmn[2], vmn[3]));
+                    *reinterpret_cast<uchar4*>(p.oamx + o) = make_uchar4(imx[0], imx[1], imx[2], imx[3]);
+                    *reinterpret_cast<uchar4*>(p.oamn + o) = make_uchar4(imn[0], imn[1], imn[2], imn[3]);
+                }
+                if (EMODE == E_BWD_GATHER) st4(p.dP + gpt * p.lddp + c, dp);
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) { vmx[t] = -INFINITY; vmn[t] = INFINITY; imx[t] = 0; imn[t] = 0; }
+            dp = make_float4(0.f, 0.f, 0.f, 0.f);
+            es = 0; ++ept;
+        }
+    };
+    auto epi_flush_stats = [&]() {
+        if (EMODE == E_EDGE_FWD) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) { stS[t] += (double)s32[t]; stQ[t] += (double)q32[t]; }
+        }
+    };
+
+    // ---- prologue: stage tile 0 ---------------------------------------------------------------------------------------
+    __syncthreads();                                     // A buffers zeroed
+    int tile = blockIdx.x;
+    if (tile < p.num_tiles) {
+        if (AMODE == A_GATHER) jgv_s = load_jgv(tile);
+        if (GATHER_ACT) jgv_e = load_jgv(tile);
+    }
+    if (tile < p.num_tiles && !(p.dbg & 1)) {
+        issue_stage_loads(tile);
+#pragma unroll
+        for (int u = 0; u < SR_PB; ++u) commit_row(Abuf0, u);
+    }
+    if (AMODE == A_GATHER && tile < p.num_tiles) jgv_s = load_jgv(tile + (int)gridDim.x < p.num_tiles ? tile + gridDim.x : tile);
+    __syncthreads();
+
+    int buf = 0, prev = -1;
+    for (; tile < p.num_tiles; tile += gridDim.x) {
+        SR_REFRESH_SCALARS()
+        const int next = tile + gridDim.x;
+        const float* As = buf ? Abuf1 : Abuf0;
+        float* An = buf ? Abuf0 : Abuf1;
+        const bool do_epi = prev >= 0 && !(p.dbg & 2);
+        const bool do_stage = next < p.num_tiles && !(p.dbg & 1);
+
+        f32x4 acc[4][AQ], accL[BQ > 0 ? BQ : 1];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int i = 0; i < AQ; ++i) acc[mt][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int b = 0; b < (BQ > 0 ? BQ : 1); ++b) accL[b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+        float4 an[4], anL = make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 zq[EPC];
+#pragma unroll
+        for (int q = 0; q < EPC; ++q) zq[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) an[mt] = ld4(&As[(16 * mt + j) * LDA + 4 * g]);
+        if (BQ > 0) anL = ld4(&As[(16 * wave + j) * LDA + 4 * g]);
+
+#pragma unroll
+        for (int kc = 0; kc < KCH; ++kc) {
+            float a[4][4], aL[4];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) { a[mt][0] = an[mt].x; a[mt][1] = an[mt].y; a[mt][2] = an[mt].z; a[mt][3] = an[mt].w; }
+            aL[0] = anL.x; aL[1] = anL.y; aL[2] = anL.z; aL[3] = anL.w;
+            if (kc + 1 < KCH) {
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) an[mt] = ld4(&As[(16 * mt + j) * LDA + 16 * (kc + 1) + 4 * g]);
+                if (BQ > 0) anL = ld4(&As[(16 * wave + j) * LDA + 16 * (kc + 1) + 4 * g]);
+            }
+            // ---- this chunk's slice of the memory pipeline ----
+            if (kc == 0) {
+                issue_epi_loads(prev >= 0 ? prev : tile);            // clamped: results unused when !do_epi
+                issue_stage_loads(next < p.num_tiles ? next : tile); // clamped: results unused when !do_stage
+                if (GATHER_ACT) jgv_e = load_jgv(tile);              // this tile is finished in the next iteration
+                if (AMODE == A_GATHER) {
+                    const int nn = next + (int)gridDim.x;
+                    jgv_s = load_jgv(nn < p.num_tiles ? nn : tile);
+                }
+            }
+            if (kc >= CM_START && kc < CM_START + CM_CH) {
+                if (do_stage) {
+#pragma unroll
+                    for (int q = 0; q < CMC; ++q) {
+                        const int u = (kc - CM_START) * CMC + q;
+                        if (u < SR_PB) commit_row(An, u);
+                    }
+                }
+            }
+            if (kc >= EP_START) {
+                if (do_epi) {
+#pragma unroll
+                    for (int q = 0; q < EPC; ++q) {
+                        const int u = (kc - EP_START) * EPC + q;
+                        if (u < SR_PB) epi_row(u, zq[q]);
+                    }
+                }
+            }
+            if (kc + 1 >= EP_START && kc + 1 < KCH) {            // C rows of the NEXT chunk's epilogue slice (LDS prefetch)
+#pragma unroll
+                for (int q = 0; q < EPC; ++q) {
+                    const int u = (kc + 1 - EP_START) * EPC + q;
+                    const int rr = rbl + ((u < SR_PB) ? u : SR_PB - 1);
+                    zq[q] = ld4(&Cs[((rr < RG_BM) ? rr : RG_BM - 1) * LDC + cn]);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);           // memory slice stays in front of this chunk's MFMAs
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+#pragma unroll
+                for (int i = 0; i < AQ; ++i) {
+                    const float bv = (t == 0) ? wA[i][kc].x : (t == 1) ? wA[i][kc].y : (t == 2) ? wA[i][kc].z : wA[i][kc].w;
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt)
+                        acc[mt][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt][t], bv, acc[mt][i], 0, 0, 0);
+                }
+#pragma unroll
+                for (int b = 0; b < BQ; ++b) {
+                    const float bv = (t == 0) ? wL[b][kc].x : (t == 1) ? wL[b][kc].y : (t == 2) ? wL[b][kc].z : wL[b][kc].w;
+                    accL[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(aL[t], bv, accL[b], 0, 0, 0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (do_epi) epi_flush_stats();
+        __syncthreads();                                 // (1) every wave is done with C (epilogue of the previous tile)
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int i = 0; i < AQ; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    Cs[(16 * mt + 4 * g + r) * LDC + 16 * (AQ * wave + i) + j] = acc[mt][i][r];
+#pragma unroll
+        for (int b = 0; b < BQ; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Cs[(16 * wave + 4 * g + r) * LDC + 16 * (4 * AQ + b) + j] = accL[b][r];
+        __syncthreads();                                 // (2) C complete, next A tile complete
+        prev = tile;
+        buf ^= 1;
+    }
+    // ---- tail: epilogue of the last tile -------------------------------------------------------------------------------
+    if (prev >= 0 && !(p.dbg & 2)) {
+        issue_epi_loads(prev);
+#pragma unroll
+        for (int u = 0; u < SR_PB; ++u) {
+            const int rr = rbl + u;
+            epi_row(u, ld4(&Cs[((rr < RG_BM) ? rr : RG_BM - 1) * LDC + cn]));
+        }
+        epi_flush_stats();
+    }
+    __syncthreads();
+    if (EMODE == E_EDGE_FWD && p.stats_part) {
+        double* red = reinterpret_cast<double*>(smem);          // [4 waves][2][16*NT]
+        if (n_on) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                red[(wave * 2 + 0) * (16 * NT) + c + t] = stS[t];
+                red[(wave * 2 + 1) * (16 * NT) + c + t] = stQ[t];
+            }
+        }
+        __syncthreads();
+        if (tid < p.N) {
+            constexpr int NC = 16 * NT;
+            const double ss = (red[0 * NC + tid] + red[2 * NC + tid]) + (red[4 * NC + tid] + red[6 * NC + tid]);
+            const double qq = (red[1 * NC + tid] + red[3 * NC + tid]) + (red[5 * NC + tid] + red[7 * NC + tid]);
+            for (int b = blockIdx.x; b < stats_nblk; b += gridDim.x) {
+                double* dst = p.stats_part + (size_t)b * 2 * p.N;
+                dst[tid] = (b == (int)blockIdx.x) ? ss : 0.0;
+                dst[p.N + tid] = (b == (int)blockIdx.x) ? qq : 0.0;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+static int sr_num_cus()
+{
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+            cus = prop.multiProcessorCount;
+        if (cus <= 0) cus = 256;
+    }
+    return cus;
+}
+
+template <int AQ, int BQ, int KCH, int AMODE, int EMODE>
+static int sr_launch(const RgParams& p, int stats_nblk, hipStream_t s)
+{
+    constexpr int NT = 4 * AQ + BQ;
+    constexpr int LDA = 16 * KCH + 4, LDC = 16 * NT + 4;
+    const size_t lds = (size_t)RG_BM * (2 * LDA + LDC) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gpe_edgegemm_sr_kernel<AQ, BQ, KCH, AMODE, EMODE>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            return GPE_ELAUNCH;
+        attr_set = true;
+    }
+    int gx = sr_num_cus();
+    if (gx > p.num_tiles) gx = p.num_tiles;
+    if (stats_nblk > 0 && gx > stats_nblk) gx = stats_nblk;
+    hipLaunchKernelGGL((gpe_edgegemm_sr_kernel<AQ, BQ, KCH, AMODE, EMODE>), dim3(gx), dim3(256), lds, s, p, stats_nblk);
+    GPE_CHECK_LAUNCH();
+    return GPE_OK;
+}
+
+template <int AMODE, int EMODE>
+static int sr_dispatch(int NT, int KCH, const RgParams& p, int stats_nblk, hipStream_t s)
+{
+    // (K = N = 200 with the in-place backward epilogue does not fit 512 VGPRs without heavy spilling: left to the
+    // producer/consumer kernel; no shipped layer has that shape)
+    if (NT == 13 && KCH == 13 && EMODE == E_BWD_INPLACE) return GPE_ENOTSUP_SHAPE;
+    if (NT == 13 && KCH == 13) return sr_launch<3, 1, 13, AMODE, EMODE>(p, stats_nblk, s);
+    if (NT == 13 && KCH == 10) return sr_launch<3, 1, 10, AMODE, EMODE>(p, stats_nblk, s);
+    if (NT == 10 && KCH == 13) return sr_launch<2, 2, 13, AMODE, EMODE>(p, stats_nblk, s);
+    if (NT == 10 && KCH == 10) return sr_launch<2, 2, 10, AMODE, EMODE>(p, stats_nblk, s);
+    return GPE_EINVAL;
+}
+
+// Returns 1 and launches when the shape is on this kernel's menu, 0 when the caller should try the next kernel,
+// < 0 on a launch error.  `p` comes with the generic tiling (R = (64/k)*k); this kernel re-tiles so that every wave
+// owns whole points: R = 4 * npw * k with npw * k <= 16.
+int gpe_edgegemm_sr_try(const RgParams& p_in, int amode, int emode, int stats_nblk, hipStream_t s)
+{
+    RgParams p = p_in;
+    if (p.N <= 96 || p.N > 208 || p.K <= 96 || p.K > 208) return 0;
+    if (emode != E_EDGE_FWD && (p.N & 3)) return 0;      // the backward epilogues use aligned 16-B coefficient loads
+    if (amode == A_GATHER && (p.K & 3)) return 0;
+    if (amode == A_DENSE && (p.a.inner > 0 || (p.a.stride_outer & 3) || p.a.stride_outer < ((p.K + 3) & ~3) ||
+                             (((uintptr_t)p.a.base) & 15)))
+        return 0;                                        // dense rows must be aligned + padded for plain 16-B loads
+    if (p.k < 1 || p.k > SR_PB) return 0;
+    const int npw = SR_PB / p.k;                         // points per wave per tile
+    const bool per_point = amode == A_GATHER || emode == E_BWD_GATHER || (emode == E_EDGE_FWD && p.agg);
+    if (per_point && npw > SR_NPW) return 0;
+    p.R = 4 * npw * p.k;
+    p.num_tiles = gpe_cdiv(p.M, p.R);
+    const int NT = (p.N <= 160) ? 10 : 13;
+    const int KCH = (p.K <= 160) ? 10 : 13;
+    int rc = GPE_EINVAL;
+    if (amode == A_GATHER && emode == E_EDGE_FWD) rc = sr_dispatch<A_GATHER, E_EDGE_FWD>(NT, KCH, p, stats_nblk, s);
+    else if (amode == A_DENSE && emode == E_EDGE_FWD) rc = sr_dispatch<A_DENSE, E_EDGE_FWD>(NT, KCH, p, stats_nblk, s);
+    else if (amode == A_DENSE && emode == E_BWD_INPLACE) rc = sr_dispatch<A_DENSE, E_BWD_INPLACE>(NT, KCH, p, stats_nblk, s);
+    else if (amode == A_DENSE && emode == E_BWD_GATHER) rc = sr_dispatch<A_DENSE, E_BWD_GATHER>(NT, KCH, p, stats_nblk, s);
+    if (rc == GPE_ENOTSUP_SHAPE) return 0;
+    return rc == GPE_OK ? 1 : rc;
+}
