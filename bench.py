@@ -91,8 +91,9 @@ def call_work(name, a):
 # HBM traffic per launch from the committed PMC passes (profiles/*_hbm_traffic.json, made by scripts/collect_profiles.sh
 # from two `rocprofv3 --pmc` runs of this same command); C-ABI entry -> device kernels it launches
 _TRAFFIC_KERNELS = {
-    'gpe_edge_mlp_fwd': r'gpe_(edgegemm|rowgemm)_kernel<.*, 1>$',
-    'gpe_edge_mlp_bwd': r'gpe_(edgegemm|rowgemm)_kernel<.*, [23]>$',
+    # template tails: rowgemm <NT, AMODE, EMODE>; edgegemm (paired) <.., AMODE, EMODE, MATH>; edgegemm_sr <.., AMODE, EMODE, K16>
+    'gpe_edge_mlp_fwd': r'gpe_rowgemm_kernel<.*, 1>$|gpe_edgegemm(_sr)?_kernel<.*, 1, \w+>$',
+    'gpe_edge_mlp_bwd': r'gpe_rowgemm_kernel<.*, [23]>$|gpe_edgegemm(_sr)?_kernel<.*, [23], \w+>$',
     'gpe_edge_redgemm': r'gpe_redgemm_pc_kernel<',
     'gpe_edge_gather_stats': r'gpe_gather_stats_kernel',
 }

@@ -16,13 +16,13 @@ cd /tmp && export TMPDIR=/tmp
 STEPS=10
 rm -rf $OUT/prof_kt $OUT/prof_fetch $OUT/prof_write
 timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/prof_kt -- python $ROOT/bench.py --steps $STEPS --warmup 3 \
-    --no-cpu-baseline --no-kernel-timing > $OUT/${TAG}_kt.log 2>&1
+    --no-cpu-baseline --no-kernel-timing --no-fast-math-line > $OUT/${TAG}_kt.log 2>&1
 DB=$(find $OUT/prof_kt -name '*.db' | head -1)
 python $ROOT/profiles/summarize_rocpd.py $DB $((STEPS + 3)) > $OUT/${TAG}_kernel_trace.md
 for C in FETCH_SIZE WRITE_SIZE; do
   D=$OUT/prof_$(echo $C | tr A-Z a-z | sed s/_size//)
   timeout 600 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $D -- python $ROOT/bench.py --steps 2 --warmup 1 \
-      --no-cpu-baseline --no-kernel-timing > $OUT/${TAG}_pmc_$C.log 2>&1
+      --no-cpu-baseline --no-kernel-timing --no-fast-math-line > $OUT/${TAG}_pmc_$C.log 2>&1
 done
 python $ROOT/profiles/summarize_pmc.py $OUT/prof_fetch $OUT/prof_write > $OUT/${TAG}_hbm_traffic.json
 # keep the merge-back small: raw traces stay on the box
