@@ -200,13 +200,17 @@ def main():
 
     # ---- per-kernel durations: HIP events on the launch stream, same workload, right after the timed region ----
     roof, roof_gather, breakdown = None, None, None
-    if rank == 0 and not args.no_kernel_timing:
+    rec = None
+    if not args.no_kernel_timing:
+        # every rank runs these extra steps (they contain the gradient all-reduce); only rank 0 records events
         nsteps = min(args.steps, 5)
-        _lib.TIMING = []
+        if rank == 0:
+            _lib.TIMING = []
         for i in range(nsteps):
             step(args.warmup + args.steps + i)
-        torch.cuda.synchronize()
+        barrier()
         rec, _lib.TIMING = _lib.TIMING, None
+    if rank == 0 and rec is not None:
         agg = {}
         for name, ints, e0, e1 in rec:
             fl, by = call_work(name, ints)
