@@ -337,12 +337,14 @@ extern "C" int gpe_bn_bwd_coef(const double* part, int nblk, const float* stats,
 }
 
 // dz3 = (a3>0) ? [slot==argsel]*s*g - c1 - (a3-mean)*k2 : 0, written IN PLACE over the stored activation
-// a3 [E][lda3].  One wave per edge row (lanes = column quads), point/slot indices wave-uniform: no divisions.
+// a3 [E][lda3].  One wave per POINT (lanes = column quads): the point's selectors and upstream gradient are loaded once,
+// its k message rows are streamed DZ3_RB at a time so that a wave always has DZ3_RB independent 16-B loads in flight
+// (one row per wave-iteration was latency-bound at 3.5 TB/s of read+write traffic).
+#define DZ3_RB 8
 __global__ __launch_bounds__(256) void gpe_dz3_kernel(float* __restrict__ a3, int lda3, const float* __restrict__ g,
                                                       int ldg, const uint8_t* __restrict__ amx,
                                                       const uint8_t* __restrict__ amn, int ldagg,
-                                                      const float* __restrict__ coef, long E, int k, double rcp_k,
-                                                      int F)
+                                                      const float* __restrict__ coef, long npts, int k, int F)
 {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -355,27 +357,41 @@ __global__ __launch_bounds__(256) void gpe_dz3_kernel(float* __restrict__ a3, in
         cs_[t] = coef[cc]; c1_[t] = coef[F + cc]; k2_[t] = coef[2 * F + cc]; mu_[t] = coef[3 * F + cc];
     }
     const long nw = (long)gridDim.x * 4;
-    for (long row = (long)blockIdx.x * 4 + wave; row < E; row += nw) {
-        const long i = (long)gpe_udiv((unsigned)row, (unsigned)k, rcp_k);
-        const int slot = (int)(row - i * k);
-        float* ap = a3 + row * lda3 + c;
-        const float4 a = pw_ld4(ap);
+    for (long i = (long)blockIdx.x * 4 + wave; i < npts; i += nw) {
         const uchar4 smx = *reinterpret_cast<const uchar4*>(amx + i * ldagg + c);
         const uchar4 smn = *reinterpret_cast<const uchar4*>(amn + i * ldagg + c);
-        const float av[4] = {a.x, a.y, a.z, a.w};
         const uint8_t mxv[4] = {smx.x, smx.y, smx.z, smx.w};
         const uint8_t mnv[4] = {smn.x, smn.y, smn.z, smn.w};
-        float o[4];
+        int sel[4];
+        float sg[4];                                   // s * g of this point, per column of the quad
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            o[t] = 0.f;
-            if (c + t < F && av[t] > 0.f) {
-                const uint8_t sel = (cs_[t] >= 0.f) ? mxv[t] : mnv[t];
-                const float hit = (sel == slot) ? cs_[t] * g[i * ldg + c + t] : 0.f;
-                o[t] = hit - c1_[t] - (av[t] - mu_[t]) * k2_[t];
+            const int cc = (c + t < F) ? c + t : c;
+            sel[t] = (cs_[t] >= 0.f) ? mxv[t] : mnv[t];
+            sg[t] = cs_[t] * g[i * ldg + cc];
+        }
+        float* base = a3 + i * k * lda3 + c;
+        for (int s0 = 0; s0 < k; s0 += DZ3_RB) {
+            float4 a[DZ3_RB];
+#pragma unroll
+            for (int u = 0; u < DZ3_RB; ++u) {
+                const int s_ = (s0 + u < k) ? s0 + u : k - 1;          // clamped: unconditional loads
+                a[u] = pw_ld4(base + (long)s_ * lda3);
+            }
+#pragma unroll
+            for (int u = 0; u < DZ3_RB; ++u) {
+                if (s0 + u < k) {
+                    const float av[4] = {a[u].x, a[u].y, a[u].z, a[u].w};
+                    float o[4];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const float hit = (sel[t] == s0 + u) ? sg[t] : 0.f;
+                        o[t] = (c + t < F && av[t] > 0.f) ? hit - c1_[t] - (av[t] - mu_[t]) * k2_[t] : 0.f;
+                    }
+                    pw_st4(base + (long)(s0 + u) * lda3, make_float4(o[0], o[1], o[2], o[3]));
+                }
             }
         }
-        pw_st4(ap, make_float4(o[0], o[1], o[2], o[3]));
     }
 }
 
@@ -387,9 +403,10 @@ extern "C" int gpe_edge_dz3(float* a3, int lda3, const float* g, int ldg, const 
         return GPE_EINVAL;
     const long E = (long)B * N * k;
     if (F > 256 || E >= (1L << 31)) return GPE_EINVAL;
-    const int blocks = (int)((E + 3) / 4 < 4096 ? (E + 3) / 4 : 4096);
+    const long npts = (long)B * N;
+    const int blocks = (int)((npts + 3) / 4 < 4096 ? (npts + 3) / 4 : 4096);
     hipLaunchKernelGGL(gpe_dz3_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a3, lda3, g, ldg, amx, amn,
-                       ldagg, coef, E, k, 1.0 / k, F);
+                       ldagg, coef, npts, k, F);
     GPE_CHECK_LAUNCH();
     return GPE_OK;
 }
