@@ -416,34 +416,55 @@ extern "C" int gpe_edge_dz3(float* a3, int lda3, const float* g, int ldg, const 
 //   sum dy     = sum_f w[f][c] * db[f]
 //   sum dy*xhat = rstd_c * sum_f w[f][c] * Gc[f][c]
 //   dW_next[f][c] = Gc[f][c]*s_c + db[f]*beta_c          (since mean*s + t = beta)
-__global__ void gpe_bn_bwd_from_G_kernel(const float* __restrict__ G, int ldG, const float* __restrict__ db,
-                                         const float* __restrict__ w, int ldw, int Cn, int C,
-                                         const float* __restrict__ stats, double* __restrict__ sums,
-                                         float* __restrict__ dw, int lddw)
+#define BNG_FQ 4            // f-lanes per column: 64 columns x 4 f-lanes = one 256-thread workgroup
+__global__ __launch_bounds__(64 * BNG_FQ) void gpe_bn_bwd_from_G_kernel(
+    const float* __restrict__ G, int ldG, const float* __restrict__ db, const float* __restrict__ w, int ldw, int Cn,
+    int C, const float* __restrict__ stats, double* __restrict__ sums, float* __restrict__ dw, int lddw)
 {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    const double mean = stats[c], rstd = stats[C + c];
-    const double s = stats[2 * C + c], t = stats[3 * C + c];
-    const double beta = t + mean * s;
+    // (one thread per column looping over all Cn rows was a 200-deep dependent load chain: 77 us for 120 KB of data)
+    __shared__ double red[BNG_FQ][2][64];
+    const int lane = threadIdx.x & 63, fq = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
     double a = 0, b = 0;
-    for (int f = 0; f < Cn; ++f) {
-        const double wf = w[(size_t)f * ldw + c];
-        const double gf = G[(size_t)f * ldG + c];
-        const double dbf = db[f];
-        a += wf * dbf;
-        b += wf * gf;
-        if (dw) dw[(size_t)f * lddw + c] = (float)(gf * s + dbf * beta);
+    if (c < C) {
+        const double s = stats[2 * C + c], t = stats[3 * C + c], mean = stats[c];
+        const double beta = t + mean * s;
+        double a2[2] = {0, 0}, b2[2] = {0, 0};
+        int f = fq;
+        for (; f + BNG_FQ < Cn; f += 2 * BNG_FQ) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int ff = f + BNG_FQ * u;
+                const double wf = w[(size_t)ff * ldw + c], gf = G[(size_t)ff * ldG + c], dbf = db[ff];
+                a2[u] += wf * dbf;
+                b2[u] += wf * gf;
+                if (dw) dw[(size_t)ff * lddw + c] = (float)(gf * s + dbf * beta);
+            }
+        }
+        if (f < Cn) {
+            const double wf = w[(size_t)f * ldw + c], gf = G[(size_t)f * ldG + c], dbf = db[f];
+            a2[0] += wf * dbf;
+            b2[0] += wf * gf;
+            if (dw) dw[(size_t)f * lddw + c] = (float)(gf * s + dbf * beta);
+        }
+        a = a2[0] + a2[1];
+        b = b2[0] + b2[1];
     }
+    red[fq][0][lane] = a;
+    red[fq][1][lane] = b;
+    __syncthreads();
+    if (fq != 0 || c >= C) return;
+    a = (red[0][0][lane] + red[1][0][lane]) + (red[2][0][lane] + red[3][0][lane]);
+    b = (red[0][1][lane] + red[1][1][lane]) + (red[2][1][lane] + red[3][1][lane]);
     sums[c] = a;
-    sums[C + c] = b * rstd;
+    sums[C + c] = b * (double)stats[C + c];
 }
 
 extern "C" int gpe_bn_bwd_from_G(const float* G, int ldG, const float* db, const float* w_next, int ldw, int Cn,
                                  int C, const float* stats, double* sums, float* dw, int lddw, void* stream)
 {
     if (!G || !db || !w_next || !stats || !sums || Cn <= 0 || C <= 0 || ldG < C || ldw < C) return GPE_EINVAL;
-    hipLaunchKernelGGL(gpe_bn_bwd_from_G_kernel, dim3(gpe_cdiv(C, 64)), dim3(64), 0, (hipStream_t)stream, G, ldG, db,
+    hipLaunchKernelGGL(gpe_bn_bwd_from_G_kernel, dim3(gpe_cdiv(C, 64)), dim3(64 * BNG_FQ), 0, (hipStream_t)stream, G, ldG, db,
                        w_next, ldw, Cn, C, stats, sums, dw, lddw);
     GPE_CHECK_LAUNCH();
     return GPE_OK;
@@ -583,8 +604,21 @@ __global__ __launch_bounds__(1024) void gpe_segment_mean_fwd_kernel(const float*
     const int b = blockIdx.x;
     for (int c0 = 0; c0 < C; c0 += 256) {
         double s = 0;
-        if (c0 + c < C)
-            for (int n = rg; n < N; n += 4) s += (double)x[((size_t)b * N + n) * ldx + c0 + c];
+        if (c0 + c < C) {
+            // 8 rows in flight per thread (one load per dependent fp64 add was a 512-deep latency chain: 150 us)
+            const float* px = x + ((size_t)b * N) * ldx + c0 + c;
+            double sa[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            int n = rg;
+            for (; n + 28 < N; n += 32) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = px[(size_t)(n + 4 * u) * ldx];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) sa[u] += (double)v[u];
+            }
+            for (; n < N; n += 4) sa[0] += (double)px[(size_t)n * ldx];
+            s = ((sa[0] + sa[1]) + (sa[2] + sa[3])) + ((sa[4] + sa[5]) + (sa[6] + sa[7]));
+        }
         red[rg][c] = s;
         __syncthreads();
         if (rg == 0 && c0 + c < C)
