@@ -76,21 +76,31 @@ extern "C" int gpe_pack_weight_gates(const float* w, int ldw, int H, int K, floa
     return GPE_OK;
 }
 
-__global__ void gpe_fold_bias_kernel(const float* __restrict__ w, int ldw, int N, int K,
-                                     const float* __restrict__ bias, const float* __restrict__ t, float* out)
+// one wave per output row: lanes stride over k (coalesced), butterfly-free fixed-order reduction through LDS
+__global__ __launch_bounds__(256) void gpe_fold_bias_kernel(const float* __restrict__ w, int ldw, int N, int K,
+                                                            const float* __restrict__ bias, const float* __restrict__ t,
+                                                            float* out)
 {
-    const int n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= N) return;
-    double s = bias ? (double)bias[n] : 0.0;
-    for (int k = 0; k < K; ++k) s += (double)w[(size_t)n * ldw + k] * (double)t[k];
-    out[n] = (float)s;
+    __shared__ double red[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = blockIdx.x * 4 + wave;
+    double s = 0.0;
+    if (n < N)
+        for (int k = lane; k < K; k += 64) s += (double)w[(size_t)n * ldw + k] * (double)t[k];
+    red[wave][lane] = s;
+    __syncthreads();
+    if (lane == 0 && n < N) {
+        double acc = bias ? (double)bias[n] : 0.0;
+        for (int l = 0; l < 64; ++l) acc += red[wave][l];
+        out[n] = (float)acc;
+    }
 }
 
 extern "C" int gpe_fold_bias(const float* w, int ldw, int N, int K, const float* bias, const float* t, float* out,
                              void* stream)
 {
     if (!w || !t || !out || N <= 0 || K <= 0 || ldw < K) return GPE_EINVAL;
-    hipLaunchKernelGGL(gpe_fold_bias_kernel, dim3(gpe_cdiv(N, 64)), dim3(64), 0, (hipStream_t)stream, w, ldw, N, K,
+    hipLaunchKernelGGL(gpe_fold_bias_kernel, dim3(gpe_cdiv(N, 4)), dim3(256), 0, (hipStream_t)stream, w, ldw, N, K,
                        bias, t, out);
     GPE_CHECK_LAUNCH();
     return GPE_OK;
@@ -166,21 +176,23 @@ extern "C" int gpe_edge_gather_stats(const float* pq, int ldpq, int H, const int
 // ---------------------------------------------------------------------------------------------------------
 // BatchNorm finalisation
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void gpe_bn_finalize_kernel(const double* __restrict__ part, int nblk, int C,
+#define BNF_WAVES 16
+__global__ __launch_bounds__(64 * BNF_WAVES) void gpe_bn_finalize_kernel(const double* __restrict__ part, int nblk, int C,
                                                               double count, const float* __restrict__ gamma,
                                                               const float* __restrict__ beta, float eps,
                                                               float momentum, float* running_mean,
                                                               float* running_var, int64_t* num_batches,
                                                               float* __restrict__ stats)
 {
-    // one workgroup per 64 channels; the 4 waves split the partial blocks, combined in a fixed order
-    __shared__ double red[4][2][64];
+    // one workgroup per 64 channels; the 16 waves split the partial blocks (512 partials = 32 dependent adds per wave
+    // instead of 128), combined in a fixed order
+    __shared__ double red[BNF_WAVES][2][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + lane;
     if (blockIdx.x == 0 && threadIdx.x == 0 && num_batches) *num_batches += 1;
     double s = 0, q = 0;
     if (c < C) {
-        for (int b = wave; b < nblk; b += 4) {
+        for (int b = wave; b < nblk; b += BNF_WAVES) {
             s += part[(size_t)b * 2 * C + c];
             q += part[(size_t)b * 2 * C + C + c];
         }
@@ -189,8 +201,8 @@ __global__ __launch_bounds__(256) void gpe_bn_finalize_kernel(const double* __re
     red[wave][1][lane] = q;
     __syncthreads();
     if (wave != 0 || c >= C) return;
-    s = (red[0][0][lane] + red[1][0][lane]) + (red[2][0][lane] + red[3][0][lane]);
-    q = (red[0][1][lane] + red[1][1][lane]) + (red[2][1][lane] + red[3][1][lane]);
+    s = 0; q = 0;
+    for (int w_ = 0; w_ < BNF_WAVES; ++w_) { s += red[w_][0][lane]; q += red[w_][1][lane]; }
     const double mean = s / count;
     double var = q / count - mean * mean;
     if (var < 0) var = 0;
@@ -212,7 +224,7 @@ extern "C" int gpe_bn_finalize(const double* part, int nblk, int C, double count
                                float* running_var, int64_t* num_batches, float* stats_out, void* stream)
 {
     if (!part || !gamma || !beta || !stats_out || nblk <= 0 || C <= 0 || count <= 0) return GPE_EINVAL;
-    hipLaunchKernelGGL(gpe_bn_finalize_kernel, dim3(gpe_cdiv(C, 64)), dim3(256), 0, (hipStream_t)stream, part, nblk,
+    hipLaunchKernelGGL(gpe_bn_finalize_kernel, dim3(gpe_cdiv(C, 64)), dim3(64 * BNF_WAVES), 0, (hipStream_t)stream, part, nblk,
                        C, count, gamma, beta, eps, momentum, running_mean, running_var, num_batches, stats_out);
     GPE_CHECK_LAUNCH();
     return GPE_OK;
