@@ -294,9 +294,23 @@ __global__ __launch_bounds__(256) void gpe_point_sums_kernel(const float* __rest
     double s1 = 0, s2 = 0;
     if (c < C) {
         const float mean = stats[c], rstd = stats[C + c], s = stats[2 * C + c];
-        for (long r = blockIdx.x; r < rows; r += gridDim.x) {
+        // 8 rows in flight per thread (a load per dependent fp64 add was a 512-deep latency chain: 0.4 TB/s)
+        const float* sp = (s >= 0.f) ? mx : mn;
+        const long st = gridDim.x;
+        long r = blockIdx.x;
+        for (; r + 7 * st < rows; r += 8 * st) {
+            float gv[8], sv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { gv[u] = g[(r + u * st) * ldg + c]; sv[u] = sp[(r + u * st) * ldagg + c]; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                s1 += (double)gv[u];
+                s2 += (double)gv[u] * (double)((sv[u] - mean) * rstd);
+            }
+        }
+        for (; r < rows; r += st) {
             const float gv = g[r * ldg + c];
-            const float sel = (s >= 0.f) ? mx[r * ldagg + c] : mn[r * ldagg + c];
+            const float sel = sp[r * ldagg + c];
             s1 += (double)gv;
             s2 += (double)gv * (double)((sel - mean) * rstd);
         }
