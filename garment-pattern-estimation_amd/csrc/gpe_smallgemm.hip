@@ -103,13 +103,30 @@ __global__ __launch_bounds__(256) void gpe_smallgemm_kernel(SgParams p)
         // ---- stage the packed weight block of this slab: contiguous 16-B copies -----------------------------
         {
             const int planes = (kp >> 4) * 4;       // (chunk, k-quad) planes
-            const int per_plane = 16 * NT;          // float4 per plane for this column block
+            constexpr int per_plane = 16 * NT;      // float4 per plane for this column block
             const int chunk0 = ks >> 4;
-            for (int e = tid; e < planes * per_plane; e += 256) {
-                const int pl = e / per_plane, n = e - pl * per_plane;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (n0 + n < p.Npad) v = ld4(p.wp + (((long)(chunk0 * 4 + pl)) * p.Npad + n0 + n) * 4);
-                st4(&Ws[e * 4], v);
+            const int total = planes * per_plane;
+            // WB copies in flight per thread: issued one at a time (load -> LDS store -> next load) this copy was a
+            // chain of up to 16 dependent L2 round trips, most of the kernel's run time at LSTM sizes
+            constexpr int WB = 8;
+            for (int e0 = tid; e0 < total; e0 += 256 * WB) {
+                float4 v[WB];
+#pragma unroll
+                for (int u = 0; u < WB; ++u) {
+                    const int e = e0 + 256 * u;
+                    const int ec = (e < total) ? e : total - 1;          // clamped: unconditional loads
+                    const int pl = ec / per_plane, n = ec - pl * per_plane;
+                    const int nn = (n0 + n < p.Npad) ? n0 + n : p.Npad - 1;
+                    v[u] = ld4(p.wp + (((long)(chunk0 * 4 + pl)) * p.Npad + nn) * 4);
+                }
+#pragma unroll
+                for (int u = 0; u < WB; ++u) {
+                    const int e = e0 + 256 * u;
+                    if (e < total) {
+                        const int n = e % per_plane;
+                        st4(&Ws[e * 4], (n0 + n < p.Npad) ? v[u] : make_float4(0.f, 0.f, 0.f, 0.f));
+                    }
+                }
             }
         }
         __syncthreads();
