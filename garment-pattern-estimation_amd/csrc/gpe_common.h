@@ -42,8 +42,9 @@ __device__ __forceinline__ bool gpe_aligned16(const void* p) { return (((uintptr
 // ~100+ of a 64-bit integer division; matters in the 1-wave/SIMD MFMA kernels where VALU work is not hidden)
 __device__ __forceinline__ unsigned gpe_udiv(unsigned n, unsigned d, double rcp)
 {
+    // branch-free on purpose: a branch between two global loads makes the compiler wait for the first load at the join
     unsigned q = (unsigned)__double2uint_rz((double)n * rcp);
-    if ((unsigned long long)(q + 1) * d <= n) ++q;
-    else if ((unsigned long long)q * d > n) --q;
-    return q;
+    const unsigned up = ((unsigned long long)(q + 1) * d <= n) ? 1u : 0u;
+    const unsigned dn = ((unsigned long long)q * d > n) ? 1u : 0u;
+    return q + up - dn;
 }

@@ -359,6 +359,13 @@ __global__ __launch_bounds__(512, 2) void gpe_redgemm_pc_kernel(RdParams p)
         double csd[4] = {0, 0, 0, 0};
         float4 ur[RQ], vr[RQ], vr2[VMODE == V_GATHER ? RQ : 1];
 
+        int jgv = 0;                                // V_GATHER: lane q <-> neighbour row of this wave's q-th row
+        auto load_jgv = [&](int tile) -> int {
+            const long row0 = (long)tile * RD_RT;
+            const int rv = (int)((p.rows - row0 < RD_RT) ? (p.rows - row0) : RD_RT);
+            const int r = w4 + 4 * ((lane < RQ) ? lane : RQ - 1);
+            return p.jg[row0 + ((r < rv) ? r : rv - 1)];
+        };
         auto fetch = [&](int tile) {
             const long row0 = (long)tile * RD_RT;
             const int rv = (int)((p.rows - row0 < RD_RT) ? (p.rows - row0) : RD_RT);
@@ -370,7 +377,9 @@ __global__ __launch_bounds__(512, 2) void gpe_redgemm_pc_kernel(RdParams p)
                 if (VMODE == V_DENSE) vr[q] = rd_ld4(p.v.base + gr * p.v.stride_outer + cv);
                 else {
                     const long i = (long)gpe_udiv((unsigned)gr, (unsigned)p.k, p.rcp_k);
-                    const long jj = p.jg[gr];
+                    // neighbour row: prefetched lane-distributed one tile ahead (load_jgv) — read here as p.jg[gr] it is
+                    // a vector load whose result every later load of this fetch has to wait for (in-order vmcnt)
+                    const long jj = __builtin_amdgcn_readlane(jgv, q);
                     vr[q] = rd_ld4(p.pq + i * p.ldpq + cv);
                     vr2[q] = rd_ld4(p.pq + jj * p.ldpq + p.H + cv);
                 }
@@ -418,12 +427,21 @@ __global__ __launch_bounds__(512, 2) void gpe_redgemm_pc_kernel(RdParams p)
         };
 
         int tile = blockIdx.x;
+        if (VMODE == V_GATHER) jgv = load_jgv(tile < p.num_tiles ? tile : 0);
         if (tile < p.num_tiles) { fetch(tile); commit(0, tile); }
+        if (VMODE == V_GATHER && tile < p.num_tiles)
+            jgv = load_jgv(tile + (int)gridDim.x < p.num_tiles ? tile + (int)gridDim.x : tile);
         __syncthreads();                           // prologue
         int buf = 0;
         for (; tile < p.num_tiles; tile += gridDim.x) {
             const int next = tile + gridDim.x;
-            if (next < p.num_tiles) fetch(next);
+            // unconditional (clamped tile): registers loaded under a branch are copied at the join, and that copy waits
+            // for the loads right there — the fetch then runs as 8 serial round trips and the whole kernel at its pace
+            fetch(next < p.num_tiles ? next : tile);
+            if (VMODE == V_GATHER) {
+                const int nn = next + (int)gridDim.x;
+                jgv = load_jgv(nn < p.num_tiles ? nn : tile);
+            }
             if (PMAX > 0) {
                 const float* ub = Us + buf * RD_RT * LDU;
                 const float* vb = Vs + buf * RD_RT * LDV;
@@ -598,6 +616,13 @@ __global__ __launch_bounds__(512, 2) void gpe_redgemm_b3_kernel(RdParams p)
         double csd[4] = {0, 0, 0, 0};
         float4 ur[RQ], vr[RQ], vr2[VMODE == V_GATHER ? RQ : 1];
 
+        int jgv = 0;                                // V_GATHER: lane q <-> neighbour row of this wave's q-th row
+        auto load_jgv = [&](int tile) -> int {
+            const long row0 = (long)tile * RD_RT;
+            const int rv = (int)((p.rows - row0 < RD_RT) ? (p.rows - row0) : RD_RT);
+            const int r = RQ * w4 + ((lane < RQ) ? lane : RQ - 1);
+            return p.jg[row0 + ((r < rv) ? r : rv - 1)];
+        };
         auto fetch = [&](int tile) {
             const long row0 = (long)tile * RD_RT;
             const int rv = (int)((p.rows - row0 < RD_RT) ? (p.rows - row0) : RD_RT);
@@ -609,7 +634,7 @@ __global__ __launch_bounds__(512, 2) void gpe_redgemm_b3_kernel(RdParams p)
                 if (VMODE == V_DENSE) vr[q] = rd_ld4(p.v.base + gr * p.v.stride_outer + cv);
                 else {
                     const long i = (long)gpe_udiv((unsigned)gr, (unsigned)p.k, p.rcp_k);
-                    const long jj = p.jg[gr];
+                    const long jj = __builtin_amdgcn_readlane(jgv, q);       // prefetched one tile ahead (load_jgv)
                     vr[q] = rd_ld4(p.pq + i * p.ldpq + cv);
                     vr2[q] = rd_ld4(p.pq + jj * p.ldpq + p.H + cv);
                 }
@@ -672,12 +697,19 @@ __global__ __launch_bounds__(512, 2) void gpe_redgemm_b3_kernel(RdParams p)
         };
 
         int tile = blockIdx.x;
+        if (VMODE == V_GATHER) jgv = load_jgv(tile < p.num_tiles ? tile : 0);
         if (tile < p.num_tiles) { fetch(tile); commit(0, tile); }
+        if (VMODE == V_GATHER && tile < p.num_tiles)
+            jgv = load_jgv(tile + (int)gridDim.x < p.num_tiles ? tile + (int)gridDim.x : tile);
         __syncthreads();                           // prologue
         int buf = 0;
         for (; tile < p.num_tiles; tile += gridDim.x) {
             const int next = tile + gridDim.x;
-            if (next < p.num_tiles) fetch(next);
+            fetch(next < p.num_tiles ? next : tile);          // unconditional, clamped (see gpe_redgemm_pc_kernel)
+            if (VMODE == V_GATHER) {
+                const int nn = next + (int)gridDim.x;
+                jgv = load_jgv(nn < p.num_tiles ? nn : tile);
+            }
             if (PMAX > 0) {
                 const char* ub = Ub + buf * LU::BYTES;
                 const char* vb = Vb + buf * LV::BYTES;
