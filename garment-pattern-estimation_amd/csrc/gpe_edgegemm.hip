@@ -288,7 +288,10 @@ __global__ __launch_bounds__(512, 2) void gpe_edgegemm_kernel(RgParams p, int st
                             const int s = (s0 + u < p.k) ? s0 + u : p.k - 1;     // clamp: unconditional loads
                             const int r = pt * p.k + s;
                             if (AMODE == A_GATHER) {
-                                const long jj = p.jg[row0 + r];           // wave-uniform address: scalar load
+                                // neighbour row from the lane-distributed prefetch (load_jg, all 64 lanes, outside any
+                                // exec-masked region): read as p.jg[row0 + r] it compiles to a vector load plus
+                                // s_waitcnt vmcnt(0) in front of EVERY gathered row — 16 serial round trips per point
+                                const long jj = __builtin_amdgcn_readlane(jgv, r);
                                 v[u] = ld4(p.pq + jj * p.ldpq + p.H + c);
                             } else {
                                 // rows are 16-B aligned and padded to a multiple of 4 columns (checked by the
@@ -327,6 +330,10 @@ __global__ __launch_bounds__(512, 2) void gpe_edgegemm_kernel(RgParams p, int st
             if (AMODE == A_GATHER || EMODE == E_BWD_GATHER) {
                 const long gr = (long)tile * p.R + lane;
                 v = p.jg[(tile < p.num_tiles && gr < p.M) ? gr : 0];
+                // pin the load HERE, under the full exec mask: the value is consumed by v_readlane inside `if (k_on)`
+                // regions, and the compiler is free to sink a plain load next to that use — where the lanes past K are
+                // switched off and their copy of the row index would never be loaded (wild gather address, GPU fault)
+                asm volatile("" : "+v"(v));
             }
             return v;
         };
@@ -376,7 +383,7 @@ __global__ __launch_bounds__(512, 2) void gpe_edgegemm_kernel(RgParams p, int st
                             const int r = pt * p.k + s;
                             if (EMODE == E_BWD_INPLACE) act[u] = ld4(p.out + (row0 + r) * p.ldo + c);
                             else {
-                                const long jj = p.jg[row0 + r];
+                                const long jj = __builtin_amdgcn_readlane(jgv, r);
                                 act[u] = ld4(p.pq + jj * p.ldpq + p.H + c);
                             }
                         }
