@@ -206,7 +206,9 @@ __global__ __launch_bounds__(256, 1) void gpe_redgemm_kernel(RdParams p)
     for (; tile < p.num_tiles; tile += gridDim.x) {
         commit(buf);
         __syncthreads();            // tile visible; every wave is past the MFMAs that read buffer buf^1
-        if (tile + (int)gridDim.x < p.num_tiles) fetch(tile + gridDim.x);    // in flight under the MFMAs below
+        // in flight under the MFMAs below.  Unconditional (the last iteration re-fetches its own tile and drops it):
+        // registers loaded under a branch are copied at the join, which waits for the loads before the first MFMA
+        fetch(tile + (int)gridDim.x < p.num_tiles ? tile + (int)gridDim.x : tile);
         const float* ub = Us + buf * RD_RT * LDU;
         const float* vb = Vs + buf * RD_RT * LDV;
         if (tid < ucols) {
@@ -923,9 +925,9 @@ static bool rd_rows_vec(const GpeRows& r, int cols)
 static int rd_run(RdParams& p, int vmode, float* G, int ldG, float* colsum, float* part, int accumulate,
                   hipStream_t s)
 {
-    // measured (scripts/ablate_edge.py): in this single-role kernel the burst of unconditional loads stalls the MFMA
-    // stream more than the guarded loader does; kept off until the kernel is split into producer/consumer waves
-    p.vec = 0 && rd_rows_vec(p.u, p.Mg) && (vmode == V_GATHER || rd_rows_vec(p.v, p.Ng));
+    // aligned, 4-padded rows take the plain unconditional 16-B loader (all RQ loads in flight); anything else the
+    // guarded scalar-tail loader
+    p.vec = rd_rows_vec(p.u, p.Mg) && (vmode == V_GATHER || rd_rows_vec(p.v, p.Ng));
     int MH, NH, gy, MgPad, NgPad;
     rd_geometry(p.Mg, p.Ng, &MH, &NH, &gy, &MgPad, &NgPad);
     if (MH < 0 || NH < 0) return GPE_EINVAL;

@@ -190,19 +190,34 @@ __global__ __launch_bounds__(256) void gpe_smallgemm_kernel(SgParams p)
         const int u = tid & 15;
         const int unit = blockIdx.y * 16 + u;
         if (unit < p.H) {
-            for (int r = tid >> 4; r < rv; r += 16) {
-                const long gr = row0 + r;
+            // all four row-iterations' global operands are loaded up front (clamped rows): consumed one iteration at a
+            // time they were four serial L2 round trips at the tail of a 13 us kernel
+            constexpr int IT = RG_BM / 16;
+            float xi[IT], xf[IT], xg[IT], xo[IT], cp[IT];
+#pragma unroll
+            for (int it = 0; it < IT; ++it) {
+                const int r = (tid >> 4) + 16 * it;
+                const long gr = row0 + (r < rv ? r : rv - 1);
                 const float* xp = p.xproj + gr * p.xp_stride;
-                const float zi = Cs[r * ldc + u] + xp[unit];
-                const float zf = Cs[r * ldc + 16 + u] + xp[p.H + unit];
-                const float zg = Cs[r * ldc + 32 + u] + xp[2 * p.H + unit];
-                const float zo = Cs[r * ldc + 48 + u] + xp[3 * p.H + unit];
-                const float ig = sg_sigmoid(zi), fg = sg_sigmoid(zf), gg = tanhf(zg), og = sg_sigmoid(zo);
-                const float cn = fg * p.c_prev[gr * p.ldc_prev + unit] + ig * gg;
-                float* go = p.gates + gr * 4 * p.H;
-                go[unit] = ig; go[p.H + unit] = fg; go[2 * p.H + unit] = gg; go[3 * p.H + unit] = og;
-                p.c_out[gr * p.H + unit] = cn;
-                p.h_out[gr * p.h_stride + unit] = og * tanhf(cn);
+                xi[it] = xp[unit]; xf[it] = xp[p.H + unit]; xg[it] = xp[2 * p.H + unit]; xo[it] = xp[3 * p.H + unit];
+                cp[it] = p.c_prev[gr * p.ldc_prev + unit];
+            }
+#pragma unroll
+            for (int it = 0; it < IT; ++it) {
+                const int r = (tid >> 4) + 16 * it;
+                if (r < rv) {
+                    const long gr = row0 + r;
+                    const float zi = Cs[r * ldc + u] + xi[it];
+                    const float zf = Cs[r * ldc + 16 + u] + xf[it];
+                    const float zg = Cs[r * ldc + 32 + u] + xg[it];
+                    const float zo = Cs[r * ldc + 48 + u] + xo[it];
+                    const float ig = sg_sigmoid(zi), fg = sg_sigmoid(zf), gg = tanhf(zg), og = sg_sigmoid(zo);
+                    const float cn = fg * cp[it] + ig * gg;
+                    float* go = p.gates + gr * 4 * p.H;
+                    go[unit] = ig; go[p.H + unit] = fg; go[2 * p.H + unit] = gg; go[3 * p.H + unit] = og;
+                    p.c_out[gr * p.H + unit] = cn;
+                    p.h_out[gr * p.h_stride + unit] = og * tanhf(cn);
+                }
             }
         }
     }
