@@ -173,8 +173,12 @@ def _product_conv(gpe, oconv, C, H, Fo, k):
     return pconv.cuda()
 
 
+# the (200, 150) cases run the register-stationary edge kernels: k = 16 the compile-time-slot variant, k = 5 / 8 / 10 the
+# generic one (3 / 2 / 1 points per wave, ragged last tile: E is not a multiple of the tile), k = 20 the paired fallback
 @pytest.mark.parametrize('B,N,C,H,Fo,k', [(2, 64, 3, 32, 24, 4), (2, 96, 24, 32, 24, 5), (2, 128, 3, 200, 150, 16),
-                                          (1, 256, 150, 200, 150, 16), (3, 50, 6, 64, 30, 20)])
+                                          (1, 256, 150, 200, 150, 16), (3, 50, 6, 64, 30, 20),
+                                          (2, 100, 3, 200, 150, 5), (1, 77, 150, 200, 150, 8), (2, 67, 3, 200, 150, 10),
+                                          (1, 90, 150, 200, 150, 20)])
 def test_edgeconv_layer_fwd_bwd(gpe, math_mode, B, N, C, H, Fo, k):
     from oracle import ref_path as O
     tol = TOL[math_mode]
