@@ -48,3 +48,94 @@ __device__ __forceinline__ unsigned gpe_udiv(unsigned n, unsigned d, double rcp)
     const unsigned dn = ((unsigned long long)q * d > n) ? 1u : 0u;
     return q + up - dn;
 }
+
+// ---- per-device launch state ------------------------------------------------------------------------------------------
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a PER-DEVICE property of a kernel: a process that drives several
+// GPUs (nn.DataParallel-style) must set it once on each.  One bit per device ordinal per call site.
+#define GPE_ENSURE_MAX_LDS(fn)                                                                                   \
+    do {                                                                                                         \
+        static unsigned long long done_ = 0;                                                                     \
+        int dev_ = 0;                                                                                            \
+        if (hipGetDevice(&dev_) != hipSuccess) return GPE_ELAUNCH;                                               \
+        const unsigned long long bit_ = 1ull << (dev_ & 63);                                                     \
+        if (!(done_ & bit_)) {                                                                                   \
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                    160 * 1024) != hipSuccess)                                                   \
+                return GPE_ELAUNCH;                                                                              \
+            done_ |= bit_;                                                                                       \
+        }                                                                                                        \
+    } while (0)
+
+// compute units of the CURRENT device (cached per device ordinal); defined in gpe_pointwise.hip
+int gpe_num_cus();
+
+// ---- cloud -> XCD pinning ---------------------------------------------------------------------------------------------
+// Workgroup b is dispatched to XCD b % 8 (observed placement; a wrong guess costs speed, never correctness), and every
+// XCD has its own 4 MiB L2.  Kernels that re-read a cloud's per-point table (kNN candidates, the Q rows of the EdgeConv
+// gather: 1.2-3.3 MB per cloud) therefore keep all work of cloud c on XCD c % 8, so the table is fetched from HBM by ONE
+// L2 instead of eight.  The map below turns (xcd = id % 8, slot = id / 8) into a position in that XCD's own work list:
+//   cloud = xcd + 8 * (slot / units_per_cloud),  unit = slot % units_per_cloud.
+// Used when B >= 8 (otherwise it would idle whole XCDs); clouds past B are skipped by the caller (b >= B).
+#define GPE_NXCD 8
+static inline bool gpe_pin_clouds(int B) { return B >= GPE_NXCD; }
+
+// wave-granular walk over the B*N points of a batch, one point per wave per step (4 waves per 256-thread block):
+//   unpinned: wave w of block g visits points g*4+w, +4*gridDim.x, ...
+//   pinned (gridDim.x % 8 == 0): the blocks of XCD x visit the points of clouds x, x+8, ... in order.
+struct GpePointWalk { long first, count, stride; int xcd, pin; };
+__device__ __forceinline__ GpePointWalk gpe_point_walk(int B, int N, int pin)
+{
+    GpePointWalk w;
+    const int wave = threadIdx.x >> 6;
+    w.pin = pin;
+    if (pin) {
+        w.xcd = blockIdx.x & (GPE_NXCD - 1);
+        const int nbx = (B - w.xcd + GPE_NXCD - 1) / GPE_NXCD;          // clouds b = xcd (mod 8), b < B
+        w.first = (long)(blockIdx.x >> 3) * 4 + wave;
+        w.count = (long)nbx * N;
+        w.stride = (long)(gridDim.x >> 3) * 4;
+    } else {
+        w.xcd = 0;
+        w.first = (long)blockIdx.x * 4 + wave;
+        w.count = (long)B * N;
+        w.stride = (long)gridDim.x * 4;
+    }
+    return w;
+}
+// step u -> (cloud b, point i inside the cloud); B*N < 2^31 is a precondition of every caller
+__device__ __forceinline__ void gpe_walk_split(const GpePointWalk& w, long u, int N, int& b, int& i)
+{
+    const unsigned jc = (unsigned)u / (unsigned)N;
+    i = (int)((unsigned)u - jc * (unsigned)N);
+    b = w.pin ? w.xcd + GPE_NXCD * (int)jc : (int)jc;
+}
+__device__ __forceinline__ long gpe_walk_point(const GpePointWalk& w, long u, int N)
+{
+    if (!w.pin) return u;
+    int b, i;
+    gpe_walk_split(w, u, N, b, i);
+    return (long)b * N + i;
+}
+
+// tile sequence of a persistent workgroup over B equal clouds of `tpc` tiles each:
+//   unpinned (tpc == 0): blockIdx.x, +gridDim.x, ...
+//   pinned: XCD x = blockIdx.x % 8 takes clouds x, x+8, ...; its gridDim.x/8 workgroups stride through each cloud's tiles.
+// Requires (host-checked) gridDim.x % 8 == 0, B % 8 == 0, gridDim.x / 8 <= tpc.  Positions past the end give tile numbers
+// >= num_tiles in both modes, so `tile < num_tiles` stays the loop condition.
+struct GpeTileSeq { int t, c, step, tpc; };
+__device__ __forceinline__ GpeTileSeq gpe_tile_seq(int tpc)
+{
+    GpeTileSeq s;
+    s.tpc = tpc;
+    s.step = tpc ? (int)(gridDim.x >> 3) : (int)gridDim.x;
+    s.t = tpc ? (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    s.c = tpc ? (int)(blockIdx.x & (GPE_NXCD - 1)) : 0;
+    return s;
+}
+__device__ __forceinline__ int gpe_seq_tile(const GpeTileSeq& s) { return s.tpc ? s.c * s.tpc + s.t : s.t; }
+__device__ __forceinline__ void gpe_seq_advance(GpeTileSeq& s)
+{
+    s.t += s.step;
+    if (s.tpc && s.t >= s.tpc) { s.t -= s.tpc; s.c += GPE_NXCD; }
+}
+

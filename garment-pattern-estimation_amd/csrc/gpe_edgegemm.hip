@@ -519,18 +519,7 @@ __global__ __launch_bounds__(512, 2) void gpe_edgegemm_kernel(RgParams p, int st
 }
 
 // ---------------------------------------------------------------------------------------------------------
-static int eg_num_cus()
-{
-    static int cus = 0;
-    if (!cus) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-            cus = prop.multiProcessorCount;
-        if (cus <= 0) cus = 256;
-    }
-    return cus;
-}
+static int eg_num_cus() { return gpe_num_cus(); }
 
 template <int AQ, int BQ, int KCH, int AMODE, int EMODE, int MATH>
 static int eg_launch(const RgParams& p, int stats_nblk, hipStream_t s)
@@ -538,13 +527,7 @@ static int eg_launch(const RgParams& p, int stats_nblk, hipStream_t s)
     constexpr int NT = 4 * AQ + BQ;
     constexpr int LDA = 16 * KCH + 4, LDC = 16 * NT + 4;
     const size_t lds = (size_t)RG_BM * (2 * LDA + LDC) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gpe_edgegemm_kernel<AQ, BQ, KCH, AMODE, EMODE, MATH>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-            return GPE_ELAUNCH;
-        attr_set = true;
-    }
+    GPE_ENSURE_MAX_LDS((gpe_edgegemm_kernel<AQ, BQ, KCH, AMODE, EMODE, MATH>));
     int gx = eg_num_cus();
     if (gx > p.num_tiles) gx = p.num_tiles;
     if (stats_nblk > 0 && gx > stats_nblk) gx = stats_nblk;

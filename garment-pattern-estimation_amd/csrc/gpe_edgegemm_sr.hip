@@ -297,9 +297,27 @@ __global__ __launch_bounds__(256, 1) void gpe_edgegemm_sr_kernel(RgParams p, int
         }
     };
 
+    // ---- tile sequence of this workgroup --------------------------------------------------------------------------------
+    // unpinned: blockIdx.x, +gridDim.x, ...   pinned (p.pin_tpc > 0; gridDim.x % 8 == 0, B % 8 == 0, tiles never straddle
+    // clouds): this workgroup sits on XCD x = blockIdx.x % 8 and takes every (gridDim.x/8)-th tile of clouds x, x+8, ... —
+    // the gathered Q table of a cloud (3.3 MB at the shipped sizes) is then read through ONE 4 MiB L2 instead of eight.
+    // Sequence positions past the end map to tile numbers >= num_tiles in both modes.
+    const int seq_step = p.pin_tpc ? (int)(gridDim.x >> 3) : (int)gridDim.x;
+    int seq_t = p.pin_tpc ? (int)(blockIdx.x >> 3) : (int)blockIdx.x;      // pinned: tile inside the cloud
+    int seq_c = p.pin_tpc ? (int)(blockIdx.x & 7) : 0;                     // pinned: cloud
+    auto seq_tile = [&]() -> int { return p.pin_tpc ? seq_c * p.pin_tpc + seq_t : seq_t; };
+    auto seq_advance = [&]() {
+        seq_t += seq_step;
+        if (p.pin_tpc && seq_t >= p.pin_tpc) { seq_t -= p.pin_tpc; seq_c += GPE_NXCD; }   // host: seq_step <= pin_tpc
+    };
+
     // ---- prologue: stage tile 0 ---------------------------------------------------------------------------------------
     __syncthreads();                                     // A buffers zeroed
-    int tile = blockIdx.x;
+    int tile = seq_tile();
+    seq_advance();
+    int next = seq_tile();
+    seq_advance();
+    int next2 = seq_tile();
     if (tile < p.num_tiles) {
         if (AMODE == A_GATHER) jgv_s = load_jgv(tile);
         if (GATHER_ACT) jgv_e = load_jgv(tile);
@@ -309,13 +327,12 @@ __global__ __launch_bounds__(256, 1) void gpe_edgegemm_sr_kernel(RgParams p, int
 #pragma unroll
         for (int u = 0; u < SR_PB; ++u) commit_row(Abuf0, u);
     }
-    if (AMODE == A_GATHER && tile < p.num_tiles) jgv_s = load_jgv(tile + (int)gridDim.x < p.num_tiles ? tile + gridDim.x : tile);
+    if (AMODE == A_GATHER && tile < p.num_tiles) jgv_s = load_jgv(next < p.num_tiles ? next : tile);
     __syncthreads();
 
     int buf = 0, prev = -1;
-    for (; tile < p.num_tiles; tile += gridDim.x) {
+    for (; tile < p.num_tiles; tile = next, next = next2, seq_advance(), next2 = seq_tile()) {
         SR_REFRESH_SCALARS()
-        const int next = tile + gridDim.x;
         const float* As = buf ? Abuf1 : Abuf0;
         float* An = buf ? Abuf0 : Abuf1;
         const bool do_epi = prev >= 0 && !(p.dbg & 2);
@@ -353,10 +370,7 @@ __global__ __launch_bounds__(256, 1) void gpe_edgegemm_sr_kernel(RgParams p, int
                 issue_epi_loads(prev >= 0 ? prev : tile);            // clamped: results unused when !do_epi
                 issue_stage_loads(next < p.num_tiles ? next : tile); // clamped: results unused when !do_stage
                 if (GATHER_ACT) jgv_e = load_jgv(tile);              // this tile is finished in the next iteration
-                if (AMODE == A_GATHER) {
-                    const int nn = next + (int)gridDim.x;
-                    jgv_s = load_jgv(nn < p.num_tiles ? nn : tile);
-                }
+                if (AMODE == A_GATHER) jgv_s = load_jgv(next2 < p.num_tiles ? next2 : tile);
             }
             if (kc >= CM_START && kc < CM_START + CM_CH) {
                 if (do_stage) {
@@ -454,18 +468,7 @@ __global__ __launch_bounds__(256, 1) void gpe_edgegemm_sr_kernel(RgParams p, int
 }
 
 // ---------------------------------------------------------------------------------------------------------
-static int sr_num_cus()
-{
-    static int cus = 0;
-    if (!cus) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-            cus = prop.multiProcessorCount;
-        if (cus <= 0) cus = 256;
-    }
-    return cus;
-}
+static int sr_num_cus() { return gpe_num_cus(); }
 
 template <int AQ, int BQ, int KCH, int AMODE, int EMODE, bool K16>
 static int sr_launch_k(const RgParams& p, int stats_nblk, hipStream_t s)
@@ -473,13 +476,7 @@ static int sr_launch_k(const RgParams& p, int stats_nblk, hipStream_t s)
     constexpr int NT = 4 * AQ + BQ;
     constexpr int LDA = 16 * KCH + 4, LDC = 16 * NT + 4;
     const size_t lds = (size_t)RG_BM * (2 * LDA + LDC) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gpe_edgegemm_sr_kernel<AQ, BQ, KCH, AMODE, EMODE, K16>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-            return GPE_ELAUNCH;
-        attr_set = true;
-    }
+    GPE_ENSURE_MAX_LDS((gpe_edgegemm_sr_kernel<AQ, BQ, KCH, AMODE, EMODE, K16>));
     int gx = sr_num_cus();
     if (gx > p.num_tiles) gx = p.num_tiles;
     if (stats_nblk > 0 && gx > stats_nblk) gx = stats_nblk;
@@ -526,6 +523,17 @@ int gpe_edgegemm_sr_try(const RgParams& p_in, int amode, int emode, int stats_nb
     if (per_point && npw > SR_NPW) return 0;
     p.R = 4 * npw * p.k;
     p.num_tiles = gpe_cdiv(p.M, p.R);
+    p.pin_tpc = 0;
+    if ((amode == A_GATHER || emode == E_BWD_GATHER) && p.pin_clouds > 0 && gpe_pin_clouds(p.pin_clouds) &&
+        p.pin_clouds % GPE_NXCD == 0) {
+        // gather variants only (dense streaming tiles have nothing to keep in L2): tiles must not straddle clouds and
+        // the launcher must keep gridDim.x a multiple of 8 with gridDim.x / 8 <= tiles per cloud
+        const long rows_per_cloud = p.M / p.pin_clouds;
+        const int gx = gpe_num_cus();
+        if (rows_per_cloud % p.R == 0 && gx % GPE_NXCD == 0 && gx <= p.num_tiles &&
+            (stats_nblk <= 0 || gx <= stats_nblk) && rows_per_cloud / p.R >= gx / GPE_NXCD)
+            p.pin_tpc = (int)(rows_per_cloud / p.R);
+    }
     const int NT = (p.N <= 160) ? 10 : 13;
     const int KCH = (p.K <= 160) ? 10 : 13;
     int rc = GPE_EINVAL;

@@ -19,7 +19,8 @@
 #define KNN_LD 68           // row stride (floats) of channel-major LDS tiles: 16-B aligned, rows shifted by 1 slot
 
 __global__ __launch_bounds__(256) void gpe_knn_kernel(const float* __restrict__ x, int N, int C, int ldx, int k,
-                                                      int32_t* __restrict__ idx, int32_t* __restrict__ idx_glob, int Cq /* C rounded up to CCH */)
+                                                      int32_t* __restrict__ idx, int32_t* __restrict__ idx_glob, int Cq /* C rounded up to CCH */,
+                                                      int B, int tiles, int pin)
 {
     extern __shared__ __align__(16) float smem[];
     // both operand tiles are staged per 32-channel chunk (35 KB of LDS per workgroup -> 4 workgroups per CU; a resident
@@ -31,8 +32,20 @@ __global__ __launch_bounds__(256) void gpe_knn_kernel(const float* __restrict__ 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int b = blockIdx.y;
-    const int q0 = blockIdx.x * KNN_TQ;
+    // 1-D grid.  pin: all 64-query tiles of cloud c run on XCD c % 8 (gpe_common.h), so the cloud's candidate table
+    // (N x C floats, re-read by every tile) is fetched from HBM by one L2 instead of eight
+    int b, qt;
+    if (pin) {
+        const int xcd = blockIdx.x & (GPE_NXCD - 1), slot = blockIdx.x >> 3;
+        const int jc = slot / tiles;
+        b = xcd + GPE_NXCD * jc;
+        qt = slot - jc * tiles;
+        if (b >= B) return;
+    } else {
+        b = blockIdx.x / tiles;
+        qt = blockIdx.x - b * tiles;
+    }
+    const int q0 = qt * KNN_TQ;
     const float* cloud = x + (size_t)b * N * ldx;
 
     // lane-distributed top-k lists for the 16 queries this wave selects for
@@ -180,15 +193,13 @@ extern "C" int gpe_knn(const float* x, int B, int N, int C, int ldx, int k, int3
     if (B == 0) return GPE_OK;
     const int Cq = gpe_round_up(C, KNN_CCH);
     const size_t lds = ((size_t)2 * KNN_CCH * KNN_LD + 64 * KNN_LD) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gpe_knn_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-            return GPE_ELAUNCH;
-        attr_set = true;
-    }
-    dim3 grid(gpe_cdiv(N, KNN_TQ), B);
-    hipLaunchKernelGGL(gpe_knn_kernel, grid, dim3(256), lds, (hipStream_t)stream, x, N, C, ldx, k, idx, idx_glob, Cq);
+    GPE_ENSURE_MAX_LDS((gpe_knn_kernel));
+    const int tiles = gpe_cdiv(N, KNN_TQ);
+    const int pin = gpe_pin_clouds(B) ? 1 : 0;
+    const long nblocks = pin ? (long)GPE_NXCD * gpe_cdiv(B, GPE_NXCD) * tiles : (long)B * tiles;
+    if (nblocks >= (1L << 31)) return GPE_EINVAL;
+    hipLaunchKernelGGL(gpe_knn_kernel, dim3((unsigned)nblocks), dim3(256), lds, (hipStream_t)stream, x, N, C, ldx, k, idx,
+                       idx_glob, Cq, B, tiles, pin);
     GPE_CHECK_LAUNCH();
     return GPE_OK;
 }

@@ -5,7 +5,21 @@
 #include "gpe_common.h"
 #include <math.h>
 
-extern "C" int gpe_abi_version(void) { return 1; }
+extern "C" int gpe_abi_version(void) { return 2; }
+
+int gpe_num_cus()
+{
+    static int cus[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    int& c = cus[dev & 63];
+    if (!c) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, dev) == hipSuccess) c = prop.multiProcessorCount;
+        if (c <= 0) c = 256;
+    }
+    return c;
+}
 
 __device__ __forceinline__ float4 pw_ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void pw_st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
@@ -115,15 +129,18 @@ extern "C" int gpe_fold_bias(const float* w, int ldw, int N, int K, const float*
 template <int KU>
 __global__ __launch_bounds__(256) void gpe_gather_stats_kernel(const float* __restrict__ pq, int ldpq, int H,
                                                                const int32_t* __restrict__ jg, int k,
-                                                               long total_pts, double* __restrict__ part)
+                                                               int B, int N, int pin, double* __restrict__ part)
 {
     __shared__ double red[4][2][256];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = 4 * lane;
     const bool active = c < H;
     double s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
-    const long nw = (long)gridDim.x * 4;
-    for (long i = (long)blockIdx.x * 4 + wave; i < total_pts; i += nw) {
+    // pin: the waves of XCD x (blocks x, x+8, ...) walk the points of clouds x, x+8, ... only, one cloud at a time, so a
+    // cloud's Q table (N x H floats, gathered k-fold) is served by that XCD's L2 alone (gpe_common.h)
+    const GpePointWalk wk = gpe_point_walk(B, N, pin);
+    for (long u = wk.first; u < wk.count; u += wk.stride) {
+        const long i = gpe_walk_point(wk, u, N);
         const int myidx = (lane < k) ? jg[i * k + lane] : 0;
         float4 p4 = make_float4(0.f, 0.f, 0.f, 0.f);
         if (active) p4 = pw_ld4(pq + i * ldpq + c);
@@ -168,7 +185,7 @@ extern "C" int gpe_edge_gather_stats(const float* pq, int ldpq, int H, const int
         ldpq < 2 * H)
         return GPE_EINVAL;
     hipLaunchKernelGGL(gpe_gather_stats_kernel<8>, dim3(GS_BLOCKS), dim3(256), 0, (hipStream_t)stream, pq, ldpq, H,
-                       jg, k, (long)B * N, part);
+                       jg, k, B, N, gpe_pin_clouds(B) ? 1 : 0, part);
     GPE_CHECK_LAUNCH();
     return GPE_OK;
 }
@@ -561,13 +578,7 @@ extern "C" int gpe_knn_reverse(const int32_t* idx, int B, int N, int k, int32_t*
     if (!idx || !rev_off || !rev_edge || B <= 0 || N <= 0 || k <= 0) return GPE_EINVAL;
     const size_t lds = (size_t)(2 * N + 1) * sizeof(int);
     if (lds > 150 * 1024) return GPE_EINVAL;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gpe_knn_reverse_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess)
-            return GPE_ELAUNCH;
-        attr_set = true;
-    }
+    GPE_ENSURE_MAX_LDS((gpe_knn_reverse_kernel));
     hipLaunchKernelGGL(gpe_knn_reverse_kernel, dim3(B), dim3(1024), lds, (hipStream_t)stream, idx, N, k, rev_off,
                        rev_edge);
     GPE_CHECK_LAUNCH();
@@ -576,16 +587,19 @@ extern "C" int gpe_knn_reverse(const int32_t* idx, int B, int N, int k, int32_t*
 
 __global__ __launch_bounds__(256) void gpe_pull_dq_kernel(const float* __restrict__ dz, int lddz,
                                                           const int32_t* __restrict__ rev_off,
-                                                          const int32_t* __restrict__ rev_edge, int N, int k, int H,
-                                                          long total_pts, float* __restrict__ dQ, int lddq)
+                                                          const int32_t* __restrict__ rev_edge, int B, int N, int k, int H,
+                                                          int pin, float* __restrict__ dQ, int lddq)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = 4 * lane;
     const bool active = c < H;
-    const long nw = (long)gridDim.x * 4;
-    for (long pt = (long)blockIdx.x * 4 + wave; pt < total_pts; pt += nw) {
-        const long b = pt / N;
-        const int jn = (int)(pt - b * N);
+    // pin: a cloud's dz rows (N*k x H, each read once here, right after the kernel that wrote them) stay on one XCD
+    const GpePointWalk wk = gpe_point_walk(B, N, pin);
+    for (long u = wk.first; u < wk.count; u += wk.stride) {
+        int bi, jn;
+        gpe_walk_split(wk, u, N, bi, jn);
+        const long b = bi;
+        const long pt = b * N + jn;
         const int32_t* ro = rev_off + b * (N + 1);
         const int32_t* re = rev_edge + b * (long)N * k;
         const long e0 = b * (long)N * k;
@@ -612,9 +626,11 @@ extern "C" int gpe_edge_pull_dq(const float* dz, int lddz, const int32_t* rev_of
         (lddz & 3) || (lddq & 3))
         return GPE_EINVAL;
     const long pts = (long)B * N;
-    const int blocks = (int)((pts + 3) / 4 < 2048 ? (pts + 3) / 4 : 2048);
+    const int pin = gpe_pin_clouds(B) ? 1 : 0;
+    int blocks = (int)((pts + 3) / 4 < 2048 ? (pts + 3) / 4 : 2048);
+    if (pin) blocks = gpe_round_up(blocks, GPE_NXCD);
     hipLaunchKernelGGL(gpe_pull_dq_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dz, lddz, rev_off,
-                       rev_edge, N, k, H, pts, dQ, lddq);
+                       rev_edge, B, N, k, H, pin, dQ, lddq);
     GPE_CHECK_LAUNCH();
     return GPE_OK;
 }

@@ -31,8 +31,10 @@ struct RdParams {
     GpeRows u;
     GpeRows v;                                   // V_DENSE
     const float* pq; int ldpq; int H; const int32_t* jg; int k; double rcp_k;   // V_GATHER (global neighbour rows)
+    int pin_clouds;                              // B when the rows are B equal clouds (gpe_edge_redgemm), else 0
     const float* v_shift;                        // optional [Ng]: V := V - shift on valid rows (BN centring)
     int vec;                                     // rows aligned to 16 B and padded to 4 columns: plain 16-B loads
+    int pin_tpc;                                 // gather variants of the pc/b3 kernels: tiles per cloud when pinned (gpe_common.h)
     float* part;                                 // [gridDim.x][MgPad][NgPad]
     double* part_cs;                             // [gridDim.x][MgPad]
 };
@@ -303,7 +305,8 @@ __global__ __launch_bounds__(512, 2) void gpe_redgemm_pc_kernel(RdParams p)
             for (int n = 0; n < NB; ++n) acc[q][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
         __syncthreads();                           // prologue: tile 0 staged
         int buf = 0;
-        for (int tile = blockIdx.x; tile < p.num_tiles; tile += gridDim.x) {
+        GpeTileSeq sq = gpe_tile_seq(p.pin_tpc);
+        for (int tile = gpe_seq_tile(sq); tile < p.num_tiles; gpe_seq_advance(sq), tile = gpe_seq_tile(sq)) {
             const float* ub = Us + buf * RD_RT * LDU;
             const float* vb = Vs + buf * RD_RT * LDV;
 #pragma unroll
@@ -428,22 +431,22 @@ __global__ __launch_bounds__(512, 2) void gpe_redgemm_pc_kernel(RdParams p)
             for (int t = 0; t < 4; ++t) csd[t] += (double)c32[t];
         };
 
-        int tile = blockIdx.x;
+        GpeTileSeq sq = gpe_tile_seq(p.pin_tpc);
+        int tile = gpe_seq_tile(sq);
+        gpe_seq_advance(sq);
+        int next = gpe_seq_tile(sq);
+        gpe_seq_advance(sq);
+        int next2 = gpe_seq_tile(sq);
         if (VMODE == V_GATHER) jgv = load_jgv(tile < p.num_tiles ? tile : 0);
         if (tile < p.num_tiles) { fetch(tile); commit(0, tile); }
-        if (VMODE == V_GATHER && tile < p.num_tiles)
-            jgv = load_jgv(tile + (int)gridDim.x < p.num_tiles ? tile + (int)gridDim.x : tile);
+        if (VMODE == V_GATHER && tile < p.num_tiles) jgv = load_jgv(next < p.num_tiles ? next : tile);
         __syncthreads();                           // prologue
         int buf = 0;
-        for (; tile < p.num_tiles; tile += gridDim.x) {
-            const int next = tile + gridDim.x;
+        for (; tile < p.num_tiles; tile = next, next = next2, gpe_seq_advance(sq), next2 = gpe_seq_tile(sq)) {
             // unconditional (clamped tile): registers loaded under a branch are copied at the join, and that copy waits
             // for the loads right there — the fetch then runs as 8 serial round trips and the whole kernel at its pace
             fetch(next < p.num_tiles ? next : tile);
-            if (VMODE == V_GATHER) {
-                const int nn = next + (int)gridDim.x;
-                jgv = load_jgv(nn < p.num_tiles ? nn : tile);
-            }
+            if (VMODE == V_GATHER) jgv = load_jgv(next2 < p.num_tiles ? next2 : tile);
             if (PMAX > 0) {
                 const float* ub = Us + buf * RD_RT * LDU;
                 const float* vb = Vs + buf * RD_RT * LDV;
@@ -557,7 +560,8 @@ __global__ __launch_bounds__(512, 2) void gpe_redgemm_b3_kernel(RdParams p)
             for (int n = 0; n < NB; ++n) acc[q][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
         __syncthreads();                           // prologue: tile 0 staged
         int buf = 0;
-        for (int tile = blockIdx.x; tile < p.num_tiles; tile += gridDim.x) {
+        GpeTileSeq sq = gpe_tile_seq(p.pin_tpc);
+        for (int tile = gpe_seq_tile(sq); tile < p.num_tiles; gpe_seq_advance(sq), tile = gpe_seq_tile(sq)) {
             const char* ub = Ub + buf * LU::BYTES;
             const char* vb = Vb + buf * LV::BYTES;
             uint4 bh[NB], bl[NB];
@@ -698,20 +702,20 @@ __global__ __launch_bounds__(512, 2) void gpe_redgemm_b3_kernel(RdParams p)
             for (int t = 0; t < 4; ++t) csd[t] += (double)c32[t];
         };
 
-        int tile = blockIdx.x;
+        GpeTileSeq sq = gpe_tile_seq(p.pin_tpc);
+        int tile = gpe_seq_tile(sq);
+        gpe_seq_advance(sq);
+        int next = gpe_seq_tile(sq);
+        gpe_seq_advance(sq);
+        int next2 = gpe_seq_tile(sq);
         if (VMODE == V_GATHER) jgv = load_jgv(tile < p.num_tiles ? tile : 0);
         if (tile < p.num_tiles) { fetch(tile); commit(0, tile); }
-        if (VMODE == V_GATHER && tile < p.num_tiles)
-            jgv = load_jgv(tile + (int)gridDim.x < p.num_tiles ? tile + (int)gridDim.x : tile);
+        if (VMODE == V_GATHER && tile < p.num_tiles) jgv = load_jgv(next < p.num_tiles ? next : tile);
         __syncthreads();                           // prologue
         int buf = 0;
-        for (; tile < p.num_tiles; tile += gridDim.x) {
-            const int next = tile + gridDim.x;
+        for (; tile < p.num_tiles; tile = next, next = next2, gpe_seq_advance(sq), next2 = gpe_seq_tile(sq)) {
             fetch(next < p.num_tiles ? next : tile);          // unconditional, clamped (see gpe_redgemm_pc_kernel)
-            if (VMODE == V_GATHER) {
-                const int nn = next + (int)gridDim.x;
-                jgv = load_jgv(nn < p.num_tiles ? nn : tile);
-            }
+            if (VMODE == V_GATHER) jgv = load_jgv(next2 < p.num_tiles ? next2 : tile);
             if (PMAX > 0) {
                 const char* ub = Ub + buf * LU::BYTES;
                 const char* vb = Vb + buf * LV::BYTES;
@@ -817,18 +821,7 @@ static int rd_pick(int need, const int* opts, int n)
 static const int RD_MH_OPTS[3] = {2, 5, 7};
 static const int RD_NH_OPTS[4] = {1, 5, 7, 8};
 
-static int rd_num_cus()
-{
-    static int cus = 0;
-    if (!cus) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-            cus = prop.multiProcessorCount;
-        if (cus <= 0) cus = 256;
-    }
-    return cus;
-}
+static int rd_num_cus() { return gpe_num_cus(); }
 
 // geometry shared by the workspace query and the launcher (no device query here: the ws size must be computable on a
 // CPU-only box, so it is sized for the largest grid we ever launch)
@@ -859,13 +852,7 @@ template <int MH, int NH, int VMODE>
 static int rd_launch(const RdParams& p, dim3 grid, hipStream_t s)
 {
     const size_t lds = (size_t)2 * RD_RT * ((32 * MH + 16) + (32 * NH + 16)) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gpe_redgemm_kernel<MH, NH, VMODE>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-            return GPE_ELAUNCH;
-        attr_set = true;
-    }
+    GPE_ENSURE_MAX_LDS((gpe_redgemm_kernel<MH, NH, VMODE>));
     hipLaunchKernelGGL((gpe_redgemm_kernel<MH, NH, VMODE>), grid, dim3(256), lds, s, p);
     GPE_CHECK_LAUNCH();
     return GPE_OK;
@@ -878,13 +865,7 @@ static int rd_pc_launch(const RdParams& p, int gx, hipStream_t s)
     constexpr int LDU = (UC % 32 == 16) ? UC : UC + 16;
     constexpr int LDV = (VC % 32 == 16) ? VC : VC + 16;
     const size_t lds = (size_t)2 * RD_RT * (LDU + LDV) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gpe_redgemm_pc_kernel<MT, NT, VMODE>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-            return GPE_ELAUNCH;
-        attr_set = true;
-    }
+    GPE_ENSURE_MAX_LDS((gpe_redgemm_pc_kernel<MT, NT, VMODE>));
     hipLaunchKernelGGL((gpe_redgemm_pc_kernel<MT, NT, VMODE>), dim3(gx), dim3(512), lds, s, p);
     GPE_CHECK_LAUNCH();
     return GPE_OK;
@@ -894,13 +875,7 @@ template <int MT, int NT, int VMODE>
 static int rd_b3_launch(const RdParams& p, int gx, hipStream_t s)
 {
     const size_t lds = (size_t)2 * (RdB3Layout<MT>::BYTES + RdB3Layout<NT>::BYTES);
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gpe_redgemm_b3_kernel<MT, NT, VMODE>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-            return GPE_ELAUNCH;
-        attr_set = true;
-    }
+    GPE_ENSURE_MAX_LDS((gpe_redgemm_b3_kernel<MT, NT, VMODE>));
     hipLaunchKernelGGL((gpe_redgemm_b3_kernel<MT, NT, VMODE>), dim3(gx), dim3(512), lds, s, p);
     GPE_CHECK_LAUNCH();
     return GPE_OK;
@@ -947,6 +922,12 @@ static int rd_run(RdParams& p, int vmode, float* G, int ldG, float* colsum, floa
     const int mt_all = gpe_cdiv(p.Mg, 16), nt_all = gpe_cdiv(p.Ng, 16);
     const bool pc_ok = gy == 1 && nt_all == 13 && (mt_all == 13 || mt_all == 10) && rd_rows_vec(p.u, p.Mg) &&
                        (vmode == V_GATHER || rd_rows_vec(p.v, p.Ng)) && p.num_tiles >= 4 * gx;
+    p.pin_tpc = 0;
+    if (pc_ok && vmode == V_GATHER && p.pin_clouds > 0 && gpe_pin_clouds(p.pin_clouds) && p.pin_clouds % GPE_NXCD == 0) {
+        const long rows_per_cloud = p.rows / p.pin_clouds;
+        if (rows_per_cloud % RD_RT == 0 && gx % GPE_NXCD == 0 && rows_per_cloud / RD_RT >= gx / GPE_NXCD)
+            p.pin_tpc = (int)(rows_per_cloud / RD_RT);
+    }
     if (pc_ok && g_rd_math == 1) {
         if (mt_all == 13 && vmode == V_DENSE) rc = rd_b3_launch<13, 13, V_DENSE>(p, gx, s);
         else if (mt_all == 13) rc = rd_b3_launch<13, 13, V_GATHER>(p, gx, s);
@@ -995,5 +976,6 @@ extern "C" int gpe_edge_redgemm(const float* u, int ldu, int v_mode, const float
     p.u = GpeRows{u, ldu, 0, 0};
     p.v = GpeRows{v, ldv, 0, 0};
     p.pq = pq; p.ldpq = ldpq; p.H = Ng; p.jg = jg; p.k = k; p.rcp_k = 1.0 / k; p.v_shift = v_shift;
+    p.pin_clouds = B;
     return rd_run(p, v_mode == 0 ? V_GATHER : V_DENSE, G, ldG, colsum, part, 0, (hipStream_t)stream);
 }

@@ -31,6 +31,10 @@ struct RgParams {
     const float* coef_out;  // E_BWD_*: [4][N] = {s, c1, k2, mean}
     float* dP; int lddp;    // E_BWD_GATHER
     int dbg;                // ablation switches for profiling (0 in production): see gpe_debug_set
+    // cloud -> XCD pinning of the persistent edge kernels (gpe_common.h): tiles of cloud c are processed by the workgroups
+    // of XCD c % 8.  tpc = tiles per cloud (N*k / R, exact); 0 = off.
+    int pin_tpc;
+    int pin_clouds;         // B when the caller's rows are B equal clouds (edge kernels), else 0
 };
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }

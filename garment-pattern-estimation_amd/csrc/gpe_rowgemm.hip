@@ -174,13 +174,7 @@ static int rg_launch(const RgParams& p, dim3 grid, hipStream_t stream)
 {
     const size_t lds = rg_lds_bytes(NT, p.K);
     if (lds > 160 * 1024) return GPE_EINVAL;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gpe_rowgemm_kernel<NT, AMODE, EMODE>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-            return GPE_ELAUNCH;
-        attr_set = true;
-    }
+    GPE_ENSURE_MAX_LDS((gpe_rowgemm_kernel<NT, AMODE, EMODE>));
     hipLaunchKernelGGL((gpe_rowgemm_kernel<NT, AMODE, EMODE>), grid, dim3(256), lds, stream, p);
     GPE_CHECK_LAUNCH();
     return GPE_OK;
@@ -281,7 +275,7 @@ extern "C" int gpe_edge_mlp_fwd(int a_mode, const float* pq, int ldpq, const int
     p.wp = wp; p.Npad = gpe_round_up(Cout, 16); p.bias = bias;
     p.out = out; p.ldo = ldo; p.stats_part = stats_part;
     p.agg = agg; p.mx = mx; p.mn = mn; p.oamx = amx; p.oamn = amn; p.oldagg = ldagg;
-    p.dbg = g_gpe_dbg;
+    p.dbg = g_gpe_dbg; p.pin_clouds = B;
     const int fast = gpe_edgegemm_try(p, a_mode == 0 ? A_GATHER : A_DENSE, E_EDGE_FWD,
                                       stats_part ? GPE_STATS_BLOCKS : 0, (hipStream_t)stream);
     if (fast != 0) return fast == 1 ? GPE_OK : fast;
@@ -308,7 +302,7 @@ extern "C" int gpe_edge_mlp_bwd(const float* a, int lda, int act_mode, const flo
     p.wp = wp; p.Npad = gpe_round_up(Cout, 16);
     p.out = dz_out; p.ldo = ldo; p.coef_out = coef_out; p.dP = dP; p.lddp = lddp;
     hipStream_t s = (hipStream_t)stream;
-    p.dbg = g_gpe_dbg;
+    p.dbg = g_gpe_dbg; p.pin_clouds = B;
     const int fast = gpe_edgegemm_try(p, A_DENSE, act_mode == 1 ? E_BWD_GATHER : E_BWD_INPLACE, 0, s);
     if (fast != 0) return fast == 1 ? GPE_OK : fast;
     dim3 grid(p.num_tiles < 2048 ? p.num_tiles : 2048, 1);

@@ -236,13 +236,7 @@ static int sg_launch(const SgParams& p, dim3 grid, hipStream_t s)
 {
     const size_t lds = sg_lds_bytes(NT, p.K);
     if (lds > 160 * 1024) return GPE_EINVAL;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gpe_smallgemm_kernel<NT, EPI>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-            return GPE_ELAUNCH;
-        attr_set = true;
-    }
+    GPE_ENSURE_MAX_LDS((gpe_smallgemm_kernel<NT, EPI>));
     hipLaunchKernelGGL((gpe_smallgemm_kernel<NT, EPI>), grid, dim3(256), lds, s, p);
     GPE_CHECK_LAUNCH();
     return GPE_OK;
