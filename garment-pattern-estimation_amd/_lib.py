@@ -97,6 +97,16 @@ TIMING = None
 def call(name, *args):
     """Invoke a C-ABI entry point on torch's current HIP stream (appended as the trailing `stream` argument)."""
     fn = getattr(lib(), name)
+    # kernels run on the CURRENT device's stream: refuse tensors that live elsewhere (a model on cuda:1 while cuda:0 is
+    # current would otherwise hand foreign pointers to the wrong device's queue)
+    cur = torch.cuda.current_device()
+    for a in args:
+        if isinstance(a, torch.Tensor):
+            if not a.is_cuda or a.device.index != cur:
+                raise RuntimeError('%s: tensor on %s but the current device is cuda:%d — wrap the call in '
+                                   'torch.cuda.device(...) (one process per GPU is the supported layout)'
+                                   % (name, a.device, cur))
+            break
     stream = torch.cuda.current_stream()
     if TIMING is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

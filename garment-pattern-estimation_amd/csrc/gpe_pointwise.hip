@@ -59,6 +59,72 @@ extern "C" int gpe_pack_weight(const float* w, int ldw, int N, int K, int transp
     return GPE_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// multi-pack: every weight-derived operand of a model (plain / transposed / gate-interleaved packs, the P|Q split of
+// the first edge-MLP Linear, b_ih + b_hh) refreshed by ONE launch after an optimizer step, instead of ~45 launches
+// per training step.  Job table in device memory, 64 bytes per job (mirrored by ops.PackPlan):
+// ---------------------------------------------------------------------------------------------------------
+struct GpePackJob {
+    const float* w;         // source matrix / vector
+    const float* w2;        // second source (kind 5)
+    float* out;
+    long total;             // output elements
+    long first_block;       // first 256-thread block of this job
+    int ldw, N, K, kind, Npad, aux;
+};
+static_assert(sizeof(GpePackJob) == 64, "job layout is part of the ABI (ops.PackPlan builds it with numpy)");
+
+__global__ __launch_bounds__(256) void gpe_pack_multi_kernel(const GpePackJob* __restrict__ jobs, int njobs)
+{
+    // wave-uniform job lookup: jobs are sorted by first_block
+    int ji = 0;
+    for (int q = 1; q < njobs; ++q) ji = ((long)blockIdx.x >= jobs[q].first_block) ? q : ji;
+    const GpePackJob jb = jobs[ji];
+    const long e = ((long)blockIdx.x - jb.first_block) * 256 + threadIdx.x;
+    if (e >= jb.total) return;
+    if (jb.kind == 5) { jb.out[e] = jb.w[e] + jb.w2[e]; return; }                 // b_ih + b_hh
+    if (jb.kind == 6) { jb.out[e] = (e < jb.aux) ? jb.w[e] : 0.f; return; }       // [b1 | 0]
+    const int t = (int)(e & 3);
+    const long r = e >> 2;
+    const int n = (int)(r % jb.Npad);
+    const int k = (int)((r / jb.Npad) * 4 + t);
+    float v = 0.f;
+    const float* w = jb.w;
+    const int ldw = jb.ldw;
+    switch (jb.kind) {
+        case 0: if (n < jb.N && k < jb.K) v = w[(size_t)n * ldw + k]; break;
+        case 1: if (n < jb.N && k < jb.K) v = w[(size_t)k * ldw + n]; break;
+        case 2: {                                                   // LSTM gates, aux = H
+            const int H = jb.aux;
+            const int b = n >> 6, gate = (n >> 4) & 3, u = (b << 4) + (n & 15);
+            if (u < H && k < jb.K) v = w[(size_t)(gate * H + u) * ldw + k];
+            break;
+        }
+        case 3: {                                                   // [W1a - W1b ; W1b] (N = 2H rows, K = C), aux = H
+            const int H = jb.aux, C = jb.K;
+            if (n < jb.N && k < C)
+                v = (n < H) ? w[(size_t)n * ldw + k] - w[(size_t)n * ldw + C + k] : w[(size_t)(n - H) * ldw + C + k];
+            break;
+        }
+        case 4: {                                                   // transpose of the above (N = C, K = 2H), aux = H
+            const int H = jb.aux, C = jb.N;
+            if (n < C && k < jb.K)
+                v = (k < H) ? w[(size_t)k * ldw + n] - w[(size_t)k * ldw + C + n] : w[(size_t)(k - H) * ldw + C + n];
+            break;
+        }
+    }
+    jb.out[e] = v;
+}
+
+extern "C" int gpe_pack_multi(const void* jobs_dev, int njobs, long total_blocks, void* stream)
+{
+    if (!jobs_dev || njobs <= 0 || total_blocks <= 0 || total_blocks >= (1L << 31)) return GPE_EINVAL;
+    hipLaunchKernelGGL(gpe_pack_multi_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const GpePackJob*>(jobs_dev), njobs);
+    GPE_CHECK_LAUNCH();
+    return GPE_OK;
+}
+
 // gate-interleaved packing of an LSTM weight [4H][ldw] (rows i|f|g|o x H, torch.nn.LSTM layout): packed row
 // b*64 + gate*16 + u'  <->  original row gate*H + 16*b + u', so one 64-column block holds the four gates of 16 units.
 __global__ void gpe_pack_gates_kernel(const float* __restrict__ w, int ldw, int H, int K, float* __restrict__ wp,
@@ -307,7 +373,7 @@ __global__ __launch_bounds__(256) void gpe_point_sums_kernel(const float* __rest
                                                              const float* __restrict__ stats, long rows, int C,
                                                              double* __restrict__ part)
 {
-    const int c = threadIdx.x;
+    const int c = blockIdx.y * 256 + threadIdx.x;
     double s1 = 0, s2 = 0;
     if (c < C) {
         const float mean = stats[c], rstd = stats[C + c], s = stats[2 * C + c];
@@ -341,8 +407,8 @@ extern "C" int gpe_point_sums_blocks(void) { return PS_BLOCKS; }
 extern "C" int gpe_edge_bwd_point_sums(const float* g, int ldg, const float* mx, const float* mn, int ldagg,
                                        const float* stats, long rows, int C, double* part, void* stream)
 {
-    if (!g || !mx || !mn || !stats || !part || rows <= 0 || C <= 0 || C > 256) return GPE_EINVAL;
-    hipLaunchKernelGGL(gpe_point_sums_kernel, dim3(PS_BLOCKS), dim3(256), 0, (hipStream_t)stream, g, ldg, mx, mn,
+    if (!g || !mx || !mn || !stats || !part || rows <= 0 || C <= 0) return GPE_EINVAL;
+    hipLaunchKernelGGL(gpe_point_sums_kernel, dim3(PS_BLOCKS, gpe_cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, g, ldg, mx, mn,
                        ldagg, stats, rows, C, part);
     GPE_CHECK_LAUNCH();
     return GPE_OK;
@@ -387,12 +453,14 @@ extern "C" int gpe_bn_bwd_coef(const double* part, int nblk, const float* stats,
 __global__ __launch_bounds__(256) void gpe_dz3_kernel(float* __restrict__ a3, int lda3, const float* __restrict__ g,
                                                       int ldg, const uint8_t* __restrict__ amx,
                                                       const uint8_t* __restrict__ amn, int ldagg,
-                                                      const float* __restrict__ coef, long npts, int k, int F)
+                                                      const float* __restrict__ coef, long npts, int k, int F,
+                                                      float gscale)
 {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int c = lane << 2;
+    const int c = (blockIdx.y * 64 + lane) << 2;
     if (c >= F) return;
+    const bool all_slots = amx == nullptr;             // aggr 'add' / 'mean': every message carries the point's gradient
     float cs_[4], c1_[4], k2_[4], mu_[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
@@ -401,17 +469,20 @@ __global__ __launch_bounds__(256) void gpe_dz3_kernel(float* __restrict__ a3, in
     }
     const long nw = (long)gridDim.x * 4;
     for (long i = (long)blockIdx.x * 4 + wave; i < npts; i += nw) {
-        const uchar4 smx = *reinterpret_cast<const uchar4*>(amx + i * ldagg + c);
-        const uchar4 smn = *reinterpret_cast<const uchar4*>(amn + i * ldagg + c);
-        const uint8_t mxv[4] = {smx.x, smx.y, smx.z, smx.w};
-        const uint8_t mnv[4] = {smn.x, smn.y, smn.z, smn.w};
+        uint8_t mxv[4] = {0, 0, 0, 0}, mnv[4] = {0, 0, 0, 0};
+        if (!all_slots) {
+            const uchar4 smx = *reinterpret_cast<const uchar4*>(amx + i * ldagg + c);
+            const uchar4 smn = *reinterpret_cast<const uchar4*>(amn + i * ldagg + c);
+            mxv[0] = smx.x; mxv[1] = smx.y; mxv[2] = smx.z; mxv[3] = smx.w;
+            mnv[0] = smn.x; mnv[1] = smn.y; mnv[2] = smn.z; mnv[3] = smn.w;
+        }
         int sel[4];
         float sg[4];                                   // s * g of this point, per column of the quad
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const int cc = (c + t < F) ? c + t : c;
             sel[t] = (cs_[t] >= 0.f) ? mxv[t] : mnv[t];
-            sg[t] = cs_[t] * g[i * ldg + cc];
+            sg[t] = cs_[t] * g[i * ldg + cc] * gscale;
         }
         float* base = a3 + i * k * lda3 + c;
         for (int s0 = 0; s0 < k; s0 += DZ3_RB) {
@@ -428,7 +499,7 @@ __global__ __launch_bounds__(256) void gpe_dz3_kernel(float* __restrict__ a3, in
                     float o[4];
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
-                        const float hit = (sel[t] == s0 + u) ? sg[t] : 0.f;
+                        const float hit = (all_slots || sel[t] == s0 + u) ? sg[t] : 0.f;
                         o[t] = (c + t < F && av[t] > 0.f) ? hit - c1_[t] - (av[t] - mu_[t]) * k2_[t] : 0.f;
                     }
                     pw_st4(base + (long)(s0 + u) * lda3, make_float4(o[0], o[1], o[2], o[3]));
@@ -438,20 +509,32 @@ __global__ __launch_bounds__(256) void gpe_dz3_kernel(float* __restrict__ a3, in
     }
 }
 
+static int dz3_launch(float* a3, int lda3, const float* g, int ldg, const uint8_t* amx, const uint8_t* amn, int ldagg,
+                      const float* coef, int B, int N, int k, int F, float gscale, hipStream_t stream)
+{
+    if (!a3 || !g || !coef || B <= 0 || N <= 0 || k <= 0 || F <= 0 || (lda3 & 3) || lda3 < F) return GPE_EINVAL;
+    if (amx && (!amn || (ldagg & 3) || ldagg < F)) return GPE_EINVAL;
+    const long E = (long)B * N * k;
+    if (E >= (1L << 31)) return GPE_EINVAL;
+    const long npts = (long)B * N;
+    const int blocks = (int)((npts + 3) / 4 < 4096 ? (npts + 3) / 4 : 4096);
+    hipLaunchKernelGGL(gpe_dz3_kernel, dim3(blocks, gpe_cdiv(F, 256)), dim3(256), 0, stream, a3, lda3, g, ldg, amx, amn,
+                       ldagg, coef, npts, k, F, gscale);
+    GPE_CHECK_LAUNCH();
+    return GPE_OK;
+}
+
 extern "C" int gpe_edge_dz3(float* a3, int lda3, const float* g, int ldg, const uint8_t* amx, const uint8_t* amn,
                             int ldagg, const float* coef, int B, int N, int k, int F, void* stream)
 {
-    if (!a3 || !g || !amx || !amn || !coef || B <= 0 || N <= 0 || k <= 0 || F <= 0 || (lda3 & 3) || (ldagg & 3) ||
-        lda3 < F || ldagg < F)
-        return GPE_EINVAL;
-    const long E = (long)B * N * k;
-    if (F > 256 || E >= (1L << 31)) return GPE_EINVAL;
-    const long npts = (long)B * N;
-    const int blocks = (int)((npts + 3) / 4 < 4096 ? (npts + 3) / 4 : 4096);
-    hipLaunchKernelGGL(gpe_dz3_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a3, lda3, g, ldg, amx, amn,
-                       ldagg, coef, npts, k, F);
-    GPE_CHECK_LAUNCH();
-    return GPE_OK;
+    if (!amx || !amn) return GPE_EINVAL;
+    return dz3_launch(a3, lda3, g, ldg, amx, amn, ldagg, coef, B, N, k, F, 1.f, (hipStream_t)stream);
+}
+
+extern "C" int gpe_edge_dz3_all(float* a3, int lda3, const float* g, int ldg, float gscale, const float* coef, int B,
+                                int N, int k, int F, void* stream)
+{
+    return dz3_launch(a3, lda3, g, ldg, nullptr, nullptr, 0, coef, B, N, k, F, gscale, (hipStream_t)stream);
 }
 
 // sums for an inner BN + true weight gradient of the next Linear, from the CENTRED product
@@ -844,24 +927,30 @@ extern "C" int gpe_sparsemax_bwd(const float* out, int ldo, const float* g, int 
 
 // y[r][c] = s[c]*a[r][c] + t[c]   (BatchNorm applied to a stored post-ReLU activation; dense-MLP last layer)
 __global__ void gpe_bn_apply_kernel(const float* __restrict__ a, int lda, const float* __restrict__ stats, long rows,
-                                    int C, float* __restrict__ y, int ldy)
+                                    int C, float a_scale, float t_scale, float* __restrict__ y, int ldy)
 {
     const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= rows * C) return;
     const long r = e / C;
     const int c = (int)(e - r * C);
-    y[r * ldy + c] = stats[2 * C + c] * a[r * lda + c] + stats[3 * C + c];
+    y[r * ldy + c] = stats[2 * C + c] * (a[r * lda + c] * a_scale) + stats[3 * C + c] * t_scale;
+}
+
+extern "C" int gpe_bn_apply_scaled(const float* a, int lda, const float* stats, long rows, int C, float a_scale,
+                                   float t_scale, float* y, int ldy, void* stream)
+{
+    if (!a || !stats || !y || rows < 0 || C <= 0 || lda < C || ldy < C) return GPE_EINVAL;
+    if (rows == 0) return GPE_OK;
+    hipLaunchKernelGGL(gpe_bn_apply_kernel, dim3(gpe_cdiv(rows * C, 256)), dim3(256), 0, (hipStream_t)stream, a, lda,
+                       stats, rows, C, a_scale, t_scale, y, ldy);
+    GPE_CHECK_LAUNCH();
+    return GPE_OK;
 }
 
 extern "C" int gpe_bn_apply(const float* a, int lda, const float* stats, long rows, int C, float* y, int ldy,
                             void* stream)
 {
-    if (!a || !stats || !y || rows < 0 || C <= 0 || lda < C || ldy < C) return GPE_EINVAL;
-    if (rows == 0) return GPE_OK;
-    hipLaunchKernelGGL(gpe_bn_apply_kernel, dim3(gpe_cdiv(rows * C, 256)), dim3(256), 0, (hipStream_t)stream, a, lda,
-                       stats, rows, C, y, ldy);
-    GPE_CHECK_LAUNCH();
-    return GPE_OK;
+    return gpe_bn_apply_scaled(a, lda, stats, rows, C, 1.f, 1.f, y, ldy, stream);
 }
 
 // ---------------------------------------------------------------------------------------------------------

@@ -259,14 +259,18 @@ extern "C" int gpe_edge_mlp_fwd(int a_mode, const float* pq, int ldpq, const int
                                 const float* bias, float* out, int ldo, double* stats_part, int agg, float* mx,
                                 float* mn, uint8_t* amx, uint8_t* amn, int ldagg, void* stream)
 {
-    if (!wp || !out || B <= 0 || N <= 0 || k <= 0 || k > 64 || Cin <= 0 || Cout <= 0 || Cin > RG_KSLAB ||
-        (ldo & 3) || ldo < Cout)
+    if (!wp || !out || B <= 0 || N <= 0 || k <= 0 || k > 64 || Cin <= 0 || Cout <= 0 || (ldo & 3) || ldo < Cout)
         return GPE_EINVAL;
-    if (a_mode == 0 && (!pq || !jg || (ldpq & 3) || (Cin & 3))) return GPE_EINVAL;
+    // the gather producer builds one <= 256-wide K slab; dense rows stream any K in 256-wide slabs
+    if (a_mode == 0 && (!pq || !jg || (ldpq & 3) || (Cin & 3) || Cin > RG_KSLAB)) return GPE_EINVAL;
     if (a_mode == 1 && (!a_in || lda < Cin)) return GPE_EINVAL;
     if (agg && (!mx || !mn || !amx || !amn || ldagg < Cout)) return GPE_EINVAL;
-    const int NT = rg_pick_nt_single(Cout);
+    // one column block up to 256 outputs; wider layers (dense MLPs of the attention / MLP-decoder variants) run as
+    // several 208-column blocks (grid.y), each with its own slice of the statistics / epilogue
+    const int NT = (Cout > 256) ? 13 : rg_pick_nt_single(Cout);
     if (NT < 0) return GPE_EINVAL;
+    const int ny = gpe_cdiv(Cout, 16 * NT);
+    if (ny > 1 && a_mode == 0) return GPE_EINVAL;
     RgParams p = {};
     p.M = (long)B * N * k; p.N = Cout; p.K = Cin;
     p.R = (RG_BM / k) * k; p.num_tiles = gpe_cdiv(p.M, p.R);
@@ -279,7 +283,7 @@ extern "C" int gpe_edge_mlp_fwd(int a_mode, const float* pq, int ldpq, const int
     const int fast = gpe_edgegemm_try(p, a_mode == 0 ? A_GATHER : A_DENSE, E_EDGE_FWD,
                                       stats_part ? GPE_STATS_BLOCKS : 0, (hipStream_t)stream);
     if (fast != 0) return fast == 1 ? GPE_OK : fast;
-    dim3 grid(GPE_STATS_BLOCKS, 1);
+    dim3 grid(GPE_STATS_BLOCKS, ny);
     if (a_mode == 0) return rg_dispatch_nt<A_GATHER, E_EDGE_FWD>(NT, p, grid, (hipStream_t)stream);
     return rg_dispatch_nt<A_DENSE, E_EDGE_FWD>(NT, p, grid, (hipStream_t)stream);
 }
@@ -289,11 +293,12 @@ extern "C" int gpe_edge_mlp_bwd(const float* a, int lda, int act_mode, const flo
                                 const float* coef_out, float* dz_out, int ldo, float* dP, int lddp, void* stream)
 {
     if (!a || !wp || !coef_out || !dz_out || B <= 0 || N <= 0 || k <= 0 || k > 64 || Cin <= 0 || Cout <= 0 ||
-        Cin > RG_KSLAB || (ldo & 3) || ldo < Cout || lda < Cin)
+        (ldo & 3) || ldo < Cout || lda < Cin)
         return GPE_EINVAL;
-    if (act_mode == 1 && (!pq || !jg || !dP || (ldpq & 3) || (Cout & 3))) return GPE_EINVAL;
-    const int NT = rg_pick_nt_single(Cout);
+    if (act_mode == 1 && (!pq || !jg || !dP || (ldpq & 3) || (Cout & 3) || Cout > 256)) return GPE_EINVAL;
+    const int NT = (Cout > 256) ? 13 : rg_pick_nt_single(Cout);       // wide dense layers: several column blocks
     if (NT < 0) return GPE_EINVAL;
+    const int ny = gpe_cdiv(Cout, 16 * NT);
     RgParams p = {};
     p.M = (long)B * N * k; p.N = Cout; p.K = Cin;
     p.R = (RG_BM / k) * k; p.num_tiles = gpe_cdiv(p.M, p.R);
@@ -305,7 +310,7 @@ extern "C" int gpe_edge_mlp_bwd(const float* a, int lda, int act_mode, const flo
     p.dbg = g_gpe_dbg; p.pin_clouds = B;
     const int fast = gpe_edgegemm_try(p, A_DENSE, act_mode == 1 ? E_BWD_GATHER : E_BWD_INPLACE, 0, s);
     if (fast != 0) return fast == 1 ? GPE_OK : fast;
-    dim3 grid(p.num_tiles < 2048 ? p.num_tiles : 2048, 1);
+    dim3 grid(p.num_tiles < 2048 ? p.num_tiles : 2048, ny);
     if (act_mode == 1) return rg_dispatch_nt<A_DENSE, E_BWD_GATHER>(NT, p, grid, s);
     return rg_dispatch_nt<A_DENSE, E_BWD_INPLACE>(NT, p, grid, s);
 }

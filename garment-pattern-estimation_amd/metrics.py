@@ -1,11 +1,19 @@
-"""Loss terms that seed the backward pass (the reference's nn/metrics/composed_loss.py:129-334 and
-nn/metrics/losses.py:8-51), restated batched on the device.
+"""Loss terms that seed the backward pass — the reference's nn/metrics/composed_loss.py:129-334,428-703 and
+nn/metrics/losses.py:8-51 behind the same classes, config keys, call signature and loss-dict keys.
 
-Scope note: the loss is the caller-side step right AFTER the hot path.  The reference's
-PanelLoopLoss walks B*23 panels in a Python loop with a tensor-valued `if` per panel — one host sync per panel
-on a GPU — so here it is a masked batched reduction with identical value and gradient.  It is written with
-torch tensor ops (device glue), not yet as a HIP kernel; the model's own arithmetic never goes through torch.
-Components other than shape / loop / rotation / translation raise."""
+On device tensors (the only thing a model of this package can produce) everything runs in libgpe_hip.so:
+  * shape / loop / rotation / translation terms, value and gradient: ONE forward and ONE backward launch
+    (ops.PatternLossFn) — the reference's PanelLoopLoss walks B*23 panels in a Python loop with a tensor-valued `if` per
+    panel, i.e. one host sync per panel on a GPU;
+  * `panel_origin_invariant_loss` (the default of GarmentFullPattern3D's own loss config): ops.origin_match, one wave per
+    panel instead of a Python loop over panels x edge shifts;
+  * `panel_order_inariant_loss`: ops.order_match, the greedy assignment of composed_loss.py:530-570 as one workgroup per
+    pattern; the random pre-matching permutation (epoch < epoch_with_order_matching) and the gathers stay torch calls.
+CPU tensors (host-logic tests feed hand-made predictions) take a batched torch restatement of the same formulas.
+
+Not built (raise): stitch / free_class / segmentation terms — off the hot path and inactive before
+`epoch_with_stitches`.  Quality components are evaluation-side bookkeeping: `with_quality_eval` is accepted and ignored,
+no quality keys are added to the loss dict."""
 import torch
 import torch.nn as nn
 
@@ -43,6 +51,47 @@ class PanelLoopLoss:
         return sq.sum() / (sq.shape[0] * sq.shape[1])
 
 
+class ComposedLoss:
+    """nn/metrics/composed_loss.py:11-128 (the base used by StitchOnEdge3DPairs): BCE-with-logits on edge pairs.
+    Caller-side torch ops (§8f rank 4 row; the model's MLP is the kernel path)."""
+
+    def __init__(self, data_config, in_config={}):
+        self.config = {'loss_components': [], 'quality_components': []}
+        self.config.update(in_config)
+        self.with_quality_eval = True
+        self.training = False
+        self.l_components = self.config['loss_components']
+        self.q_components = self.config['quality_components']
+        if 'edge_pair_class' in self.l_components:
+            self.bce_logits_loss = nn.BCEWithLogitsLoss()
+
+    def __call__(self, preds, ground_truth, names=None, epoch=1000):
+        self.device = preds.device
+        ground_truth = ground_truth.to(self.device)
+        full_loss, loss_dict = 0., {}
+        if 'edge_pair_class' in self.l_components:
+            pair_loss = self.bce_logits_loss(preds.view(-1), ground_truth.view(-1).float())
+            loss_dict.update(edge_pair_class_loss=pair_loss)
+            full_loss = full_loss + pair_loss
+        if self.with_quality_eval:
+            with torch.no_grad():
+                cls = torch.round(torch.sigmoid(preds))
+                if 'edge_pair_class' in self.q_components:
+                    loss_dict.update(edge_pair_class_acc=(cls == ground_truth).sum().float() / ground_truth.numel())
+                if 'edge_pair_stitch_recall' in self.q_components:
+                    hit = ((cls == 1) & (ground_truth == 1)).sum().float()
+                    n_pred, n_gt = (cls == 1).sum().float(), (ground_truth == 1).sum().float()
+                    loss_dict.update(stitch_precision=hit / n_pred if n_pred else 0,
+                                     stitch_recall=hit / n_gt if n_gt else 0)
+        return full_loss, loss_dict, False
+
+    def eval(self):
+        self.training = False
+
+    def train(self, mode=True):
+        self.training = mode
+
+
 class ComposedPatternLoss:
     """Same constructor / call signature / config keys / loss-dict keys as the reference class."""
 
@@ -69,44 +118,198 @@ class ComposedPatternLoss:
             self.regression_loss = nn.MSELoss()
         if 'loop' in self.l_components:
             self.loop_loss = PanelLoopLoss(self.max_panel_len, data_stats=self.gt_outline_stats)
+        self.last_permutation = None          # [B, P] int64 of the last order matching (diagnostics / tests)
+        self.last_leading_edges = None        # [B*P] int32 of the last origin matching
 
+    # ---- helpers ---------------------------------------------------------------------------------------------
+    def _stitch_terms_active(self, epoch):
+        return epoch >= self.config['epoch_with_stitches'] and any(
+            c in self.l_components for c in ('stitch', 'stitch_supervised', 'free_class'))
+
+    @staticmethod
+    def _feature_permute(feat, perm):
+        """composed_loss.py:572-590: gather along the panel dimension."""
+        ext = perm
+        while ext.dim() < feat.dim():
+            ext = ext.unsqueeze(-1)
+        return torch.gather(feat, 1, ext.expand(feat.shape))
+
+    def _order_features(self, preds, gt):
+        """composed_loss.py:437-488: which features drive the panel-order matching."""
+        by = self.config['order_by']
+        if by == 'placement':
+            if 'translations' not in preds or 'rotations' not in preds:
+                raise ValueError('ComposedPatternLoss::Error::Ordering by placement requested but placement is not predicted')
+            return (torch.cat([preds['translations'], preds['rotations']], dim=-1),
+                    torch.cat([gt['translations'], gt['rotations']], dim=-1))
+        if by == 'translation':
+            if 'translations' not in preds:
+                raise ValueError('ComposedPatternLoss::Error::Ordering by translation requested but translation is not predicted')
+            return preds['translations'], gt['translations']
+        if by == 'shape_translation':
+            if 'translations' not in preds:
+                raise ValueError('ComposedPatternLoss::Error::Ordering by translation requested but translation is not predicted')
+            B, P = preds['outlines'].shape[:2]
+            return (torch.cat([preds['translations'], preds['outlines'].contiguous().view(B, P, -1)], dim=-1),
+                    torch.cat([gt['translations'], gt['outlines'].contiguous().view(B, P, -1)], dim=-1))
+        if by == 'stitches':
+            if self.epoch >= self.config['epoch_with_stitches']:
+                raise NotImplementedError("order_by='stitches' with active stitch terms is outside the built path")
+            return (torch.cat([preds['translations'], preds['rotations']], dim=-1),
+                    torch.cat([gt['translations'], gt['rotations']], dim=-1))
+        raise NotImplementedError(
+            'ComposedPatternLoss::Error::Ordering by requested feature <{}> is not implemented'.format(by))
+
+    def _panel_order_match(self, pred_feat, gt_feat):
+        """composed_loss.py:530-570."""
+        B, P = pred_feat.shape[0], gt_feat.shape[1]
+        if self.epoch < self.config['epoch_with_order_matching']:
+            return torch.stack([torch.randperm(P, dtype=torch.long, device=pred_feat.device) for _ in range(B)])
+        pf = pred_feat.detach().reshape(B, P, -1).float()
+        gf = gt_feat.reshape(B, P, -1).float()
+        if pf.is_cuda:
+            from . import ops
+            perm, fail = ops.order_match(pf, gf)
+            self._order_fail = fail              # device flag; checked lazily (no host sync on the hot path)
+            return perm
+        dist = torch.cdist(pf, gf)
+        perm = torch.full((B, P), -1, dtype=torch.long)
+        for _ in range(P):
+            flat = dist.view(B, -1).argmin(dim=1)
+            rows, cols = flat // P, flat % P
+            for i in range(B):
+                perm[i, rows[i]] = cols[i]
+                dist[i, rows[i], :] = float('inf')
+                dist[i, :, cols[i]] = float('inf')
+        if torch.isfinite(dist).any():
+            raise ValueError('ComposedPatternLoss::Error::Failed to match panel order')
+        return perm
+
+    def check_order_match(self):
+        """Host-side check of the last device order matching (the reference raises inside the loss; here the flag is read
+        only when asked, so the training step stays free of host syncs)."""
+        fail = getattr(self, '_order_fail', None)
+        if fail is not None and int(fail.item()):
+            raise ValueError('ComposedPatternLoss::Error::Failed to match panel order')
+
+    def _gt_order_match(self, preds, gt):
+        """composed_loss.py:428-528 without the stitch re-numbering (stitch terms raise before this point)."""
+        with torch.no_grad():
+            pf, gf = self._order_features(preds, gt)
+            perm = self._panel_order_match(pf, gf)
+            self.last_permutation = perm
+            out = dict(gt)
+            out['outlines'] = self._feature_permute(gt['outlines'], perm)
+            out['num_edges'] = self._feature_permute(gt['num_edges'], perm)
+            if 'empty_panels_mask' in gt:
+                out['empty_panels_mask'] = self._feature_permute(gt['empty_panels_mask'], perm)
+            if 'rotation' in self.l_components:
+                out['rotations'] = self._feature_permute(gt['rotations'], perm)
+            if 'translation' in self.l_components:
+                out['translations'] = self._feature_permute(gt['translations'], perm)
+        return out
+
+    def _rotate_gt(self, preds, gt, gt_num_edges):
+        """composed_loss.py:593-623,656-703 without the stitch shifts."""
+        with torch.no_grad():
+            out = dict(gt)
+            ol, gto = preds['outlines'], gt['outlines']
+            if ol.is_cuda:
+                from . import ops
+                out['outlines'], lead = ops.origin_match(ol, gto.float().contiguous(), gt_num_edges.contiguous())
+                self.last_leading_edges = lead
+            else:
+                B, P, L, D = gto.shape
+                pr, g = ol.detach().reshape(B * P, L, D), gto.reshape(B * P, L, D)
+                n = gt_num_edges.view(-1).long().clamp(0, L)
+                l_idx = torch.arange(L)
+                best = torch.full((B * P,), float('inf'))
+                lead = torch.zeros(B * P, dtype=torch.long)
+                chosen = g.clone()
+                for r in range(L):
+                    src = torch.where(l_idx[None, :] < n[:, None],
+                                      (l_idx[None, :] + r) % n.clamp(min=1)[:, None], l_idx[None, :].expand(B * P, L))
+                    cand = torch.gather(g, 1, src[:, :, None].expand(-1, -1, D))
+                    d = ((pr - cand) ** 2).sum(dim=(1, 2))
+                    ok = (d < best) & ((r < n) | (r == 0))
+                    best = torch.where(ok, d, best)
+                    lead = torch.where(ok, torch.full_like(lead, r), lead)
+                    chosen = torch.where(ok[:, None, None], cand, chosen)
+                out['outlines'] = chosen.view(B, P, L, D)
+                self.last_leading_edges = lead.int()
+        return out
+
+    # ---- main entry ------------------------------------------------------------------------------------------
     def __call__(self, preds, ground_truth, names=None, epoch=1000):
         self.device = preds['outlines'].device
         self.epoch = epoch
-        if self.config['panel_order_inariant_loss'] or self.config['panel_origin_invariant_loss']:
-            raise NotImplementedError(
-                'panel order / origin matching (composed_loss.py:530-703) is a "next" row of the scope table; '
-                'the shipped YAMLs switch both off')
         if 'segmentation' in self.l_components:
             raise NotImplementedError('segmentation loss (entmax.SparsemaxLoss) is outside the built path')
-        if epoch >= self.config['epoch_with_stitches'] and any(
-                c in self.l_components for c in ('stitch', 'stitch_supervised', 'free_class')):
+        if self._stitch_terms_active(epoch):
             raise NotImplementedError('stitch losses (epoch >= epoch_with_stitches) are outside the built path')
         for key in ground_truth:
             ground_truth[key] = ground_truth[key].to(self.device)
-        gt_num_edges = ground_truth['num_edges'].int().view(-1)
-        full_loss, loss_dict = 0., {}
-        if 'shape' in self.l_components:
-            v = self.regression_loss(preds['outlines'], ground_truth['outlines'])
-            full_loss = full_loss + v
-            loss_dict.update(pattern_loss=v)
-        if 'loop' in self.l_components:
-            v = self.loop_loss(preds['outlines'], gt_num_edges)
-            full_loss = full_loss + self.config['loop_loss_weight'] * v
-            loss_dict.update(loop_loss=v)
-        if 'rotation' in self.l_components:
-            v = self.regression_loss(preds['rotations'], ground_truth['rotations'])
-            full_loss = full_loss + v
-            loss_dict.update(rotation_loss=v)
-        if 'translation' in self.l_components:
-            v = self.regression_loss(preds['translations'], ground_truth['translations'])
-            full_loss = full_loss + v
-            loss_dict.update(translation_loss=v)
+        gt = ground_truth
+        if self.config['panel_order_inariant_loss']:
+            gt = self._gt_order_match(preds, gt)
+        gt_num_edges = gt['num_edges'].int().view(-1)
+        if self.config['panel_origin_invariant_loss']:
+            gt = self._rotate_gt(preds, gt, gt_num_edges)
+        full_loss, loss_dict = self._main_losses(preds, gt, gt_num_edges)
         loss_update_ind = (
             epoch == self.config['epoch_with_stitches'] and any(
                 el in self.l_components for el in ['stitch', 'stitch_supervised', 'free_class'])
             or epoch == self.config['epoch_with_order_matching'] and self.config['panel_order_inariant_loss'])
         return full_loss, loss_dict, loss_update_ind
+
+    def _main_losses(self, preds, gt, gt_num_edges):
+        """composed_loss.py:294-321."""
+        comps = self.l_components
+        ol = preds['outlines']
+        if ol.is_cuda and ol.dtype == torch.float32:
+            from . import ops
+            flags = (ops.LOSS_SHAPE if 'shape' in comps else 0) | (ops.LOSS_LOOP if 'loop' in comps else 0) | \
+                    (ops.LOSS_ROT if 'rotation' in comps else 0) | (ops.LOSS_TR if 'translation' in comps else 0)
+            pad0 = pad1 = 0.0
+            if 'loop' in comps:
+                if self.loop_loss.pad_vector is None:
+                    raise ValueError('PanelLoopLoss needs data_stats')
+                pad0, pad1 = float(self.loop_loss.pad_vector[0]), float(self.loop_loss.pad_vector[1])
+            rot = preds['rotations'] if 'rotation' in comps else None
+            tr = preds['translations'] if 'translation' in comps else None
+            out = ops.PatternLossFn.apply(
+                ol, rot, tr, gt['outlines'].float().contiguous(),
+                gt['rotations'].float().contiguous() if rot is not None else None,
+                gt['translations'].float().contiguous() if tr is not None else None,
+                gt_num_edges.contiguous(), flags, pad0, pad1, float(self.config['loop_loss_weight']))
+            loss_dict = {}
+            if 'shape' in comps:
+                loss_dict.update(pattern_loss=out[1])
+            if 'loop' in comps:
+                loss_dict.update(loop_loss=out[2])
+            if 'rotation' in comps:
+                loss_dict.update(rotation_loss=out[3])
+            if 'translation' in comps:
+                loss_dict.update(translation_loss=out[4])
+            return out[0], loss_dict
+        full_loss, loss_dict = 0., {}
+        if 'shape' in comps:
+            v = self.regression_loss(ol, gt['outlines'])
+            full_loss = full_loss + v
+            loss_dict.update(pattern_loss=v)
+        if 'loop' in comps:
+            v = self.loop_loss(ol, gt_num_edges)
+            full_loss = full_loss + self.config['loop_loss_weight'] * v
+            loss_dict.update(loop_loss=v)
+        if 'rotation' in comps:
+            v = self.regression_loss(preds['rotations'], gt['rotations'])
+            full_loss = full_loss + v
+            loss_dict.update(rotation_loss=v)
+        if 'translation' in comps:
+            v = self.regression_loss(preds['translations'], gt['translations'])
+            full_loss = full_loss + v
+            loss_dict.update(translation_loss=v)
+        return full_loss, loss_dict
 
     def eval(self):
         self.training = False

@@ -17,22 +17,30 @@ def MLP(channels, batch_norm=True):
 
 
 class DynamicEdgeConv(nn.Module):
-    """Holder with PyG's attribute name `.nn` (state-dict compatibility); the arithmetic is ops.EdgeConvFn."""
+    """Holder with PyG's attribute name `.nn` (state-dict compatibility); the arithmetic is ops.EdgeConvFn.
+    aggr: 'max' (shipped), 'mean', 'add'; the edge MLP may have any number of blocks >= 2 (EConv_hidden_depth >= 1)."""
 
     def __init__(self, nn_module, k, aggr='max'):
         super().__init__()
-        if aggr != 'max':
-            raise NotImplementedError("EConv_aggr='%s': only 'max' (all shipped configs) has kernels" % aggr)
-        if len(nn_module) != 3:
-            raise NotImplementedError('EConv_hidden_depth must be 2 (edge MLP of 3 blocks), got %d blocks'
+        if aggr not in ('max', 'mean', 'add'):
+            raise ValueError("unsupported aggregation '%s' (PyG MessagePassing accepts max / mean / add here)" % aggr)
+        if len(nn_module) < 2:
+            raise NotImplementedError('EConv_hidden_depth must be >= 1 (edge MLP of at least 2 blocks), got %d block(s)'
                                       % len(nn_module))
         self.nn = nn_module
         self.k = k
         self.aggr = aggr
         self.last_knn = None
 
+    def register_packs(self, plan):
+        blocks = [self.nn[i] for i in range(len(self.nn))]
+        plan.add_edge_first(blocks[0][0].weight, blocks[0][0].bias)
+        for b in blocks[1:]:
+            plan.add_linear(b[0].weight, fwd=False, bwd=True)     # forward packs carry the folded BatchNorm scale
+
     def forward(self, x, n_clouds, n_points):
-        blocks = [self.nn[i] for i in range(3)]
+        nb = len(self.nn)
+        blocks = [self.nn[i] for i in range(nb)]
         lin = [b[0] for b in blocks]
         bn = [b[2] for b in blocks]
         eps, mom = bn[0].eps, bn[0].momentum
@@ -41,7 +49,7 @@ class DynamicEdgeConv(nn.Module):
             args += [l.weight, l.bias, b.weight, b.bias]
         for b in bn:
             args += [b.running_mean, b.running_var, b.num_batches_tracked]
-        out, idx = ops.EdgeConvFn.apply(x, n_clouds, n_points, self.k, self.training, eps, mom, *args)
+        out, idx = ops.EdgeConvFn.apply(x, n_clouds, n_points, self.k, self.training, eps, mom, nb, self.aggr, *args)
         self.last_knn = idx
         return out
 
@@ -72,16 +80,22 @@ class EdgeConvFeatures(nn.Module):
             self.conv_layers.append(DynamicEdgeConv(
                 MLP([2 * feat[c - 1]] + [hid[c]] * mlp_depth + [feat[c]]),
                 k=self.config['k_neighbors'], aggr=self.config['EConv_aggr']))
-        if self.config['global_pool'] == 'mean':
+        if self.config['global_pool'] == 'max':
+            self.global_pool = ops.segment_max
+        elif self.config['global_pool'] == 'mean':
             self.global_pool = ops.segment_mean
-        elif self.config['global_pool'] in ('max', 'add'):
-            raise NotImplementedError("global_pool='%s': only 'mean' (all shipped configs) has kernels"
-                                      % self.config['global_pool'])
+        elif self.config['global_pool'] == 'add':
+            self.global_pool = ops.segment_add
         else:
             raise ValueError('{} pooling is not supported'.format(self.config['global_pool']))
         out_features = self.config['EConv_feature'] + 3 if self.config['skip_connections'] \
             else self.config['EConv_feature']
         self.lin = nn.Linear(out_features, out_size)
+
+    def register_packs(self, plan):
+        for conv in self.conv_layers:
+            conv.register_packs(plan)
+        plan.add_linear(self.lin.weight)
 
     def forward(self, positions, global_pool=True):
         B, N = positions.size(0), positions.size(1)
@@ -191,6 +205,16 @@ class LSTMDecoderModule(nn.Module):
         _init_weights(self.lstm, init_type=custom_init)
         self.last_states = None
 
+    def register_packs(self, plan):
+        H = self.hidden_size
+        for l in range(self.n_layers):
+            w_ih, w_hh = getattr(self.lstm, 'weight_ih_l%d' % l), getattr(self.lstm, 'weight_hh_l%d' % l)
+            plan.add_linear(w_ih)
+            plan.add_gates(w_hh, H)
+            plan.add_linear(w_hh, fwd=False, bwd=True)
+            plan.add_bias_sum(getattr(self.lstm, 'bias_ih_l%d' % l), getattr(self.lstm, 'bias_hh_l%d' % l))
+        plan.add_linear(self.lin.weight)
+
     def forward(self, batch_enc, out_len):
         device = batch_enc.device
         bs = batch_enc.size(0)
@@ -207,6 +231,29 @@ class LSTMDecoderModule(nn.Module):
                                        *params)
 
 
+class MLPDecoder(nn.Module):
+    """nn/net_blocks.py:273-298: latent code -> MLP([enc, hid*out_len x n_layers, out_elem*out_len]) -> [B, out_len, out_elem].
+    The arithmetic is ops.DenseMLPFn (wide layers run as several column blocks of the row GEMM)."""
+
+    def __init__(self, encoding_size, hidden_size, out_elem_size, n_layers, out_len=1, dropout=0,
+                 custom_init='kaiming_normal'):
+        super().__init__()
+        self.out_len = out_len
+        self.mlp = MLP([encoding_size] + [hidden_size * out_len for _ in range(n_layers)] + [out_elem_size * out_len])
+        _init_weights(self.mlp, init_type=custom_init)
+
+    def register_packs(self, plan):
+        blocks = [self.mlp[i] for i in range(len(self.mlp))]
+        plan.add_linear(blocks[0][0].weight)                      # first block: nothing folded in
+        for b in blocks[1:]:
+            plan.add_linear(b[0].weight, fwd=False, bwd=True)
+
+    def forward(self, batch_enc, *args):
+        batch_size = batch_enc.size(0)
+        out = ops.dense_mlp(batch_enc, self.mlp, self.training)
+        return out.contiguous().view(batch_size, self.out_len, -1)
+
+
 def _not_accelerated(name):
     class _Missing(nn.Module):
         def __init__(self, *a, **kw):
@@ -220,7 +267,6 @@ def _not_accelerated(name):
 PointNetPlusPlus = _not_accelerated('PointNetPlusPlus')
 EdgeConvPoolingFeatures = _not_accelerated('EdgeConvPoolingFeatures')
 DynamicASAPool = _not_accelerated('DynamicASAPool')
-MLPDecoder = _not_accelerated('MLPDecoder')
 LSTMEncoderModule = _not_accelerated('LSTMEncoderModule')
 LSTMDoubleReverseDecoderModule = _not_accelerated('LSTMDoubleReverseDecoderModule')
 GRUDecoderModule = _not_accelerated('GRUDecoderModule')

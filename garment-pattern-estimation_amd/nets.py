@@ -6,7 +6,7 @@ import torch.nn as nn
 
 from . import net_blocks as blocks
 from . import ops
-from .metrics import ComposedPatternLoss
+from .metrics import ComposedLoss, ComposedPatternLoss
 
 
 class BaseModule(nn.Module):
@@ -27,6 +27,23 @@ class BaseModule(nn.Module):
         if isinstance(self.loss, object):
             self.loss.train(mode)
         return self
+
+    # ---- weight-derived kernel operands (ops.PackPlan): one refresh launch per optimizer step ----------------
+    def _pack_modules(self):
+        return [m for m in self.children() if hasattr(m, 'register_packs')]
+
+    def _register_own_packs(self, plan):
+        pass
+
+    def refresh_packs(self):
+        plan = self.__dict__.get('_pack_plan')
+        if plan is None:
+            plan = ops.PackPlan()
+            for m in self._pack_modules():
+                m.register_packs(plan)
+            self._register_own_packs(plan)
+            self.__dict__['_pack_plan'] = plan
+        plan.refresh()
 
     def eval(self):
         super().eval()
@@ -112,7 +129,11 @@ class GarmentFullPattern3D(BaseModule):
         flat_panel_encodings = self.forward_pattern_decode(garment_encodings)
         return self.forward_panel_decode(flat_panel_encodings, garment_encodings.size(0))
 
+    def _register_own_packs(self, plan):
+        plan.add_linear(self.placement_decoder.weight)
+
     def forward(self, positions_batch, **kwargs):
+        self.refresh_packs()
         return self.forward_decode(self.forward_encode(positions_batch))
 
 
@@ -158,17 +179,63 @@ class GarmentSegmentPattern3D(GarmentFullPattern3D):
             att_in = torch.cat([glob, point_features_flat], dim=-1)
         logits = ops.dense_mlp(att_in, self.point_segment_mlp[0], self.training)
         points_weights = ops.SparsemaxFn.apply(logits)
-        pooled = ops.AttentionPoolFn.apply(points_weights, point_features_flat, batch_size, num_points)
+        # "same pool as in initial extractor" (nn/nets.py:271-272): mean / max / add over the weighted features
+        pooled = ops.AttentionPoolFn.apply(points_weights, point_features_flat, batch_size, num_points,
+                                           self.feature_extractor.global_pool.pool_mode)
         panel_encodings = ops.linear(pooled, self.panel_dec_lin.weight, self.panel_dec_lin.bias)
         panel_encodings = panel_encodings.view(batch_size, -1, panel_encodings.shape[-1])
         points_weights = points_weights.view(batch_size, -1, points_weights.shape[-1]) \
             if self.save_att_weights else []
         return panel_encodings, points_weights
 
+    def _register_own_packs(self, plan):
+        plan.add_linear(self.placement_decoder.weight)
+        plan.add_linear(self.panel_dec_lin.weight)
+        blocks = [self.point_segment_mlp[0][i] for i in range(len(self.point_segment_mlp[0]))]
+        plan.add_linear(blocks[0][0].weight)
+        for b in blocks[1:]:
+            plan.add_linear(b[0].weight, fwd=False, bwd=True)
+
     def forward(self, positions_batch, **kwargs):
+        self.refresh_packs()
         batch_size = positions_batch.shape[0]
         panel_encodings, att_weights = self.forward_panel_enc_from_3d(positions_batch)
         panels = self.forward_panel_decode(panel_encodings.view(-1, panel_encodings.shape[-1]), batch_size)
         if len(att_weights) > 0:
             panels.update(att_weights=att_weights)
         return panels
+
+
+class StitchOnEdge3DPairs(BaseModule):
+    """nn/nets.py:303-353: binary classifier on pairs of 3D edges — MLP([element_size, 200 x 3, 1]) on every pair row.
+    The reference ships trained weights for it (models/att/neural_tailor_stitch_model.pth)."""
+
+    def __init__(self, data_config, config={}, in_loss_config={}):
+        super().__init__()
+        self.pair_feature_len = data_config['element_size']
+        self.config.update({'stitch_hidden_size': 200, 'stitch_mlp_n_layers': 3})
+        self.config.update(config)
+        self.config['loss'] = {
+            'loss_components': ['edge_pair_class'],
+            'quality_components': ['edge_pair_class', 'edge_pair_stitch_recall'],
+            'panel_origin_invariant_loss': False, 'panel_order_inariant_loss': False}
+        self.config['loss'].update(in_loss_config)
+        self.loss = ComposedLoss(data_config, self.config['loss'])
+        self.config['loss'] = self.loss.config
+        mid_layers = [self.config['stitch_hidden_size']] * self.config['stitch_mlp_n_layers']
+        self.mlp = blocks.MLP([self.pair_feature_len] + mid_layers + [1])
+
+    def _register_own_packs(self, plan):
+        mlp_blocks = [self.mlp[i] for i in range(len(self.mlp))]
+        plan.add_linear(mlp_blocks[0][0].weight)
+        for b in mlp_blocks[1:]:
+            plan.add_linear(b[0].weight, fwd=False, bwd=True)
+
+    def forward(self, pairs_batch, **kwargs):
+        self.refresh_packs()
+        self.device = pairs_batch.device
+        self.batch_size = pairs_batch.size(0)
+        return_shape = list(pairs_batch.shape)
+        return_shape.pop(-1)
+        out = ops.dense_mlp(pairs_batch.contiguous().view(-1, pairs_batch.shape[-1]), self.mlp, self.training)
+        return out.view(return_shape)

@@ -5,7 +5,16 @@ LSTM states — every arithmetic step of the path is a call into libgpe_hip.so. 
 to torch math: a missing library or a failing launch raises.
 
 Reference lines restated by each Function are cited in its docstring (paths relative to /root/reference).
+
+Two per-model services live here as well (both optional; without them every Function behaves like a plain autograd op):
+  * PackPlan  — all weight-derived kernel operands of a model (MFMA-packed / transposed / gate-interleaved weights, the
+                P|Q split of the first edge Linear, b_ih + b_hh) are rebuilt by ONE launch when the weights changed,
+                instead of ~45 small launches per training step;
+  * grad sink — when a model's parameters live in a flat arena (optim.FlatArena), backward kernels write weight gradients
+                straight into the arena's gradient buffer (no per-parameter tensors, no cat/copy for the all-reduce
+                buckets, one fused Adam launch).
 """
+import numpy as np
 import torch
 
 from . import _lib as L
@@ -37,16 +46,186 @@ def round_up(a, b):
 
 
 # -------------------------------------------------------------------------------------------------
+# PackPlan: weight-derived operands refreshed by one launch
+# -------------------------------------------------------------------------------------------------
+WEIGHTS_EPOCH = 0          # bumped by optimizers that update parameters through raw pointers (optim.FusedAdam)
+_PACKS = {}                # (param data_ptr, kind) -> (plan, output tensor)
+
+K_PLAIN, K_TRANS, K_GATES, K_PQ, K_PQT, K_VADD, K_BPQ = 0, 1, 2, 3, 4, 5, 6
+_JOB = np.dtype([('w', '<u8'), ('w2', '<u8'), ('out', '<u8'), ('total', '<i8'), ('first_block', '<i8'),
+                 ('ldw', '<i4'), ('N', '<i4'), ('K', '<i4'), ('kind', '<i4'), ('Npad', '<i4'), ('aux', '<i4')])
+assert _JOB.itemsize == 64
+
+
+def bump_weights_epoch():
+    global WEIGHTS_EPOCH
+    WEIGHTS_EPOCH += 1
+
+
+class PackPlan:
+    """Collects the static pack jobs of a model (net_blocks modules call `add_*` from their `register_packs`) and
+    re-runs them all with gpe_pack_multi whenever a parameter changed since the last run (torch version counters +
+    WEIGHTS_EPOCH).  Outputs are persistent buffers, so backward reads what forward used."""
+
+    def __init__(self):
+        self.specs = []        # (param, param2, kind, N, K, aux)
+        self.outs = []
+        self.table = None
+        self.blocks = 0
+        self.vers = None
+        self.epoch = -1
+        self.home = None
+        self.keys = []
+
+    def _add(self, p, kind, N, K, aux=0, p2=None, out_numel=None):
+        self.specs.append((p, p2, kind, N, K, aux, out_numel))
+
+    def add_linear(self, w, fwd=True, bwd=True):
+        if fwd:
+            self._add(w, K_PLAIN, w.shape[0], w.shape[1])
+        if bwd:
+            self._add(w, K_TRANS, w.shape[1], w.shape[0])
+
+    def add_gates(self, w_hh, H):
+        self._add(w_hh, K_GATES, 4 * H, w_hh.shape[1], aux=H)
+
+    def add_edge_first(self, w1, b1):
+        H, C2 = w1.shape
+        C = C2 // 2
+        self._add(w1, K_PQ, 2 * H, C, aux=H)
+        self._add(w1, K_PQT, C, 2 * H, aux=H)
+        self._add(b1, K_BPQ, 2 * H, 0, aux=H, out_numel=2 * H)
+
+    def add_bias_sum(self, b_ih, b_hh):
+        self._add(b_ih, K_VADD, b_ih.numel(), 0, p2=b_hh, out_numel=b_ih.numel())
+
+    def _versions(self):
+        return [p._version + (p2._version if p2 is not None else 0) for p, p2, *_ in self.specs]
+
+    def _build(self):
+        for k in self.keys:
+            _PACKS.pop(k, None)
+        self.keys, self.outs = [], []
+        dev = self.specs[0][0].device
+        tab = np.zeros(len(self.specs), dtype=_JOB)
+        blk = 0
+        for i, (p, p2, kind, N, K, aux, out_numel) in enumerate(self.specs):
+            if kind in (K_VADD, K_BPQ):
+                total, npad = out_numel, 0
+            elif kind == K_GATES:
+                npad = 64 * ((aux + 15) // 16)
+                total = npad * round_up(K, 16)
+            else:
+                npad = round_up(N, 16)
+                total = npad * round_up(K, 16)
+            out = torch.empty(total, device=dev, dtype=F32)
+            self.outs.append(out)
+            tab[i] = (p.data_ptr(), p2.data_ptr() if p2 is not None else 0, out.data_ptr(), total, blk,
+                      p.stride(0) if p.dim() == 2 else 0, N, K, kind, npad, aux)
+            blk += (total + 255) // 256
+            key = (p.data_ptr(), kind)
+            _PACKS[key] = (self, out, i)
+            self.keys.append(key)
+        self.blocks = blk
+        self.table = torch.from_numpy(tab.view(np.uint8).copy()).to(dev)
+        self.home = (self.specs[0][0].data_ptr(), dev)
+
+    def refresh(self):
+        """Called at the start of a model forward: one gpe_pack_multi launch if any parameter changed since the last."""
+        if not self.specs:
+            return
+        vers = self._versions()
+        first = self.specs[0][0]
+        if self.table is None or self.home != (first.data_ptr(), first.device):
+            self._build()                      # first use, or the parameters moved (.to(device), arena re-homing)
+        elif self.vers == vers and self.epoch == WEIGHTS_EPOCH:
+            return
+        L.call('gpe_pack_multi', self.table, len(self.specs), self.blocks)
+        self.vers, self.epoch = vers, WEIGHTS_EPOCH
+
+
+def _planned(t, kind, t2=None):
+    """The persistent packed operand of parameter `t` if a PackPlan owns one that is still current, else None."""
+    hit = _PACKS.get((t.data_ptr(), kind))
+    if hit is None:
+        return None
+    plan, out, i = hit
+    if plan.vers is None or plan.epoch != WEIGHTS_EPOCH:
+        return None
+    if plan.vers[i] != t._version + (t2._version if t2 is not None else 0):
+        return None
+    return out
+
+
+# -------------------------------------------------------------------------------------------------
+# gradient sink (optim.FlatArena): weight gradients are written straight into the arena
+# -------------------------------------------------------------------------------------------------
+_SINK = {}                 # param data_ptr -> (arena, flat gradient view shaped like the parameter)
+
+
+def _gbuf(param, shape=None):
+    """Output buffer for the gradient of `param`: the arena view if the parameter is registered, else a new tensor."""
+    hit = _SINK.get(param.data_ptr())
+    if hit is not None:
+        return hit[1]
+    return torch.empty(param.shape if shape is None else shape, device=param.device, dtype=F32)
+
+
+def _gret(param, buf):
+    """What backward returns for `param`: None when the gradient already sits in the arena (and the arena is told, so that
+    a gradient bucket can leave for the all-reduce), else the tensor itself."""
+    hit = _SINK.get(param.data_ptr())
+    if hit is None:
+        return buf
+    hit[0].mark_written(param)
+    return None
+
+
+# -------------------------------------------------------------------------------------------------
 # raw wrappers
 # -------------------------------------------------------------------------------------------------
 def pack_weight(w, transpose=False, col_scale=None):
     """w: [N,K] (nn.Linear layout).  transpose=True packs w^T (operand [K_src_cols][K_src_rows])."""
     _dev_check(w)
     assert w.dim() == 2 and w.stride(1) == 1
+    if col_scale is None:
+        hit = _planned(w, K_TRANS if transpose else K_PLAIN)
+        if hit is not None:
+            return hit
     N, K = (w.shape[1], w.shape[0]) if transpose else (w.shape[0], w.shape[1])
     wp = torch.empty(L.query('gpe_packed_size', N, K), device=w.device, dtype=F32)
     L.call('gpe_pack_weight', w, w.stride(0), N, K, int(transpose), col_scale, wp)
     return wp
+
+
+def pack_gates(w_hh, H):
+    hit = _planned(w_hh, K_GATES)
+    if hit is not None:
+        return hit
+    wp = torch.empty(L.query('gpe_packed_gates_size', H, w_hh.shape[1]), device=w_hh.device, dtype=F32)
+    L.call('gpe_pack_weight_gates', w_hh, w_hh.stride(0), H, w_hh.shape[1], wp)
+    return wp
+
+
+def bias_sum(b_ih, b_hh):
+    hit = _planned(b_ih, K_VADD, b_hh)
+    if hit is not None:
+        return hit
+    out = torch.empty_like(b_ih)
+    L.call('gpe_add', b_ih, b_hh, out, b_ih.numel())
+    return out
+
+
+def edge_first_operands(W1, b1):
+    """-> (packed [W1a-W1b ; W1b], its packed transpose, bias [b1 | 0]) for the per-point P|Q projection."""
+    H, C = W1.shape[0], W1.shape[1] // 2
+    a, b, c = _planned(W1, K_PQ), _planned(W1, K_PQT), _planned(b1, K_BPQ)
+    if a is not None and b is not None and c is not None:
+        return a, b, c
+    wpq = torch.empty(2 * H, C, device=W1.device, dtype=F32)
+    bpq = torch.empty(2 * H, device=W1.device, dtype=F32)
+    L.call('gpe_w1_split', W1, W1.stride(0), b1, H, C, wpq, C, bpq)
+    return pack_weight(wpq), pack_weight(wpq, transpose=True), bpq
 
 
 def fold_bias(w, bias, t):
@@ -61,11 +240,13 @@ def linear_raw(a_desc, wp, bias, M, N, K, y_desc, act=0, addend_desc=None):
            ad[0], ad[1], ad[2], ad[3], y_desc[0], y_desc[1], y_desc[2], y_desc[3], M, N, K, act)
 
 
-def redgemm_raw(u_desc, v_desc, rows, Mg, Ng, want_colsum=True, accumulate_into=None):
-    """G[Mg,Ng] = sum_r U[r,:]^T V[r,:], colsum[Mg] = sum_r U[r,:]."""
+def redgemm_raw(u_desc, v_desc, rows, Mg, Ng, want_colsum=True, accumulate_into=None, v_shift=None, out=None):
+    """G[Mg,Ng] = sum_r U[r,:]^T (V[r,:] - v_shift), colsum[Mg] = sum_r U[r,:].  `out` = (G, colsum) buffers to fill."""
     dev = u_desc[0].device
     if accumulate_into is not None:
         G, cs = accumulate_into
+    elif out is not None:
+        G, cs = out
     else:
         G = torch.empty(Mg, Ng, device=dev, dtype=F32)
         cs = torch.empty(Mg, device=dev, dtype=F32) if want_colsum else None
@@ -74,7 +255,7 @@ def redgemm_raw(u_desc, v_desc, rows, Mg, Ng, want_colsum=True, accumulate_into=
         nb = min(256, Ng - n0)
         ws = torch.empty(L.query('gpe_redgemm_ws', Mg, nb), device=dev, dtype=F32)
         L.call('gpe_redgemm', u_desc[0], u_desc[1], u_desc[2], u_desc[3],
-               v_desc[0][..., n0:], v_desc[1], v_desc[2], v_desc[3], None,
+               v_desc[0][..., n0:], v_desc[1], v_desc[2], v_desc[3], None if v_shift is None else v_shift[n0:],
                rows, Mg, nb, G[:, n0:], G.stride(0), cs if n0 == 0 else None, ws, acc)
     return G, cs
 
@@ -112,12 +293,16 @@ def bn_from_running(rm, rv, gamma, beta, eps):
     return stats
 
 
-def bn_bwd_coef(part, nblk, stats, C, count, want_param_grads=True):
+def bn_bwd_coef(part, nblk, stats, C, count, gamma=None, beta=None, training=True):
+    """-> coef [4][C] = {s, c1, k2, mean}, dgamma, dbeta (written into the parameters' gradient buffers).  In eval mode the
+    statistics are constants, so the projection terms c1 / k2 vanish (dz = s * dy under the ReLU mask)."""
     dev = stats.device
     coef = torch.empty(4, C, device=dev, dtype=F32)
-    dg = torch.empty(C, device=dev, dtype=F32) if want_param_grads else None
-    db = torch.empty(C, device=dev, dtype=F32) if want_param_grads else None
+    dg = _gbuf(gamma) if gamma is not None else torch.empty(C, device=dev, dtype=F32)
+    db = _gbuf(beta) if beta is not None else torch.empty(C, device=dev, dtype=F32)
     L.call('gpe_bn_bwd_coef', part, nblk, stats, C, float(count), coef, dg, db)
+    if not training:
+        coef[1:3].zero_()
     return coef, dg, db
 
 
@@ -135,13 +320,12 @@ class LinearFn(torch.autograd.Function):
         N = weight.shape[0]
         y = torch.empty(M, N, device=x.device, dtype=F32)
         linear_raw(_rows2d(x), pack_weight(weight), bias, M, N, K, _rows2d(y))
-        ctx.save_for_backward(x, weight)
-        ctx.has_bias = bias is not None
+        ctx.save_for_backward(x, weight, bias)
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        x, weight = ctx.saved_tensors
+        x, weight, bias = ctx.saved_tensors
         gy = gy.contiguous()
         M, K = x.shape
         N = weight.shape[0]
@@ -149,10 +333,12 @@ class LinearFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             gx = torch.empty(M, K, device=x.device, dtype=F32)
             linear_raw(_rows2d(gy), pack_weight(weight, transpose=True), None, M, K, N, _rows2d(gx))
-        if ctx.needs_input_grad[1] or ctx.has_bias:
-            gw, gb = redgemm_raw(_rows2d(gy), _rows2d(x), M, N, K, want_colsum=True)
-            if not ctx.has_bias:
-                gb = None
+        if ctx.needs_input_grad[1] or bias is not None:
+            gw = _gbuf(weight)
+            gb = _gbuf(bias) if bias is not None else torch.empty(N, device=x.device, dtype=F32)
+            redgemm_raw(_rows2d(gy), _rows2d(x), M, N, K, out=(gw, gb))
+            gw = _gret(weight, gw)
+            gb = _gret(bias, gb) if bias is not None else None
         return gx, gw, gb
 
 
@@ -161,8 +347,11 @@ def linear(x, weight, bias=None):
 
 
 # -------------------------------------------------------------------------------------------------
-# global mean pool
+# global pooling
 # -------------------------------------------------------------------------------------------------
+POOL_MODES = {'mean': 0, 'max': 1, 'add': 2}
+
+
 class SegmentMeanFn(torch.autograd.Function):
     """torch_geometric.nn.global_mean_pool over equal-sized clouds (nn/net_blocks.py:148,184; nn/nets.py:272)."""
 
@@ -184,137 +373,235 @@ class SegmentMeanFn(torch.autograd.Function):
         return gx, None, None
 
 
+class SegmentPoolFn(torch.autograd.Function):
+    """torch_geometric.nn.global_max_pool / global_add_pool over equal-sized clouds (nn/net_blocks.py:145-150)."""
+
+    @staticmethod
+    def forward(ctx, x, B, N, mode):
+        _dev_check(x)
+        C = x.shape[1]
+        y = torch.empty(B, C, device=x.device, dtype=F32)
+        arg = torch.empty(B, C, device=x.device, dtype=torch.int32) if mode == 1 else None
+        L.call('gpe_segment_pool_fwd', x, x.stride(0), B, N, C, mode, y, C, arg)
+        ctx.dims = (B, N, C, mode)
+        ctx.arg = arg
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        B, N, C, mode = ctx.dims
+        gy = gy.contiguous()
+        gx = torch.empty(B * N, C, device=gy.device, dtype=F32)
+        L.call('gpe_segment_pool_bwd', gy, C, ctx.arg, B, N, C, mode, gx, C)
+        return gx, None, None, None
+
+
 def segment_mean(x, B, N):
     return SegmentMeanFn.apply(x, B, N)
+
+
+def segment_max(x, B, N):
+    return SegmentPoolFn.apply(x, B, N, 1)
+
+
+def segment_add(x, B, N):
+    return SegmentPoolFn.apply(x, B, N, 2)
+
+
+segment_mean.pool_mode, segment_max.pool_mode, segment_add.pool_mode = 0, 1, 2
 
 
 # -------------------------------------------------------------------------------------------------
 # EdgeConv layer
 # -------------------------------------------------------------------------------------------------
 class EdgeConvFn(torch.autograd.Function):
-    """One DynamicEdgeConv(MLP([2C, H, H, F]), k, aggr='max') layer (nn/net_blocks.py:43-47,124-135,174):
-    kNN graph on the input features -> per-edge [Linear->ReLU->BatchNorm]x3 -> max over the k messages.
+    """One DynamicEdgeConv(MLP([2C, H, .., H, F]), k, aggr) layer (nn/net_blocks.py:43-47,124-135,174):
+    kNN graph on the input features -> per-edge [Linear->ReLU->BatchNorm] x nb -> max / mean / add over the k messages.
 
-    Pipeline (training): kNN | split W1 -> per-point P,Q GEMM | gather+stats(a1) | fold BN1->W2, fused
-    gather+GEMM+ReLU(+stats) | fold BN2->W3, fused GEMM+ReLU(+stats)+max/min | BN3 after the max.
-    Saved for backward: idx, PQ, a2 [E,H], a3 [E,F], max/min + arg slots, the three BN stat blocks."""
+    Pipeline (training): kNN | per-point P,Q GEMM (block 0 split: W1.[x_i, x_j-x_i] = P_i + Q_j) | gather+stats(a_0) |
+    for every further block: fold the previous BatchNorm into this Linear, fused (gather|dense)+GEMM+ReLU(+stats)
+    (+max/min over the point's messages in the last block) | last BatchNorm applied AFTER the aggregation.
+    Saved for backward: the graph, PQ, the post-ReLU activations a_1..a_{nb-1} [E, .], the aggregates, the BN stat blocks.
+    nb = EConv_hidden_depth + 1 >= 2; the shipped configs use nb = 3, aggr = 'max'."""
 
     @staticmethod
-    def forward(ctx, x, B, N, k, training, eps, momentum,
-                W1, b1, g1, be1, W2, b2, g2, be2, W3, b3, g3, be3,
-                rm1, rv1, nb1, rm2, rv2, nb2, rm3, rv3, nb3):
+    def forward(ctx, x, B, N, k, training, eps, momentum, nb, aggr, *tensors):
         _dev_check(x)
         dev = x.device
         BN, C = x.shape
         assert BN == B * N
-        H, Fo = W1.shape[0], W3.shape[0]
-        assert W1.shape[1] == 2 * C and W2.shape == (H, H) and W3.shape[1] == H
-        if H % 4:
-            raise ValueError('EConv_hidden must be a multiple of 4 (got %d)' % H)
+        params, bufs = tensors[:4 * nb], tensors[4 * nb:]
+        Ws = [params[4 * l] for l in range(nb)]
+        widths = [w.shape[0] for w in Ws]
+        H0 = widths[0]
+        assert Ws[0].shape[1] == 2 * C
+        if H0 % 4 or H0 > 256:
+            raise ValueError('EConv_hidden must be a multiple of 4 and <= 256 (got %d)' % H0)
         E = BN * k
-        ldF = round_up(Fo, 4)
         nblk = L.query('gpe_stats_blocks')
-
         idx, jg = knn(x, B, N, k, want_global=True)
-        # per-point projection: [P|Q] = x [W1a-W1b | W1b]^T + [b1|0]
-        wpq = torch.empty(2 * H, C, device=dev, dtype=F32)
-        bpq = torch.empty(2 * H, device=dev, dtype=F32)
-        L.call('gpe_w1_split', W1, W1.stride(0), b1, H, C, wpq, C, bpq)
-        PQ = torch.empty(BN, 2 * H, device=dev, dtype=F32)
-        linear_raw(_rows2d(x), pack_weight(wpq), bpq, BN, 2 * H, C, _rows2d(PQ))
+        wpq_p, _, bpq = edge_first_operands(Ws[0], params[1])
+        PQ = torch.empty(BN, 2 * H0, device=dev, dtype=F32)
+        linear_raw(_rows2d(x), wpq_p, bpq, BN, 2 * H0, C, _rows2d(PQ))
 
-        def stats_of(part, Cc, g, be, rm, rv, nb):
+        def stats_of(part, l):
+            g, be = params[4 * l + 2], params[4 * l + 3]
+            rm, rv, nbt = bufs[3 * l: 3 * l + 3]
             if training:
-                return bn_finalize(part, nblk, Cc, E, g, be, eps, momentum, rm, rv, nb)
+                return bn_finalize(part, nblk, widths[l], E, g, be, eps, momentum, rm, rv, nbt)
             return bn_from_running(rm, rv, g, be, eps)
 
-        part = torch.empty(nblk, 2, H, device=dev, dtype=torch.float64) if training else None
+        part = torch.empty(nblk, 2, H0, device=dev, dtype=torch.float64) if training else None
         if training:
-            L.call('gpe_edge_gather_stats', PQ, 2 * H, H, jg, B, N, k, part)
-        st1 = stats_of(part, H, g1, be1, rm1, rv1, nb1)
-
-        a2 = torch.empty(E, H, device=dev, dtype=F32)
-        L.call('gpe_edge_mlp_fwd', 0, PQ, 2 * H, jg, None, 0, B, N, k, H, H,
-               pack_weight(W2, col_scale=st1[2]), fold_bias(W2, b2, st1[3]), a2, H, part,
-               0, None, None, None, None, 0)
-        st2 = stats_of(part, H, g2, be2, rm2, rv2, nb2)
-
-        a3 = torch.empty(E, ldF, device=dev, dtype=F32)
-        mx = torch.empty(BN, ldF, device=dev, dtype=F32)
-        mn = torch.empty(BN, ldF, device=dev, dtype=F32)
-        amx = torch.empty(BN, ldF, device=dev, dtype=torch.uint8)
-        amn = torch.empty(BN, ldF, device=dev, dtype=torch.uint8)
-        part3 = torch.empty(nblk, 2, Fo, device=dev, dtype=torch.float64) if training else None
-        L.call('gpe_edge_mlp_fwd', 1, None, 0, None, a2, H, B, N, k, H, Fo,
-               pack_weight(W3, col_scale=st2[2]), fold_bias(W3, b3, st2[3]), a3, ldF, part3,
-               1, mx, mn, amx, amn, ldF)
-        st3 = stats_of(part3, Fo, g3, be3, rm3, rv3, nb3)
-
+            L.call('gpe_edge_gather_stats', PQ, 2 * H0, H0, jg, B, N, k, part)
+        stats = [stats_of(part, 0)]
+        acts = [None]
+        mx = mn = amx = amn = abar = None
+        for l in range(1, nb):
+            Cin, Cout = widths[l - 1], widths[l]
+            ldo = round_up(Cout, 4)
+            last = l == nb - 1
+            a = torch.empty(E, ldo, device=dev, dtype=F32)
+            part = torch.empty(nblk, 2, Cout, device=dev, dtype=torch.float64) if training else None
+            agg = int(last and aggr == 'max')
+            if agg:
+                mx = torch.empty(BN, ldo, device=dev, dtype=F32)
+                mn = torch.empty(BN, ldo, device=dev, dtype=F32)
+                amx = torch.empty(BN, ldo, device=dev, dtype=torch.uint8)
+                amn = torch.empty(BN, ldo, device=dev, dtype=torch.uint8)
+            wp = pack_weight(Ws[l], col_scale=stats[l - 1][2])
+            bf = fold_bias(Ws[l], params[4 * l + 1], stats[l - 1][3])
+            if l == 1:
+                L.call('gpe_edge_mlp_fwd', 0, PQ, 2 * H0, jg, None, 0, B, N, k, Cin, Cout, wp, bf, a, ldo, part,
+                       agg, mx, mn, amx, amn, ldo)
+            else:
+                prev = acts[l - 1]
+                L.call('gpe_edge_mlp_fwd', 1, None, 0, None, prev, prev.stride(0), B, N, k, Cin, Cout, wp, bf, a, ldo,
+                       part, agg, mx, mn, amx, amn, ldo)
+            acts.append(a)
+            stats.append(stats_of(part, l))
+        Fo = widths[-1]
+        ldF = round_up(Fo, 4)
         out = torch.empty(BN, ldF, device=dev, dtype=F32)[:, :Fo]
-        L.call('gpe_edge_finish', mx, mn, ldF, st3, BN, Fo, out, ldF)
-
-        ctx.dims = (B, N, k, C, H, Fo, ldF)
-        ctx.save_for_backward(x, idx, jg, PQ, a2, a3, mx, mn, amx, amn, st1, st2, st3, W1, W2, W3, wpq)
+        if aggr == 'max':
+            L.call('gpe_edge_finish', mx, mn, ldF, stats[-1], BN, Fo, out, ldF)
+        else:
+            # mean / add: BatchNorm is affine, so it commutes with the sum over the k messages
+            abar = torch.empty(BN, ldF, device=dev, dtype=F32)
+            L.call('gpe_edge_sum_k', acts[-1], ldF, BN, k, Fo, abar, ldF)
+            L.call('gpe_scale', abar, 1.0 / k, abar, abar.numel())
+            a_s, t_s = (1.0, 1.0) if aggr == 'mean' else (float(k), float(k))
+            L.call('gpe_bn_apply_scaled', abar, ldF, stats[-1], BN, Fo, a_s, t_s, out, ldF)
+        ctx.dims = (B, N, k, C, nb, aggr, training)
+        ctx.widths = widths
+        ctx.done = False
+        ctx.save_for_backward(x, idx, jg, PQ, *params, *acts[1:], *stats,
+                              *([mx, mn, amx, amn] if aggr == 'max' else [abar]))
         ctx.mark_non_differentiable(idx)
         return out, idx
 
     @staticmethod
     def backward(ctx, g_out, _g_idx):
-        (x, idx, jg, PQ, a2, a3, mx, mn, amx, amn, st1, st2, st3, W1, W2, W3, wpq) = ctx.saved_tensors
-        B, N, k, C, H, Fo, ldF = ctx.dims
+        if ctx.done:
+            raise RuntimeError('EdgeConvFn.backward ran twice on the same graph: the stored activations are overwritten '
+                               'in place by the first pass (retain_graph is not supported)')
+        ctx.done = True
+        B, N, k, C, nb, aggr, training = ctx.dims
+        widths = ctx.widths
+        sv = ctx.saved_tensors
+        x, idx, jg, PQ = sv[:4]
+        params = sv[4: 4 + 4 * nb]
+        acts = [None] + list(sv[4 + 4 * nb: 4 + 4 * nb + (nb - 1)])
+        stats = list(sv[4 + 5 * nb - 1: 4 + 6 * nb - 1])
+        tail = sv[4 + 6 * nb - 1:]
+        Ws = [params[4 * l] for l in range(nb)]
         dev = x.device
         BN, E = B * N, B * N * k
+        H0, Fo = widths[0], widths[-1]
+        ldF = round_up(Fo, 4)
         if g_out.stride(1) != 1:
             g_out = g_out.contiguous()
         ldg = g_out.stride(0)
+        grads = [None] * (4 * nb)
 
-        # ---- block 3: BN3 applied after the max -------------------------------------------------------
+        # ---- last block: BatchNorm applied after the aggregation -----------------------------------------
         psb = L.query('gpe_point_sums_blocks')
         part = torch.empty(psb, 2, Fo, device=dev, dtype=torch.float64)
-        L.call('gpe_edge_bwd_point_sums', g_out, ldg, mx, mn, ldF, st3, BN, Fo, part)
-        coef3, dg3, dbe3 = bn_bwd_coef(part, psb, st3, Fo, E)
-        # dz3 in place over a3 (one coalesced pass), then everything downstream reads dense rows
-        L.call('gpe_edge_dz3', a3, ldF, g_out, ldg, amx, amn, ldF, coef3, B, N, k, Fo)
-        G3 = torch.empty(Fo, H, device=dev, dtype=F32)
-        db3 = torch.empty(Fo, device=dev, dtype=F32)
-        ws = torch.empty(max(L.query('gpe_redgemm_ws', Fo, H), L.query('gpe_redgemm_ws', H, H)), device=dev,
+        g_last, be_last = params[4 * (nb - 1) + 2], params[4 * (nb - 1) + 3]
+        a_last = acts[-1]
+        if aggr == 'max':
+            mx, mn, amx, amn = tail
+            L.call('gpe_edge_bwd_point_sums', g_out, ldg, mx, mn, ldF, stats[-1], BN, Fo, part)
+            coef, dg, dbe = bn_bwd_coef(part, psb, stats[-1], Fo, E, g_last, be_last, training)
+            # dz in place over the stored activation (one coalesced pass)
+            L.call('gpe_edge_dz3', a_last, ldF, g_out, ldg, amx, amn, ldF, coef, B, N, k, Fo)
+        else:
+            # every message carries dy_e = w * g_i (w = 1/k mean, 1 add): sums over edges = (w*k) * per-point sums at
+            # the mean activation of the point
+            abar, = tail
+            gs = g_out
+            if aggr == 'add':
+                gs = torch.empty(BN, Fo, device=dev, dtype=F32)
+                L.call('gpe_scale', g_out.contiguous(), float(k), gs, gs.numel())
+            L.call('gpe_edge_bwd_point_sums', gs, gs.stride(0), abar, abar, ldF, stats[-1], BN, Fo, part)
+            coef, dg, dbe = bn_bwd_coef(part, psb, stats[-1], Fo, E, g_last, be_last, training)
+            L.call('gpe_edge_dz3_all', a_last, ldF, g_out, ldg, 1.0 / k if aggr == 'mean' else 1.0, coef, B, N, k, Fo)
+        grads[4 * (nb - 1) + 2], grads[4 * (nb - 1) + 3] = _gret(g_last, dg), _gret(be_last, dbe)
+
+        # ---- blocks nb-1 .. 1: weight gradient (centred reduce-GEMM) -> previous BN coefficients -> propagate ----
+        ws = torch.empty(max(L.query('gpe_redgemm_ws', widths[l], widths[l - 1]) for l in range(1, nb)), device=dev,
                          dtype=F32)
-        L.call('gpe_edge_redgemm', a3, ldF, 1, a2, H, None, 0, None, st2[0], B, N, k, Fo, H, G3, H, db3, ws)
-        sums = torch.empty(1, 2, H, device=dev, dtype=torch.float64)
-        dW3 = torch.empty(Fo, H, device=dev, dtype=F32)
-        L.call('gpe_bn_bwd_from_G', G3, H, db3, W3, W3.stride(0), Fo, H, st2, sums, dW3, H)
-        coef2, dg2, dbe2 = bn_bwd_coef(sums, 1, st2, H, E)
-        # dz2 = (a2>0) ? s2*(dz3 W3) - k1 - a2*k2 : 0, in place over a2
-        L.call('gpe_edge_mlp_bwd', a3, ldF, 0, None, 0, None, B, N, k, Fo, H,
-               pack_weight(W3, transpose=True), coef2, a2, H, None, 0)
+        dPQ = torch.empty(BN, 2 * H0, device=dev, dtype=F32)
+        dz = a_last
+        for l in range(nb - 1, 0, -1):
+            Cl, Cp = widths[l], widths[l - 1]
+            W, b = Ws[l], params[4 * l + 1]
+            G = torch.empty(Cl, Cp, device=dev, dtype=F32)
+            db = _gbuf(b)
+            if l == 1:
+                L.call('gpe_edge_redgemm', dz, dz.stride(0), 0, None, 0, PQ, 2 * H0, jg, stats[0][0], B, N, k, Cl, Cp, G,
+                       Cp, db, ws)
+            else:
+                prev = acts[l - 1]
+                L.call('gpe_edge_redgemm', dz, dz.stride(0), 1, prev, prev.stride(0), None, 0, None, stats[l - 1][0],
+                       B, N, k, Cl, Cp, G, Cp, db, ws)
+            sums = torch.empty(1, 2, Cp, device=dev, dtype=torch.float64)
+            dW = _gbuf(W)
+            L.call('gpe_bn_bwd_from_G', G, Cp, db, W, W.stride(0), Cl, Cp, stats[l - 1], sums, dW, Cp)
+            gp, bp = params[4 * (l - 1) + 2], params[4 * (l - 1) + 3]
+            coef_p, dgp, dbp = bn_bwd_coef(sums, 1, stats[l - 1], Cp, E, gp, bp, training)
+            grads[4 * l], grads[4 * l + 1] = _gret(W, dW), _gret(b, db)
+            grads[4 * (l - 1) + 2], grads[4 * (l - 1) + 3] = _gret(gp, dgp), _gret(bp, dbp)
+            wt = pack_weight(W, transpose=True)
+            if l == 1:
+                # dz_0 = (a_0>0) ? s_0*(dz_1 W_1) - c1 - (a_0-mean)*k2 : 0 with a_0 re-gathered; dP = sum over slots.
+                # In place over dz_1's buffer when the row pitch fits, else a fresh [E, H0]
+                dst = dz if dz.stride(0) == H0 else torch.empty(E, H0, device=dev, dtype=F32)
+                L.call('gpe_edge_mlp_bwd', dz, dz.stride(0), 1, PQ, 2 * H0, jg, B, N, k, Cl, Cp, wt, coef_p, dst, H0,
+                       dPQ, 2 * H0)
+                dz = dst
+            else:
+                prev = acts[l - 1]
+                L.call('gpe_edge_mlp_bwd', dz, dz.stride(0), 0, None, 0, None, B, N, k, Cl, Cp, wt, coef_p, prev,
+                       prev.stride(0), None, 0)
+                dz = prev
 
-        # ---- block 2 -----------------------------------------------------------------------------------
-        G2 = torch.empty(H, H, device=dev, dtype=F32)
-        db2 = torch.empty(H, device=dev, dtype=F32)
-        L.call('gpe_edge_redgemm', a2, H, 0, None, 0, PQ, 2 * H, jg, st1[0], B, N, k, H, H, G2, H, db2, ws)
-        sums1 = torch.empty(1, 2, H, device=dev, dtype=torch.float64)
-        dW2 = torch.empty(H, H, device=dev, dtype=F32)
-        L.call('gpe_bn_bwd_from_G', G2, H, db2, W2, W2.stride(0), H, H, st1, sums1, dW2, H)
-        coef1, dg1, dbe1 = bn_bwd_coef(sums1, 1, st1, H, E)
-        # dz1 = (a1>0) ? s1*(dz2 W2) - k1 - a1*k2 : 0 (a1 re-gathered), in place over a2; dP = sum over slots
-        dPQ = torch.empty(BN, 2 * H, device=dev, dtype=F32)
-        L.call('gpe_edge_mlp_bwd', a2, H, 1, PQ, 2 * H, jg, B, N, k, H, H,
-               pack_weight(W2, transpose=True), coef1, a2, H, dPQ, 2 * H)
-
-        # ---- block 1: gather backward = deterministic pull through the transposed graph -----------------
+        # ---- block 0: gather backward = deterministic pull through the transposed graph -----------------
         rev_off, rev_edge = knn_reverse(idx)
-        L.call('gpe_edge_pull_dq', a2, H, rev_off, rev_edge, B, N, k, H, dPQ[:, H:], 2 * H)
-        dWpq, dbpq = redgemm_raw(_rows2d(dPQ), _rows2d(x), BN, 2 * H, C, want_colsum=True)
-        dW1 = torch.empty(H, 2 * C, device=dev, dtype=F32)
-        L.call('gpe_w1_grad_from_pq', dWpq, C, H, C, dW1, 2 * C)
-        db1 = dbpq[:H].clone()
+        L.call('gpe_edge_pull_dq', dz, dz.stride(0), rev_off, rev_edge, B, N, k, H0, dPQ[:, H0:], 2 * H0)
+        dWpq, dbpq = redgemm_raw(_rows2d(dPQ), _rows2d(x), BN, 2 * H0, C, want_colsum=True)
+        W1, b1 = Ws[0], params[1]
+        dW1 = _gbuf(W1)
+        L.call('gpe_w1_grad_from_pq', dWpq, C, H0, C, dW1, 2 * C)
+        db1 = _gbuf(b1)
+        db1.copy_(dbpq[:H0])
+        grads[0], grads[1] = _gret(W1, dW1), _gret(b1, db1)
         gx = None
         if ctx.needs_input_grad[0]:
+            _, wpq_t, _ = edge_first_operands(W1, b1)
             gx = torch.empty(BN, C, device=dev, dtype=F32)
-            linear_raw(_rows2d(dPQ), pack_weight(wpq, transpose=True), None, BN, C, 2 * H, _rows2d(gx))
-        return (gx, None, None, None, None, None, None,
-                dW1, db1, dg1, dbe1, dW2, db2, dg2, dbe2, dW3, db3, dg3, dbe3,
-                None, None, None, None, None, None, None, None, None)
+            linear_raw(_rows2d(dPQ), wpq_t, None, BN, C, 2 * H0, _rows2d(gx))
+        return (gx, None, None, None, None, None, None, None, None, *grads, *([None] * (3 * nb)))
 
 
 # -------------------------------------------------------------------------------------------------
@@ -333,12 +620,10 @@ class LSTMDecoderFn(torch.autograd.Function):
         Bn, In = enc.shape
         Hh = h0.shape[2]
         saved_layers = []
-        x_desc, x_is_enc = None, True
         prev_hs = None
         for l in range(n_layers):
             w_ih, w_hh, b_ih, b_hh = lstm_params[4 * l: 4 * l + 4]
-            bias = torch.empty(4 * Hh, device=dev, dtype=F32)
-            L.call('gpe_add', b_ih, b_hh, bias, 4 * Hh)
+            bias = bias_sum(b_ih, b_hh)
             # row pitch padded to 16 B (zero pad) so the recurrence's A operand is staged with plain aligned loads
             Hp = round_up(Hh, 4)
             hs = torch.zeros(Bn, T + 1, Hp, device=dev, dtype=F32)[:, :, :Hh]
@@ -353,8 +638,7 @@ class LSTMDecoderFn(torch.autograd.Function):
                 xproj = torch.empty(Bn, T, 4 * Hh, device=dev, dtype=F32)
                 linear_raw(_rows3d(prev_hs[:, 1:]), pack_weight(w_ih), bias, Bn * T, 4 * Hh, Hh,
                            (xproj, 4 * Hh, 0, 0))
-            whh_p = torch.empty(L.query('gpe_packed_gates_size', Hh, Hh), device=dev, dtype=F32)
-            L.call('gpe_pack_weight_gates', w_hh, w_hh.stride(0), Hh, Hh, whh_p)
+            whh_p = pack_gates(w_hh, Hh)
             for t in range(T):
                 xp, xps = (xproj, 4 * Hh) if l == 0 else (xproj[:, t], T * 4 * Hh)
                 # gates = h_{t-1} W_hh^T + xproj_t, cell update, h_t / c_t / activated gates: one launch
@@ -366,27 +650,28 @@ class LSTMDecoderFn(torch.autograd.Function):
         out = torch.empty(Bn, T, out_sz, device=dev, dtype=F32)
         linear_raw(_rows3d(prev_hs[:, 1:]), pack_weight(lin_w), lin_b, Bn * T, out_sz, Hh, (out, out_sz, 0, 0))
         ctx.dims = (Bn, In, Hh, T, n_layers, out_sz)
-        ctx.save_for_backward(enc, lin_w, *lstm_params, *saved_layers)
+        ctx.save_for_backward(enc, lin_w, lin_b, *lstm_params, *saved_layers)
         return out
 
     @staticmethod
     def backward(ctx, g_out):
         Bn, In, Hh, T, n_layers, out_sz = ctx.dims
         sv = ctx.saved_tensors
-        enc, lin_w = sv[0], sv[1]
-        lstm_params = sv[2: 2 + 4 * n_layers]
-        saved_layers = sv[2 + 4 * n_layers:]
+        enc, lin_w, lin_b = sv[0], sv[1], sv[2]
+        lstm_params = sv[3: 3 + 4 * n_layers]
+        saved_layers = sv[3 + 4 * n_layers:]
         dev = enc.device
         g_out = g_out.contiguous()
         top_hs = saved_layers[3 * (n_layers - 1)]
-        d_lin_w, d_lin_b = redgemm_raw((g_out, out_sz, 0, 0), _rows3d(top_hs[:, 1:]), Bn * T, out_sz, Hh)
+        d_lin_w, d_lin_b = _gbuf(lin_w), _gbuf(lin_b)
+        redgemm_raw((g_out, out_sz, 0, 0), _rows3d(top_hs[:, 1:]), Bn * T, out_sz, Hh, out=(d_lin_w, d_lin_b))
         dH = torch.empty(Bn, T, Hh, device=dev, dtype=F32)
         linear_raw((g_out, out_sz, 0, 0), pack_weight(lin_w, transpose=True), None, Bn * T, Hh, out_sz,
                    (dH, Hh, 0, 0))
         grads = [None] * (4 * n_layers)
         d_enc = None
         for l in reversed(range(n_layers)):
-            w_ih, w_hh = lstm_params[4 * l], lstm_params[4 * l + 1]
+            w_ih, w_hh, b_ih, b_hh = lstm_params[4 * l: 4 * l + 4]
             hs, cs, gates = saved_layers[3 * l: 3 * l + 3]
             dG = torch.empty(Bn, T, 4 * Hh, device=dev, dtype=F32)
             nz = (4 * Hh + 255) // 256                     # split-K partials of dh_rec = dG_t . W_hh
@@ -401,9 +686,14 @@ class LSTMDecoderFn(torch.autograd.Function):
                 if t > 0:
                     L.call('gpe_linear_splitk', dG[:, t], T * 4 * Hh, whh_t, dh_rec, Bn, Hh, 4 * Hh)
             dG_rows = (dG, 4 * Hh, 0, 0)
-            d_whh, d_b = redgemm_raw(dG_rows, _rows3d(hs[:, :T]), Bn * T, 4 * Hh, Hh)
+            d_whh, d_bih = _gbuf(w_hh), _gbuf(b_ih)
+            redgemm_raw(dG_rows, _rows3d(hs[:, :T]), Bn * T, 4 * Hh, Hh, out=(d_whh, d_bih))
+            d_bhh = _gbuf(b_hh)
+            d_bhh.copy_(d_bih)
+            d_wih = _gbuf(w_ih)
             if l == 0:
-                d_wih, _ = redgemm_raw(dG_rows, (enc, enc.stride(0), 0, T), Bn * T, 4 * Hh, In, want_colsum=False)
+                redgemm_raw(dG_rows, (enc, enc.stride(0), 0, T), Bn * T, 4 * Hh, In, want_colsum=False,
+                            out=(d_wih, None))
                 if ctx.needs_input_grad[0]:
                     dGs = torch.empty(Bn, 4 * Hh, device=dev, dtype=F32)
                     L.call('gpe_reduce_inner', dG, T * 4 * Hh, 4 * Hh, T, Bn, 4 * Hh, dGs, 4 * Hh, 0)
@@ -412,21 +702,25 @@ class LSTMDecoderFn(torch.autograd.Function):
                                _rows2d(d_enc))
             else:
                 lower_hs = saved_layers[3 * (l - 1)]
-                d_wih, _ = redgemm_raw(dG_rows, _rows3d(lower_hs[:, 1:]), Bn * T, 4 * Hh, Hh, want_colsum=False)
+                redgemm_raw(dG_rows, _rows3d(lower_hs[:, 1:]), Bn * T, 4 * Hh, Hh, want_colsum=False,
+                            out=(d_wih, None))
                 dH = torch.empty(Bn, T, Hh, device=dev, dtype=F32)
                 linear_raw(dG_rows, pack_weight(w_ih, transpose=True), None, Bn * T, Hh, 4 * Hh, (dH, Hh, 0, 0))
-            grads[4 * l: 4 * l + 4] = [d_wih, d_whh, d_b, d_b.clone()]
-        return (d_enc, None, None, None, None, d_lin_w, d_lin_b, *grads)
+            grads[4 * l: 4 * l + 4] = [_gret(w_ih, d_wih), _gret(w_hh, d_whh), _gret(b_ih, d_bih),
+                                       _gret(b_hh, d_bhh)]
+        return (d_enc, None, None, None, None, _gret(lin_w, d_lin_w), _gret(lin_b, d_lin_b), *grads)
 
 
 # -------------------------------------------------------------------------------------------------
-# attention variant (GarmentSegmentPattern3D)
+# dense MLP (attention variant, MLP decoder, stitch model)
 # -------------------------------------------------------------------------------------------------
 class DenseMLPFn(torch.autograd.Function):
     """MLP(channels) = [Linear -> ReLU -> BatchNorm1d] x n on dense rows (nn/net_blocks.py:43-47 as used by
-    point_segment_mlp, nn/nets.py:223-226).  Same kernels as the edge MLP with one "message" per row (k = 1):
-    fused Linear+ReLU(+fp64 BN statistics), every BatchNorm folded into the next Linear, the last one applied
-    explicitly; backward = the edge MLP's chain (centred reduce-GEMM -> BN coefficients -> propagate in place)."""
+    point_segment_mlp, nn/nets.py:223-226; MLPDecoder, nn/net_blocks.py:273-298; StitchOnEdge3DPairs, nn/nets.py:342).
+    Same kernels as the edge MLP with one "message" per row (k = 1): fused Linear+ReLU(+fp64 BN statistics), every
+    BatchNorm folded into the next Linear, the last one applied explicitly; backward = the edge MLP's chain (centred
+    reduce-GEMM -> BN coefficients -> propagate in place).  Layers wider than 256 (the global-attention MLP is 403 wide,
+    an MLP decoder thousands) run as K slabs / several column blocks of the generic row GEMM."""
 
     @staticmethod
     def forward(ctx, x, training, eps, momentum, n_blocks, *tensors):
@@ -458,12 +752,18 @@ class DenseMLPFn(torch.autograd.Function):
         y = torch.empty(M, Cin, device=dev, dtype=F32)
         L.call('gpe_bn_apply', a_in, a_in.stride(0), stats[-1], M, Cin, y, Cin)
         ctx.n_blocks = n_blocks
+        ctx.training = training
+        ctx.done = False
         ctx.save_for_backward(x, *params, *acts, *stats)
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        n = ctx.n_blocks
+        if ctx.done:
+            raise RuntimeError('DenseMLPFn.backward ran twice on the same graph: the stored activations are overwritten '
+                               'in place by the first pass (retain_graph is not supported)')
+        ctx.done = True
+        n, training = ctx.n_blocks, ctx.training
         sv = ctx.saved_tensors
         x, params, acts, stats = sv[0], sv[1:1 + 4 * n], sv[1 + 4 * n:1 + 5 * n], sv[1 + 5 * n:1 + 6 * n]
         dev = x.device
@@ -473,37 +773,43 @@ class DenseMLPFn(torch.autograd.Function):
         # last block: BN applied explicitly -> same algebra as the edge layer's BN-after-max with one slot per row
         a, st = acts[-1], stats[-1]
         C = params[4 * (n - 1)].shape[0]
+        g_l, be_l = params[4 * (n - 1) + 2], params[4 * (n - 1) + 3]
         psb = L.query('gpe_point_sums_blocks')
         part = torch.empty(psb, 2, C, device=dev, dtype=torch.float64)
         L.call('gpe_edge_bwd_point_sums', gy, C, a, a, a.stride(0), st, M, C, part)
-        coef, dgam, dbet = bn_bwd_coef(part, psb, st, C, M)
-        slot0 = torch.zeros(M, a.stride(0), device=dev, dtype=torch.uint8)
-        L.call('gpe_edge_dz3', a, a.stride(0), gy, C, slot0, slot0, a.stride(0), coef, 1, M, 1, C)
-        grads[4 * (n - 1) + 2], grads[4 * (n - 1) + 3] = dgam, dbet
+        coef, dgam, dbet = bn_bwd_coef(part, psb, st, C, M, g_l, be_l, training)
+        L.call('gpe_edge_dz3_all', a, a.stride(0), gy, C, 1.0, coef, 1, M, 1, C)
+        grads[4 * (n - 1) + 2], grads[4 * (n - 1) + 3] = _gret(g_l, dgam), _gret(be_l, dbet)
         for l in reversed(range(n)):
-            W = params[4 * l]
+            W, b = params[4 * l], params[4 * l + 1]
             dz = acts[l]                          # holds dz_l now
             C = W.shape[0]
             if l > 0:
                 prev, stp = acts[l - 1], stats[l - 1]
                 Cp = params[4 * (l - 1)].shape[0]
                 G = torch.empty(C, Cp, device=dev, dtype=F32)
-                db = torch.empty(C, device=dev, dtype=F32)
-                ws = torch.empty(L.query('gpe_redgemm_ws', C, Cp), device=dev, dtype=F32)
-                L.call('gpe_edge_redgemm', dz, dz.stride(0), 1, prev, prev.stride(0), None, 0, None, stp[0],
-                       1, M, 1, C, Cp, G, Cp, db, ws)
+                db = _gbuf(b)
+                if Cp > 256:
+                    redgemm_raw((dz, dz.stride(0), 0, 0), (prev, prev.stride(0), 0, 0), M, C, Cp, v_shift=stp[0],
+                                out=(G, db))
+                else:
+                    ws = torch.empty(L.query('gpe_redgemm_ws', C, Cp), device=dev, dtype=F32)
+                    L.call('gpe_edge_redgemm', dz, dz.stride(0), 1, prev, prev.stride(0), None, 0, None, stp[0],
+                           1, M, 1, C, Cp, G, Cp, db, ws)
                 sums = torch.empty(1, 2, Cp, device=dev, dtype=torch.float64)
-                dW = torch.empty(C, Cp, device=dev, dtype=F32)
+                dW = _gbuf(W)
                 L.call('gpe_bn_bwd_from_G', G, Cp, db, W, W.stride(0), C, Cp, stp, sums, dW, Cp)
-                coef_p, dgam_p, dbet_p = bn_bwd_coef(sums, 1, stp, Cp, M)
+                gp, bp = params[4 * (l - 1) + 2], params[4 * (l - 1) + 3]
+                coef_p, dgam_p, dbet_p = bn_bwd_coef(sums, 1, stp, Cp, M, gp, bp, training)
                 L.call('gpe_edge_mlp_bwd', dz, dz.stride(0), 0, None, 0, None, 1, M, 1, C, Cp,
                        pack_weight(W, transpose=True), coef_p, prev, prev.stride(0), None, 0)
-                grads[4 * l], grads[4 * l + 1] = dW, db
-                grads[4 * (l - 1) + 2], grads[4 * (l - 1) + 3] = dgam_p, dbet_p
+                grads[4 * l], grads[4 * l + 1] = _gret(W, dW), _gret(b, db)
+                grads[4 * (l - 1) + 2], grads[4 * (l - 1) + 3] = _gret(gp, dgam_p), _gret(bp, dbet_p)
             else:
                 K0 = x.shape[1]
-                dW, db = redgemm_raw((dz, dz.stride(0), 0, 0), _rows2d(x), M, C, K0)
-                grads[0], grads[1] = dW, db
+                dW, db = _gbuf(W), _gbuf(b)
+                redgemm_raw((dz, dz.stride(0), 0, 0), _rows2d(x), M, C, K0, out=(dW, db))
+                grads[0], grads[1] = _gret(W, dW), _gret(b, db)
         gx = None
         if ctx.needs_input_grad[0]:
             dz0, W0 = acts[0], params[0]
@@ -548,39 +854,128 @@ class SparsemaxFn(torch.autograd.Function):
 
 
 class AttentionPoolFn(torch.autograd.Function):
-    """pooled[b, p, :] = mean_n w[b, n, p] * feat[b, n, :]  — the reference's 23-iteration loop of
-    `w[:, p] * features -> global_mean_pool` (nn/nets.py:263-276) as one reduce-GEMM [P x N].[N x C] per cloud."""
+    """pooled[b, p, :] = pool_n w[b, n, p] * feat[b, n, :]  — the reference's 23-iteration loop of
+    `w[:, p] * features -> global_pool` (nn/nets.py:263-276) as one batched launch for all clouds and panels.
+    mode: 0 mean (shipped), 1 max, 2 add — the encoder's `global_pool` setting."""
 
     @staticmethod
-    def forward(ctx, w, feat, B, N):
+    def forward(ctx, w, feat, B, N, mode=0):
         _dev_check(w)
         dev = w.device
         P, C = w.shape[1], feat.shape[1]
         pooled = torch.empty(B, P, C, device=dev, dtype=F32)
-        for b in range(B):
-            G = pooled[b]
-            ws = torch.empty(L.query('gpe_redgemm_ws', P, C), device=dev, dtype=F32)
-            L.call('gpe_redgemm', w[b * N:(b + 1) * N], w.stride(0), 0, 0, feat[b * N:(b + 1) * N], feat.stride(0),
-                   0, 0, None, N, P, C, G, C, None, ws, 0)
-        L.call('gpe_scale', pooled, 1.0 / N, pooled, pooled.numel())
-        ctx.dims = (B, N, P, C)
+        nws = L.query('gpe_attn_pool_ws', B, N, P, C)
+        part = torch.empty(nws, device=dev, dtype=F32)
+        arg = torch.empty(B, P, C, device=dev, dtype=torch.int32) if mode == 1 else None
+        part_arg = torch.empty(nws, device=dev, dtype=torch.int32) if mode == 1 else None
+        L.call('gpe_attn_pool_fwd', w, w.stride(0), feat, feat.stride(0), B, N, P, C, mode, pooled, arg, part, part_arg)
+        ctx.dims = (B, N, P, C, mode)
+        ctx.arg = arg
         ctx.save_for_backward(w, feat)
         return pooled.view(B * P, C)
 
     @staticmethod
     def backward(ctx, g):
         w, feat = ctx.saved_tensors
-        B, N, P, C = ctx.dims
+        B, N, P, C, mode = ctx.dims
         dev = w.device
-        g = g.contiguous().view(B, P, C)
-        gs = torch.empty_like(g)
-        L.call('gpe_scale', g, 1.0 / N, gs, g.numel())
+        g = g.contiguous()
         gw = torch.empty(B * N, P, device=dev, dtype=F32)
         gf = torch.empty(B * N, C, device=dev, dtype=F32)
-        for b in range(B):
-            sl = slice(b * N, (b + 1) * N)
-            # dw[n, p] = sum_c feat[n, c] * gs[b, p, c]
-            linear_raw(_rows2d(feat[sl]), pack_weight(gs[b]), None, N, P, C, _rows2d(gw[sl]))
-            # dfeat[n, c] = sum_p w[n, p] * gs[b, p, c]
-            linear_raw(_rows2d(w[sl]), pack_weight(gs[b], transpose=True), None, N, C, P, _rows2d(gf[sl]))
-        return gw, gf, None, None
+        L.call('gpe_attn_pool_bwd', w, w.stride(0), feat, feat.stride(0), g, ctx.arg, B, N, P, C, mode, gw, P, gf, C)
+        return gw, gf, None, None, None
+
+
+# -------------------------------------------------------------------------------------------------
+# loss (the caller-side step right after the path) and its ground-truth matching
+# -------------------------------------------------------------------------------------------------
+LOSS_SHAPE, LOSS_LOOP, LOSS_ROT, LOSS_TR = 1, 2, 4, 8
+
+
+def _view_strides(ol):
+    """(sb, sp, sl) of an outlines view [B,P,L,4] whose last dim is unit-stride (a slice of the [B,P,L,8] output)."""
+    assert ol.dim() == 4 and ol.stride(3) == 1, (ol.shape, ol.stride())
+    return ol.stride(0), ol.stride(1), ol.stride(2)
+
+
+def _row_stride(t, P):
+    """row pitch of a [B,P,c] view of a [B*P, ld] tensor."""
+    assert t.dim() == 3 and t.stride(2) == 1 and t.stride(0) == P * t.stride(1), (t.shape, t.stride())
+    return t.stride(1)
+
+
+class PatternLossFn(torch.autograd.Function):
+    """ComposedPatternLoss._main_losses (nn/metrics/composed_loss.py:294-321) + PanelLoopLoss (nn/metrics/losses.py:19-51)
+    in one forward and one backward launch.  Returns a [5] tensor {total, shape, loop, rotation, translation}; only
+    element 0 carries gradient."""
+
+    @staticmethod
+    def forward(ctx, outlines, rotations, translations, gt_ol, gt_rot, gt_tr, num_edges, flags, pad0, pad1, loop_w):
+        _dev_check(outlines)
+        dev = outlines.device
+        B, P, Lp = outlines.shape[:3]
+        sb, sp, sl = _view_strides(outlines)
+        R = rotations.shape[-1] if rotations is not None else 0
+        T = translations.shape[-1] if translations is not None else 0
+        rs = _row_stride(rotations, P) if rotations is not None else 0
+        ts = _row_stride(translations, P) if translations is not None else 0
+        part = torch.empty(B, 4, device=dev, dtype=torch.float64)
+        loop_sums = torch.empty(B * P, 2, device=dev, dtype=F32)
+        out = torch.empty(5, device=dev, dtype=F32)
+        args = (outlines, sb, sp, sl, rotations, rs, translations, ts, gt_ol, gt_rot, gt_tr, num_edges, B, P, Lp, R, T,
+                flags, float(pad0), float(pad1), float(loop_w))
+        L.call('gpe_pattern_loss_fwd', *args, part, loop_sums, out)
+        ctx.args = args
+        ctx.loop_sums = loop_sums
+        ctx.shapes = (B, P, Lp, R, T)
+        ctx.need = (rotations is not None and rotations.requires_grad,
+                    translations is not None and translations.requires_grad)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        B, P, Lp, R, T = ctx.shapes
+        dev = g.device
+        g = g.contiguous()
+        g_ol = torch.empty(B, P, Lp, 4, device=dev, dtype=F32)
+        g_rot = torch.empty(B, P, R, device=dev, dtype=F32) if ctx.need[0] else None
+        g_tr = torch.empty(B, P, T, device=dev, dtype=F32) if ctx.need[1] else None
+        # g[0] is the upstream gradient of `total` (a device scalar: no host sync)
+        L.call('gpe_pattern_loss_bwd', *ctx.args, ctx.loop_sums, g, g_ol, g_rot, g_tr)
+        return g_ol, g_rot, g_tr, None, None, None, None, None, None, None, None
+
+
+def origin_match(outlines, gt_ol, num_edges):
+    """composed_loss.py:656-703 `_batch_edge_order_match`: -> (gt outlines with every panel's edge loop shifted to the
+    origin that best matches the prediction, leading edge per panel int32 [B*P])."""
+    _dev_check(outlines)
+    B, P, Lp, D = gt_ol.shape
+    sb, sp, sl = _view_strides(outlines)
+    out = torch.empty_like(gt_ol)
+    lead = torch.empty(B * P, device=gt_ol.device, dtype=torch.int32)
+    L.call('gpe_origin_match', outlines.detach(), sb, sp, sl, gt_ol, D, num_edges, B, P, Lp, out, lead)
+    return out, lead
+
+
+def order_match(pred_feat, gt_feat):
+    """composed_loss.py:530-570 `_panel_order_match` (the greedy assignment): -> int64 [B, P] permutation of GT panels,
+    and a device flag that is non-zero if the matching left a finite distance behind (the reference raises then)."""
+    _dev_check(pred_feat)
+    B, P, D = pred_feat.shape
+    perm = torch.empty(B, P, device=pred_feat.device, dtype=torch.int64)
+    fail = torch.zeros(1, device=pred_feat.device, dtype=torch.int32)
+    L.call('gpe_order_match', pred_feat.contiguous(), gt_feat.contiguous(), B, P, D, perm, fail)
+    return perm, fail
+
+
+def standardize(x, shift, scale):
+    """nn/data/transforms.py:35-50 FeatureStandartization on the device: (x - shift) / scale per column."""
+    import ctypes
+    _dev_check(x)
+    x = x.contiguous()
+    C = x.shape[-1]
+    sh = (ctypes.c_float * C)(*[float(v) for v in shift])
+    sc = (ctypes.c_float * C)(*[float(v) for v in scale])
+    out = torch.empty_like(x)
+    L.call('gpe_standardize', x, x.numel() // C, C, sh, sc, out)
+    return out

@@ -1,67 +1,88 @@
 """Data parallelism for the path: one process per GPU, local BatchNorm statistics (as the reference's
 nn.DataParallel replicas, nn/train.py:124 — no SyncBN), and ONE exchange per step: a bucketed RCCL all-reduce
-(average) of the gradients over xGMI, launched from autograd hooks so the decoder's 91 % of the bytes travel
-while the encoder backward is still running.  `backend="nccl"` IS RCCL on ROCm; the CPU
-tests run the same code over gloo."""
+(average) of the gradients over xGMI, launched while backward is still running so the decoder's 91 % of the bytes
+travel under the encoder backward.  `backend="nccl"` IS RCCL on ROCm; the CPU tests run the same
+code over gloo.
+
+Gradients live in the flat arena of optim.FlatArena: a bucket is a contiguous slice of the arena's gradient buffer, the
+all-reduce runs in place on that slice — no torch.cat into a staging tensor, no copy back per parameter."""
+import os
+
 import torch
 import torch.distributed as dist
 import torch.nn as nn
 
+from .optim import FlatArena
+
 
 class DistributedHotPath(nn.Module):
-    """Wrapper exposing what the reference's trainer touches on an nn.DataParallel object: `.module`,
-    `.device_ids`, `__call__`.  Call `finish_gradient_sync()` after `loss.backward()` and before
-    `optimizer.step()`."""
+    """Wrapper exposing what the reference's trainer touches on an nn.DataParallel object: `.module`, `.device_ids`,
+    `__call__`.  Call `finish_gradient_sync()` after `loss.backward()` and before the optimizer step.
 
-    def __init__(self, module, device_ids=None, bucket_bytes=8 << 20, process_group=None):
+    A gradient reaches the arena in one of two ways, both tracked here: written in place by a backward kernel of ops.py
+    (FlatArena.mark_written -> `_on_written`), or accumulated by autograd into the parameter's permanent `.grad` view
+    (post-accumulate hook -> `_on_hook`; used by plain torch modules, e.g. in the CPU tests).  When the last parameter of
+    a bucket has its gradient, the bucket's slice leaves for the all-reduce.  The arena gradient buffer must be zero when
+    a backward pass starts (FusedAdam.step clears it; otherwise call `arena.zero_grad()`)."""
+
+    def __init__(self, module, device_ids=None, bucket_bytes=8 << 20, process_group=None, arena=None):
         super().__init__()
         self.module = module
         self.device_ids = list(device_ids) if device_ids is not None else []
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
-        # buckets in reverse registration order ~= the order gradients become ready (decoder first)
-        params = [p for p in module.parameters() if p.requires_grad]
-        self._buckets, cur, size = [], [], 0
-        for p in reversed(params):
-            cur.append(p)
+        self.arena = arena if arena is not None else FlatArena(module)
+        a = self.arena
+        # buckets = consecutive parameter ranges of the arena (already in gradient-ready order)
+        self._buckets, start, size = [], 0, 0
+        for i, p in enumerate(a.params):
             size += p.numel() * p.element_size()
-            if size >= bucket_bytes:
-                self._buckets.append(cur)
-                cur, size = [], 0
-        if cur:
-            self._buckets.append(cur)
-        self._bucket_of = {}
-        for bi, b in enumerate(self._buckets):
-            for p in b:
-                self._bucket_of[p] = bi
-        self._pending = [0] * len(self._buckets)
-        self._inflight = []
-        self._launched = set()
+            if size >= bucket_bytes or i == len(a.params) - 1:
+                lo = a.offsets[start]
+                hi = a.offsets[i] + (a.params[i].numel() + 3) // 4 * 4
+                self._buckets.append((start, i + 1, lo, hi))
+                start, size = i + 1, 0
+        self._bucket_of = [0] * len(a.params)
+        for bi, (s, e, _, _) in enumerate(self._buckets):
+            for i in range(s, e):
+                self._bucket_of[i] = bi
         if self.world > 1:
-            for p in params:
-                p.register_post_accumulate_grad_hook(self._on_grad)
+            a.listeners.append(self._on_written)
+            for i, p in enumerate(a.params):
+                p.register_post_accumulate_grad_hook(lambda _p, i=i: self._on_hook(_p, i))
         self._reset()
 
     def forward(self, *args, **kwargs):
         return self.module(*args, **kwargs)
 
     def _reset(self):
-        self._pending = [len(b) for b in self._buckets]
+        self._pending = [e - s for s, e, _, _ in self._buckets]
+        self._seen = set()
         self._inflight = []
         self._launched = set()
 
     def _launch(self, bi):
-        ps = [p for p in self._buckets[bi] if p.grad is not None]
         self._launched.add(bi)
-        if not ps:
-            return
-        flat = torch.cat([p.grad.reshape(-1) for p in ps])
+        _, _, lo, hi = self._buckets[bi]
+        flat = self.arena.grad[lo:hi]
         flat.div_(self.world)
-        work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-        self._inflight.append((work, flat, ps))
+        self._inflight.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
-    def _on_grad(self, p):
-        bi = self._bucket_of[p]
+    def _on_written(self, i):
+        self._on_ready(i)
+
+    def _on_hook(self, p, i):
+        o, n = self.arena.segment(i)
+        if p.grad is None or p.grad.data_ptr() != self.arena.grad.data_ptr() + o * self.arena.grad.element_size():
+            raise RuntimeError('DistributedHotPath: a parameter lost its arena gradient view (zero_grad(set_to_none=True) '
+                               'or `p.grad = None`?) — clear gradients with arena.zero_grad() / FusedAdam.step()')
+        self._on_ready(i)
+
+    def _on_ready(self, i):
+        if i in self._seen:
+            return
+        self._seen.add(i)
+        bi = self._bucket_of[i]
         self._pending[bi] -= 1
         if self._pending[bi] == 0 and bi not in self._launched:
             self._launch(bi)
@@ -73,19 +94,13 @@ class DistributedHotPath(nn.Module):
             for bi in range(len(self._buckets)):
                 if bi not in self._launched:
                     self._launch(bi)
-            for work, flat, ps in self._inflight:
+            for work in self._inflight:
                 work.wait()
-                off = 0
-                for p in ps:
-                    n = p.numel()
-                    p.grad.copy_(flat[off:off + n].view_as(p.grad))
-                    off += n
         self._reset()
 
 
 def init_distributed(backend=None):
     """Reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* (torch.distributed.run) and binds this process to its GPU."""
-    import os
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
@@ -95,7 +110,7 @@ def init_distributed(backend=None):
         if os.environ.get('GPE_SHARE_DEVICE') == '1':
             local = 0
         torch.cuda.set_device(local)
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or os.environ.get('GPE_FORCE_DIST') == '1') and not dist.is_initialized():
         backend = backend or os.environ.get('GPE_DIST_BACKEND')
         dist.init_process_group(backend or ('nccl' if torch.cuda.is_available() else 'gloo'),
                                 rank=rank, world_size=world)

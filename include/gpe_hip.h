@@ -8,7 +8,10 @@
  *
  * Conventions (all functions):
  *   - plain C symbols; raw DEVICE pointers + dims + a hipStream_t passed as void*; caller owns every buffer,
- *     no hidden allocation, no global state; work is enqueued on `stream` and the call returns immediately;
+ *     no hidden allocation; work is enqueued on `stream` of the CURRENT device and the call returns immediately;
+ *     process-global state is limited to (a) the arithmetic mode (gpe_math_set) and the profiling switches
+ *     (gpe_debug_set), which apply to every stream and device of the process, and (b) per-device caches of the
+ *     CU count and of the >64 KB LDS opt-in (hipFuncSetAttribute), keyed by device ordinal;
  *   - return 0 on success, -22 (EINVAL) on bad arguments, -5 (EIO) if the launch failed;
  *   - fp32 storage and arithmetic unless stated; matrix products run on v_mfma_f32_16x16x4_f32 (exact fp32);
  *     BatchNorm statistics are accumulated in fp64;
@@ -53,6 +56,12 @@ int gpe_knn_reverse(const int32_t* idx, int B, int N, int k, int32_t* rev_off, i
 long gpe_packed_size(int N, int K);
 int gpe_pack_weight(const float* w, int ldw, int N, int K, int transpose, const float* col_scale,
                     float* wp, void* stream);
+/* every weight-derived operand of a model refreshed by ONE launch (after an optimizer step): `jobs_dev` is a device array
+ * of njobs 64-byte records {const float* w, w2; float* out; long total, first_block; int ldw, N, K, kind, Npad, aux}
+ * sorted by first_block (256 outputs per block).  kind 0 plain pack, 1 transposed pack, 2 gate-interleaved pack (aux = H),
+ * 3 pack of [W1a-W1b ; W1b] from W1 [H][2C] (gpe_w1_split + pack; aux = H), 4 its transpose, 5 out = w + w2 (N floats),
+ * 6 out = [w[0:aux] | 0] (N floats). */
+int gpe_pack_multi(const void* jobs_dev, int njobs, long total_blocks, void* stream);
 /* folded bias: out[n] = bias[n] + sum_k w[n][k]*t[k]   (t = beta - mean*s of the previous BatchNorm) */
 int gpe_fold_bias(const float* w, int ldw, int N, int K, const float* bias, const float* t, float* out,
                   void* stream);
@@ -190,6 +199,67 @@ int gpe_sparsemax_bwd(const float* out, int ldo, const float* g, int ldg, long r
                       void* stream);
 /* y = s*a + t with {s,t} = stats rows 2,3: BatchNorm of a stored post-ReLU activation (last block of a dense MLP) */
 int gpe_bn_apply(const float* a, int lda, const float* stats, long rows, int C, float* y, int ldy, void* stream);
+
+/* y = s*(a*a_scale) + t*t_scale: BatchNorm of a SUM (t_scale = k, EdgeConv aggr 'add') or MEAN (a_scale = 1/k) over the k
+ * messages of a point, applied after the aggregation (nn/net_blocks.py:129 with EConv_aggr != 'max') */
+int gpe_bn_apply_scaled(const float* a, int lda, const float* stats, long rows, int C, float a_scale, float t_scale,
+                        float* y, int ldy, void* stream);
+/* out[i][c] = sum over the k messages of point i of a[i*k+s][c] */
+int gpe_edge_sum_k(const float* a, int lda, long npts, int k, int F, float* out, int ldo, void* stream);
+/* gpe_edge_dz3 for aggr 'add' / 'mean': every message of a point receives gscale * g[i] (no arg-slot selection) */
+int gpe_edge_dz3_all(float* a3, int lda3, const float* g, int ldg, float gscale, const float* coef, int B, int N, int k,
+                     int F, void* stream);
+
+/* ---- pooling variants (torch_geometric global_max_pool / global_add_pool, nn/net_blocks.py:145-150) -----------------
+ * mode 1 = max (arg [B][C] int32 = the winning point, first maximum), 2 = add. */
+int gpe_segment_pool_fwd(const float* x, int ldx, int B, int N, int C, int mode, float* y, int ldy, int32_t* arg,
+                         void* stream);
+int gpe_segment_pool_bwd(const float* gy, int ldgy, const int32_t* arg, int B, int N, int C, int mode, float* gx,
+                         int ldgx, void* stream);
+
+/* attention pooling (nn/nets.py:263-276: `w[:, p] * features -> global_pool`, for all P panels at once):
+ * out[b][p][c] = pool_n w[b*N+n][p] * feat[b*N+n][c];  mode 0 mean, 1 max, 2 add (the encoder's global_pool).
+ * part / part_arg: workspaces of gpe_attn_pool_ws(B,N,P,C) floats / int32 (part_arg and arg only for max). */
+long gpe_attn_pool_ws(int B, int N, int P, int C);
+int gpe_attn_pool_fwd(const float* w, int ldw, const float* feat, int ldf, int B, int N, int P, int C, int mode,
+                      float* out, int32_t* arg, float* part, int32_t* part_arg, void* stream);
+/* g [B][P][C] -> gw [B*N][ldgw], gf [B*N][ldgf] (both fully written) */
+int gpe_attn_pool_bwd(const float* w, int ldw, const float* feat, int ldf, const float* g, const int32_t* arg, int B,
+                      int N, int P, int C, int mode, float* gw, int ldgw, float* gf, int ldgf, void* stream);
+
+/* ---- loss (nn/metrics/composed_loss.py:294-334 main terms; nn/metrics/losses.py:19-51 PanelLoopLoss) ----------------
+ * Predictions are strided views of the decoder outputs: outlines (b,p,l,c<4) at ol + b*ol_sb + p*ol_sp + l*ol_sl + c,
+ * rotations (b,p,c<R) at rot + (b*P+p)*rot_s + c, translations likewise.  Ground truth dense fp32; num_edges int32 [B*P].
+ * flags: 1 shape | 2 loop | 4 rotation | 8 translation.  pad0/pad1: the standardised padding vector's first two entries.
+ * fwd: part [B][4] fp64 and loop_sums [B*P][2] are workspaces (loop_sums is re-used by bwd);
+ *      out5 = {total, shape, loop, rotation, translation} (each term a mean, total = shape + loop_w*loop + rot + tr).
+ * bwd: gradients of `total`, times the device scalar *gscale (NULL = 1), dense: g_ol [B,P,L,4], g_rot [B,P,R], g_tr [B,P,T]. */
+int gpe_pattern_loss_fwd(const float* ol, long ol_sb, long ol_sp, long ol_sl, const float* rot, long rot_s,
+                         const float* tr, long tr_s, const float* gt_ol, const float* gt_rot, const float* gt_tr,
+                         const int32_t* num_edges, int B, int P, int L, int R, int T, int flags, float pad0, float pad1,
+                         float loop_w, double* part, float* loop_sums, float* out5, void* stream);
+int gpe_pattern_loss_bwd(const float* ol, long ol_sb, long ol_sp, long ol_sl, const float* rot, long rot_s,
+                         const float* tr, long tr_s, const float* gt_ol, const float* gt_rot, const float* gt_tr,
+                         const int32_t* num_edges, int B, int P, int L, int R, int T, int flags, float pad0, float pad1,
+                         float loop_w, const float* loop_sums, const float* gscale, float* g_ol, float* g_rot,
+                         float* g_tr, void* stream);
+/* panel-origin matching (composed_loss.py:656-703): gt_out [B,P,L,D] = each GT panel's edge loop cyclically shifted (first
+ * num_edges rows only) to the FIRST shift with the smallest squared distance to the prediction; lead [B*P] = that shift. */
+int gpe_origin_match(const float* ol, long ol_sb, long ol_sp, long ol_sl, const float* gt_ol, int D,
+                     const int32_t* num_edges, int B, int P, int L, float* gt_out, int32_t* lead, void* stream);
+/* greedy panel-order matching (composed_loss.py:530-570) on feature rows [B][P][D]: perm [B][P] int64 with
+ * perm[b][pred panel] = gt panel; *fail set to 1 if a finite distance is left unmatched (the reference raises). */
+int gpe_order_match(const float* pred_feat, const float* gt_feat, int B, int P, int D, int64_t* perm, int32_t* fail,
+                    void* stream);
+
+/* ---- optimizer / input side (nn/trainer.py:162-185; nn/data/transforms.py:35-50) ----------------------------------- */
+/* one torch.optim.Adam step (amsgrad off) over a flat arena of n floats (16-B aligned p, g, m, v); `step` counts from 1;
+ * the gradient is read as g*gscale; zero_grad != 0 clears g afterwards.  The OneCycleLR value is passed in as lr. */
+int gpe_adam_step(float* p, float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
+                  float weight_decay, long step, float gscale, int zero_grad, void* stream);
+/* out = (x - shift) / scale per column; shift_host / scale_host are HOST arrays of C <= 8 floats */
+int gpe_standardize(const float* x, long rows, int C, const float* shift_host, const float* scale_host, float* out,
+                    void* stream);
 
 /* split-K product y[z][M][N] = A[:, z*256:(z+1)*256] . W[:, z*256:...]^T for z < ceil(K/256): one K slab per workgroup
  * (latency-bound long-K shapes: the LSTM backward recurrence).  The partials are summed by the consumer. */

@@ -10,9 +10,12 @@ What it follows (paths relative to /root/reference):
   * nn/net_blocks.py:93-191    EdgeConvFeatures (defaults, 2x DynamicEdgeConv, pool, Linear)
   * nn/net_blocks.py:302-333   _init_tenzor / _init_weights
   * nn/net_blocks.py:363-402   LSTMDecoderModule
+  * nn/net_blocks.py:273-298,405-497   MLPDecoder, LSTMDoubleReverseDecoderModule, GRUDecoderModule
   * nn/nets.py:11-184          BaseModule, GarmentFullPattern3D
   * nn/nets.py:187-299         GarmentSegmentPattern3D
-  * nn/metrics/composed_loss.py:222-334, nn/metrics/losses.py:8-51  main loss terms (backward seed)
+  * nn/metrics/composed_loss.py:222-334,428-703, nn/metrics/losses.py:8-51  main loss terms (backward seed) and the
+    panel-order / panel-origin matching of the ground truth in front of them
+  * nn/nets.py:303-353         StitchOnEdge3DPairs (model)
   * nn/trainer.py:92-99        the fwd -> loss -> bwd step
 
 Pinning status:
@@ -311,7 +314,82 @@ class LSTMDecoderModule(nn.Module):
         return out.contiguous().view(bs, out_len, -1)
 
 
-_BLOCKS = {'EdgeConvFeatures': EdgeConvFeatures, 'LSTMDecoderModule': LSTMDecoderModule}
+class MLPDecoder(nn.Module):
+    """nn/net_blocks.py:273-298."""
+
+    def __init__(self, encoding_size, hidden_size, out_elem_size, n_layers, out_len=1, dropout=0,
+                 custom_init='kaiming_normal'):
+        super().__init__()
+        self.out_len = out_len
+        self.mlp = MLP([encoding_size] + [hidden_size * out_len for _ in range(n_layers)] + [out_elem_size * out_len])
+        _init_weights(self.mlp, init_type=custom_init)
+
+    def forward(self, batch_enc, *args):
+        out = self.mlp(batch_enc)
+        return out.contiguous().view(batch_enc.size(0), self.out_len, -1)
+
+
+class GRUDecoderModule(nn.Module):
+    """nn/net_blocks.py:457-497."""
+
+    def __init__(self, encoding_size, hidden_size, out_elem_size, n_layers, dropout=0,
+                 custom_init='kaiming_normal', **kwargs):
+        super().__init__()
+        self.custom_init = custom_init
+        self.n_layers = n_layers
+        self.encoding_size = encoding_size
+        self.hidden_size = hidden_size
+        self.out_elem_size = out_elem_size
+        self.recurrent_cell = nn.GRU(encoding_size, hidden_size, n_layers, dropout=dropout, batch_first=True)
+        self.lin = nn.Linear(hidden_size, out_elem_size)
+        _init_weights(self.recurrent_cell, init_type=custom_init)
+        self.last_states = None
+
+    def forward(self, batch_enc, out_len):
+        bs = batch_enc.size(0)
+        dec_input = batch_enc.unsqueeze(1).repeat(1, out_len, 1)
+        h0 = _init_tenzor(self.n_layers, bs, self.hidden_size, init_type=self.custom_init).to(batch_enc.dtype)
+        self.last_states = (h0,)
+        out, _ = self.recurrent_cell(dec_input, h0)
+        out = self.lin(out.contiguous().view(-1, self.hidden_size))
+        return out.contiguous().view(bs, out_len, -1)
+
+
+class LSTMDoubleReverseDecoderModule(nn.Module):
+    """nn/net_blocks.py:405-454."""
+
+    def __init__(self, encoding_size, hidden_size, out_elem_size, n_layers, dropout=0,
+                 custom_init='kaiming_normal', **kwargs):
+        super().__init__()
+        self.custom_init = custom_init
+        self.n_layers = n_layers
+        self.encoding_size = encoding_size
+        self.hidden_size = hidden_size
+        self.out_elem_size = out_elem_size
+        self.lstm_reverse = nn.LSTM(encoding_size, hidden_size, n_layers, dropout=dropout, batch_first=True)
+        self.lstm_forward = nn.LSTM(hidden_size + encoding_size, hidden_size, n_layers, dropout=dropout,
+                                    batch_first=True)
+        self.lin = nn.Linear(hidden_size, out_elem_size)
+        _init_weights(self.lstm_reverse, init_type=custom_init)
+        _init_weights(self.lstm_forward, init_type=custom_init)
+        self.last_states = None
+
+    def forward(self, batch_enc, out_len):
+        bs = batch_enc.size(0)
+        dec_input = batch_enc.unsqueeze(1).repeat(1, out_len, 1)
+        h0 = _init_tenzor(self.n_layers, bs, self.hidden_size, init_type=self.custom_init).to(batch_enc.dtype)
+        c0 = _init_tenzor(self.n_layers, bs, self.hidden_size, init_type=self.custom_init).to(batch_enc.dtype)
+        self.last_states = (h0, c0)
+        out, state = self.lstm_reverse(dec_input, (h0, c0))
+        out = torch.flip(out, [1])
+        out = torch.cat([out, dec_input], -1)
+        out, _ = self.lstm_forward(out, state)
+        out = self.lin(out.contiguous().view(-1, self.hidden_size))
+        return out.contiguous().view(bs, out_len, -1)
+
+
+_BLOCKS = {'EdgeConvFeatures': EdgeConvFeatures, 'LSTMDecoderModule': LSTMDecoderModule, 'MLPDecoder': MLPDecoder,
+           'GRUDecoderModule': GRUDecoderModule, 'LSTMDoubleReverseDecoderModule': LSTMDoubleReverseDecoderModule}
 
 
 # ---------------------------------------------------------------------------------------------
@@ -350,8 +428,9 @@ def eval_pad_vector(data_stats):
 
 class ComposedPatternLoss:
     """nn/metrics/composed_loss.py:129-334 restricted to the components the shipped YAMLs evaluate before
-    `epoch_with_stitches`: shape / loop / rotation / translation, with order- and origin-matching off
-    (models/att/att.yaml:124-137).  Anything else raises, so a silent mismatch is impossible."""
+    `epoch_with_stitches` (shape / loop / rotation / translation), INCLUDING the ground-truth pre-processing in front of
+    them: panel-order matching (:428-590) and panel-origin matching (:593-703), restated with the reference's own loops.
+    Stitch / segmentation terms raise, so a silent mismatch is impossible."""
 
     def __init__(self, data_config, in_config={}):
         self.config = {
@@ -370,33 +449,120 @@ class ComposedPatternLoss:
         stats = data_config.get('standardize')
         outl = {'shift': stats['gt_shift']['outlines'], 'scale': stats['gt_scale']['outlines']} if stats else {}
         self.loop_loss = PanelLoopLoss(eval_pad_vector(outl))
+        self.last_permutation = None
+        self.last_leading_edges = None
+
+    # -- composed_loss.py:572-590
+    @staticmethod
+    def _feature_permute(feat, perm):
+        ext = perm
+        while ext.dim() < feat.dim():
+            ext = ext.unsqueeze(-1)
+        return torch.gather(feat, 1, ext.expand(feat.shape))
+
+    # -- composed_loss.py:530-570
+    def _panel_order_match(self, pred_features, gt_features):
+        B, P = pred_features.shape[0], gt_features.shape[1]
+        if self.epoch < self.config['epoch_with_order_matching']:
+            return torch.stack([torch.randperm(P, dtype=torch.long) for _ in range(B)])
+        dist = torch.cdist(pred_features.reshape(B, P, -1), gt_features.reshape(B, P, -1))
+        flat = dist.view(B, -1)
+        perm = torch.full((B, P), -1, dtype=torch.long)
+        for _ in range(P):
+            ids = flat.argmin(dim=1)
+            rows, cols = ids // P, ids % P
+            for i in range(B):
+                perm[i, rows[i]] = cols[i]
+                dist[i, rows[i], :] = float('inf')
+                dist[i, :, cols[i]] = float('inf')
+        if torch.isfinite(dist).any():
+            raise ValueError('ComposedPatternLoss::Error::Failed to match panel order')
+        return perm
+
+    # -- composed_loss.py:428-528 (stitch re-numbering not restated: stitch terms raise)
+    def _gt_order_match(self, preds, gt):
+        with torch.no_grad():
+            by = self.config['order_by']
+            if by == 'placement':
+                pf = torch.cat([preds['translations'], preds['rotations']], dim=-1)
+                gf = torch.cat([gt['translations'], gt['rotations']], dim=-1)
+            elif by == 'translation':
+                pf, gf = preds['translations'], gt['translations']
+            elif by == 'shape_translation':
+                B, P = preds['outlines'].shape[:2]
+                pf = torch.cat([preds['translations'], preds['outlines'].contiguous().view(B, P, -1)], dim=-1)
+                gf = torch.cat([gt['translations'], gt['outlines'].contiguous().view(B, P, -1)], dim=-1)
+            else:
+                raise NotImplementedError(by)
+            perm = self._panel_order_match(pf.detach().to(gf.dtype), gf)
+            self.last_permutation = perm
+            out = dict(gt)
+            out['outlines'] = self._feature_permute(gt['outlines'], perm)
+            out['num_edges'] = self._feature_permute(gt['num_edges'], perm)
+            if 'empty_panels_mask' in gt:
+                out['empty_panels_mask'] = self._feature_permute(gt['empty_panels_mask'], perm)
+            if 'rotation' in self.l_components:
+                out['rotations'] = self._feature_permute(gt['rotations'], perm)
+            if 'translation' in self.l_components:
+                out['translations'] = self._feature_permute(gt['translations'], perm)
+        return out
+
+    # -- composed_loss.py:656-703,757-765: per panel, try every edge-loop origin, keep the first best
+    def _rotate_gt(self, preds, gt, gt_num_edges):
+        with torch.no_grad():
+            pr = preds['outlines'].detach()
+            gto = gt['outlines'].to(pr.dtype)
+            B = pr.shape[0]
+            pr = pr.reshape(-1, pr.shape[-2], pr.shape[-1])
+            g = gto.reshape(-1, gto.shape[-2], gto.shape[-1])
+            chosen, leads = [], []
+            for el in range(pr.shape[0]):
+                n = int(gt_num_edges[el])
+                shifted = g[el]
+                best = ((pr[el] - shifted) ** 2).sum()
+                keep, lead = shifted, 0
+                for i in range(1, n):
+                    shifted = torch.cat((shifted[1:n], shifted[0:1, :], shifted[n:]))
+                    d = ((pr[el] - shifted) ** 2).sum()
+                    if d < best:
+                        best, keep, lead = d, shifted, i
+                chosen.append(keep)
+                leads.append(lead)
+            out = dict(gt)
+            out['outlines'] = torch.stack(chosen).view(B, -1, g.shape[-2], g.shape[-1])
+            self.last_leading_edges = torch.tensor(leads, dtype=torch.int32)
+        return out
 
     def __call__(self, preds, ground_truth, names=None, epoch=1000):
-        if self.config['panel_order_inariant_loss'] or self.config['panel_origin_invariant_loss']:
-            raise NotImplementedError('oracle restates the loss with order/origin matching off '
-                                      '(as in the shipped YAMLs)')
+        self.epoch = epoch
         if epoch >= self.config['epoch_with_stitches'] and any(
                 c in self.l_components for c in ('stitch', 'stitch_supervised', 'free_class')):
             raise NotImplementedError('stitch losses are outside the restated path')
         if 'segmentation' in self.l_components:
             raise NotImplementedError('segmentation loss is outside the restated path')
+        gt = ground_truth
+        if self.config['panel_order_inariant_loss']:
+            gt = self._gt_order_match(preds, gt)
         dt = preds['outlines'].dtype
-        num_edges = ground_truth['num_edges'].int().view(-1)
+        num_edges = gt['num_edges'].int().view(-1)
+        if self.config['panel_origin_invariant_loss']:
+            gt = self._rotate_gt(preds, gt, num_edges)
         loss, d = 0., {}
         mse = nn.functional.mse_loss
         if 'shape' in self.l_components:
-            d['pattern_loss'] = mse(preds['outlines'], ground_truth['outlines'].to(dt))
+            d['pattern_loss'] = mse(preds['outlines'], gt['outlines'].to(dt))
             loss = loss + d['pattern_loss']
         if 'loop' in self.l_components:
             d['loop_loss'] = self.loop_loss(preds['outlines'], num_edges)
             loss = loss + self.config['loop_loss_weight'] * d['loop_loss']
         if 'rotation' in self.l_components:
-            d['rotation_loss'] = mse(preds['rotations'], ground_truth['rotations'].to(dt))
+            d['rotation_loss'] = mse(preds['rotations'], gt['rotations'].to(dt))
             loss = loss + d['rotation_loss']
         if 'translation' in self.l_components:
-            d['translation_loss'] = mse(preds['translations'], ground_truth['translations'].to(dt))
+            d['translation_loss'] = mse(preds['translations'], gt['translations'].to(dt))
             loss = loss + d['translation_loss']
-        return loss, d, False
+        update = (epoch == self.config['epoch_with_order_matching'] and self.config['panel_order_inariant_loss'])
+        return loss, d, update
 
     def train(self, mode=True):
         self.training = mode
@@ -558,6 +724,22 @@ class GarmentSegmentPattern3D(GarmentFullPattern3D):
         if len(att) > 0:
             panels.update(att_weights=att)
         return panels
+
+
+class StitchOnEdge3DPairs(nn.Module):
+    """nn/nets.py:303-353 (model only: MLP([element_size, 200 x 3, 1]) on every pair row)."""
+
+    def __init__(self, data_config, config={}, in_loss_config={}):
+        super().__init__()
+        self.config = {'stitch_hidden_size': 200, 'stitch_mlp_n_layers': 3}
+        self.config.update(config)
+        mid = [self.config['stitch_hidden_size']] * self.config['stitch_mlp_n_layers']
+        self.mlp = MLP([data_config['element_size']] + mid + [1])
+
+    def forward(self, pairs_batch, **kwargs):
+        shape = list(pairs_batch.shape)
+        shape.pop(-1)
+        return self.mlp(pairs_batch.contiguous().view(-1, pairs_batch.shape[-1])).view(shape)
 
 
 # ---------------------------------------------------------------------------------------------

@@ -40,11 +40,13 @@ def load_cfg(rel):
     return data_config, cfg['NN']
 
 
-def run_case(model_name, yaml_rel, nn_override, B, N, seed, tag, keep_state):
+def run_case(model_name, yaml_rel, nn_override, B, N, seed, tag, keep_state, loss_override=None, gt_extra=False):
     data_config, nn_cfg = load_cfg(yaml_rel)
     nn_cfg = copy.deepcopy(nn_cfg)
     nn_cfg.update(nn_override)
     loss_cfg = copy.deepcopy(nn_cfg['loss'])
+    if loss_override:
+        loss_cfg.update(loss_override)
     # stitch/free_class terms only switch on at epoch >= 40; the timed unit runs at epoch 0
     torch.manual_seed(seed)
     model = getattr(ref_nets, model_name)(data_config, copy.deepcopy(nn_cfg), copy.deepcopy(loss_cfg))
@@ -56,6 +58,8 @@ def run_case(model_name, yaml_rel, nn_override, B, N, seed, tag, keep_state):
     gt = {'outlines': torch.randn(B, P, L, 4, generator=g), 'rotations': torch.randn(B, P, 4, generator=g),
           'translations': torch.randn(B, P, 3, generator=g),
           'num_edges': torch.randint(0, L + 1, (B, P), generator=g)}   # includes < 3 (skipped panels)
+    if gt_extra:   # keys the order matching permutes (nn/metrics/composed_loss.py:497-499)
+        gt['empty_panels_mask'] = gt['num_edges'] < 3
     state0 = copy.deepcopy(model.state_dict())
     torch.manual_seed(seed + 2)            # fixes the random LSTM h0/c0 draw
     preds = model(feats, log_step=0, epoch=0)
@@ -77,6 +81,23 @@ def run_case(model_name, yaml_rel, nn_override, B, N, seed, tag, keep_state):
                      if 'conv_layers.0.nn.0.2.running' in k or 'num_batches' in k and 'conv_layers.0.nn.0' in k},
         'torch': torch.__version__, 'threads': 1,
     }
+    if loss_cfg.get('panel_order_inariant_loss') or loss_cfg.get('panel_origin_invariant_loss'):
+        # what the matching decided, re-derived with the reference's own helpers on the same predictions
+        with torch.no_grad():
+            L_ = model.loss
+            L_.epoch = 0
+            L_.device = feats.device
+            gt2 = {k: v.clone() for k, v in gt.items()}
+            if loss_cfg.get('panel_order_inariant_loss'):
+                gt2 = L_._gt_order_match(preds, gt2)
+            ne = gt2['num_edges'].int().view(-1)
+            fx['gt_num_edges_after_order'] = ne.clone()
+            if loss_cfg.get('panel_origin_invariant_loss'):
+                rot, lead = L_._batch_edge_order_match(preds['outlines'], gt2['outlines'], ne)
+                fx['gt_outlines_matched'] = rot.clone()
+                fx['leading_edges'] = torch.tensor([int(v) for v in lead], dtype=torch.int32)
+            else:
+                fx['gt_outlines_matched'] = gt2['outlines'].clone()
     if keep_state:
         fx['state_dict'] = state0
         fx['grads'] = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
@@ -95,3 +116,36 @@ if __name__ == '__main__':
     run_case('GarmentFullPattern3D', lstm_yaml, {}, 2, 128, 300, 'full3d_shipped', False)
     run_case('GarmentSegmentPattern3D', att_yaml, {}, 2, 128, 400, 'segment3d_shipped', False)
     run_case('GarmentFullPattern3D', lstm_yaml, {'k_neighbors': 16}, 2, 256, 500, 'full3d_k16', False)
+    # ---- round 2 ------------------------------------------------------------------------------------------------
+    # cfg 4's neighbourhood size (k = 20 > 16: the paired fallback kernel) at model level, shipped attention YAML
+    run_case('GarmentSegmentPattern3D', att_yaml, {'k_neighbors': 20}, 2, 256, 600, 'segment3d_k20', False)
+    # global attention (local_attention False -> 403-wide point MLP; old checkpoints rely on it, nn/nets.py:210-216)
+    run_case('GarmentSegmentPattern3D', att_yaml, {'local_attention': False}, 2, 128, 700, 'segment3d_globalatt', False)
+    run_case('GarmentSegmentPattern3D', att_yaml, dict(SMALL_NN, local_attention=False), 2, 64, 710,
+             'segment3d_globalatt_small', True)
+    # the model's OWN default loss config: panel-origin matching on (nn/nets.py:83-97), and order matching on top
+    run_case('GarmentFullPattern3D', lstm_yaml, SMALL_NN, 2, 64, 800, 'full3d_originmatch', True,
+             loss_override={'panel_origin_invariant_loss': True})
+    run_case('GarmentFullPattern3D', lstm_yaml, SMALL_NN, 2, 64, 810, 'full3d_ordermatch', True,
+             loss_override={'panel_origin_invariant_loss': True, 'panel_order_inariant_loss': True,
+                            'order_by': 'shape_translation'}, gt_extra=True)
+    run_case('GarmentFullPattern3D', lstm_yaml, SMALL_NN, 2, 64, 820, 'full3d_ordermatch_placement', False,
+             loss_override={'panel_origin_invariant_loss': False, 'panel_order_inariant_loss': True,
+                            'order_by': 'placement'}, gt_extra=True)
+    # alternative blocks behind the same YAML keys (nn/net_blocks.py:121-152,273-298,405-497)
+    run_case('GarmentFullPattern3D', lstm_yaml, dict(SMALL_NN, global_pool='max'), 2, 64, 900, 'full3d_poolmax', True)
+    run_case('GarmentFullPattern3D', lstm_yaml, dict(SMALL_NN, global_pool='add'), 2, 64, 910, 'full3d_pooladd', True)
+    run_case('GarmentFullPattern3D', lstm_yaml, dict(SMALL_NN, EConv_aggr='mean'), 2, 64, 920, 'full3d_aggrmean', True)
+    run_case('GarmentFullPattern3D', lstm_yaml, dict(SMALL_NN, EConv_aggr='add'), 2, 64, 930, 'full3d_aggradd', True)
+    run_case('GarmentFullPattern3D', lstm_yaml, dict(SMALL_NN, EConv_hidden_depth=1), 2, 64, 940, 'full3d_depth1', True)
+    run_case('GarmentFullPattern3D', lstm_yaml, dict(SMALL_NN, EConv_hidden_depth=3), 2, 64, 950, 'full3d_depth3', True)
+    run_case('GarmentFullPattern3D', lstm_yaml, dict(SMALL_NN, panel_decoder='MLPDecoder', panel_n_layers=2,
+                                                     pattern_decoder='MLPDecoder', pattern_n_layers=1),
+             2, 64, 960, 'full3d_mlpdec', False)
+    run_case('GarmentFullPattern3D', lstm_yaml, dict(SMALL_NN, panel_decoder='GRUDecoderModule',
+                                                     pattern_decoder='GRUDecoderModule'), 2, 64, 970, 'full3d_gru', True)
+    run_case('GarmentFullPattern3D', lstm_yaml, dict(SMALL_NN, panel_decoder='LSTMDoubleReverseDecoderModule',
+                                                     pattern_decoder='LSTMDoubleReverseDecoderModule'),
+             2, 64, 980, 'full3d_lstm2rev', True)
+    run_case('GarmentSegmentPattern3D', att_yaml, dict(SMALL_NN, global_pool='max'), 2, 64, 990, 'segment3d_poolmax', True)
+    run_case('GarmentSegmentPattern3D', att_yaml, dict(SMALL_NN, global_pool='add'), 2, 64, 995, 'segment3d_pooladd', True)

@@ -31,16 +31,25 @@ WORKER = textwrap.dedent('''
     model.load_state_dict(ref.state_dict())
     ddp = DistributedHotPath(model, device_ids=[], bucket_bytes=2048)      # several buckets
     assert len(ddp._buckets) > 1
+    g0 = ddp.arena.grad
     for step in range(2):                                                  # hooks must re-arm after each step
-        model.zero_grad(set_to_none=True)
+        ddp.arena.zero_grad()
         sl = slice(rank * 4, rank * 4 + 4)
         ((ddp(full_x[sl]) - full_y[sl]) ** 2).mean().backward()
         ddp.finish_gradient_sync()
         for (n, p), (_, q) in zip(model.named_parameters(), ref.named_parameters()):
+            # gradients are permanent views into the arena: reduced in place, no per-parameter copies
+            assert p.grad.untyped_storage().data_ptr() == g0.untyped_storage().data_ptr(), n
             if q.grad is None:
-                assert p.grad is None, n
+                assert not p.grad.any(), n                                  # never produced: stays zero on every rank
             else:
                 assert torch.allclose(p.grad, q.grad, rtol=1e-5, atol=1e-7), (n, step)
+    try:                                                                   # dropping the views must fail loudly
+        model.zero_grad(set_to_none=True)
+        ((ddp(full_x[:4]) - full_y[:4]) ** 2).mean().backward()
+        raise SystemExit('expected the lost-view check to fire')
+    except RuntimeError as e:
+        assert 'arena gradient view' in str(e)
     dist.barrier()
     dist.destroy_process_group()
     print('rank', rank, 'ok')

@@ -13,7 +13,12 @@ import torch
 
 from oracle import ref_path as O
 
-CASES = ['full3d_small', 'segment3d_small', 'full3d_shipped', 'segment3d_shipped', 'full3d_k16']
+CASES = ['full3d_small', 'segment3d_small', 'full3d_shipped', 'segment3d_shipped', 'full3d_k16',
+         # round 2: k = 20, global attention, the matching pre-processing of the loss, the alternative blocks
+         'segment3d_k20', 'segment3d_globalatt', 'segment3d_globalatt_small', 'full3d_originmatch', 'full3d_ordermatch',
+         'full3d_ordermatch_placement', 'full3d_poolmax', 'full3d_pooladd', 'full3d_aggrmean', 'full3d_aggradd',
+         'full3d_depth1', 'full3d_depth3', 'full3d_mlpdec', 'full3d_gru', 'full3d_lstm2rev', 'segment3d_poolmax',
+         'segment3d_pooladd']
 
 
 def _build(fx):
@@ -57,6 +62,9 @@ def test_oracle_matches_reference_fixture(tag, golden_dir):
                 torch.testing.assert_close(p.grad, fx['grads'][n], rtol=1e-5, atol=1e-8)
     for k, v in fx['bn_after'].items():
         torch.testing.assert_close(model.state_dict()[k], v, rtol=1e-6, atol=1e-8)
+    # the ground-truth matching in front of the loss: same decisions as the reference's own helpers
+    if 'leading_edges' in fx:
+        assert torch.equal(model.loss.last_leading_edges, fx['leading_edges'])
 
 
 def test_oracle_fp64_mode_runs(golden_dir):
