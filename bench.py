@@ -13,8 +13,12 @@ Rank 0 prints ONE JSON line.  `value` = garments processed by all ranks / max-ov
 steps (barrier + synchronize on both sides).  Extra objects:
   roofline      — the dominant kernel family of the step (MFMA-bound fp32 edge-MLP GEMMs): algorithmic FLOPs per
                   launch / average launch duration from HIP events on the launch stream, vs 157.3 TFLOP/s;
-  roofline_gather — the EdgeConv neighbourhood gather (HBM/L2-bound): algorithmic bytes / duration vs 8 TB/s;
-  cpu_baseline  — the CPU oracle (oracle/ref_path.py, kind "port") timed on this box's host cores on a bounded sample.
+  roofline_gather — the EdgeConv neighbourhood gather: bytes_gather = N*k*(C*s+4) + N*C*s + N*F*s
+                  per garment and layer, for (a) the kernel that carries the layer-2 gather (the fused gather->GEMM
+                  forward, MFMA-bound: its time is NOT a bandwidth measurement) and (b) the stand-alone gather + BN
+                  statistics pass (bandwidth-bound), each next to the counter-derived HBM bytes of the committed PMC pass;
+  cpu_baseline  — the CPU oracle (oracle/ref_path.py, kind "port") timed on this box's host cores on a bounded sample
+                  (cfg-2 shape and the reference's own cfg-1 shape).
 """
 import argparse
 import json
@@ -42,12 +46,13 @@ def parse():
     ap.add_argument('--k', type=int, default=16)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-batch', type=int, default=8)
-    ap.add_argument('--cpu-steps', type=int, default=2)
-    ap.add_argument('--cpu-threads', type=int, default=32)
+    ap.add_argument('--cpu-steps', type=int, default=3)
+    ap.add_argument('--cpu-threads', type=int, default=0, help='0 = all host cores (nproc)')
     ap.add_argument('--no-kernel-timing', action='store_true')
-    ap.add_argument('--math', choices=['f32', 'bf16x3'], default='f32',
+    ap.add_argument('--math', choices=['f32', 'mixed', 'bf16x3'], default='f32',
                     help="arithmetic of the fused edge GEMMs for the timed region (gpe_math_set); 'f32' = exact")
-    ap.add_argument('--no-fast-math-line', action='store_true', help='skip the extra bf16x3 measurement')
+    ap.add_argument('--no-fast-math-line', action='store_true', help='skip the extra mixed / bf16x3 measurements')
+    ap.add_argument('--torch-adam', action='store_true', help='torch.optim.Adam instead of the fused arena optimizer')
     return ap.parse_args()
 
 
@@ -79,9 +84,9 @@ def call_work(name, a):
     if name == 'gpe_redgemm':               # ..., rows, Mg, Ng, ldg, accumulate
         rows, Mg, Ng = a[-5], a[-4], a[-3]
         return 2.0 * rows * Mg * Ng, 0.0
-    if name == 'gpe_edge_gather_stats':     # ldpq, H, B, N, k : compulsory bytes = PQ once + the kNN graph once
-        H, B, N, k = a[1], a[2], a[3], a[4]  # (the k-fold neighbour re-reads are L2/MALL hits, not HBM work)
-        return 0.0, float(B) * N * (2 * H * 4 + k * 4)
+    if name == 'gpe_edge_gather_stats':     # ldpq, H, B, N, k : SURVEY 8(d) bytes_gather with C = H (P|Q rows), no output row
+        H, B, N, k = a[1], a[2], a[3], a[4]
+        return 0.0, float(B) * (N * k * (H * 4 + 4) + N * H * 4)
     if name == 'gpe_edge_pull_dq':          # lddz, B, N, k, H, lddq : dz rows read once through the reversed graph
         B, N, k, H = a[1], a[2], a[3], a[4]
         return 0.0, float(B) * N * (k * (H * 4 + 4) + H * 4)
@@ -96,6 +101,9 @@ _TRAFFIC_KERNELS = {
     'gpe_edge_mlp_bwd': r'gpe_rowgemm_kernel<.*, [23]>$|gpe_edgegemm(_sr)?_kernel<.*, [23], \w+>$',
     'gpe_edge_redgemm': r'gpe_redgemm_pc_kernel<',
     'gpe_edge_gather_stats': r'gpe_gather_stats_kernel',
+    'gpe_edge_mlp_fwd:gather': r'gpe_edgegemm(_sr)?_kernel<\d+, \d+, \d+, 1, 1, \w+>$',     # AMODE = A_GATHER, EMODE = fwd
+    'gpe_knn': r'gpe_knn_kernel',
+    'gpe_edge_pull_dq': r'gpe_pull_dq_kernel',
 }
 
 
@@ -114,39 +122,51 @@ def pmc_traffic(entry):
     return (b / n, 'profiles/' + os.path.basename(files[-1])) if n else (None, None)
 
 
-def cpu_baseline(args, data_config, nn_cfg):
-    """The CPU oracle (pure torch restatement of the reference path + C kNN) on this box's host cores."""
-    import copy
-    from oracle import ref_path as O
-    # torch's intra-op pool stops scaling (and then collapses) long before a 2-socket EPYC's core count on this
-    # op mix; 32 threads is the measured sweet spot class for oneDNN/MKL at these sizes
-    ncores = min(os.cpu_count() or 1, args.cpu_threads)
-    torch.set_num_threads(ncores)
-    O.KNN_IMPL = 'torch'          # cdist+topk: a fair CPU kNN (the parity oracle's scalar C loop is a definition, not a baseline)
-    torch.manual_seed(0)
-    model = O.GarmentFullPattern3D(data_config, copy.deepcopy(nn_cfg), copy.deepcopy(nn_cfg['loss'])).train()
-    feats, gt = O.synthetic_batch(args.cpu_batch, args.points, data_config, seed=0)
-    times = []
-    for step in range(1 + args.cpu_steps):
-        t0 = time.perf_counter()
-        model.zero_grad(set_to_none=True)
-        O.train_step(model, feats, {k: v.clone() for k, v in gt.items()}, epoch=0, seed=step)
-        times.append(time.perf_counter() - t0)
-    t = sum(times[1:]) / len(times[1:])
-    cpu_name = ''
+def _cpu_name():
     try:
         with open('/proc/cpuinfo') as f:
             for line in f:
                 if line.startswith('model name'):
-                    cpu_name = line.split(':', 1)[1].strip()
-                    break
+                    return line.split(':', 1)[1].strip()
     except OSError:
         pass
+    return ''
+
+
+def cpu_baseline(args, data_config, nn_cfg):
+    """The CPU oracle (pure torch restatement of the reference path; kNN by cdist+topk, a fair CPU kNN — the parity
+    oracle's scalar C loop is a definition, not a baseline) on this box's host cores: all of them (nproc) unless
+    --cpu-threads says otherwise, 1 warm-up + >= 3 timed steps of fwd + loss + bwd."""
+    import copy
+    from oracle import ref_path as O
+    ncores = args.cpu_threads if args.cpu_threads > 0 else (os.cpu_count() or 1)
+    torch.set_num_threads(ncores)
+    O.KNN_IMPL = 'torch'
+
+    def timed(B, N, k, steps):
+        cfg = copy.deepcopy(nn_cfg)
+        cfg['k_neighbors'] = k
+        torch.manual_seed(0)
+        model = O.GarmentFullPattern3D(data_config, copy.deepcopy(cfg), copy.deepcopy(cfg['loss'])).train()
+        feats, gt = O.synthetic_batch(B, N, data_config, seed=0)
+        times = []
+        for step in range(1 + steps):
+            t0 = time.perf_counter()
+            model.zero_grad(set_to_none=True)
+            O.train_step(model, feats, {k_: v.clone() for k_, v in gt.items()}, epoch=0, seed=step)
+            times.append(time.perf_counter() - t0)
+        return sum(times[1:]) / len(times[1:])
+
+    t2 = timed(args.cpu_batch, args.points, args.k, args.cpu_steps)
+    t1 = timed(8, 1024, 5, max(args.cpu_steps, 5))          # BASELINE cfg 1: the reference's own CPU-runnable case
     O.KNN_IMPL = 'c'
-    return {'value': args.cpu_batch / t, 'unit': 'garments/s', 'cores': ncores, 'kind': 'port',
-            'sample': 'oracle/ref_path.py (kNN by cdist+topk) fwd+loss+bwd, B=%d N=%d k=%d fp32, 1 warm-up + %d timed steps, %.2f s/step'
-                      % (args.cpu_batch, args.points, args.k, args.cpu_steps, t),
-            'cpu': cpu_name}
+    return {'value': args.cpu_batch / t2, 'unit': 'garments/s', 'cores': ncores, 'kind': 'port',
+            'sample': 'oracle/ref_path.py (kNN by cdist+topk) fwd+loss+bwd, B=%d N=%d k=%d fp32, 1 warm-up + %d timed '
+                      'steps, %.2f s/step' % (args.cpu_batch, args.points, args.k, args.cpu_steps, t2),
+            'cfg1': {'value': 8 / t1, 'unit': 'garments/s',
+                     'sample': 'BASELINE cfg 1 (N=1024, B=8, k=5), 1 warm-up + %d timed steps, %.3f s/step'
+                               % (max(args.cpu_steps, 5), t1)},
+            'cpu': _cpu_name(), 'nproc': os.cpu_count()}
 
 
 def main():
@@ -165,8 +185,16 @@ def main():
     torch.manual_seed(0)                               # identical replicas on every rank
     model = nets.GarmentFullPattern3D(data_config, dict(nn_cfg), dict(nn_cfg['loss'])).to(dev).train()
     model.loss.with_quality_eval = False
-    wrapped = parallel.DistributedHotPath(model, device_ids=[dev])
-    opt = torch.optim.Adam(model.parameters(), lr=2e-3)
+    from gpe_amd import optim
+    if args.torch_adam:
+        arena = optim.FlatArena(model, register_sink=False)
+        opt = torch.optim.Adam(model.parameters(), lr=2e-3)
+    else:
+        # parameters + gradients in one flat arena: backward kernels write gradients in place, the all-reduce buckets are
+        # slices of it, Adam (+ zero_grad) is one launch (nn/trainer.py:162-185: Adam, lr 0.002)
+        arena = optim.FlatArena(model)
+        opt = optim.FusedAdam(arena, lr=2e-3)
+    wrapped = parallel.DistributedHotPath(model, device_ids=[dev], arena=arena)
     feats, gt = synthetic(args.batch, args.points, data_config, seed=1000 + rank, device=dev)
 
     def step(i):
@@ -176,7 +204,8 @@ def main():
         loss.backward()
         wrapped.finish_gradient_sync()
         opt.step()
-        opt.zero_grad(set_to_none=True)
+        if args.torch_adam:
+            arena.zero_grad()
         return loss
 
     def barrier():
@@ -231,33 +260,63 @@ def main():
                 'frac': ach / PEAK_F32_TFLOPS, 'traffic': traffic, 'traffic_unit': 'HBM bytes/launch',
                 'traffic_source': tsrc, 'launches_per_step': n_l / nsteps,
                 'avg_launch_ms': ms / n_l, 'flops_per_launch': fl / n_l}
+        # ---- the EdgeConv gather, SURVEY.md §8(d) row 5: bytes_gather(layer) per garment, s = 4 (fp32) -------------
+        H, F = nn_cfg['EConv_hidden'], nn_cfg['EConv_feature']
+
+        def bytes_gather(C):
+            return float(args.batch) * (args.points * args.k * (C * 4 + 4) + args.points * C * 4 + args.points * F * 4)
+
+        roof_gather = {'definition': 'bytes_gather(layer) = N*k*(C_in*s+4) + N*C_in*s + N*F*s per garment (SURVEY.md 8d), '
+                                     'x batch; layer 1 C_in=3, layer 2 C_in=%d; s=4' % F,
+                       'bytes_layer1': bytes_gather(3), 'bytes_layer2': bytes_gather(F), 'peak': PEAK_HBM_GBS,
+                       'unit': 'GB/s'}
         if 'gpe_edge_gather_stats' in agg:
             n_l, ms, _, by = agg['gpe_edge_gather_stats']
             ach = by / (ms * 1e-3) / 1e9
-            roof_gather = {'kernel': 'gpe_edge_gather_stats', 'bound': 'hbm', 'achieved': ach, 'peak': PEAK_HBM_GBS,
-                           'unit': 'GB/s', 'frac': ach / PEAK_HBM_GBS,
-                           'traffic': pmc_traffic('gpe_edge_gather_stats')[0],
-                           'avg_launch_ms': ms / n_l, 'bytes_per_launch': by / n_l}
+            roof_gather['stats_pass'] = {
+                'kernel': 'gpe_edge_gather_stats (k-fold neighbour gather of the [P|Q] rows + fp64 BN statistics)',
+                'bound': 'hbm', 'algorithmic_bytes_per_launch': by / n_l, 'avg_launch_ms': ms / n_l,
+                'achieved': ach, 'frac': ach / PEAK_HBM_GBS,
+                'traffic': pmc_traffic('gpe_edge_gather_stats')[0],
+                'note': 'algorithmic bytes = N*k*(H*4+4) + N*H*4 per garment: what the gather touches; the Q table of a '
+                        'cloud is L2-resident by design, so achieved > HBM peak means the gather is served by L2 and the '
+                        'counter bytes (traffic) are the HBM side'}
+        # the kernel that carries the layer-2 gather into the matrix pipe (gather -> GEMM -> ReLU -> stats, fused)
+        gl = [(ints, e0.elapsed_time(e1)) for name, ints, e0, e1 in rec if name == 'gpe_edge_mlp_fwd' and ints[0] == 0]
+        if gl:
+            ms = sum(t for _, t in gl) / len(gl)
+            by = float(args.batch) * (args.points * args.k * (H * 4 + 4) + args.points * H * 4)
+            roof_gather['fused_forward'] = {
+                'kernel': 'gpe_edge_mlp_fwd a_mode=0 (gather -> LDS tile -> fp32 MFMA): MFMA-bound, the gather hides under '
+                          'the matrix pipe', 'bound': 'mfma', 'gather_bytes_per_launch': by, 'avg_launch_ms': ms,
+                'gather_rate_GBs': by / (ms * 1e-3) / 1e9, 'traffic': pmc_traffic('gpe_edge_mlp_fwd:gather')[0]}
+        roof_gather['frac'] = roof_gather.get('stats_pass', {}).get('frac')
+        roof_gather['achieved'] = roof_gather.get('stats_pass', {}).get('achieved')
+        roof_gather['traffic'] = roof_gather.get('stats_pass', {}).get('traffic')
+        roof_gather['bound'] = 'hbm'
 
     # the opt-in fast mode, measured the same way on the same workload (reported beside `value`, never as `value`)
     fast = None
     if world == 1 and args.math == 'f32' and not args.no_fast_math_line:
-        gpe_amd.set_math('bf16x3')
-        n_f = max(3, min(args.steps, 10))
-        for i in range(2):
-            step(10_000 + i)
-        barrier()
-        t1 = time.perf_counter()
-        for i in range(n_f):
-            step(10_002 + i)
-        barrier()
-        dt = time.perf_counter() - t1
+        fast = {}
+        for mode, note in (('mixed', 'split-bf16 row GEMMs (forward + input-gradient half) on the bf16 matrix pipe, exact-fp32 '
+                                     'weight-gradient / BN-coefficient products: meets the same gradient tolerances as f32 in '
+                                     'tests/test_gpu_model.py; opt-in via gpe_math_set(2) / GPE_MATH=mixed'),
+                           ('bf16x3', 'every fused edge GEMM split-bf16: forward within 1e-4 of the reference, encoder '
+                                      'gradients within ~1e-2 (tests/test_gpu_kernels.py TOL); gpe_math_set(1)')):
+            gpe_amd.set_math(mode)
+            n_f = max(3, min(args.steps, 10))
+            for i in range(2):
+                step(10_000 + i)
+            barrier()
+            t1 = time.perf_counter()
+            for i in range(n_f):
+                step(10_002 + i)
+            barrier()
+            dt = time.perf_counter() - t1
+            fast[mode] = {'value': args.batch * n_f / dt, 'unit': 'garments/s', 'steps': n_f,
+                          'ms_per_step': dt / n_f * 1e3, 'note': note}
         gpe_amd.set_math('f32')
-        fast = {'math': 'bf16x3', 'value': args.batch * n_f / dt, 'unit': 'garments/s', 'steps': n_f,
-                'ms_per_step': dt / n_f * 1e3,
-                'note': 'split-bf16 edge GEMMs on the bf16 matrix pipe, fp32 accumulate: forward within 1e-4 of the '
-                        'reference, encoder gradients within ~1e-2 (tests/test_gpu_kernels.py TOL); opt-in via '
-                        'gpe_math_set(1) / GPE_MATH=bf16x3'}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -274,7 +333,8 @@ def main():
                                    ' + LSTM decoders' % (args.points, args.batch, args.k),
                        'global_batch': args.batch * world, 'parallelism': 'dp%d' % world,
                        'step': 'fwd + ComposedPatternLoss + bwd' + (' + RCCL grad all-reduce' if world > 1 else '')
-                               + ' + Adam', 'final_loss': final_loss},
+                               + (' + Adam (torch)' if args.torch_adam else ' + fused Adam (flat arena)'),
+                       'final_loss': final_loss},
             'roofline': roof, 'roofline_gather': roof_gather, 'cpu_baseline': cpu, 'fast_math': fast,
             'kernel_ms_per_step': breakdown}
         print(json.dumps(out))

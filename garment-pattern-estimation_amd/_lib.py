@@ -62,12 +62,12 @@ def lib():
     return _lib
 
 
-MATH_MODES = {'f32': 0, 'bf16x3': 1}
+MATH_MODES = {'f32': 0, 'bf16x3': 1, 'mixed': 2}
 
 
 def set_math(mode):
-    """Arithmetic of the fused per-edge GEMMs: 'f32' (exact fp32 MFMA) or 'bf16x3' (split-bf16 on the bf16 matrix
-    pipe, fp32 accumulate) — include/gpe_hip.h gpe_math_set.  Returns the previous mode's name.  The environment
+    """Arithmetic of the fused per-edge GEMMs: 'f32' (exact fp32 MFMA), 'bf16x3' (split-bf16 on the bf16 matrix
+    pipe, fp32 accumulate) or 'mixed' (split-bf16 row GEMMs, exact-fp32 weight-gradient reduce-GEMM) — include/gpe_hip.h gpe_math_set.  Returns the previous mode's name.  The environment
     variable GPE_MATH selects the mode at library load."""
     if mode not in MATH_MODES:
         raise ValueError('unknown math mode %r (choose from %s)' % (mode, sorted(MATH_MODES)))

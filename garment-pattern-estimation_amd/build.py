@@ -25,9 +25,15 @@ def _stale(obj, src):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+COMPILED, REUSED = [], []
+
+
 def _compile(src):
     obj = os.path.join(CSRC, src[:-4] + '.o')
-    if _stale(obj, src):
+    if not _stale(obj, src):
+        REUSED.append(src)
+    else:
+        COMPILED.append(src)
         cmd = [HIPCC] + FLAGS + ['-c', os.path.join(CSRC, src), '-o', obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
@@ -38,6 +44,8 @@ def _compile(src):
 
 
 def build(force=False, verbose=True):
+    force = force or os.environ.get('GPE_FORCE_BUILD') == '1'
+    del COMPILED[:], REUSED[:]
     srcs = _sources()
     if force:
         for s in srcs:
@@ -53,6 +61,10 @@ def build(force=False, verbose=True):
             raise RuntimeError('link failed:\n' + r.stderr[-4000:])
         if verbose:
             print('built', OUT)
+    if verbose:
+        # say what this call actually did: a driver-side "does it build" check must not mistake reuse for a compile
+        print('build: compiled %d source(s) %s; reused %d up-to-date object(s) %s (force=%s; GPE_FORCE_BUILD=1 or '
+              'build(force=True) recompiles everything)' % (len(COMPILED), COMPILED, len(REUSED), REUSED, force))
     return OUT
 
 

@@ -32,6 +32,10 @@ int gpe_debug_set(int flags);
  *   0 = "f32"    exact fp32 matrix instruction (v_mfma_f32_16x16x4_f32)
  *   1 = "bf16x3" split-bf16: every fp32 operand x = hi + lo (two bf16), a*b ~= ah*bh + ah*bl + al*bh on the bf16 matrix
  *                pipe with fp32 accumulation (relative error ~1e-5 per product instead of ~1e-7).
+ *   2 = "mixed"  split-bf16 for the per-edge ROW GEMMs (forward and the input-gradient half of backward, whose
+ *                rounding errors are independent per element and average out), exact fp32 for the weight-gradient
+ *                reduce-GEMM  G = dz^T (a - mean): G also feeds the BatchNorm-backward coefficients, residuals of large
+ *                sums where a coherent 1e-5 product error would surface as a 1e-2 gradient error.
  * Returns the previous mode, or -22 for an unknown one.  kNN, BatchNorm statistics, the LSTM decoder and every
  * elementwise op are fp32 (fp64 for reductions) in both modes. */
 int gpe_math_set(int mode);

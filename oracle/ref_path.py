@@ -301,6 +301,7 @@ class LSTMDecoderModule(nn.Module):
         self.lin = nn.Linear(hidden_size, out_elem_size)
         _init_weights(self.lstm, init_type=custom_init)
         self.last_states = None
+        self.state_override = None
 
     def forward(self, batch_enc, out_len):
         bs = batch_enc.size(0)
@@ -308,6 +309,8 @@ class LSTMDecoderModule(nn.Module):
         # reference order: hidden first, then cell (nn/net_blocks.py:391-392); fp32 draw, then cast
         h0 = _init_tenzor(self.n_layers, bs, self.hidden_size, init_type=self.custom_init).to(batch_enc.dtype)
         c0 = _init_tenzor(self.n_layers, bs, self.hidden_size, init_type=self.custom_init).to(batch_enc.dtype)
+        if self.state_override is not None:       # tests: replay the start states another run drew (slice checks)
+            h0, c0 = (t.to(batch_enc.dtype) for t in self.state_override)
         self.last_states = (h0, c0)
         out, _ = self.lstm(dec_input, (h0, c0))
         out = self.lin(out.contiguous().view(-1, self.hidden_size))

@@ -107,6 +107,44 @@ def run_case(model_name, yaml_rel, nn_override, B, N, seed, tag, keep_state, los
                                                           os.path.getsize(out) / 1024))
 
 
+def run_stitch_known_answer():
+    """The only trained weights the reference ships (models/att/neural_tailor_stitch_model.pth): StitchOnEdge3DPairs =
+    MLP([16, 200, 200, 200, 1]) with real BatchNorm running statistics.  Eval-mode outputs of the reference's own class
+    on seeded pair features are a true known-answer test for the eval path of the dense-MLP kernels; a training-mode
+    fwd/bwd (batch statistics) from the same weights is stored as well."""
+    with open(os.path.join(REF, 'models/att/stitch_model.yaml')) as f:
+        cfg = yaml.safe_load(f)
+    data_config = dict(cfg['dataset'])
+    ckpt = torch.load(os.path.join(REF, 'models/att/neural_tailor_stitch_model.pth'), map_location='cpu',
+                      weights_only=False)
+    sd = {k[len('module.'):]: v.clone() for k, v in ckpt['model_state_dict'].items()}
+    nn_cfg = copy.deepcopy(cfg['NN'])
+    model = ref_nets.StitchOnEdge3DPairs(data_config, copy.deepcopy(nn_cfg), copy.deepcopy(nn_cfg.get('loss', {})))
+    model.load_state_dict(sd)
+    g = torch.Generator().manual_seed(4242)
+    pairs = torch.randn(6, 50, data_config['element_size'], generator=g)
+    labels = (torch.rand(6, 50, generator=g) < 0.2)
+    model.eval()
+    with torch.no_grad():
+        out_eval = model(pairs).clone()
+    model.train()
+    model.loss.with_quality_eval = False
+    out_train = model(pairs)
+    loss, loss_dict, _ = model.loss(out_train, labels)
+    loss.backward()
+    fx = {'model': 'StitchOnEdge3DPairs', 'data_config': {'element_size': data_config['element_size']},
+          'nn_config': {k: nn_cfg[k] for k in ('stitch_hidden_size', 'stitch_mlp_n_layers') if k in nn_cfg},
+          'state_dict': sd, 'pairs': pairs, 'labels': labels, 'out_eval': out_eval,
+          'out_train': out_train.detach().clone(), 'loss': loss.detach().clone(),
+          'grads': {n: p.grad.clone() for n, p in model.named_parameters()},
+          'state_after_train': {k: v.clone() for k, v in model.state_dict().items()},
+          'torch': torch.__version__, 'threads': 1}
+    out = os.path.join(REPO, 'tests', 'golden', 'stitch_pairs_known_answer.pt')
+    torch.save(fx, out)
+    print('%-28s eval |out| max %.4f  loss=%.6f  %.1f KB' % ('stitch_pairs_known_answer', out_eval.abs().max().item(),
+                                                         loss.item(), os.path.getsize(out) / 1024))
+
+
 if __name__ == '__main__':
     os.makedirs(os.path.join(REPO, 'tests', 'golden'), exist_ok=True)
     lstm_yaml, att_yaml = 'models/baseline/lstm_stitch_tags.yaml', 'models/att/att.yaml'
@@ -149,3 +187,4 @@ if __name__ == '__main__':
              2, 64, 980, 'full3d_lstm2rev', True)
     run_case('GarmentSegmentPattern3D', att_yaml, dict(SMALL_NN, global_pool='max'), 2, 64, 990, 'segment3d_poolmax', True)
     run_case('GarmentSegmentPattern3D', att_yaml, dict(SMALL_NN, global_pool='add'), 2, 64, 995, 'segment3d_pooladd', True)
+    run_stitch_known_answer()

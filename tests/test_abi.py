@@ -37,6 +37,7 @@ def test_math_mode_switch_is_host_only():
     assert _lib.get_math() in _lib.MATH_MODES
     prev = _lib.set_math('bf16x3')
     assert _lib.get_math() == 'bf16x3' and _lib.lib().gpe_math_set(7) == -22
+    assert _lib.set_math('mixed') == 'bf16x3' and _lib.set_math('bf16x3') == 'mixed'
     assert _lib.set_math(prev) == 'bf16x3' and _lib.get_math() == prev
 
 
