@@ -52,7 +52,7 @@ __device__ __forceinline__ unsigned gpe_udiv(unsigned n, unsigned d, double rcp)
 // ---- per-device launch state ------------------------------------------------------------------------------------------
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a PER-DEVICE property of a kernel: a process that drives several
 // GPUs (nn.DataParallel-style) must set it once on each.  One bit per device ordinal per call site.
-#define GPE_ENSURE_MAX_LDS(fn)                                                                                   \
+#define GPE_ENSURE_MAX_LDS_N(fn, bytes_)                                                                         \
     do {                                                                                                         \
         static unsigned long long done_ = 0;                                                                     \
         int dev_ = 0;                                                                                            \
@@ -60,11 +60,14 @@ __device__ __forceinline__ unsigned gpe_udiv(unsigned n, unsigned d, double rcp)
         const unsigned long long bit_ = 1ull << (dev_ & 63);                                                     \
         if (!(done_ & bit_)) {                                                                                   \
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                    160 * 1024) != hipSuccess)                                                   \
+                                    (bytes_)) != hipSuccess)                                                     \
                 return GPE_ELAUNCH;                                                                              \
             done_ |= bit_;                                                                                       \
         }                                                                                                        \
     } while (0)
+
+// kernels with static __shared__ arrays must leave room for them below the 160 KB of a CU
+#define GPE_ENSURE_MAX_LDS(fn) GPE_ENSURE_MAX_LDS_N(fn, 160 * 1024)
 
 // compute units of the CURRENT device (cached per device ordinal); defined in gpe_pointwise.hip
 int gpe_num_cus();

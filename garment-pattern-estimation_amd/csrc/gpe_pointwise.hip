@@ -661,7 +661,7 @@ extern "C" int gpe_knn_reverse(const int32_t* idx, int B, int N, int k, int32_t*
     if (!idx || !rev_off || !rev_edge || B <= 0 || N <= 0 || k <= 0) return GPE_EINVAL;
     const size_t lds = (size_t)(2 * N + 1) * sizeof(int);
     if (lds > 150 * 1024) return GPE_EINVAL;
-    GPE_ENSURE_MAX_LDS((gpe_knn_reverse_kernel));
+    GPE_ENSURE_MAX_LDS_N((gpe_knn_reverse_kernel), 150 * 1024);
     hipLaunchKernelGGL(gpe_knn_reverse_kernel, dim3(B), dim3(1024), lds, (hipStream_t)stream, idx, N, k, rev_off,
                        rev_edge);
     GPE_CHECK_LAUNCH();

@@ -421,7 +421,7 @@ extern "C" int gpe_attn_pool_fwd(const float* w, int ldw, const float* feat, int
     const int nslab = gpe_cdiv(N, AP_ROWS);
     const size_t lds = (size_t)AP_ROWS * (P + C) * sizeof(float);
     if (lds > 150 * 1024) return GPE_EINVAL;
-    GPE_ENSURE_MAX_LDS((gpe_attn_pool_part_kernel));
+    GPE_ENSURE_MAX_LDS_N((gpe_attn_pool_part_kernel), 150 * 1024);
     hipLaunchKernelGGL(gpe_attn_pool_part_kernel, dim3(nslab, B), dim3(256), lds, (hipStream_t)stream, w, ldw, feat, ldf, N,
                        P, C, mode, nslab, part, part_arg);
     hipLaunchKernelGGL(gpe_attn_pool_final_kernel, dim3(gpe_cdiv(P * C, 256), B), dim3(256), 0, (hipStream_t)stream, part,
@@ -504,7 +504,7 @@ extern "C" int gpe_attn_pool_bwd(const float* w, int ldw, const float* feat, int
     } else {
         const size_t lds = (size_t)P * C * sizeof(float);
         if (lds > 150 * 1024) return GPE_EINVAL;
-        GPE_ENSURE_MAX_LDS((gpe_attn_pool_bwd_kernel));
+        GPE_ENSURE_MAX_LDS_N((gpe_attn_pool_bwd_kernel), 150 * 1024);
         int chunks = gpe_cdiv(2048, B);                    // ~2048 workgroups in total
         if (chunks > gpe_cdiv(N, 4)) chunks = gpe_cdiv(N, 4);
         if (chunks < 1) chunks = 1;
