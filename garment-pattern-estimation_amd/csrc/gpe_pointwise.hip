@@ -94,9 +94,9 @@ __global__ __launch_bounds__(256) void gpe_pack_multi_kernel(const GpePackJob* _
     switch (jb.kind) {
         case 0: if (n < jb.N && k < jb.K) v = w[(size_t)n * ldw + k]; break;
         case 1: if (n < jb.N && k < jb.K) v = w[(size_t)k * ldw + n]; break;
-        case 2: {                                                   // LSTM gates, aux = H
-            const int H = jb.aux;
-            const int b = n >> 6, gate = (n >> 4) & 3, u = (b << 4) + (n & 15);
+        case 2: {                                                   // gate-interleaved (LSTM G = 4, GRU G = 3), aux = H
+            const int H = jb.aux, G = jb.N / H;
+            const int b = n / (16 * G), gate = (n / 16) % G, u = (b << 4) + (n & 15);
             if (u < H && k < jb.K) v = w[(size_t)(gate * H + u) * ldw + k];
             break;
         }
@@ -144,6 +144,36 @@ __global__ void gpe_pack_gates_kernel(const float* __restrict__ w, int ldw, int 
 }
 
 extern "C" long gpe_packed_gates_size(int H, int K) { return 64L * gpe_cdiv(H, 16) * gpe_round_up(K, 16); }
+
+// the same for G gates (G = 3: nn.GRU rows r|z|n): packed row b*16G + gate*16 + u'  <->  original row gate*H + 16b + u'
+__global__ void gpe_pack_ngates_kernel(const float* __restrict__ w, int ldw, int H, int G, int K, float* __restrict__ wp,
+                                       int Npad, long total)
+{
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= total) return;
+    const int t = (int)(e & 3);
+    const long r = e >> 2;
+    const int n = (int)(r % Npad);
+    const long kq = r / Npad;
+    const int k = (int)(kq * 4 + t);
+    const int b = n / (16 * G), gate = (n / 16) % G, u = (b << 4) + (n & 15);
+    float v = 0.f;
+    if (u < H && k < K) v = w[(size_t)(gate * H + u) * ldw + k];
+    wp[e] = v;
+}
+
+extern "C" long gpe_packed_ngates_size(int H, int G, int K) { return 16L * G * gpe_cdiv(H, 16) * gpe_round_up(K, 16); }
+
+extern "C" int gpe_pack_weight_ngates(const float* w, int ldw, int H, int G, int K, float* wp, void* stream)
+{
+    if (!w || !wp || H <= 0 || K <= 0 || G <= 0 || G > 8 || ldw < K) return GPE_EINVAL;
+    const int Npad = 16 * G * gpe_cdiv(H, 16);
+    const long total = (long)Npad * gpe_round_up(K, 16);
+    hipLaunchKernelGGL(gpe_pack_ngates_kernel, dim3(gpe_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, w, ldw, H,
+                       G, K, wp, Npad, total);
+    GPE_CHECK_LAUNCH();
+    return GPE_OK;
+}
 
 extern "C" int gpe_pack_weight_gates(const float* w, int ldw, int H, int K, float* wp, void* stream)
 {
@@ -854,6 +884,50 @@ extern "C" int gpe_lstm_cell_bwd(const float* dh_out, long dho_stride, const flo
     hipLaunchKernelGGL(gpe_lstm_cell_bwd_kernel, dim3(gpe_cdiv((long)Bn * H, 256)), dim3(256), 0,
                        (hipStream_t)stream, dh_out, dho_stride, dh_rec, n_rec, dc_next, gates, c, c_prev, ldc_prev, dgates,
                        dg_stride, dc_prev, Bn, H);
+    GPE_CHECK_LAUNCH();
+    return GPE_OK;
+}
+
+// GRU cell backward (pointwise).  dh = dh_out + dh_dir_next (the z-gated direct path of step t+1) + sum of the n_rec
+// partials of dGh_{t+1}.W_hh;  saved = {r, z, n, hn} of this step (gpe_gru_step_fwd), h_prev rows.
+//   dGx [.][3H] = {dr_pre, dz_pre, dn_pre}   (gradient w.r.t. the INPUT-side pre-activations: W_ih, b_ih, x)
+//   dGh [.][3H] = {dr_pre, dz_pre, dn_pre*r} (w.r.t. the RECURRENT-side pre-activations: W_hh, b_hh, h_prev)
+//   dh_dir_prev = dh * z
+__global__ void gpe_gru_cell_bwd_kernel(const float* __restrict__ dh_out, long dho_stride,
+                                        const float* __restrict__ dh_rec, int n_rec, const float* __restrict__ dh_dir_next,
+                                        const float* __restrict__ saved, const float* __restrict__ h_prev, long hp_stride,
+                                        float* __restrict__ dgx, float* __restrict__ dgh, long dg_stride,
+                                        float* __restrict__ dh_dir_prev, int Bn, int H)
+{
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (long)Bn * H) return;
+    const long b = e / H;
+    const int u = (int)(e - b * H);
+    const float* sv = saved + b * 4 * H;
+    const float rg = sv[u], zg = sv[H + u], ng = sv[2 * H + u], hn = sv[3 * H + u];
+    float dh = dh_out ? dh_out[b * dho_stride + u] : 0.f;
+    if (dh_dir_next) dh += dh_dir_next[b * H + u];
+    if (dh_rec)
+        for (int z = 0; z < n_rec; ++z) dh += dh_rec[(long)z * Bn * H + b * H + u];
+    const float hp = h_prev[b * hp_stride + u];
+    const float dn_pre = dh * (1.f - zg) * (1.f - ng * ng);
+    const float dz_pre = dh * (hp - ng) * zg * (1.f - zg);
+    const float dr_pre = dn_pre * hn * rg * (1.f - rg);
+    float* gx = dgx + b * dg_stride;
+    float* gh = dgh + b * dg_stride;
+    gx[u] = dr_pre; gx[H + u] = dz_pre; gx[2 * H + u] = dn_pre;
+    gh[u] = dr_pre; gh[H + u] = dz_pre; gh[2 * H + u] = dn_pre * rg;
+    dh_dir_prev[b * H + u] = dh * zg;
+}
+
+extern "C" int gpe_gru_cell_bwd(const float* dh_out, long dho_stride, const float* dh_rec, int n_rec,
+                                const float* dh_dir_next, const float* saved, const float* h_prev, long hp_stride,
+                                float* dgx, float* dgh, long dg_stride, float* dh_dir_prev, int Bn, int H, void* stream)
+{
+    if (!saved || !h_prev || !dgx || !dgh || !dh_dir_prev || Bn <= 0 || H <= 0) return GPE_EINVAL;
+    hipLaunchKernelGGL(gpe_gru_cell_bwd_kernel, dim3(gpe_cdiv((long)Bn * H, 256)), dim3(256), 0, (hipStream_t)stream,
+                       dh_out, dho_stride, dh_rec, n_rec, dh_dir_next, saved, h_prev, hp_stride, dgx, dgh, dg_stride,
+                       dh_dir_prev, Bn, H);
     GPE_CHECK_LAUNCH();
     return GPE_OK;
 }

@@ -12,7 +12,7 @@
 #include "gpe_rowgemm.h"
 #include <math.h>
 
-enum { EPI_LINEAR = 0, EPI_LSTM = 1 };
+enum { EPI_LINEAR = 0, EPI_LSTM = 1, EPI_GRU = 2 };
 
 struct SgParams {
     int M, N, K;                 // N = 4*H for EPI_LSTM (H hidden units)
@@ -26,6 +26,7 @@ struct SgParams {
     const float* xproj; long xp_stride;          // [M][4H] rows (b_ih + b_hh already folded in)
     const float* c_prev; long ldc_prev;
     float* gates; float* c_out; float* h_out; long h_stride;
+    const float* bhn;            // EPI_GRU: b_hn [H] (stays inside the r-gated recurrent term)
     int a_padded;                // A rows may be read up to round4(K) (finite pad): enables plain 16-B staging loads
     // split-K (gridDim.z > 1): block z handles K slab z only and writes its partial product to y + z * y_zstride
     long y_zstride;
@@ -185,6 +186,39 @@ __global__ __launch_bounds__(256) void gpe_smallgemm_kernel(SgParams p)
                 }
             }
         }
+    } else if (EPI == EPI_GRU) {
+        // NT == 3: the block's 48 columns are [r|z|n] x 16 units of W_hh.h (recurrent part only); xproj holds the input part
+        // x.W_ih^T + b_ih (+ b_hr, b_hz).  nn.GRU: r = s(xr + hr), z = s(xz + hz), n = tanh(xn + r*(hn + b_hn)),
+        // h' = (1-z)*n + z*h.  Saved for backward: [r | z | n | hn + b_hn] (4H per row).
+        const int u = tid & 15;
+        const int unit = blockIdx.y * 16 + u;
+        if (unit < p.H) {
+            constexpr int IT = RG_BM / 16;
+            float xr[IT], xz[IT], xn[IT], hp[IT];
+            const float bhn = p.bhn[unit];
+#pragma unroll
+            for (int it = 0; it < IT; ++it) {
+                const int r = (tid >> 4) + 16 * it;
+                const long gr = row0 + (r < rv ? r : rv - 1);
+                const float* xp = p.xproj + gr * p.xp_stride;
+                xr[it] = xp[unit]; xz[it] = xp[p.H + unit]; xn[it] = xp[2 * p.H + unit];
+                hp[it] = p.a.base[gr * p.a.stride_outer + unit];
+            }
+#pragma unroll
+            for (int it = 0; it < IT; ++it) {
+                const int r = (tid >> 4) + 16 * it;
+                if (r < rv) {
+                    const long gr = row0 + r;
+                    const float rg = sg_sigmoid(Cs[r * ldc + u] + xr[it]);
+                    const float zg = sg_sigmoid(Cs[r * ldc + 16 + u] + xz[it]);
+                    const float hn = Cs[r * ldc + 32 + u] + bhn;
+                    const float ng = tanhf(xn[it] + rg * hn);
+                    float* go = p.gates + gr * 4 * p.H;
+                    go[unit] = rg; go[p.H + unit] = zg; go[2 * p.H + unit] = ng; go[3 * p.H + unit] = hn;
+                    p.h_out[gr * p.h_stride + unit] = (1.f - zg) * ng + zg * hp[it];
+                }
+            }
+        }
     } else {
         // NT == 4: the block's 64 columns are [i|f|g|o] x 16 units.  thread -> (row = tid/16 + 16*it, unit = tid%16)
         const int u = tid & 15;
@@ -291,4 +325,22 @@ extern "C" int gpe_linear_splitk(const float* a, long a_so, const float* wp, flo
     p.a_padded = !(K & 3);
     const int nz = gpe_cdiv(K, RG_KSLAB);
     return sg_launch<4, EPI_LINEAR>(p, dim3(gpe_cdiv(M, RG_BM), gpe_cdiv(N, 64), nz), (hipStream_t)stream);
+}
+
+// fused GRU step (nn.GRU recurrence, gate order r,z,n; GRUDecoderModule, /root/reference/nn/net_blocks.py:457-497):
+// W_hh packed gate-interleaved with 3 gates (gpe_pack_weight_ngates(.., 3, ..)); xproj rows [Bn][3H] = x.W_ih^T + b_ih
+// (+ b_hr, b_hz folded in); saved [Bn][4H] = {r, z, n, W_hn.h + b_hn}.
+extern "C" int gpe_gru_step_fwd(const float* h_prev, long hp_stride, const float* whh_gates_packed, const float* xproj,
+                                long xp_stride, const float* bhn, float* saved, float* h_out, long h_stride, int Bn,
+                                int H, void* stream)
+{
+    if (!h_prev || !whh_gates_packed || !xproj || !bhn || !saved || !h_out || Bn <= 0 || H <= 0) return GPE_EINVAL;
+    SgParams p = {};
+    p.M = Bn; p.N = 3 * H; p.K = H;
+    p.a = GpeRows{h_prev, hp_stride, 0, 0};
+    p.a_padded = !(hp_stride & 3);
+    p.wp = whh_gates_packed; p.Npad = 48 * gpe_cdiv(H, 16);
+    p.H = H; p.xproj = xproj; p.xp_stride = xp_stride; p.bhn = bhn;
+    p.gates = saved; p.h_out = h_out; p.h_stride = h_stride;
+    return sg_launch<3, EPI_GRU>(p, dim3(gpe_cdiv(Bn, RG_BM), gpe_cdiv(H, 16)), (hipStream_t)stream);
 }

@@ -186,9 +186,54 @@ def _init_weights(module, init_type=''):
                 raise NotImplementedError('{} weight initialization is not implemented'.format(init_type))
 
 
+def _rnn_params(rnn, n_layers):
+    ps = []
+    for l in range(n_layers):
+        ps += [getattr(rnn, 'weight_ih_l%d' % l), getattr(rnn, 'weight_hh_l%d' % l),
+               getattr(rnn, 'bias_ih_l%d' % l), getattr(rnn, 'bias_hh_l%d' % l)]
+    return ps
+
+
+def _register_rnn_packs(plan, rnn, n_layers, hidden, gates):
+    for l in range(n_layers):
+        w_ih, w_hh = getattr(rnn, 'weight_ih_l%d' % l), getattr(rnn, 'weight_hh_l%d' % l)
+        plan.add_linear(w_ih)
+        plan.add_gates(w_hh, hidden, gates)
+        plan.add_linear(w_hh, fwd=False, bwd=True)
+        if gates == 4:
+            plan.add_bias_sum(getattr(rnn, 'bias_ih_l%d' % l), getattr(rnn, 'bias_hh_l%d' % l))
+
+
+class LSTMEncoderModule(nn.Module):
+    """nn/net_blocks.py:336-360: sequence -> final hidden state of the last LSTM layer."""
+
+    def __init__(self, elem_len, encoding_size, n_layers, dropout=0, custom_init='kaiming_normal'):
+        super().__init__()
+        if dropout:
+            raise NotImplementedError('LSTM dropout > 0 has no kernel (shipped configs use 0)')
+        self.custom_init = custom_init
+        self.n_layers = n_layers
+        self.encoding_size = encoding_size
+        self.lstm = nn.LSTM(elem_len, encoding_size, n_layers, dropout=dropout, batch_first=True)
+        _init_weights(self.lstm, init_type=custom_init)
+
+    def register_packs(self, plan):
+        _register_rnn_packs(plan, self.lstm, self.n_layers, self.encoding_size, 4)
+
+    def forward(self, batch_sequence):
+        device = batch_sequence.device
+        bs = batch_sequence.size(0)
+        h0 = _init_tenzor(self.n_layers, bs, self.encoding_size, device=device, init_type=self.custom_init)
+        c0 = _init_tenzor(self.n_layers, bs, self.encoding_size, device=device, init_type=self.custom_init)
+        seq = batch_sequence if batch_sequence.stride(-1) == 1 else batch_sequence.contiguous()
+        _, hN, _ = ops.rnn_stack(seq, h0, c0, seq.size(1), self.n_layers, 'lstm', _rnn_params(self.lstm, self.n_layers),
+                                 want_state=True)
+        return hN[-1]
+
+
 class LSTMDecoderModule(nn.Module):
     """nn/net_blocks.py:363-402.  `self.lstm` is a torch.nn.LSTM used ONLY as the parameter container
-    (weight_ih_l*, weight_hh_l*, bias_ih_l*, bias_hh_l*); the recurrence runs in ops.LSTMDecoderFn."""
+    (weight_ih_l*, weight_hh_l*, bias_ih_l*, bias_hh_l*); the recurrence runs in ops.RNNStackFn."""
 
     def __init__(self, encoding_size, hidden_size, out_elem_size, n_layers, dropout=0,
                  custom_init='kaiming_normal', **kwargs):
@@ -206,13 +251,7 @@ class LSTMDecoderModule(nn.Module):
         self.last_states = None
 
     def register_packs(self, plan):
-        H = self.hidden_size
-        for l in range(self.n_layers):
-            w_ih, w_hh = getattr(self.lstm, 'weight_ih_l%d' % l), getattr(self.lstm, 'weight_hh_l%d' % l)
-            plan.add_linear(w_ih)
-            plan.add_gates(w_hh, H)
-            plan.add_linear(w_hh, fwd=False, bwd=True)
-            plan.add_bias_sum(getattr(self.lstm, 'bias_ih_l%d' % l), getattr(self.lstm, 'bias_hh_l%d' % l))
+        _register_rnn_packs(plan, self.lstm, self.n_layers, self.hidden_size, 4)
         plan.add_linear(self.lin.weight)
 
     def forward(self, batch_enc, out_len):
@@ -222,13 +261,85 @@ class LSTMDecoderModule(nn.Module):
         h0 = _init_tenzor(self.n_layers, bs, self.hidden_size, device=device, init_type=self.custom_init)
         c0 = _init_tenzor(self.n_layers, bs, self.hidden_size, device=device, init_type=self.custom_init)
         self.last_states = (h0, c0)
-        params = []
-        for l in range(self.n_layers):
-            params += [getattr(self.lstm, 'weight_ih_l%d' % l), getattr(self.lstm, 'weight_hh_l%d' % l),
-                       getattr(self.lstm, 'bias_ih_l%d' % l), getattr(self.lstm, 'bias_hh_l%d' % l)]
         enc = batch_enc if batch_enc.is_contiguous() else batch_enc.contiguous()
-        return ops.LSTMDecoderFn.apply(enc, h0, c0, out_len, self.n_layers, self.lin.weight, self.lin.bias,
-                                       *params)
+        top, _, _ = ops.rnn_stack(enc, h0, c0, out_len, self.n_layers, 'lstm', _rnn_params(self.lstm, self.n_layers))
+        return ops.linear(top, self.lin.weight, self.lin.bias).view(bs, out_len, -1)
+
+
+class LSTMDoubleReverseDecoderModule(nn.Module):
+    """nn/net_blocks.py:405-454: decode the sequence in reverse order, then refine it with a second LSTM that reads
+    [flipped first pass | encoding] and starts from the first LSTM's final state."""
+
+    def __init__(self, encoding_size, hidden_size, out_elem_size, n_layers, dropout=0,
+                 custom_init='kaiming_normal', **kwargs):
+        super().__init__()
+        if dropout:
+            raise NotImplementedError('LSTM dropout > 0 has no kernel (shipped configs use 0)')
+        self.custom_init = custom_init
+        self.n_layers = n_layers
+        self.encoding_size = encoding_size
+        self.hidden_size = hidden_size
+        self.out_elem_size = out_elem_size
+        self.lstm_reverse = nn.LSTM(encoding_size, hidden_size, n_layers, dropout=dropout, batch_first=True)
+        self.lstm_forward = nn.LSTM(hidden_size + encoding_size, hidden_size, n_layers, dropout=dropout,
+                                    batch_first=True)
+        self.lin = nn.Linear(hidden_size, out_elem_size)
+        _init_weights(self.lstm_reverse, init_type=custom_init)
+        _init_weights(self.lstm_forward, init_type=custom_init)
+        self.last_states = None
+
+    def register_packs(self, plan):
+        _register_rnn_packs(plan, self.lstm_reverse, self.n_layers, self.hidden_size, 4)
+        _register_rnn_packs(plan, self.lstm_forward, self.n_layers, self.hidden_size, 4)
+        plan.add_linear(self.lin.weight)
+
+    def forward(self, batch_enc, out_len):
+        device = batch_enc.device
+        bs = batch_enc.size(0)
+        h0 = _init_tenzor(self.n_layers, bs, self.hidden_size, device=device, init_type=self.custom_init)
+        c0 = _init_tenzor(self.n_layers, bs, self.hidden_size, device=device, init_type=self.custom_init)
+        self.last_states = (h0, c0)
+        enc = batch_enc if batch_enc.is_contiguous() else batch_enc.contiguous()
+        out, hN, cN = ops.rnn_stack(enc, h0, c0, out_len, self.n_layers, 'lstm',
+                                    _rnn_params(self.lstm_reverse, self.n_layers), want_state=True)
+        dec_input = enc.unsqueeze(1).expand(-1, out_len, -1)
+        seq = torch.cat([torch.flip(out, [1]), dec_input], -1)            # skip connection with the original input
+        top, _, _ = ops.rnn_stack(seq, hN, cN, out_len, self.n_layers, 'lstm',
+                                  _rnn_params(self.lstm_forward, self.n_layers))
+        return ops.linear(top, self.lin.weight, self.lin.bias).view(bs, out_len, -1)
+
+
+class GRUDecoderModule(nn.Module):
+    """nn/net_blocks.py:457-497; `self.recurrent_cell` is the parameter container, ops.RNNStackFn the arithmetic."""
+
+    def __init__(self, encoding_size, hidden_size, out_elem_size, n_layers, dropout=0,
+                 custom_init='kaiming_normal', **kwargs):
+        super().__init__()
+        if dropout:
+            raise NotImplementedError('GRU dropout > 0 has no kernel (shipped configs use 0)')
+        self.custom_init = custom_init
+        self.n_layers = n_layers
+        self.encoding_size = encoding_size
+        self.hidden_size = hidden_size
+        self.out_elem_size = out_elem_size
+        self.recurrent_cell = nn.GRU(encoding_size, hidden_size, n_layers, dropout=dropout, batch_first=True)
+        self.lin = nn.Linear(hidden_size, out_elem_size)
+        _init_weights(self.recurrent_cell, init_type=custom_init)
+        self.last_states = None
+
+    def register_packs(self, plan):
+        _register_rnn_packs(plan, self.recurrent_cell, self.n_layers, self.hidden_size, 3)
+        plan.add_linear(self.lin.weight)
+
+    def forward(self, batch_enc, out_len):
+        device = batch_enc.device
+        bs = batch_enc.size(0)
+        h0 = _init_tenzor(self.n_layers, bs, self.hidden_size, device=device, init_type=self.custom_init)
+        self.last_states = (h0,)
+        enc = batch_enc if batch_enc.is_contiguous() else batch_enc.contiguous()
+        top, _, _ = ops.rnn_stack(enc, h0, None, out_len, self.n_layers, 'gru',
+                                  _rnn_params(self.recurrent_cell, self.n_layers))
+        return ops.linear(top, self.lin.weight, self.lin.bias).view(bs, out_len, -1)
 
 
 class MLPDecoder(nn.Module):
@@ -267,6 +378,3 @@ def _not_accelerated(name):
 PointNetPlusPlus = _not_accelerated('PointNetPlusPlus')
 EdgeConvPoolingFeatures = _not_accelerated('EdgeConvPoolingFeatures')
 DynamicASAPool = _not_accelerated('DynamicASAPool')
-LSTMEncoderModule = _not_accelerated('LSTMEncoderModule')
-LSTMDoubleReverseDecoderModule = _not_accelerated('LSTMDoubleReverseDecoderModule')
-GRUDecoderModule = _not_accelerated('GRUDecoderModule')

@@ -86,8 +86,9 @@ class PackPlan:
         if bwd:
             self._add(w, K_TRANS, w.shape[1], w.shape[0])
 
-    def add_gates(self, w_hh, H):
-        self._add(w_hh, K_GATES, 4 * H, w_hh.shape[1], aux=H)
+    def add_gates(self, w, H, G=4):
+        """gate-interleaved pack of a recurrent weight [G*H, K] (LSTM G = 4, GRU G = 3)."""
+        self._add(w, K_GATES, G * H, w.shape[1], aux=H)
 
     def add_edge_first(self, w1, b1):
         H, C2 = w1.shape
@@ -113,7 +114,7 @@ class PackPlan:
             if kind in (K_VADD, K_BPQ):
                 total, npad = out_numel, 0
             elif kind == K_GATES:
-                npad = 64 * ((aux + 15) // 16)
+                npad = 16 * (N // aux) * ((aux + 15) // 16)
                 total = npad * round_up(K, 16)
             else:
                 npad = round_up(N, 16)
@@ -198,12 +199,13 @@ def pack_weight(w, transpose=False, col_scale=None):
     return wp
 
 
-def pack_gates(w_hh, H):
-    hit = _planned(w_hh, K_GATES)
+def pack_gates(w, H, G=4):
+    """gate-interleaved pack of a recurrent weight [G*H, K]: one column block = the G gates of 16 units."""
+    hit = _planned(w, K_GATES)
     if hit is not None:
         return hit
-    wp = torch.empty(L.query('gpe_packed_gates_size', H, w_hh.shape[1]), device=w_hh.device, dtype=F32)
-    L.call('gpe_pack_weight_gates', w_hh, w_hh.stride(0), H, w_hh.shape[1], wp)
+    wp = torch.empty(L.query('gpe_packed_ngates_size', H, G, w.shape[1]), device=w.device, dtype=F32)
+    L.call('gpe_pack_weight_ngates', w, w.stride(0), H, G, w.shape[1], wp)
     return wp
 
 
@@ -311,15 +313,17 @@ def bn_bwd_coef(part, nblk, stats, C, count, gamma=None, beta=None, training=Tru
 # -------------------------------------------------------------------------------------------------
 class LinearFn(torch.autograd.Function):
     """y = act(x W^T + b) on the MFMA row-GEMM; backward = row-GEMM (dx) + reduce-GEMM (dW, db).
-    Replaces torch.nn.Linear at nn/net_blocks.py:158,187,397 and nn/nets.py:128-130,153,229-233."""
+    Replaces torch.nn.Linear at nn/net_blocks.py:158,187,397 and nn/nets.py:128-130,153,229-233.
+    x: [M, K] rows, or a strided [R, T, K] view (e.g. the top-layer h history of a recurrent stack) -> y [R*T, N]."""
 
     @staticmethod
     def forward(ctx, x, weight, bias):
         _dev_check(x)
-        M, K = x.shape
+        K = x.shape[-1]
+        M = x.numel() // K
         N = weight.shape[0]
         y = torch.empty(M, N, device=x.device, dtype=F32)
-        linear_raw(_rows2d(x), pack_weight(weight), bias, M, N, K, _rows2d(y))
+        linear_raw(_rows3d(x) if x.dim() == 3 else _rows2d(x), pack_weight(weight), bias, M, N, K, _rows2d(y))
         ctx.save_for_backward(x, weight, bias)
         return y
 
@@ -327,16 +331,18 @@ class LinearFn(torch.autograd.Function):
     def backward(ctx, gy):
         x, weight, bias = ctx.saved_tensors
         gy = gy.contiguous()
-        M, K = x.shape
+        K = x.shape[-1]
+        M = x.numel() // K
         N = weight.shape[0]
+        xd = _rows3d(x) if x.dim() == 3 else _rows2d(x)
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
-            gx = torch.empty(M, K, device=x.device, dtype=F32)
-            linear_raw(_rows2d(gy), pack_weight(weight, transpose=True), None, M, K, N, _rows2d(gx))
+            gx = torch.empty(*x.shape, device=x.device, dtype=F32)
+            linear_raw(_rows2d(gy), pack_weight(weight, transpose=True), None, M, K, N, (gx, K, 0, 0))
         if ctx.needs_input_grad[1] or bias is not None:
             gw = _gbuf(weight)
             gb = _gbuf(bias) if bias is not None else torch.empty(N, device=x.device, dtype=F32)
-            redgemm_raw(_rows2d(gy), _rows2d(x), M, N, K, out=(gw, gb))
+            redgemm_raw(_rows2d(gy), xd, M, N, K, out=(gw, gb))
             gw = _gret(weight, gw)
             gb = _gret(bias, gb) if bias is not None else None
         return gx, gw, gb
@@ -605,110 +611,159 @@ class EdgeConvFn(torch.autograd.Function):
 
 
 # -------------------------------------------------------------------------------------------------
-# LSTM decoder
+# recurrent stacks (LSTM / GRU)
 # -------------------------------------------------------------------------------------------------
-class LSTMDecoderFn(torch.autograd.Function):
-    """nn.LSTM(enc, hid, n_layers, batch_first) fed the SAME encoding at every step + the output Linear
-    (LSTMDecoderModule.forward, nn/net_blocks.py:382-402).  Layer 0's input projection is computed once
-    (the input is time-invariant, :388); layers > 0 project all T steps in one GEMM; the recurrence runs
-    T x (row-GEMM with fused `+xproj` addend, pointwise cell).  Gate order i,f,g,o."""
+class RNNStackFn(torch.autograd.Function):
+    """torch.nn.LSTM / torch.nn.GRU (batch_first, n_layers, no dropout) as used by the reference's decoders / encoder
+    (nn/net_blocks.py:336-497): returns (top-layer outputs [Bn, T, H] as a view of the h history, h_T [L, Bn, H],
+    c_T [L, Bn, H] or None).
+
+    x is either [Bn, In] — the SAME input at every step (decoders feed the encoding T times, :388,430,483): layer 0's input
+    projection is then computed once — or a sequence [Bn, T, In].  Layers > 0 project all T steps of the layer below in one
+    GEMM.  The recurrence runs T fused steps per layer (gate GEMM on h_{t-1} + `xproj` addend + cell update in one launch);
+    backward = pointwise cell backward + split-K GEMM per step, then the weight gradients as reduce-GEMMs over all Bn*T rows.
+    Gate orders follow torch: LSTM i,f,g,o; GRU r,z,n.  Start states may carry gradient (LSTMDoubleReverseDecoderModule
+    threads the first LSTM's final state into the second), final states too."""
 
     @staticmethod
-    def forward(ctx, enc, h0, c0, T, n_layers, lin_w, lin_b, *lstm_params):
-        _dev_check(enc)
-        dev = enc.device
-        Bn, In = enc.shape
+    def forward(ctx, x, h0, c0, T, n_layers, kind, want_state, *params):
+        _dev_check(x)
+        ctx.set_materialize_grads(False)
+        dev = x.device
+        lstm = kind == 'lstm'
+        G = 4 if lstm else 3
+        seq = x.dim() == 3
+        Bn, In = x.shape[0], x.shape[-1]
         Hh = h0.shape[2]
+        Hp = round_up(Hh, 4)
         saved_layers = []
         prev_hs = None
         for l in range(n_layers):
-            w_ih, w_hh, b_ih, b_hh = lstm_params[4 * l: 4 * l + 4]
-            bias = bias_sum(b_ih, b_hh)
+            w_ih, w_hh, b_ih, b_hh = params[4 * l: 4 * l + 4]
             # row pitch padded to 16 B (zero pad) so the recurrence's A operand is staged with plain aligned loads
-            Hp = round_up(Hh, 4)
             hs = torch.zeros(Bn, T + 1, Hp, device=dev, dtype=F32)[:, :, :Hh]
             hs[:, 0].copy_(h0[l])
-            cs = torch.empty(T + 1, Bn, Hh, device=dev, dtype=F32)
-            cs[0].copy_(c0[l])
-            gates = torch.empty(T, Bn, 4 * Hh, device=dev, dtype=F32)
-            if l == 0:
-                xproj = torch.empty(Bn, 4 * Hh, device=dev, dtype=F32)
-                linear_raw(_rows2d(enc), pack_weight(w_ih), bias, Bn, 4 * Hh, In, _rows2d(xproj))
+            if lstm:
+                bias = bias_sum(b_ih, b_hh)
+                cs = torch.empty(T + 1, Bn, Hh, device=dev, dtype=F32)
+                cs[0].copy_(c0[l])
             else:
-                xproj = torch.empty(Bn, T, 4 * Hh, device=dev, dtype=F32)
-                linear_raw(_rows3d(prev_hs[:, 1:]), pack_weight(w_ih), bias, Bn * T, 4 * Hh, Hh,
-                           (xproj, 4 * Hh, 0, 0))
-            whh_p = pack_gates(w_hh, Hh)
+                # nn.GRU keeps b_hn inside the r-gated term: xproj carries b_ih + [b_hr | b_hz | 0]
+                bias = torch.empty(G * Hh, device=dev, dtype=F32)
+                L.call('gpe_add', b_ih, b_hh, bias, 2 * Hh)
+                bias[2 * Hh:].copy_(b_ih[2 * Hh:])
+                cs = None
+            gates = torch.empty(T, Bn, 4 * Hh, device=dev, dtype=F32)
+            per_step = not (l == 0 and not seq)
+            if not per_step:
+                xproj = torch.empty(Bn, G * Hh, device=dev, dtype=F32)
+                linear_raw(_rows2d(x), pack_weight(w_ih), bias, Bn, G * Hh, In, _rows2d(xproj))
+            else:
+                src = _rows3d(x if l == 0 else prev_hs[:, 1:])
+                xproj = torch.empty(Bn, T, G * Hh, device=dev, dtype=F32)
+                linear_raw(src, pack_weight(w_ih), bias, Bn * T, G * Hh, In if l == 0 else Hh, (xproj, G * Hh, 0, 0))
+            whh_p = pack_gates(w_hh, Hh, G)
             for t in range(T):
-                xp, xps = (xproj, 4 * Hh) if l == 0 else (xproj[:, t], T * 4 * Hh)
-                # gates = h_{t-1} W_hh^T + xproj_t, cell update, h_t / c_t / activated gates: one launch
-                L.call('gpe_lstm_step_fwd', hs[:, t], hs.stride(0), whh_p, xp, xps, cs[t], Hh,
-                       gates[t], cs[t + 1], hs[:, t + 1], hs.stride(0), Bn, Hh)
-            saved_layers += [hs, cs, gates]
+                xp, xps = (xproj[:, t], T * G * Hh) if per_step else (xproj, G * Hh)
+                if lstm:
+                    L.call('gpe_lstm_step_fwd', hs[:, t], hs.stride(0), whh_p, xp, xps, cs[t], Hh,
+                           gates[t], cs[t + 1], hs[:, t + 1], hs.stride(0), Bn, Hh)
+                else:
+                    L.call('gpe_gru_step_fwd', hs[:, t], hs.stride(0), whh_p, xp, xps, b_hh[2 * Hh:], gates[t],
+                           hs[:, t + 1], hs.stride(0), Bn, Hh)
+            saved_layers += [hs, gates] + ([cs] if lstm else [])
             prev_hs = hs
-        out_sz = lin_w.shape[0]
-        out = torch.empty(Bn, T, out_sz, device=dev, dtype=F32)
-        linear_raw(_rows3d(prev_hs[:, 1:]), pack_weight(lin_w), lin_b, Bn * T, out_sz, Hh, (out, out_sz, 0, 0))
-        ctx.dims = (Bn, In, Hh, T, n_layers, out_sz)
-        ctx.save_for_backward(enc, lin_w, lin_b, *lstm_params, *saved_layers)
-        return out
+        per = 3 if lstm else 2
+        hN = cN = None
+        if want_state:
+            hN = torch.stack([saved_layers[per * l][:, T] for l in range(n_layers)])
+            cN = torch.stack([saved_layers[per * l + 2][T] for l in range(n_layers)]) if lstm else None
+        ctx.dims = (Bn, In, Hh, T, n_layers, kind, seq)
+        ctx.save_for_backward(x, *params, *saved_layers)
+        ctx.needs_state_grad = (h0.requires_grad, c0 is not None and c0.requires_grad)
+        top = prev_hs[:, 1:]
+        if lstm:
+            return top, hN, cN
+        return top, hN
 
     @staticmethod
-    def backward(ctx, g_out):
-        Bn, In, Hh, T, n_layers, out_sz = ctx.dims
+    def backward(ctx, g_top, g_hN, g_cN=None):
+        Bn, In, Hh, T, n_layers, kind, seq = ctx.dims
+        lstm = kind == 'lstm'
+        G = 4 if lstm else 3
+        per = 3 if lstm else 2
         sv = ctx.saved_tensors
-        enc, lin_w, lin_b = sv[0], sv[1], sv[2]
-        lstm_params = sv[3: 3 + 4 * n_layers]
-        saved_layers = sv[3 + 4 * n_layers:]
-        dev = enc.device
-        g_out = g_out.contiguous()
-        top_hs = saved_layers[3 * (n_layers - 1)]
-        d_lin_w, d_lin_b = _gbuf(lin_w), _gbuf(lin_b)
-        redgemm_raw((g_out, out_sz, 0, 0), _rows3d(top_hs[:, 1:]), Bn * T, out_sz, Hh, out=(d_lin_w, d_lin_b))
-        dH = torch.empty(Bn, T, Hh, device=dev, dtype=F32)
-        linear_raw((g_out, out_sz, 0, 0), pack_weight(lin_w, transpose=True), None, Bn * T, Hh, out_sz,
-                   (dH, Hh, 0, 0))
+        x = sv[0]
+        params = sv[1: 1 + 4 * n_layers]
+        saved_layers = sv[1 + 4 * n_layers:]
+        dev = x.device
+        want_h0, want_c0 = ctx.needs_state_grad
+        if g_top is None:
+            g_top = torch.zeros(Bn, T, Hh, device=dev, dtype=F32)
+        dH = g_top if g_top.is_contiguous() else g_top.contiguous()
         grads = [None] * (4 * n_layers)
-        d_enc = None
+        d_x = None
+        d_h0 = torch.empty(n_layers, Bn, Hh, device=dev, dtype=F32) if want_h0 else None
+        d_c0 = torch.empty(n_layers, Bn, Hh, device=dev, dtype=F32) if want_c0 else None
+        nz = (G * Hh + 255) // 256                         # split-K partials of dh_rec = dG_t . W_hh
         for l in reversed(range(n_layers)):
-            w_ih, w_hh, b_ih, b_hh = lstm_params[4 * l: 4 * l + 4]
-            hs, cs, gates = saved_layers[3 * l: 3 * l + 3]
-            dG = torch.empty(Bn, T, 4 * Hh, device=dev, dtype=F32)
-            nz = (4 * Hh + 255) // 256                     # split-K partials of dh_rec = dG_t . W_hh
+            w_ih, w_hh, b_ih, b_hh = params[4 * l: 4 * l + 4]
+            hs, gates = saved_layers[per * l], saved_layers[per * l + 1]
+            cs = saved_layers[per * l + 2] if lstm else None
+            dGx = torch.empty(Bn, T, G * Hh, device=dev, dtype=F32)
+            dGh = dGx if lstm else torch.empty(Bn, T, G * Hh, device=dev, dtype=F32)
             dh_rec = torch.empty(nz, Bn, Hh, device=dev, dtype=F32)
-            dc = [torch.empty(Bn, Hh, device=dev, dtype=F32) for _ in range(2)]
+            carry = [torch.empty(Bn, Hh, device=dev, dtype=F32) for _ in range(2)]     # dc (LSTM) / z-gated dh (GRU)
             whh_t = pack_weight(w_hh, transpose=True)
+            ghN = g_hN[l].contiguous() if g_hN is not None else None
+            gcN = g_cN[l].contiguous() if (lstm and g_cN is not None) else None
             for t in reversed(range(T)):
                 last = t == T - 1
-                L.call('gpe_lstm_cell_bwd', dH[:, t], T * Hh, None if last else dh_rec, nz,
-                       None if last else dc[(t + 1) & 1], gates[t], cs[t + 1], cs[t], Hh,
-                       dG[:, t], T * 4 * Hh, dc[t & 1], Bn, Hh)
-                if t > 0:
-                    L.call('gpe_linear_splitk', dG[:, t], T * 4 * Hh, whh_t, dh_rec, Bn, Hh, 4 * Hh)
-            dG_rows = (dG, 4 * Hh, 0, 0)
-            d_whh, d_bih = _gbuf(w_hh), _gbuf(b_ih)
-            redgemm_raw(dG_rows, _rows3d(hs[:, :T]), Bn * T, 4 * Hh, Hh, out=(d_whh, d_bih))
-            d_bhh = _gbuf(b_hh)
-            d_bhh.copy_(d_bih)
-            d_wih = _gbuf(w_ih)
-            if l == 0:
-                redgemm_raw(dG_rows, (enc, enc.stride(0), 0, T), Bn * T, 4 * Hh, In, want_colsum=False,
-                            out=(d_wih, None))
+                rec, n_rec = (ghN, 1 if ghN is not None else 0) if last else (dh_rec, nz)
+                if lstm:
+                    L.call('gpe_lstm_cell_bwd', dH[:, t], T * Hh, rec, n_rec, gcN if last else carry[(t + 1) & 1],
+                           gates[t], cs[t + 1], cs[t], Hh, dGx[:, t], T * G * Hh, carry[t & 1], Bn, Hh)
+                else:
+                    L.call('gpe_gru_cell_bwd', dH[:, t], T * Hh, rec, n_rec, None if last else carry[(t + 1) & 1],
+                           gates[t], hs[:, t], hs.stride(0), dGx[:, t], dGh[:, t], T * G * Hh, carry[t & 1], Bn, Hh)
+                if t > 0 or want_h0:
+                    L.call('gpe_linear_splitk', dGh[:, t], T * G * Hh, whh_t, dh_rec, Bn, Hh, G * Hh)
+            if want_h0:
+                L.call('gpe_reduce_inner', dh_rec, Hh, Bn * Hh, nz, Bn, Hh, d_h0[l], Hh, 0)
+                if not lstm:
+                    L.call('gpe_add', d_h0[l], carry[0], d_h0[l], Bn * Hh)
+            if want_c0:
+                d_c0[l].copy_(carry[0])
+            gx_rows, gh_rows = (dGx, G * Hh, 0, 0), (dGh, G * Hh, 0, 0)
+            d_whh, d_bhh = _gbuf(w_hh), _gbuf(b_hh)
+            redgemm_raw(gh_rows, _rows3d(hs[:, :T]), Bn * T, G * Hh, Hh, out=(d_whh, d_bhh))
+            d_wih, d_bih = _gbuf(w_ih), _gbuf(b_ih)
+            if l == 0 and not seq:
+                redgemm_raw(gx_rows, (x, x.stride(0), 0, T), Bn * T, G * Hh, In, out=(d_wih, d_bih))
                 if ctx.needs_input_grad[0]:
-                    dGs = torch.empty(Bn, 4 * Hh, device=dev, dtype=F32)
-                    L.call('gpe_reduce_inner', dG, T * 4 * Hh, 4 * Hh, T, Bn, 4 * Hh, dGs, 4 * Hh, 0)
-                    d_enc = torch.empty(Bn, In, device=dev, dtype=F32)
-                    linear_raw(_rows2d(dGs), pack_weight(w_ih, transpose=True), None, Bn, In, 4 * Hh,
-                               _rows2d(d_enc))
+                    dGs = torch.empty(Bn, G * Hh, device=dev, dtype=F32)
+                    L.call('gpe_reduce_inner', dGx, T * G * Hh, G * Hh, T, Bn, G * Hh, dGs, G * Hh, 0)
+                    d_x = torch.empty(Bn, In, device=dev, dtype=F32)
+                    linear_raw(_rows2d(dGs), pack_weight(w_ih, transpose=True), None, Bn, In, G * Hh, _rows2d(d_x))
             else:
-                lower_hs = saved_layers[3 * (l - 1)]
-                redgemm_raw(dG_rows, _rows3d(lower_hs[:, 1:]), Bn * T, 4 * Hh, Hh, want_colsum=False,
-                            out=(d_wih, None))
-                dH = torch.empty(Bn, T, Hh, device=dev, dtype=F32)
-                linear_raw(dG_rows, pack_weight(w_ih, transpose=True), None, Bn * T, Hh, 4 * Hh, (dH, Hh, 0, 0))
+                Kin = In if l == 0 else Hh
+                src = _rows3d(x if l == 0 else saved_layers[per * (l - 1)][:, 1:])
+                redgemm_raw(gx_rows, src, Bn * T, G * Hh, Kin, out=(d_wih, d_bih))
+                if l > 0 or ctx.needs_input_grad[0]:
+                    nxt = torch.empty(Bn, T, Kin, device=dev, dtype=F32)
+                    linear_raw(gx_rows, pack_weight(w_ih, transpose=True), None, Bn * T, Kin, G * Hh, (nxt, Kin, 0, 0))
+                    if l > 0:
+                        dH = nxt
+                    else:
+                        d_x = nxt
             grads[4 * l: 4 * l + 4] = [_gret(w_ih, d_wih), _gret(w_hh, d_whh), _gret(b_ih, d_bih),
                                        _gret(b_hh, d_bhh)]
-        return (d_enc, None, None, None, None, _gret(lin_w, d_lin_w), _gret(lin_b, d_lin_b), *grads)
+        return (d_x, d_h0, d_c0, None, None, None, None, *grads)
+
+
+def rnn_stack(x, h0, c0, T, n_layers, kind, params, want_state=False):
+    out = RNNStackFn.apply(x, h0, c0, T, n_layers, kind, want_state, *params)
+    return out if kind == 'lstm' else (out[0], out[1], None)
 
 
 # -------------------------------------------------------------------------------------------------

@@ -196,6 +196,21 @@ int gpe_lstm_step_fwd(const float* h_prev, long hp_stride, const float* whh_gate
                       long xp_stride, const float* c_prev, long ldc_prev, float* gates, float* c_out, float* h_out,
                       long h_stride, int Bn, int H, void* stream);
 
+/* ---- GRU decoder (nn.GRU, gate order r,z,n; GRUDecoderModule, nn/net_blocks.py:457-497) ------------------------------
+ * gate-interleaved packing for G gates (G = 3 here; gpe_pack_weight_gates is the G = 4 case) */
+long gpe_packed_ngates_size(int H, int G, int K);
+int gpe_pack_weight_ngates(const float* w, int ldw, int H, int G, int K, float* wp, void* stream);
+/* fused step: r = s(xr + W_hr.h), z = s(xz + W_hz.h), n = tanh(xn + r*(W_hn.h + b_hn)), h' = (1-z)*n + z*h in ONE launch.
+ * xproj rows [Bn][3H] = x.W_ih^T + b_ih (+ b_hr, b_hz); saved [Bn][4H] = {r, z, n, W_hn.h + b_hn} (for backward). */
+int gpe_gru_step_fwd(const float* h_prev, long hp_stride, const float* whh_gates_packed, const float* xproj,
+                     long xp_stride, const float* bhn, float* saved, float* h_out, long h_stride, int Bn, int H,
+                     void* stream);
+/* pointwise backward of one step: dh = dh_out + dh_dir_next + sum of the n_rec partials dh_rec[z][Bn][H];
+ * dgx [..][3H] = input-side pre-activation gradients {dr, dz, dn}, dgh = recurrent-side {dr, dz, dn*r}; dh_dir_prev = dh*z */
+int gpe_gru_cell_bwd(const float* dh_out, long dho_stride, const float* dh_rec, int n_rec, const float* dh_dir_next,
+                     const float* saved, const float* h_prev, long hp_stride, float* dgx, float* dgh, long dg_stride,
+                     float* dh_dir_prev, int Bn, int H, void* stream);
+
 /* ---- attention variant (GarmentSegmentPattern3D, nn/nets.py:187-299) ------------------------------------------ */
 /* sparsemax.Sparsemax(dim=1) over rows of width W <= 32 (nn/nets.py:225): forward and backward */
 int gpe_sparsemax_fwd(const float* z, int ldz, long rows, int W, float* out, int ldo, void* stream);

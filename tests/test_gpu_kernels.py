@@ -714,3 +714,60 @@ def test_rccl_world1_gradient_exchange(gpe, golden_dir, tmp_path):
     r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     assert 'rccl ok' in r.stdout
+
+
+@pytest.mark.parametrize('cls', ['GRUDecoderModule', 'LSTMDoubleReverseDecoderModule'])
+@pytest.mark.parametrize('Bn,In,Hh,T,L,Out', [(6, 40, 40, 5, 2, 40), (46, 40, 40, 14, 3, 8), (64, 250, 250, 14, 2, 8)])
+def test_alternative_recurrent_decoders(gpe, cls, Bn, In, Hh, T, L, Out):
+    """GRUDecoderModule (nn/net_blocks.py:457-497) and LSTMDoubleReverseDecoderModule (:405-454: sequence input, start state
+    with gradient, final state out) on the general recurrent stack, vs torch.nn.GRU / LSTM in fp64."""
+    from oracle import ref_path as O
+    torch.manual_seed(Bn + T)
+    odec = getattr(O, cls)(In, Hh, Out, L, custom_init='kaiming_normal_')
+    pdec = getattr(gpe.net_blocks, cls)(In, Hh, Out, L, custom_init='kaiming_normal_')
+    pdec.load_state_dict(odec.state_dict())
+    pdec = pdec.cuda()
+    enc = torch.randn(Bn, In, generator=torch.Generator().manual_seed(1))
+    wgt = torch.randn(Bn, T, Out, generator=torch.Generator().manual_seed(2))
+    o64 = copy.deepcopy(odec).double()
+    er = enc.double().requires_grad_()
+    torch.manual_seed(77)
+    out_r = o64(er, T)
+    (out_r * wgt.double()).sum().backward()
+    ed = enc.cuda().requires_grad_()
+    torch.manual_seed(77)
+    out = pdec(ed, T)
+    (out * wgt.cuda()).sum().backward()
+    assert torch.equal(pdec.last_states[0].cpu(), o64.last_states[0].float())   # same RNG stream
+    assert relerr(out, out_r) < 3e-5
+    assert relerr(ed.grad, er.grad) < 2e-4
+    pn = dict(pdec.named_parameters())
+    for n, p in o64.named_parameters():
+        e = relerr(pn[n].grad, p.grad)
+        assert e < 2e-4, (n, e)
+
+
+def test_lstm_encoder_module(gpe):
+    """LSTMEncoderModule (nn/net_blocks.py:336-360): sequence in, last layer's final hidden state out."""
+    Bn, T, El, Hh, L = 20, 9, 6, 24, 2
+    torch.manual_seed(5)
+    penc = gpe.net_blocks.LSTMEncoderModule(El, Hh, L, custom_init='kaiming_normal_')
+    ref = torch.nn.LSTM(El, Hh, L, batch_first=True).double()
+    ref.load_state_dict({k: v.double() for k, v in penc.lstm.state_dict().items()})
+    penc = penc.cuda()
+    x = torch.randn(Bn, T, El, generator=torch.Generator().manual_seed(1))
+    wgt = torch.randn(Bn, Hh, generator=torch.Generator().manual_seed(2))
+    xd = x.cuda().requires_grad_()
+    torch.manual_seed(3)
+    out = penc(xd)
+    (out * wgt.cuda()).sum().backward()
+    torch.manual_seed(3)
+    h0 = gpe.net_blocks._init_tenzor(L, Bn, Hh, init_type='kaiming_normal_')
+    c0 = gpe.net_blocks._init_tenzor(L, Bn, Hh, init_type='kaiming_normal_')
+    xr = x.double().requires_grad_()
+    _, (hN, _) = ref(xr, (h0.double(), c0.double()))
+    (hN[-1] * wgt.double()).sum().backward()
+    assert relerr(out, hN[-1]) < 2e-5
+    assert relerr(xd.grad, xr.grad) < 1e-4
+    for (n, p), (_, q) in zip(penc.lstm.named_parameters(), ref.named_parameters()):
+        assert relerr(p.grad, q.grad) < 1e-4, n

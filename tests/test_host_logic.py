@@ -50,8 +50,6 @@ ALL_FIXTURES = ['full3d_small', 'full3d_shipped', 'full3d_k16', 'segment3d_small
 def test_every_fixture_config_constructs_with_reference_layout(tag, golden_dir):
     """Every YAML variant the reference-generated fixtures cover (alternative decoders, pools, aggregations, depths,
     global attention) builds here with the reference's state-dict keys/shapes and, same seed, the same initial weights."""
-    if tag in ('full3d_gru', 'full3d_lstm2rev'):
-        pytest.skip('decoder variant not built yet')
     fx = torch.load(os.path.join(golden_dir, tag + '.pt'), weights_only=False)
     torch.manual_seed(fx['seed'])
     model = getattr(nets, fx['model'])(fx['data_config'], copy.deepcopy(fx['nn_config']),
@@ -136,7 +134,7 @@ def test_error_types_match_reference():
     with pytest.raises(AttributeError):
         _full(feature_extractor='NoSuchExtractor')
     with pytest.raises(NotImplementedError):        # selectable in the reference, no kernels yet: loud, not silent
-        _full(panel_decoder='GRUDecoderModule')
+        _full(feature_extractor='EdgeConvPoolingFeatures')
 
 
 def test_train_eval_forward_to_loss():
