@@ -84,6 +84,7 @@ __global__ __launch_bounds__(256) void gpe_pack_multi_kernel(const GpePackJob* _
     if (e >= jb.total) return;
     if (jb.kind == 5) { jb.out[e] = jb.w[e] + jb.w2[e]; return; }                 // b_ih + b_hh
     if (jb.kind == 6) { jb.out[e] = (e < jb.aux) ? jb.w[e] : 0.f; return; }       // [b1 | 0]
+    if (jb.kind == 7) { jb.out[e] = jb.w[e] + ((e < jb.aux) ? jb.w2[e] : 0.f); return; }   // GRU: b_ih + [b_hr | b_hz | 0]
     const int t = (int)(e & 3);
     const long r = e >> 2;
     const int n = (int)(r % jb.Npad);

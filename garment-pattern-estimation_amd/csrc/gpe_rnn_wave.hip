@@ -1,0 +1,459 @@
+// Wavefront execution of stacked recurrences (nn.LSTM / nn.GRU under the reference's decoders,
+// /root/reference/nn/net_blocks.py:336-497) on gfx950.
+//
+// A stack of L layers over T steps is L*T dependent cells when run layer by layer, but cell (l, t) only needs (l, t-1)
+// and (l-1, t): all cells of one anti-diagonal d = l + t are independent.  The two entry points below walk the T + L - 1
+// diagonals and launch every cell of a diagonal TOGETHER (blockIdx.z = cell):
+//   forward : one fused launch per diagonal — gates = h_{l,t-1}.W_hh^T (+ h_{l-1,t}.W_ih^T for layers > 0, a second K
+//             segment) + addend, then the LSTM / GRU cell update in the epilogue (gate-interleaved packed weights, so
+//             the gates of a unit sit in one accumulator row);
+//   backward: two launches per diagonal — split-K products dh = dG_{l,t+1}.W_hh + dG_{l+1,t}.W_ih over all cells and
+//             K slabs at once, then the pointwise cell backward of all cells.
+// The shipped decoders (T = 23, L = 2 and T = 14, L = 3) drop from 88 + 176 dependent launches to 40 + 80.
+// Arithmetic: exact fp32 MFMA (v_mfma_f32_16x16x4_f32), same staging scheme as gpe_smallgemm.hip: a workgroup stages a
+// whole K slab (<= 256) of 64 rows and of its packed weight block, one barrier pair per slab.
+#include "gpe_rowgemm.h"
+#include <math.h>
+
+#define WV_MAXCELL 4
+
+struct WvFwdCell {
+    const float* a0; long a0_stride; const float* w0;       // h_{l,t-1} rows, gate-packed W_hh_l
+    const float* a1; long a1_stride; const float* w1;       // h_{l-1,t} rows, gate-packed W_ih_l (NULL for layer 0)
+    const float* xproj; long xp_stride;                     // addend rows [..][G*H] (stride 0: one bias row)
+    const float* c_prev; float* c_out;                      // LSTM
+    const float* bhn;                                       // GRU
+    float* saved; float* h_out; long h_stride;              // saved gates [Bn][4H]; h rows
+};
+struct WvFwdParams { int Bn, H, Npad, ncell; WvFwdCell cell[WV_MAXCELL]; };
+
+__device__ __forceinline__ float wv_sigmoid(float x) { return 1.f / (1.f + expf(-x)); }
+
+// stage rows [row0, row0+64) x K columns of `a` (row pitch `stride`, 16-B aligned, padded to 4) and the packed weight block
+// of this workgroup (columns n0 .. n0+16*NT of a [K/4][Npad][4] packed matrix) into LDS, then run the slab's MFMAs
+template <int NT>
+__device__ __forceinline__ void wv_segment(const float* __restrict__ a, long stride, const float* __restrict__ wp, int K,
+                                           int Npad, int row0, int rv, int n0, float* As, float* Ws, int lda,
+                                           f32x4 (&acc)[NT])
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 15, g = lane >> 4;
+    for (int ks = 0; ks < K; ks += RG_KSLAB) {
+        const int kslab = (K - ks < RG_KSLAB) ? (K - ks) : RG_KSLAB;
+        const int kp = (kslab + 15) & ~15;
+        __syncthreads();
+        {
+            const int c = lane << 2;
+            if (c < kp) {
+                const int nvalid = kslab - c;
+                const int cc = (nvalid > 0) ? c : 0;
+                float4 v[RG_BM / 4];
+#pragma unroll
+                for (int q = 0; q < RG_BM / 4; ++q) {
+                    const int r = wave + 4 * q;
+                    v[q] = ld4(a + (long)(row0 + (r < rv ? r : rv - 1)) * stride + ks + cc);
+                }
+#pragma unroll
+                for (int q = 0; q < RG_BM / 4; ++q) {
+                    const int r = wave + 4 * q;
+                    float4 o = v[q];
+                    if (r >= rv || nvalid <= 0) o = make_float4(0.f, 0.f, 0.f, 0.f);
+                    else {
+                        if (nvalid < 2) o.y = 0.f;
+                        if (nvalid < 3) o.z = 0.f;
+                        if (nvalid < 4) o.w = 0.f;
+                    }
+                    st4(&As[r * lda + c], o);
+                }
+            }
+        }
+        {
+            const int planes = (kp >> 4) * 4;
+            constexpr int per_plane = 16 * NT;
+            const int chunk0 = ks >> 4;
+            const int total = planes * per_plane;
+            constexpr int WB = 8;
+            for (int e0 = tid; e0 < total; e0 += 256 * WB) {
+                float4 v[WB];
+#pragma unroll
+                for (int u = 0; u < WB; ++u) {
+                    const int e = e0 + 256 * u;
+                    const int ec = (e < total) ? e : total - 1;
+                    const int pl = ec / per_plane, n = ec - pl * per_plane;
+                    const int nn = (n0 + n < Npad) ? n0 + n : Npad - 1;
+                    v[u] = ld4(wp + (((long)(chunk0 * 4 + pl)) * Npad + nn) * 4);
+                }
+#pragma unroll
+                for (int u = 0; u < WB; ++u) {
+                    const int e = e0 + 256 * u;
+                    if (e < total) {
+                        const int n = e % per_plane;
+                        st4(&Ws[e * 4], (n0 + n < Npad) ? v[u] : make_float4(0.f, 0.f, 0.f, 0.f));
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        const int nchunks = kp >> 4;
+        for (int kc = 0; kc < nchunks; ++kc) {
+            const float4 a4 = ld4(&As[(16 * wave + j) * lda + kc * 16 + 4 * g]);
+            const float av[4] = {a4.x, a4.y, a4.z, a4.w};
+            float4 b4[NT];
+#pragma unroll
+            for (int n = 0; n < NT; ++n) b4[n] = ld4(&Ws[(((kc * 4 + g) * 16 * NT) + 16 * n + j) * 4]);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    const float bv = (t == 0) ? b4[n].x : (t == 1) ? b4[n].y : (t == 2) ? b4[n].z : b4[n].w;
+                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t], bv, acc[n], 0, 0, 0);
+                }
+            }
+        }
+    }
+}
+
+// G = 4: LSTM (i,f,g,o)   G = 3: GRU (r,z,n)
+template <int G>
+__global__ __launch_bounds__(256) void gpe_rnn_wave_fwd_kernel(WvFwdParams p)
+{
+    extern __shared__ __align__(16) float smem[];
+    const int kp_max = ((p.H < RG_KSLAB ? p.H : RG_KSLAB) + 15) & ~15;
+    const int lda = kp_max + 4;
+    constexpr int ldc = 16 * 2 * G + 4;              // GRU keeps the input-side and recurrent-side products apart
+    const int a_floats = RG_BM * (lda > ldc ? lda : ldc);
+    float* As = smem;
+    float* Cs = smem;
+    float* Ws = smem + a_floats;
+    const WvFwdCell& c = p.cell[blockIdx.z];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 15, g = lane >> 4;
+    const int row0 = blockIdx.x * RG_BM;
+    const int rv = (p.Bn - row0 < RG_BM) ? (p.Bn - row0) : RG_BM;
+    const int n0 = blockIdx.y * (16 * G);
+
+    f32x4 accH[G], accX[G];
+#pragma unroll
+    for (int n = 0; n < G; ++n) { accH[n] = (f32x4){0.f, 0.f, 0.f, 0.f}; accX[n] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    wv_segment<G>(c.a0, c.a0_stride, c.w0, p.H, p.Npad, row0, rv, n0, As, Ws, lda, accH);
+    if (c.a1) {
+        if (G == 4) wv_segment<G>(c.a1, c.a1_stride, c.w1, p.H, p.Npad, row0, rv, n0, As, Ws, lda, accH);
+        else wv_segment<G>(c.a1, c.a1_stride, c.w1, p.H, p.Npad, row0, rv, n0, As, Ws, lda, accX);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int n = 0; n < G; ++n)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            Cs[(16 * wave + 4 * g + r) * ldc + 16 * n + j] = accH[n][r];
+            if (G == 3) Cs[(16 * wave + 4 * g + r) * ldc + 16 * (G + n) + j] = accX[n][r];
+        }
+    __syncthreads();
+
+    const int u = tid & 15;
+    const int unit = blockIdx.y * 16 + u;
+    if (unit >= p.H) return;
+    constexpr int IT = RG_BM / 16;
+    if (G == 4) {
+        float xi[IT], xf[IT], xg[IT], xo[IT], cp[IT];
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            const int r = (tid >> 4) + 16 * it;
+            const long gr = row0 + (r < rv ? r : rv - 1);
+            const float* xp = c.xproj + gr * c.xp_stride;
+            xi[it] = xp[unit]; xf[it] = xp[p.H + unit]; xg[it] = xp[2 * p.H + unit]; xo[it] = xp[3 * p.H + unit];
+            cp[it] = c.c_prev[gr * p.H + unit];
+        }
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            const int r = (tid >> 4) + 16 * it;
+            if (r < rv) {
+                const long gr = row0 + r;
+                const float ig = wv_sigmoid(Cs[r * ldc + u] + xi[it]);
+                const float fg = wv_sigmoid(Cs[r * ldc + 16 + u] + xf[it]);
+                const float gg = tanhf(Cs[r * ldc + 32 + u] + xg[it]);
+                const float og = wv_sigmoid(Cs[r * ldc + 48 + u] + xo[it]);
+                const float cn = fg * cp[it] + ig * gg;
+                float* go = c.saved + gr * 4 * p.H;
+                go[unit] = ig; go[p.H + unit] = fg; go[2 * p.H + unit] = gg; go[3 * p.H + unit] = og;
+                c.c_out[gr * p.H + unit] = cn;
+                c.h_out[gr * c.h_stride + unit] = og * tanhf(cn);
+            }
+        }
+    } else {
+        float xr[IT], xz[IT], xn[IT], hp[IT];
+        const float bhn = c.bhn[unit];
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            const int r = (tid >> 4) + 16 * it;
+            const long gr = row0 + (r < rv ? r : rv - 1);
+            const float* xp = c.xproj + gr * c.xp_stride;
+            xr[it] = xp[unit]; xz[it] = xp[p.H + unit]; xn[it] = xp[2 * p.H + unit];
+            hp[it] = c.a0[gr * c.a0_stride + unit];
+        }
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            const int r = (tid >> 4) + 16 * it;
+            if (r < rv) {
+                const long gr = row0 + r;
+                const float rg = wv_sigmoid(Cs[r * ldc + u] + Cs[r * ldc + 48 + u] + xr[it]);
+                const float zg = wv_sigmoid(Cs[r * ldc + 16 + u] + Cs[r * ldc + 64 + u] + xz[it]);
+                const float hn = Cs[r * ldc + 32 + u] + bhn;
+                const float ng = tanhf(Cs[r * ldc + 80 + u] + xn[it] + rg * hn);
+                float* go = c.saved + gr * 4 * p.H;
+                go[unit] = rg; go[p.H + unit] = zg; go[2 * p.H + unit] = ng; go[3 * p.H + unit] = hn;
+                c.h_out[gr * c.h_stride + unit] = (1.f - zg) * ng + zg * hp[it];
+            }
+        }
+    }
+}
+
+template <int G>
+static int wv_fwd_launch(const WvFwdParams& p, hipStream_t s)
+{
+    const int kp_max = gpe_round_up(p.H < RG_KSLAB ? p.H : RG_KSLAB, 16);
+    const int lda = kp_max + 4, ldc = 16 * 2 * G + 4;
+    const size_t lds = ((size_t)RG_BM * (lda > ldc ? lda : ldc) + (size_t)kp_max * 16 * G) * sizeof(float);
+    if (lds > 160 * 1024) return GPE_EINVAL;
+    GPE_ENSURE_MAX_LDS((gpe_rnn_wave_fwd_kernel<G>));
+    hipLaunchKernelGGL((gpe_rnn_wave_fwd_kernel<G>), dim3(gpe_cdiv(p.Bn, RG_BM), gpe_cdiv(p.H, 16), p.ncell), dim3(256), lds, s,
+                       p);
+    GPE_CHECK_LAUNCH();
+    return GPE_OK;
+}
+
+extern "C" int gpe_rnn_seq_fwd(int gates, int L, int T, int Bn, int H, const float* xproj0, long xp0_sb, long xp0_st,
+                               const void* const* whh, const void* const* wih, const void* const* bias,
+                               const void* const* bhn, float* hs, long hs_sl, long hs_sb, long hs_st, float* cs, long cs_sl, long cs_st,
+                               float* saved, long sv_sl, long sv_st, void* stream)
+{
+    if ((gates != 3 && gates != 4) || L <= 0 || T <= 0 || Bn <= 0 || H <= 0 || !xproj0 || !whh || !hs || !saved ||
+        (L > 1 && (!wih || !bias)) || (gates == 4 && !cs) || (gates == 3 && !bhn) || (hs_sb & 3) || (hs_st & 3))
+        return GPE_EINVAL;
+    const int G = gates;
+    for (int d = 0; d <= T + L - 2; ++d) {
+        const int l_lo = (d - (T - 1) > 0) ? d - (T - 1) : 0;
+        const int l_hi = (d < L - 1) ? d : L - 1;
+        for (int l0 = l_lo; l0 <= l_hi; l0 += WV_MAXCELL) {
+            WvFwdParams p = {};
+            p.Bn = Bn; p.H = H; p.Npad = 16 * G * gpe_cdiv(H, 16);
+            int n = 0;
+            for (int l = l0; l <= l_hi && n < WV_MAXCELL; ++l, ++n) {
+                const int t = d - l;
+                WvFwdCell& c = p.cell[n];
+                c.a0 = hs + l * hs_sl + (long)t * hs_st;             // h_{l,t-1} lives at time slot t
+                c.a0_stride = hs_sb;
+                c.w0 = (const float*)whh[l];
+                if (l > 0) {
+                    c.a1 = hs + (l - 1) * hs_sl + (long)(t + 1) * hs_st;   // h_{l-1,t} at slot t+1
+                    c.a1_stride = hs_sb;
+                    c.w1 = (const float*)wih[l];
+                    c.xproj = (const float*)bias[l];
+                    c.xp_stride = 0;
+                } else {
+                    c.xproj = xproj0 + (long)t * xp0_st;
+                    c.xp_stride = xp0_sb;
+                }
+                if (G == 4) {
+                    c.c_prev = cs + l * cs_sl + (long)t * cs_st;
+                    c.c_out = cs + l * cs_sl + (long)(t + 1) * cs_st;
+                } else
+                    c.bhn = (const float*)bhn[l];
+                c.saved = saved + l * sv_sl + (long)t * sv_st;
+                c.h_out = hs + l * hs_sl + (long)(t + 1) * hs_st;
+                c.h_stride = hs_sb;
+            }
+            p.ncell = n;
+            const int rc = (G == 4) ? wv_fwd_launch<4>(p, (hipStream_t)stream) : wv_fwd_launch<3>(p, (hipStream_t)stream);
+            if (rc != GPE_OK) return rc;
+        }
+    }
+    return GPE_OK;
+}
+
+// =====================================================================================================================
+// backward
+// =====================================================================================================================
+struct WvBwdCell {
+    // split-K products: segment s multiplies rows a[s] [Bn][K] (pitch as[s]) with packed w[s] ([H out] x [K]); NULL = absent
+    const float* a[2]; long as[2]; const float* w[2];
+    float* part;                                   // [2 * nz][Bn][H] partial products of this cell
+    // pointwise
+    const float* dh_out; long dho_stride;          // top-layer output gradient rows or NULL
+    const float* dh_extra;                         // d h_T of this layer (t == T-1) or NULL          [Bn][H]
+    const float* carry_in; float* carry_out;       // dc (LSTM) / z-gated dh (GRU) of step t+1 -> of step t  [Bn][H]
+    const float* saved;                            // activated gates of the cell [Bn][4H]
+    const float* c; const float* c_prev;           // LSTM: c_t, c_{t-1} [Bn][H]
+    const float* h_prev; long hp_stride;           // GRU
+    float* dgx; float* dgh; long dg_stride;        // pre-activation gradients of the cell, rows [Bn] pitch dg_stride
+    int nseg_mask;                                 // bit s: segment s present
+};
+struct WvBwdParams { int Bn, H, K, Kpad_n, nz, ncell; WvBwdCell cell[WV_MAXCELL]; };
+
+// grid (row tiles, cdiv(H, 64), ncell * 2 * nz): block z -> (cell, segment, K slab)
+__global__ __launch_bounds__(256) void gpe_rnn_wave_splitk_kernel(WvBwdParams p)
+{
+    extern __shared__ __align__(16) float smem[];
+    constexpr int NT = 4;
+    const int lda = RG_KSLAB + 4;
+    constexpr int ldc = 16 * NT + 4;
+    float* As = smem;
+    float* Cs = smem;
+    float* Ws = smem + RG_BM * lda;
+    const int zz = blockIdx.z;
+    const int ci = zz / (2 * p.nz), rem = zz - ci * 2 * p.nz;
+    const int seg = rem / p.nz, z = rem - seg * p.nz;
+    const WvBwdCell& c = p.cell[ci];
+    if (!((c.nseg_mask >> seg) & 1)) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 15, g = lane >> 4;
+    const int row0 = blockIdx.x * RG_BM;
+    const int rv = (p.Bn - row0 < RG_BM) ? (p.Bn - row0) : RG_BM;
+    const int n0 = blockIdx.y * (16 * NT);
+    const int ks = z * RG_KSLAB;
+    const int kslab = (p.K - ks < RG_KSLAB) ? (p.K - ks) : RG_KSLAB;
+    f32x4 acc[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // one slab: reuse the forward's staging helper on the slab's column window
+    wv_segment<NT>(c.a[seg] + ks, c.as[seg], c.w[seg] + (long)(ks >> 4) * 4 * p.Kpad_n * 4, kslab, p.Kpad_n, row0, rv, n0, As,
+                   Ws, lda, acc);
+    __syncthreads();
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Cs[(16 * wave + 4 * g + r) * ldc + 16 * n + j] = acc[n][r];
+    __syncthreads();
+    const int ncols = (p.H - n0 < 16 * NT) ? (p.H - n0) : 16 * NT;
+    const int cq = lane << 2;
+    if (cq < ncols) {
+        float* dst0 = c.part + ((long)(seg * p.nz + z) * p.Bn) * p.H;
+        for (int r = wave; r < rv; r += 4) {
+            const float4 v = ld4(&Cs[r * ldc + cq]);
+            float* dst = dst0 + (long)(row0 + r) * p.H + n0 + cq;
+            const float o[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int t = 0; t < 4; ++t) if (cq + t < ncols) dst[t] = o[t];
+        }
+    }
+}
+
+template <int G>
+__global__ void gpe_rnn_wave_cell_bwd_kernel(WvBwdParams p)
+{
+    const WvBwdCell& c = p.cell[blockIdx.y];
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (long)p.Bn * p.H) return;
+    const int H = p.H;
+    const long b = e / H;
+    const int u = (int)(e - b * H);
+    float dh = c.dh_out ? c.dh_out[b * c.dho_stride + u] : 0.f;
+    if (c.dh_extra) dh += c.dh_extra[e];
+    for (int s = 0; s < 2; ++s)
+        if ((c.nseg_mask >> s) & 1)
+            for (int z = 0; z < p.nz; ++z) dh += c.part[((long)(s * p.nz + z) * p.Bn) * H + e];
+    const float* sv = c.saved + b * 4 * H;
+    float* gx = c.dgx + b * c.dg_stride;
+    if (G == 4) {
+        const float ig = sv[u], fg = sv[H + u], gg = sv[2 * H + u], og = sv[3 * H + u];
+        const float tc = tanhf(c.c[e]);
+        float dc = dh * og * (1.f - tc * tc);
+        if (c.carry_in) dc += c.carry_in[e];
+        gx[u] = dc * gg * ig * (1.f - ig);
+        gx[H + u] = dc * c.c_prev[e] * fg * (1.f - fg);
+        gx[2 * H + u] = dc * ig * (1.f - gg * gg);
+        gx[3 * H + u] = dh * tc * og * (1.f - og);
+        c.carry_out[e] = dc * fg;
+    } else {
+        if (c.carry_in) dh += c.carry_in[e];
+        const float rg = sv[u], zg = sv[H + u], ng = sv[2 * H + u], hn = sv[3 * H + u];
+        const float hp = c.h_prev[b * c.hp_stride + u];
+        const float dn_pre = dh * (1.f - zg) * (1.f - ng * ng);
+        const float dz_pre = dh * (hp - ng) * zg * (1.f - zg);
+        const float dr_pre = dn_pre * hn * rg * (1.f - rg);
+        float* gh = c.dgh + b * c.dg_stride;
+        gx[u] = dr_pre; gx[H + u] = dz_pre; gx[2 * H + u] = dn_pre;
+        gh[u] = dr_pre; gh[H + u] = dz_pre; gh[2 * H + u] = dn_pre * rg;
+        c.carry_out[e] = dh * zg;
+    }
+}
+
+extern "C" long gpe_rnn_seq_bwd_ws(int gates, int L, int Bn, int H)
+{
+    const int nz = gpe_cdiv(gates * H, RG_KSLAB);
+    const int ncell = L < WV_MAXCELL ? L : WV_MAXCELL;
+    return (long)ncell * 2 * nz * Bn * H;
+}
+
+// dgx / dgh: [L][Bn][T][G*H] (for LSTM pass the same buffer twice); carry: [2][L][Bn][H] scratch;
+// whh_t / wih_t: host arrays [L] of device pointers to the plain TRANSPOSED packs (gpe_pack_weight(.., transpose = 1));
+// d_hN / d_cN: gradients of the final states [L][Bn][H] or NULL.  On return carry[0 or 1] holds dc_0 / the z-gated dh_0 of
+// every layer at carry + (T & 1 ? .. ) — see carry_final below: the slot index written last is returned through *carry_slot.
+extern "C" int gpe_rnn_seq_bwd(int gates, int L, int T, int Bn, int H, const float* dtop, long dt_sb, long dt_st,
+                               const float* d_hN, const float* d_cN, const void* const* whh_t, const void* const* wih_t,
+                               const float* hs, long hs_sl, long hs_sb, long hs_st, const float* cs, long cs_sl, long cs_st,
+                               const float* saved, long sv_sl, long sv_st, float* dgx, float* dgh, long dg_sl, long dg_sb,
+                               long dg_st, float* part, float* carry, void* stream)
+{
+    if ((gates != 3 && gates != 4) || L <= 0 || T <= 0 || Bn <= 0 || H <= 0 || !whh_t || !hs || !saved || !dgx || !dgh ||
+        !part || !carry || (L > 1 && !wih_t) || (gates == 4 && !cs) || (dg_sb & 3) || (dg_st & 3))
+        return GPE_EINVAL;
+    const int G = gates, K = G * H;
+    const int nz = gpe_cdiv(K, RG_KSLAB);
+    const long BH = (long)Bn * H;
+    hipStream_t s = (hipStream_t)stream;
+    const size_t lds = ((size_t)RG_BM * (RG_KSLAB + 4) + (size_t)RG_KSLAB * 64) * sizeof(float);
+    GPE_ENSURE_MAX_LDS((gpe_rnn_wave_splitk_kernel));
+    for (int d = T + L - 2; d >= 0; --d) {
+        const int l_lo = (d - (T - 1) > 0) ? d - (T - 1) : 0;
+        const int l_hi = (d < L - 1) ? d : L - 1;
+        for (int l0 = l_lo; l0 <= l_hi; l0 += WV_MAXCELL) {
+            WvBwdParams p = {};
+            p.Bn = Bn; p.H = H; p.K = K; p.Kpad_n = gpe_round_up(H, 16); p.nz = nz;
+            int n = 0, any_seg = 0;
+            for (int l = l0; l <= l_hi && n < WV_MAXCELL; ++l, ++n) {
+                const int t = d - l;
+                WvBwdCell& c = p.cell[n];
+                c.part = part + (long)n * 2 * nz * BH;
+                if (t < T - 1) {                 // recurrent path: dGh_{l,t+1} . W_hh_l
+                    c.a[0] = dgh + l * dg_sl + (long)(t + 1) * dg_st; c.as[0] = dg_sb; c.w[0] = (const float*)whh_t[l];
+                    c.nseg_mask |= 1;
+                }
+                if (l < L - 1) {                 // from the layer above: dGx_{l+1,t} . W_ih_{l+1}
+                    c.a[1] = dgx + (l + 1) * dg_sl + (long)t * dg_st; c.as[1] = dg_sb; c.w[1] = (const float*)wih_t[l + 1];
+                    c.nseg_mask |= 2;
+                }
+                any_seg |= c.nseg_mask;
+                if (l == L - 1 && dtop) { c.dh_out = dtop + (long)t * dt_st; c.dho_stride = dt_sb; }
+                if (t == T - 1) {
+                    if (d_hN) c.dh_extra = d_hN + (long)l * BH;
+                    c.carry_in = (G == 4 && d_cN) ? d_cN + (long)l * BH : nullptr;
+                } else
+                    c.carry_in = carry + ((long)((t + 1) & 1) * L + l) * BH;
+                c.carry_out = carry + ((long)(t & 1) * L + l) * BH;
+                c.saved = saved + l * sv_sl + (long)t * sv_st;
+                if (G == 4) {
+                    c.c = cs + l * cs_sl + (long)(t + 1) * cs_st;
+                    c.c_prev = cs + l * cs_sl + (long)t * cs_st;
+                } else {
+                    c.h_prev = hs + l * hs_sl + (long)t * hs_st; c.hp_stride = hs_sb;
+                }
+                c.dgx = dgx + l * dg_sl + (long)t * dg_st;
+                c.dgh = dgh + l * dg_sl + (long)t * dg_st;
+                c.dg_stride = dg_sb;
+            }
+            p.ncell = n;
+            if (any_seg) {
+                hipLaunchKernelGGL(gpe_rnn_wave_splitk_kernel, dim3(gpe_cdiv(Bn, RG_BM), gpe_cdiv(H, 64), n * 2 * nz), dim3(256),
+                                   lds, s, p);
+                GPE_CHECK_LAUNCH();
+            }
+            if (G == 4)
+                hipLaunchKernelGGL((gpe_rnn_wave_cell_bwd_kernel<4>), dim3(gpe_cdiv(BH, 256), n), dim3(256), 0, s, p);
+            else
+                hipLaunchKernelGGL((gpe_rnn_wave_cell_bwd_kernel<3>), dim3(gpe_cdiv(BH, 256), n), dim3(256), 0, s, p);
+            GPE_CHECK_LAUNCH();
+        }
+    }
+    return GPE_OK;
+}

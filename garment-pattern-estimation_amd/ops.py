@@ -51,7 +51,7 @@ def round_up(a, b):
 WEIGHTS_EPOCH = 0          # bumped by optimizers that update parameters through raw pointers (optim.FusedAdam)
 _PACKS = {}                # (param data_ptr, kind) -> (plan, output tensor)
 
-K_PLAIN, K_TRANS, K_GATES, K_PQ, K_PQT, K_VADD, K_BPQ = 0, 1, 2, 3, 4, 5, 6
+K_PLAIN, K_TRANS, K_GATES, K_PQ, K_PQT, K_VADD, K_BPQ, K_GRUB = 0, 1, 2, 3, 4, 5, 6, 7
 _JOB = np.dtype([('w', '<u8'), ('w2', '<u8'), ('out', '<u8'), ('total', '<i8'), ('first_block', '<i8'),
                  ('ldw', '<i4'), ('N', '<i4'), ('K', '<i4'), ('kind', '<i4'), ('Npad', '<i4'), ('aux', '<i4')])
 assert _JOB.itemsize == 64
@@ -100,6 +100,10 @@ class PackPlan:
     def add_bias_sum(self, b_ih, b_hh):
         self._add(b_ih, K_VADD, b_ih.numel(), 0, p2=b_hh, out_numel=b_ih.numel())
 
+    def add_gru_bias(self, b_ih, b_hh, H):
+        """b_ih + [b_hr | b_hz | 0]: nn.GRU keeps b_hn inside the r-gated term."""
+        self._add(b_ih, K_GRUB, b_ih.numel(), 0, aux=2 * H, p2=b_hh, out_numel=b_ih.numel())
+
     def _versions(self):
         return [p._version + (p2._version if p2 is not None else 0) for p, p2, *_ in self.specs]
 
@@ -111,7 +115,7 @@ class PackPlan:
         tab = np.zeros(len(self.specs), dtype=_JOB)
         blk = 0
         for i, (p, p2, kind, N, K, aux, out_numel) in enumerate(self.specs):
-            if kind in (K_VADD, K_BPQ):
+            if kind in (K_VADD, K_BPQ, K_GRUB):
                 total, npad = out_numel, 0
             elif kind == K_GATES:
                 npad = 16 * (N // aux) * ((aux + 15) // 16)
@@ -216,6 +220,21 @@ def bias_sum(b_ih, b_hh):
     out = torch.empty_like(b_ih)
     L.call('gpe_add', b_ih, b_hh, out, b_ih.numel())
     return out
+
+
+def gru_bias(b_ih, b_hh, H):
+    hit = _planned(b_ih, K_GRUB, b_hh)
+    if hit is not None:
+        return hit
+    out = b_ih.detach().clone()
+    L.call('gpe_add', b_ih, b_hh, out, 2 * H)
+    return out
+
+
+def _ptr_array(tensors):
+    """host array of device pointers (the `const void* const*` arguments of the wavefront recurrences)."""
+    import ctypes
+    return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() if t is not None else None for t in tensors])
 
 
 def edge_first_operands(W1, b1):
@@ -619,11 +638,13 @@ class RNNStackFn(torch.autograd.Function):
     c_T [L, Bn, H] or None).
 
     x is either [Bn, In] — the SAME input at every step (decoders feed the encoding T times, :388,430,483): layer 0's input
-    projection is then computed once — or a sequence [Bn, T, In].  Layers > 0 project all T steps of the layer below in one
-    GEMM.  The recurrence runs T fused steps per layer (gate GEMM on h_{t-1} + `xproj` addend + cell update in one launch);
-    backward = pointwise cell backward + split-K GEMM per step, then the weight gradients as reduce-GEMMs over all Bn*T rows.
-    Gate orders follow torch: LSTM i,f,g,o; GRU r,z,n.  Start states may carry gradient (LSTMDoubleReverseDecoderModule
-    threads the first LSTM's final state into the second), final states too."""
+    projection is then computed once — or a sequence [Bn, T, In] (one GEMM over all steps).  The recurrence itself runs in
+    WAVEFRONT order (csrc/gpe_rnn_wave.hip): all cells (layer l, step t) of an anti-diagonal l + t = d are independent, so a
+    diagonal is one fused launch forward (gate GEMMs on h_{l,t-1} and h_{l-1,t} + cell update) and two launches backward
+    (split-K dh products of all cells, pointwise cell backward): T + L - 1 dependent steps instead of T * L.  Weight
+    gradients are reduce-GEMMs over all Bn*T rows afterwards.  Gate orders follow torch: LSTM i,f,g,o; GRU r,z,n.
+    Start states may carry gradient (LSTMDoubleReverseDecoderModule threads the first LSTM's final state into the
+    second), final states too."""
 
     @staticmethod
     def forward(ctx, x, h0, c0, T, n_layers, kind, want_state, *params):
@@ -636,126 +657,108 @@ class RNNStackFn(torch.autograd.Function):
         Bn, In = x.shape[0], x.shape[-1]
         Hh = h0.shape[2]
         Hp = round_up(Hh, 4)
-        saved_layers = []
-        prev_hs = None
-        for l in range(n_layers):
+        Lr = n_layers
+        # h history with a 16-B row pitch (zero pad): slot 0 = h0, slot t+1 = h_t
+        hs = torch.zeros(Lr, Bn, T + 1, Hp, device=dev, dtype=F32)
+        hs[:, :, 0, :Hh].copy_(h0)
+        cs = None
+        if lstm:
+            cs = torch.empty(Lr, T + 1, Bn, Hh, device=dev, dtype=F32)
+            cs[:, 0].copy_(c0)
+        saved = torch.empty(Lr, T, Bn, 4 * Hh, device=dev, dtype=F32)
+        w_ih0, _, b_ih0, b_hh0 = params[0:4]
+        bias0 = bias_sum(b_ih0, b_hh0) if lstm else gru_bias(b_ih0, b_hh0, Hh)
+        if seq:
+            xproj = torch.empty(Bn, T, G * Hh, device=dev, dtype=F32)
+            linear_raw(_rows3d(x), pack_weight(w_ih0), bias0, Bn * T, G * Hh, In, (xproj, G * Hh, 0, 0))
+            xp_sb, xp_st = T * G * Hh, G * Hh
+        else:
+            xproj = torch.empty(Bn, G * Hh, device=dev, dtype=F32)
+            linear_raw(_rows2d(x), pack_weight(w_ih0), bias0, Bn, G * Hh, In, _rows2d(xproj))
+            xp_sb, xp_st = G * Hh, 0
+        whh, wih, biases, bhns = [], [None], [None], []
+        for l in range(Lr):
             w_ih, w_hh, b_ih, b_hh = params[4 * l: 4 * l + 4]
-            # row pitch padded to 16 B (zero pad) so the recurrence's A operand is staged with plain aligned loads
-            hs = torch.zeros(Bn, T + 1, Hp, device=dev, dtype=F32)[:, :, :Hh]
-            hs[:, 0].copy_(h0[l])
-            if lstm:
-                bias = bias_sum(b_ih, b_hh)
-                cs = torch.empty(T + 1, Bn, Hh, device=dev, dtype=F32)
-                cs[0].copy_(c0[l])
-            else:
-                # nn.GRU keeps b_hn inside the r-gated term: xproj carries b_ih + [b_hr | b_hz | 0]
-                bias = torch.empty(G * Hh, device=dev, dtype=F32)
-                L.call('gpe_add', b_ih, b_hh, bias, 2 * Hh)
-                bias[2 * Hh:].copy_(b_ih[2 * Hh:])
-                cs = None
-            gates = torch.empty(T, Bn, 4 * Hh, device=dev, dtype=F32)
-            per_step = not (l == 0 and not seq)
-            if not per_step:
-                xproj = torch.empty(Bn, G * Hh, device=dev, dtype=F32)
-                linear_raw(_rows2d(x), pack_weight(w_ih), bias, Bn, G * Hh, In, _rows2d(xproj))
-            else:
-                src = _rows3d(x if l == 0 else prev_hs[:, 1:])
-                xproj = torch.empty(Bn, T, G * Hh, device=dev, dtype=F32)
-                linear_raw(src, pack_weight(w_ih), bias, Bn * T, G * Hh, In if l == 0 else Hh, (xproj, G * Hh, 0, 0))
-            whh_p = pack_gates(w_hh, Hh, G)
-            for t in range(T):
-                xp, xps = (xproj[:, t], T * G * Hh) if per_step else (xproj, G * Hh)
-                if lstm:
-                    L.call('gpe_lstm_step_fwd', hs[:, t], hs.stride(0), whh_p, xp, xps, cs[t], Hh,
-                           gates[t], cs[t + 1], hs[:, t + 1], hs.stride(0), Bn, Hh)
-                else:
-                    L.call('gpe_gru_step_fwd', hs[:, t], hs.stride(0), whh_p, xp, xps, b_hh[2 * Hh:], gates[t],
-                           hs[:, t + 1], hs.stride(0), Bn, Hh)
-            saved_layers += [hs, gates] + ([cs] if lstm else [])
-            prev_hs = hs
-        per = 3 if lstm else 2
+            whh.append(pack_gates(w_hh, Hh, G))
+            if l > 0:
+                wih.append(pack_gates(w_ih, Hh, G))
+                biases.append(bias_sum(b_ih, b_hh) if lstm else gru_bias(b_ih, b_hh, Hh))
+            bhns.append(None if lstm else b_hh[2 * Hh:])
+        keep = (whh, wih, biases)                  # operands stay referenced until the launches are queued
+        L.call('gpe_rnn_seq_fwd', G, Lr, T, Bn, Hh, xproj, xp_sb, xp_st, _ptr_array(whh), _ptr_array(wih),
+               _ptr_array(biases), None if lstm else _ptr_array(bhns), hs, hs.stride(0), hs.stride(1), hs.stride(2),
+               cs, cs.stride(0) if lstm else 0, cs.stride(1) if lstm else 0, saved, saved.stride(0), saved.stride(1))
+        del keep
         hN = cN = None
         if want_state:
-            hN = torch.stack([saved_layers[per * l][:, T] for l in range(n_layers)])
-            cN = torch.stack([saved_layers[per * l + 2][T] for l in range(n_layers)]) if lstm else None
-        ctx.dims = (Bn, In, Hh, T, n_layers, kind, seq)
-        ctx.save_for_backward(x, *params, *saved_layers)
+            hN = hs[:, :, T, :Hh].contiguous()
+            cN = cs[:, T].contiguous() if lstm else None
+        ctx.dims = (Bn, In, Hh, T, Lr, kind, seq)
+        ctx.save_for_backward(x, hs, cs, saved, *params)
         ctx.needs_state_grad = (h0.requires_grad, c0 is not None and c0.requires_grad)
-        top = prev_hs[:, 1:]
+        top = hs[Lr - 1, :, 1:, :Hh]
         if lstm:
             return top, hN, cN
         return top, hN
 
     @staticmethod
     def backward(ctx, g_top, g_hN, g_cN=None):
-        Bn, In, Hh, T, n_layers, kind, seq = ctx.dims
+        Bn, In, Hh, T, Lr, kind, seq = ctx.dims
         lstm = kind == 'lstm'
         G = 4 if lstm else 3
-        per = 3 if lstm else 2
         sv = ctx.saved_tensors
-        x = sv[0]
-        params = sv[1: 1 + 4 * n_layers]
-        saved_layers = sv[1 + 4 * n_layers:]
+        x, hs, cs, saved = sv[:4]
+        params = sv[4:]
         dev = x.device
         want_h0, want_c0 = ctx.needs_state_grad
-        if g_top is None:
-            g_top = torch.zeros(Bn, T, Hh, device=dev, dtype=F32)
-        dH = g_top if g_top.is_contiguous() else g_top.contiguous()
-        grads = [None] * (4 * n_layers)
+        GH = G * Hh
+        GHp = round_up(GH, 4)
+        dgx = torch.empty(Lr, Bn, T, GHp, device=dev, dtype=F32)
+        dgh = dgx if lstm else torch.empty(Lr, Bn, T, GHp, device=dev, dtype=F32)
+        part = torch.empty(L.query('gpe_rnn_seq_bwd_ws', G, Lr, Bn, Hh), device=dev, dtype=F32)
+        carry = torch.empty(2, Lr, Bn, Hh, device=dev, dtype=F32)
+        whh_t = [pack_weight(params[4 * l + 1], transpose=True) for l in range(Lr)]
+        wih_t = [None] + [pack_weight(params[4 * l], transpose=True) for l in range(1, Lr)]
+        if g_top is not None and g_top.stride(2) != 1:
+            g_top = g_top.contiguous()
+        ghN = g_hN.contiguous() if g_hN is not None else None
+        gcN = g_cN.contiguous() if (lstm and g_cN is not None) else None
+        L.call('gpe_rnn_seq_bwd', G, Lr, T, Bn, Hh, g_top, g_top.stride(0) if g_top is not None else 0,
+               g_top.stride(1) if g_top is not None else 0, ghN, gcN, _ptr_array(whh_t), _ptr_array(wih_t),
+               hs, hs.stride(0), hs.stride(1), hs.stride(2), cs, cs.stride(0) if lstm else 0, cs.stride(1) if lstm else 0,
+               saved, saved.stride(0), saved.stride(1), dgx, dgh, dgx.stride(0), dgx.stride(1), dgx.stride(2), part, carry)
+        grads = [None] * (4 * Lr)
         d_x = None
-        d_h0 = torch.empty(n_layers, Bn, Hh, device=dev, dtype=F32) if want_h0 else None
-        d_c0 = torch.empty(n_layers, Bn, Hh, device=dev, dtype=F32) if want_c0 else None
-        nz = (G * Hh + 255) // 256                         # split-K partials of dh_rec = dG_t . W_hh
-        for l in reversed(range(n_layers)):
+        d_h0 = torch.empty(Lr, Bn, Hh, device=dev, dtype=F32) if want_h0 else None
+        d_c0 = carry[0].clone() if want_c0 else None
+        nz = (GH + 255) // 256
+        for l in range(Lr):
             w_ih, w_hh, b_ih, b_hh = params[4 * l: 4 * l + 4]
-            hs, gates = saved_layers[per * l], saved_layers[per * l + 1]
-            cs = saved_layers[per * l + 2] if lstm else None
-            dGx = torch.empty(Bn, T, G * Hh, device=dev, dtype=F32)
-            dGh = dGx if lstm else torch.empty(Bn, T, G * Hh, device=dev, dtype=F32)
-            dh_rec = torch.empty(nz, Bn, Hh, device=dev, dtype=F32)
-            carry = [torch.empty(Bn, Hh, device=dev, dtype=F32) for _ in range(2)]     # dc (LSTM) / z-gated dh (GRU)
-            whh_t = pack_weight(w_hh, transpose=True)
-            ghN = g_hN[l].contiguous() if g_hN is not None else None
-            gcN = g_cN[l].contiguous() if (lstm and g_cN is not None) else None
-            for t in reversed(range(T)):
-                last = t == T - 1
-                rec, n_rec = (ghN, 1 if ghN is not None else 0) if last else (dh_rec, nz)
-                if lstm:
-                    L.call('gpe_lstm_cell_bwd', dH[:, t], T * Hh, rec, n_rec, gcN if last else carry[(t + 1) & 1],
-                           gates[t], cs[t + 1], cs[t], Hh, dGx[:, t], T * G * Hh, carry[t & 1], Bn, Hh)
-                else:
-                    L.call('gpe_gru_cell_bwd', dH[:, t], T * Hh, rec, n_rec, None if last else carry[(t + 1) & 1],
-                           gates[t], hs[:, t], hs.stride(0), dGx[:, t], dGh[:, t], T * G * Hh, carry[t & 1], Bn, Hh)
-                if t > 0 or want_h0:
-                    L.call('gpe_linear_splitk', dGh[:, t], T * G * Hh, whh_t, dh_rec, Bn, Hh, G * Hh)
-            if want_h0:
-                L.call('gpe_reduce_inner', dh_rec, Hh, Bn * Hh, nz, Bn, Hh, d_h0[l], Hh, 0)
-                if not lstm:
-                    L.call('gpe_add', d_h0[l], carry[0], d_h0[l], Bn * Hh)
-            if want_c0:
-                d_c0[l].copy_(carry[0])
-            gx_rows, gh_rows = (dGx, G * Hh, 0, 0), (dGh, G * Hh, 0, 0)
+            gx_rows, gh_rows = _rows3d(dgx[l][:, :, :GH]), _rows3d(dgh[l][:, :, :GH])
             d_whh, d_bhh = _gbuf(w_hh), _gbuf(b_hh)
-            redgemm_raw(gh_rows, _rows3d(hs[:, :T]), Bn * T, G * Hh, Hh, out=(d_whh, d_bhh))
+            redgemm_raw(gh_rows, _rows3d(hs[l][:, :T, :Hh]), Bn * T, GH, Hh, out=(d_whh, d_bhh))
             d_wih, d_bih = _gbuf(w_ih), _gbuf(b_ih)
             if l == 0 and not seq:
-                redgemm_raw(gx_rows, (x, x.stride(0), 0, T), Bn * T, G * Hh, In, out=(d_wih, d_bih))
+                redgemm_raw(gx_rows, (x, x.stride(0), 0, T), Bn * T, GH, In, out=(d_wih, d_bih))
                 if ctx.needs_input_grad[0]:
-                    dGs = torch.empty(Bn, G * Hh, device=dev, dtype=F32)
-                    L.call('gpe_reduce_inner', dGx, T * G * Hh, G * Hh, T, Bn, G * Hh, dGs, G * Hh, 0)
+                    dGs = torch.empty(Bn, GH, device=dev, dtype=F32)
+                    L.call('gpe_reduce_inner', dgx[0], T * GHp, GHp, T, Bn, GH, dGs, GH, 0)
                     d_x = torch.empty(Bn, In, device=dev, dtype=F32)
-                    linear_raw(_rows2d(dGs), pack_weight(w_ih, transpose=True), None, Bn, In, G * Hh, _rows2d(d_x))
+                    linear_raw(_rows2d(dGs), pack_weight(w_ih, transpose=True), None, Bn, In, GH, _rows2d(d_x))
             else:
                 Kin = In if l == 0 else Hh
-                src = _rows3d(x if l == 0 else saved_layers[per * (l - 1)][:, 1:])
-                redgemm_raw(gx_rows, src, Bn * T, G * Hh, Kin, out=(d_wih, d_bih))
-                if l > 0 or ctx.needs_input_grad[0]:
-                    nxt = torch.empty(Bn, T, Kin, device=dev, dtype=F32)
-                    linear_raw(gx_rows, pack_weight(w_ih, transpose=True), None, Bn * T, Kin, G * Hh, (nxt, Kin, 0, 0))
-                    if l > 0:
-                        dH = nxt
-                    else:
-                        d_x = nxt
+                src = _rows3d(x) if l == 0 else _rows3d(hs[l - 1][:, 1:, :Hh])
+                redgemm_raw(gx_rows, src, Bn * T, GH, Kin, out=(d_wih, d_bih))
+                if l == 0 and ctx.needs_input_grad[0]:
+                    d_x = torch.empty(Bn, T, In, device=dev, dtype=F32)
+                    linear_raw(gx_rows, pack_weight(w_ih, transpose=True), None, Bn * T, In, GH, (d_x, In, 0, 0))
+            if want_h0:
+                # dh_0 = dG_{l,0} . W_hh (+ the z-gated direct path of a GRU)
+                rec = torch.empty(nz, Bn, Hh, device=dev, dtype=F32)
+                L.call('gpe_linear_splitk', dgh[l][:, 0], T * GHp, whh_t[l], rec, Bn, Hh, GH)
+                L.call('gpe_reduce_inner', rec, Hh, Bn * Hh, nz, Bn, Hh, d_h0[l], Hh, 0)
+                if not lstm:
+                    L.call('gpe_add', d_h0[l], carry[0][l], d_h0[l], Bn * Hh)
             grads[4 * l: 4 * l + 4] = [_gret(w_ih, d_wih), _gret(w_hh, d_whh), _gret(b_ih, d_bih),
                                        _gret(b_hh, d_bhh)]
         return (d_x, d_h0, d_c0, None, None, None, None, *grads)

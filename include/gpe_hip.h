@@ -64,7 +64,7 @@ int gpe_pack_weight(const float* w, int ldw, int N, int K, int transpose, const 
  * of njobs 64-byte records {const float* w, w2; float* out; long total, first_block; int ldw, N, K, kind, Npad, aux}
  * sorted by first_block (256 outputs per block).  kind 0 plain pack, 1 transposed pack, 2 gate-interleaved pack (aux = H),
  * 3 pack of [W1a-W1b ; W1b] from W1 [H][2C] (gpe_w1_split + pack; aux = H), 4 its transpose, 5 out = w + w2 (N floats),
- * 6 out = [w[0:aux] | 0] (N floats). */
+ * 6 out = [w[0:aux] | 0] (N floats), 7 out = w + [w2[0:aux] | 0] (N floats; GRU input-side bias b_ih + [b_hr | b_hz | 0]). */
 int gpe_pack_multi(const void* jobs_dev, int njobs, long total_blocks, void* stream);
 /* folded bias: out[n] = bias[n] + sum_k w[n][k]*t[k]   (t = beta - mean*s of the previous BatchNorm) */
 int gpe_fold_bias(const float* w, int ldw, int N, int K, const float* bias, const float* t, float* out,
@@ -210,6 +210,34 @@ int gpe_gru_step_fwd(const float* h_prev, long hp_stride, const float* whh_gates
 int gpe_gru_cell_bwd(const float* dh_out, long dho_stride, const float* dh_rec, int n_rec, const float* dh_dir_next,
                      const float* saved, const float* h_prev, long hp_stride, float* dgx, float* dgh, long dg_stride,
                      float* dh_dir_prev, int Bn, int H, void* stream);
+
+/* ---- whole recurrences, wavefront order (gpe_rnn_wave.hip) ---------------------------------------------------------------
+ * A stack of L layers over T steps (nn.LSTM gates = 4 / nn.GRU gates = 3, batch_first, no dropout) executed diagonal by
+ * diagonal: all cells (l, t) with l + t = d run in one launch.  Buffers (device, fp32):
+ *   hs    h history, element (l, b, slot) at hs + l*hs_sl + b*hs_sb + slot*hs_st, slot 0 = h0, slot t+1 = h_t (pitches % 4 == 0)
+ *   cs    LSTM c history, (l, slot) at cs + l*cs_sl + slot*cs_st, each [Bn][H]
+ *   saved activated gates per cell, (l, t) at saved + l*sv_sl + t*sv_st, each [Bn][4H] (GRU: {r, z, n, W_hn.h + b_hn})
+ *   xproj0  layer-0 input projection x.W_ih^T + bias, row (b, t) at xproj0 + b*xp0_sb + t*xp0_st (xp0_st = 0: same input at
+ *           every step, the decoders' case)
+ * whh / wih / bias / bhn are HOST arrays of L device pointers: gate-interleaved packed W_hh_l; gate-interleaved packed W_ih_l
+ * (entry 0 unused); the addend row [gates*H] of layers > 0 (LSTM b_ih + b_hh; GRU b_ih + [b_hr | b_hz | 0]; entry 0 unused);
+ * GRU b_hn [H] per layer (NULL for LSTM). */
+int gpe_rnn_seq_fwd(int gates, int L, int T, int Bn, int H, const float* xproj0, long xp0_sb, long xp0_st,
+                    const void* const* whh, const void* const* wih, const void* const* bias, const void* const* bhn,
+                    float* hs, long hs_sl, long hs_sb, long hs_st, float* cs, long cs_sl, long cs_st, float* saved,
+                    long sv_sl, long sv_st, void* stream);
+/* backward through the same recurrence.  dtop: gradient of the top layer's outputs, row (b, t) at dtop + b*dt_sb + t*dt_st
+ * (may be NULL); d_hN / d_cN [L][Bn][H]: gradients of the final states (may be NULL).  whh_t / wih_t: host arrays of the
+ * plain TRANSPOSED packs (gpe_pack_weight(.., transpose = 1)).  Outputs: dgx / dgh [L][Bn][T][ld], element (l, b, t) at
+ * + l*dg_sl + b*dg_sb + t*dg_st (pitches % 4 == 0): pre-activation gradients on the input side / recurrent side (LSTM: pass
+ * the same buffer twice).  part: workspace of gpe_rnn_seq_bwd_ws floats; carry: [2][L][Bn][H] scratch — on return
+ * carry[0][l] holds dc_0 (LSTM) / the z-gated part of dh_0 (GRU) of layer l. */
+long gpe_rnn_seq_bwd_ws(int gates, int L, int Bn, int H);
+int gpe_rnn_seq_bwd(int gates, int L, int T, int Bn, int H, const float* dtop, long dt_sb, long dt_st, const float* d_hN,
+                    const float* d_cN, const void* const* whh_t, const void* const* wih_t, const float* hs, long hs_sl,
+                    long hs_sb, long hs_st, const float* cs, long cs_sl, long cs_st, const float* saved, long sv_sl,
+                    long sv_st, float* dgx, float* dgh, long dg_sl, long dg_sb, long dg_st, float* part, float* carry,
+                    void* stream);
 
 /* ---- attention variant (GarmentSegmentPattern3D, nn/nets.py:187-299) ------------------------------------------ */
 /* sparsemax.Sparsemax(dim=1) over rows of width W <= 32 (nn/nets.py:225): forward and backward */

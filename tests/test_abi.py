@@ -20,7 +20,7 @@ def test_header_declares_expected_surface():
     for name, (res, args) in sigs.items():
         if name in ('gpe_abi_version', 'gpe_packed_size', 'gpe_packed_gates_size', 'gpe_redgemm_ws',
                     'gpe_stats_blocks', 'gpe_point_sums_blocks', 'gpe_debug_set', 'gpe_math_set', 'gpe_math_get',
-                    'gpe_attn_pool_ws', 'gpe_packed_ngates_size'):
+                    'gpe_attn_pool_ws', 'gpe_packed_ngates_size', 'gpe_rnn_seq_bwd_ws'):
             continue
         assert res == 'i' and args[-1] == 'p', name
 
