@@ -826,13 +826,20 @@ static int rd_num_cus() { return gpe_num_cus(); }
 // geometry shared by the workspace query and the launcher (no device query here: the ws size must be computable on a
 // CPU-only box, so it is sized for the largest grid we ever launch)
 #define RD_MAX_GX 256
-static void rd_geometry(int Mg, int Ng, int* MH, int* NH, int* gy, int* MgPad, int* NgPad)
+// rows < 0: workspace query -> the largest M block (an upper bound of every geometry below: gx * MgPad grows with MH).
+static void rd_geometry(int Mg, int Ng, long rows, int* MH, int* NH, int* gy, int* MgPad, int* NgPad)
 {
     // (64-row output blocks for the row-poor LSTM weight gradients were tried and measured slower: 2.43 vs 1.95 ms per
     // step — only 16 of 64 staging lanes carry U columns)
     const int mt = gpe_cdiv(Mg, 16), nt = gpe_cdiv(Ng, 16);
     const int mtb = mt < 14 ? mt : 14;
-    *MH = rd_pick(gpe_cdiv(mtb, 2), RD_MH_OPTS, 3);
+    int mh = rd_pick(gpe_cdiv(mtb, 2), RD_MH_OPTS, 3);
+    // (r02: for the row-poor LSTM weight gradients — 10 k rows against a 1000 x 250 output — a narrower M block with fewer
+    // row splits was tried: partials 52 -> 16 MB, but the reduce-GEMM time went UP, 1.85 -> 2.56 ms per step: with 2 M-tiles
+    // per wave the V operand is re-read 3.5x as often from LDS and the MFMA stream is too short to hide it.  `rows` stays in
+    // the signature for the next attempt.)
+    (void)rows;
+    *MH = mh;
     *NH = rd_pick(gpe_cdiv(nt, 2), RD_NH_OPTS, 4);
     *gy = gpe_cdiv(mt, 2 * (*MH));
     *MgPad = (*gy) * 32 * (*MH);
@@ -842,7 +849,7 @@ static void rd_geometry(int Mg, int Ng, int* MH, int* NH, int* gy, int* MgPad, i
 extern "C" long gpe_redgemm_ws(int Mg, int Ng)
 {
     int MH, NH, gy, MgPad, NgPad;
-    rd_geometry(Mg, Ng, &MH, &NH, &gy, &MgPad, &NgPad);
+    rd_geometry(Mg, Ng, -1, &MH, &NH, &gy, &MgPad, &NgPad);
     if (NH < 0) return -1;
     const long gx = RD_MAX_GX / gy > 0 ? RD_MAX_GX / gy : 1;
     return gx * MgPad * NgPad + 2L * gx * MgPad + 8;
@@ -904,7 +911,7 @@ static int rd_run(RdParams& p, int vmode, float* G, int ldG, float* colsum, floa
     // guarded scalar-tail loader
     p.vec = rd_rows_vec(p.u, p.Mg) && (vmode == V_GATHER || rd_rows_vec(p.v, p.Ng));
     int MH, NH, gy, MgPad, NgPad;
-    rd_geometry(p.Mg, p.Ng, &MH, &NH, &gy, &MgPad, &NgPad);
+    rd_geometry(p.Mg, p.Ng, p.rows, &MH, &NH, &gy, &MgPad, &NgPad);
     if (MH < 0 || NH < 0) return GPE_EINVAL;
     p.MgPad = MgPad; p.NgPad = NgPad;
     p.num_tiles = gpe_cdiv(p.rows, RD_RT);

@@ -14,6 +14,7 @@
 // whole K slab (<= 256) of 64 rows and of its packed weight block, one barrier pair per slab.
 #include "gpe_rowgemm.h"
 #include <math.h>
+#include <stdlib.h>
 
 #define WV_MAXCELL 4
 
@@ -31,15 +32,15 @@ __device__ __forceinline__ float wv_sigmoid(float x) { return 1.f / (1.f + expf(
 
 // stage rows [row0, row0+64) x K columns of `a` (row pitch `stride`, 16-B aligned, padded to 4) and the packed weight block
 // of this workgroup (columns n0 .. n0+16*NT of a [K/4][Npad][4] packed matrix) into LDS, then run the slab's MFMAs
-template <int NT>
+template <int NT, int KS>
 __device__ __forceinline__ void wv_segment(const float* __restrict__ a, long stride, const float* __restrict__ wp, int K,
                                            int Npad, int row0, int rv, int n0, float* As, float* Ws, int lda,
                                            f32x4 (&acc)[NT])
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 15, g = lane >> 4;
-    for (int ks = 0; ks < K; ks += RG_KSLAB) {
-        const int kslab = (K - ks < RG_KSLAB) ? (K - ks) : RG_KSLAB;
+    for (int ks = 0; ks < K; ks += KS) {
+        const int kslab = (K - ks < KS) ? (K - ks) : KS;
         const int kp = (kslab + 15) & ~15;
         __syncthreads();
         {
@@ -114,11 +115,11 @@ __device__ __forceinline__ void wv_segment(const float* __restrict__ a, long str
 }
 
 // G = 4: LSTM (i,f,g,o)   G = 3: GRU (r,z,n)
-template <int G>
+template <int G, int KS>
 __global__ __launch_bounds__(256) void gpe_rnn_wave_fwd_kernel(WvFwdParams p)
 {
     extern __shared__ __align__(16) float smem[];
-    const int kp_max = ((p.H < RG_KSLAB ? p.H : RG_KSLAB) + 15) & ~15;
+    const int kp_max = ((p.H < KS ? p.H : KS) + 15) & ~15;
     const int lda = kp_max + 4;
     constexpr int ldc = 16 * 2 * G + 4;              // GRU keeps the input-side and recurrent-side products apart
     const int a_floats = RG_BM * (lda > ldc ? lda : ldc);
@@ -135,10 +136,10 @@ __global__ __launch_bounds__(256) void gpe_rnn_wave_fwd_kernel(WvFwdParams p)
     f32x4 accH[G], accX[G];
 #pragma unroll
     for (int n = 0; n < G; ++n) { accH[n] = (f32x4){0.f, 0.f, 0.f, 0.f}; accX[n] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
-    wv_segment<G>(c.a0, c.a0_stride, c.w0, p.H, p.Npad, row0, rv, n0, As, Ws, lda, accH);
+    wv_segment<G, KS>(c.a0, c.a0_stride, c.w0, p.H, p.Npad, row0, rv, n0, As, Ws, lda, accH);
     if (c.a1) {
-        if (G == 4) wv_segment<G>(c.a1, c.a1_stride, c.w1, p.H, p.Npad, row0, rv, n0, As, Ws, lda, accH);
-        else wv_segment<G>(c.a1, c.a1_stride, c.w1, p.H, p.Npad, row0, rv, n0, As, Ws, lda, accX);
+        if (G == 4) wv_segment<G, KS>(c.a1, c.a1_stride, c.w1, p.H, p.Npad, row0, rv, n0, As, Ws, lda, accH);
+        else wv_segment<G, KS>(c.a1, c.a1_stride, c.w1, p.H, p.Npad, row0, rv, n0, As, Ws, lda, accX);
     }
     __syncthreads();
 #pragma unroll
@@ -208,18 +209,37 @@ __global__ __launch_bounds__(256) void gpe_rnn_wave_fwd_kernel(WvFwdParams p)
     }
 }
 
-template <int G>
-static int wv_fwd_launch(const WvFwdParams& p, hipStream_t s)
+// K slab of the wavefront kernels: 128 -> 67 KB of LDS per workgroup, two workgroups per CU (a diagonal of the shipped
+// panel decoder is 576 workgroups: with 256-wide slabs (132 KB, one per CU) it runs in three rounds).  GPE_WV_KS=256
+// selects the wide slab (A/B measurements).
+static int wv_ks()
 {
-    const int kp_max = gpe_round_up(p.H < RG_KSLAB ? p.H : RG_KSLAB, 16);
+    static int ks = 0;
+    if (!ks) {
+        const char* e = getenv("GPE_WV_KS");
+        ks = (e && atoi(e) == 256) ? 256 : 128;
+    }
+    return ks;
+}
+
+template <int G, int KS>
+static int wv_fwd_launch_ks(const WvFwdParams& p, hipStream_t s)
+{
+    const int kp_max = gpe_round_up(p.H < KS ? p.H : KS, 16);
     const int lda = kp_max + 4, ldc = 16 * 2 * G + 4;
     const size_t lds = ((size_t)RG_BM * (lda > ldc ? lda : ldc) + (size_t)kp_max * 16 * G) * sizeof(float);
     if (lds > 160 * 1024) return GPE_EINVAL;
-    GPE_ENSURE_MAX_LDS((gpe_rnn_wave_fwd_kernel<G>));
-    hipLaunchKernelGGL((gpe_rnn_wave_fwd_kernel<G>), dim3(gpe_cdiv(p.Bn, RG_BM), gpe_cdiv(p.H, 16), p.ncell), dim3(256), lds, s,
-                       p);
+    GPE_ENSURE_MAX_LDS((gpe_rnn_wave_fwd_kernel<G, KS>));
+    hipLaunchKernelGGL((gpe_rnn_wave_fwd_kernel<G, KS>), dim3(gpe_cdiv(p.Bn, RG_BM), gpe_cdiv(p.H, 16), p.ncell), dim3(256),
+                       lds, s, p);
     GPE_CHECK_LAUNCH();
     return GPE_OK;
+}
+
+template <int G>
+static int wv_fwd_launch(const WvFwdParams& p, hipStream_t s)
+{
+    return wv_ks() == 256 ? wv_fwd_launch_ks<G, 256>(p, s) : wv_fwd_launch_ks<G, 128>(p, s);
 }
 
 extern "C" int gpe_rnn_seq_fwd(int gates, int L, int T, int Bn, int H, const float* xproj0, long xp0_sb, long xp0_st,
@@ -288,14 +308,15 @@ struct WvBwdCell {
     float* dgx; float* dgh; long dg_stride;        // pre-activation gradients of the cell, rows [Bn] pitch dg_stride
     int nseg_mask;                                 // bit s: segment s present
 };
-struct WvBwdParams { int Bn, H, K, Kpad_n, nz, ncell; WvBwdCell cell[WV_MAXCELL]; };
+struct WvBwdParams { int Bn, H, K, Kpad_n, nz, ncell; WvBwdCell cell[WV_MAXCELL]; };   // nz = K slabs of the launch's slab size
 
 // grid (row tiles, cdiv(H, 64), ncell * 2 * nz): block z -> (cell, segment, K slab)
+template <int KS>
 __global__ __launch_bounds__(256) void gpe_rnn_wave_splitk_kernel(WvBwdParams p)
 {
     extern __shared__ __align__(16) float smem[];
     constexpr int NT = 4;
-    const int lda = RG_KSLAB + 4;
+    const int lda = KS + 4;
     constexpr int ldc = 16 * NT + 4;
     float* As = smem;
     float* Cs = smem;
@@ -310,14 +331,14 @@ __global__ __launch_bounds__(256) void gpe_rnn_wave_splitk_kernel(WvBwdParams p)
     const int row0 = blockIdx.x * RG_BM;
     const int rv = (p.Bn - row0 < RG_BM) ? (p.Bn - row0) : RG_BM;
     const int n0 = blockIdx.y * (16 * NT);
-    const int ks = z * RG_KSLAB;
-    const int kslab = (p.K - ks < RG_KSLAB) ? (p.K - ks) : RG_KSLAB;
+    const int ks = z * KS;
+    const int kslab = (p.K - ks < KS) ? (p.K - ks) : KS;
     f32x4 acc[NT];
 #pragma unroll
     for (int n = 0; n < NT; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
     // one slab: reuse the forward's staging helper on the slab's column window
-    wv_segment<NT>(c.a[seg] + ks, c.as[seg], c.w[seg] + (long)(ks >> 4) * 4 * p.Kpad_n * 4, kslab, p.Kpad_n, row0, rv, n0, As,
-                   Ws, lda, acc);
+    wv_segment<NT, KS>(c.a[seg] + ks, c.as[seg], c.w[seg] + (long)(ks >> 4) * 4 * p.Kpad_n * 4, kslab, p.Kpad_n, row0, rv, n0,
+                       As, Ws, lda, acc);
     __syncthreads();
 #pragma unroll
     for (int n = 0; n < NT; ++n)
@@ -380,7 +401,7 @@ __global__ void gpe_rnn_wave_cell_bwd_kernel(WvBwdParams p)
 
 extern "C" long gpe_rnn_seq_bwd_ws(int gates, int L, int Bn, int H)
 {
-    const int nz = gpe_cdiv(gates * H, RG_KSLAB);
+    const int nz = gpe_cdiv(gates * H, 128);              // sized for the narrow slab (the wide one needs half)
     const int ncell = L < WV_MAXCELL ? L : WV_MAXCELL;
     return (long)ncell * 2 * nz * Bn * H;
 }
@@ -399,11 +420,13 @@ extern "C" int gpe_rnn_seq_bwd(int gates, int L, int T, int Bn, int H, const flo
         !part || !carry || (L > 1 && !wih_t) || (gates == 4 && !cs) || (dg_sb & 3) || (dg_st & 3))
         return GPE_EINVAL;
     const int G = gates, K = G * H;
-    const int nz = gpe_cdiv(K, RG_KSLAB);
+    const int KS = wv_ks();
+    const int nz = gpe_cdiv(K, KS);
     const long BH = (long)Bn * H;
     hipStream_t s = (hipStream_t)stream;
-    const size_t lds = ((size_t)RG_BM * (RG_KSLAB + 4) + (size_t)RG_KSLAB * 64) * sizeof(float);
-    GPE_ENSURE_MAX_LDS((gpe_rnn_wave_splitk_kernel));
+    const size_t lds = ((size_t)RG_BM * (KS + 4) + (size_t)KS * 64) * sizeof(float);
+    if (KS == 256) GPE_ENSURE_MAX_LDS((gpe_rnn_wave_splitk_kernel<256>));
+    else GPE_ENSURE_MAX_LDS((gpe_rnn_wave_splitk_kernel<128>));
     for (int d = T + L - 2; d >= 0; --d) {
         const int l_lo = (d - (T - 1) > 0) ? d - (T - 1) : 0;
         const int l_hi = (d < L - 1) ? d : L - 1;
@@ -444,8 +467,9 @@ extern "C" int gpe_rnn_seq_bwd(int gates, int L, int T, int Bn, int H, const flo
             }
             p.ncell = n;
             if (any_seg) {
-                hipLaunchKernelGGL(gpe_rnn_wave_splitk_kernel, dim3(gpe_cdiv(Bn, RG_BM), gpe_cdiv(H, 64), n * 2 * nz), dim3(256),
-                                   lds, s, p);
+                const dim3 grid(gpe_cdiv(Bn, RG_BM), gpe_cdiv(H, 64), n * 2 * nz);
+                if (KS == 256) hipLaunchKernelGGL(gpe_rnn_wave_splitk_kernel<256>, grid, dim3(256), lds, s, p);
+                else hipLaunchKernelGGL(gpe_rnn_wave_splitk_kernel<128>, grid, dim3(256), lds, s, p);
                 GPE_CHECK_LAUNCH();
             }
             if (G == 4)
