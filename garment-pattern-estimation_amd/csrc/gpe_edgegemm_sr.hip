@@ -248,7 +248,10 @@ __global__ __launch_bounds__(256, 1) void gpe_edgegemm_sr_kernel(RgParams p, int
             if (EMODE == E_EDGE_FWD) {
                 const float vv[4] = {fmaxf(z.x + bias4.x, 0.f), fmaxf(z.y + bias4.y, 0.f), fmaxf(z.z + bias4.z, 0.f),
                                      fmaxf(z.w + bias4.w, 0.f)};
-                st4(p.out + (e_row0 + r) * p.ldo + c, make_float4(vv[0], vv[1], vv[2], vv[3]));
+                // gather variant: the activation rows stream out past L2 so that they do not evict the cloud's Q table
+                // (counter fetch of this kernel 199 -> <145 MB against 109 MB compulsory, same run time: profiles/r02_b)
+                if (AMODE == A_GATHER) st4_stream(p.out + (e_row0 + r) * p.ldo + c, make_float4(vv[0], vv[1], vv[2], vv[3]));
+                else st4(p.out + (e_row0 + r) * p.ldo + c, make_float4(vv[0], vv[1], vv[2], vv[3]));
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
                     s32[t] += vv[t];

@@ -39,6 +39,15 @@ struct RgParams {
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+// streaming 16-B store that does NOT keep its line in the XCD's L2 (sc1: write-through + drop, MI355X_MICROARCH.md "stores of
+// each flavour"): for activation rows that are written once and read by a later kernel, so that they do not evict the
+// gathered per-cloud table the same kernel keeps re-reading.  (vmcnt is in-order on gfx9: a store the compiler does not
+// count only makes its waits more conservative.)
+__device__ __forceinline__ void st4_stream(float* p, float4 v)
+{
+    const f32x4 vv = {v.x, v.y, v.z, v.w};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(vv) : "memory");
+}
 
 // guarded load of 4 consecutive floats p[0..3] of which `nvalid` exist; vec => p is 16-B aligned
 __device__ __forceinline__ float4 ld4_guard(const float* p, int nvalid, bool vec)
