@@ -116,6 +116,74 @@ class EdgeConvFeatures(nn.Module):
         return None, out, batch
 
 
+class _PointConvHolder(nn.Module):
+    """parameter container with PyG PointConv's attribute names (state-dict keys `conv.local_nn.*`)."""
+
+    def __init__(self, local_nn):
+        super().__init__()
+        self.local_nn = local_nn
+        self.global_nn = None
+
+
+class _SetAbstractionModule(nn.Module):
+    """nn/net_blocks.py:10-27: fps -> ball query (<= 25 neighbours) -> PointConv(MLP) with max aggregation."""
+
+    def __init__(self, ratio, conv_radius, per_point_nn):
+        super().__init__()
+        self.ratio = ratio
+        self.radius = conv_radius
+        self.conv = _PointConvHolder(per_point_nn)
+        self.last = {}
+
+    def forward(self, features, pos_flat, B, N):
+        import math
+        M = int(math.ceil(self.ratio * N))
+        idx = ops.fps(pos_flat, B, N, M)
+        nbr, cnt = ops.radius_neighbors(pos_flat, idx, B, N, self.radius, 25)
+        off = torch.zeros(B * M + 1, device=pos_flat.device, dtype=torch.int64)
+        torch.cumsum(cnt, 0, out=off[1:])
+        n_edges = int(off[-1].item())          # ragged edge list: the one host sync of this block (sizes the MLP rows)
+        msg, seg = ops.ball_messages(pos_flat, features, idx, nbr, off, n_edges, B, N)
+        h = ops.dense_mlp(msg, self.conv.local_nn, self.training)
+        out = ops.RaggedMaxFn.apply(h, off, seg, B * M)
+        gidx = (idx.long() + (torch.arange(B, device=idx.device) * N)[:, None]).view(-1)
+        self.last = {'idx': idx, 'nbr': nbr, 'cnt': cnt}
+        return out, pos_flat[gidx], M
+
+
+class _GlobalSetAbstractionModule(nn.Module):
+    """nn/net_blocks.py:30-42: MLP on [features | pos] -> global max pool."""
+
+    def __init__(self, per_point_net):
+        super().__init__()
+        self.nn = per_point_net
+
+    def forward(self, features, pos, B, M):
+        feats = torch.cat([features, pos], dim=1) if features is not None else pos
+        return ops.segment_max(ops.dense_mlp(feats, self.nn, self.training), B, M)
+
+
+class PointNetPlusPlus(nn.Module):
+    """nn/net_blocks.py:50-88 (one set-abstraction level + the global level, as in the reference).  forward(positions [B,N,3])
+    -> [B, out_size].  The upstream fps / radius / PointConv conventions are fixed as described in csrc/gpe_pointnet.hip."""
+
+    def __init__(self, out_size, config={}):
+        super().__init__()
+        self.config = {'r1': 0.3, 'r2': 0.4, 'r3': 5, 'r4': 7}
+        self.config.update(config)
+        H, F = self.config['EConv_hidden'], self.config['EConv_feature']
+        self.sa1_module = _SetAbstractionModule(0.2, self.config['r1'], MLP([3, H, H, F]))
+        self.sa_last_module = _GlobalSetAbstractionModule(MLP([3 + F, H, H, F]))
+        self.lin = nn.Linear(F, out_size)
+
+    def forward(self, positions):
+        B, N = positions.size(0), positions.size(1)
+        pos_flat = positions.reshape(-1, positions.size(-1)).float().contiguous()
+        feats, cpos, M = self.sa1_module(None, pos_flat, B, N)
+        pooled = self.sa_last_module(feats, cpos, B, M)
+        return ops.linear(pooled, self.lin.weight, self.lin.bias)
+
+
 class _StateUploader:
     """Host-drawn tensors reach the GPU without draining the compute stream.
 
@@ -380,6 +448,5 @@ def _not_accelerated(name):
     return _Missing
 
 
-PointNetPlusPlus = _not_accelerated('PointNetPlusPlus')
 EdgeConvPoolingFeatures = _not_accelerated('EdgeConvPoolingFeatures')
 DynamicASAPool = _not_accelerated('DynamicASAPool')

@@ -1037,3 +1037,62 @@ def standardize(x, shift, scale):
     out = torch.empty_like(x)
     L.call('gpe_standardize', x, x.numel() // C, C, sh, sc, out)
     return out
+
+
+# -------------------------------------------------------------------------------------------------
+# PointNet++ set abstraction (PointNetPlusPlus, nn/net_blocks.py:10-88)
+# -------------------------------------------------------------------------------------------------
+def fps(pos, B, N, M):
+    """torch_geometric.nn.fps over equal-sized clouds: -> int32 [B, M] LOCAL indices in selection order (start = the
+    cloud's first point, ties -> lower index; see csrc/gpe_pointnet.hip for the fixed conventions)."""
+    _dev_check(pos)
+    idx = torch.empty(B, M, device=pos.device, dtype=torch.int32)
+    L.call('gpe_fps', pos, pos.stride(0), B, N, pos.shape[1], M, idx)
+    return idx
+
+
+def radius_neighbors(pos, cidx, B, N, r, max_num_neighbors):
+    """torch_geometric.nn.radius(pos, pos[idx], r, ..., max_num_neighbors): -> (nbr int32 [B*M, maxn] local point indices,
+    first maxn in ascending order, cnt int32 [B*M])."""
+    _dev_check(pos)
+    M = cidx.shape[1]
+    nbr = torch.empty(B * M, max_num_neighbors, device=pos.device, dtype=torch.int32)
+    cnt = torch.empty(B * M, device=pos.device, dtype=torch.int32)
+    L.call('gpe_radius', pos, pos.stride(0), cidx, B, N, pos.shape[1], M, float(r), max_num_neighbors, nbr, cnt)
+    return nbr, cnt
+
+
+def ball_messages(pos, x, cidx, nbr, off, n_edges, B, N):
+    """PointConv message inputs [E, Cx + 3] over the compact edge list + the centroid (segment) id of every edge row."""
+    M, maxn = cidx.shape[1], nbr.shape[1]
+    C = pos.shape[1]
+    Cx = 0 if x is None else x.shape[1]
+    msg = torch.empty(n_edges, Cx + C, device=pos.device, dtype=F32)
+    seg = torch.empty(n_edges, device=pos.device, dtype=torch.int32)
+    L.call('gpe_ball_messages', pos, pos.stride(0), x, 0 if x is None else x.stride(0), Cx, cidx, nbr, off, B, N, C, M, maxn,
+           msg, Cx + C, seg)
+    return msg, seg
+
+
+class RaggedMaxFn(torch.autograd.Function):
+    """max over each centroid's (ragged) run of edge rows: PointConv's aggr='max'."""
+
+    @staticmethod
+    def forward(ctx, x, off, seg, S):
+        _dev_check(x)
+        E, C = x.shape
+        y = torch.empty(S, C, device=x.device, dtype=F32)
+        arg = torch.empty(S, C, device=x.device, dtype=torch.int64)
+        L.call('gpe_ragged_max_fwd', x, x.stride(0), off, S, C, y, C, arg)
+        ctx.save_for_backward(off, arg, seg)
+        ctx.dims = (E, C)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        off, arg, seg = ctx.saved_tensors
+        E, C = ctx.dims
+        gy = gy.contiguous()
+        gx = torch.empty(E, C, device=gy.device, dtype=F32)
+        L.call('gpe_ragged_max_bwd', gy, C, off, arg, seg, E, C, gx, C)
+        return gx, None, None, None

@@ -274,6 +274,24 @@ int gpe_attn_pool_fwd(const float* w, int ldw, const float* feat, int ldf, int B
 int gpe_attn_pool_bwd(const float* w, int ldw, const float* feat, int ldf, const float* g, const int32_t* arg, int B,
                       int N, int P, int C, int mode, float* gw, int ldgw, float* gf, int ldgf, void* stream);
 
+/* ---- PointNet++ set abstraction (PointNetPlusPlus, nn/net_blocks.py:10-88: torch_geometric fps / radius / PointConv) ------
+ * pos [B][N][ldp>=C] (C <= 8).  gpe_fps: farthest point sampling of M points per cloud, start = the cloud's first point,
+ * idx [B][M] LOCAL indices in selection order (ties -> lower index).  gpe_radius: for centroid s = (b, m) the first `maxn`
+ * points of cloud b, ascending index, with squared distance <= r^2: nbr [B*M][maxn] local indices, cnt [B*M]. */
+int gpe_fps(const float* pos, int ldp, int B, int N, int C, int M, int32_t* idx, void* stream);
+int gpe_radius(const float* pos, int ldp, const int32_t* cidx, int B, int N, int C, int M, float r, int maxn,
+               int32_t* nbr, int32_t* cnt, void* stream);
+/* PointConv message inputs over the COMPACT edge list (edges of centroid s at rows off[s]..off[s+1]-1, off = exclusive scan of
+ * cnt, int64 [B*M+1]): msg[e] = [x_j (Cx values, optional) | pos_j - pos_centroid]; seg_of_row[e] = s. */
+int gpe_ball_messages(const float* pos, int ldp, const float* x, int ldx, int Cx, const int32_t* cidx, const int32_t* nbr,
+                      const int64_t* off, int B, int N, int C, int M, int maxn, float* msg, int ldm, int32_t* seg_of_row,
+                      void* stream);
+/* max over each ragged segment of rows (PointConv aggr = 'max'): y [S][ldy], arg [S][C] = winning row or -1 (empty -> 0) */
+int gpe_ragged_max_fwd(const float* x, int ldx, const int64_t* off, long S, int C, float* y, int ldy, int64_t* arg,
+                       void* stream);
+int gpe_ragged_max_bwd(const float* gy, int ldgy, const int64_t* off, const int64_t* arg, const int32_t* seg_of_row, long E,
+                       int C, float* gx, int ldgx, void* stream);
+
 /* ---- loss (nn/metrics/composed_loss.py:294-334 main terms; nn/metrics/losses.py:19-51 PanelLoopLoss) ----------------
  * Predictions are strided views of the decoder outputs: outlines (b,p,l,c<4) at ol + b*ol_sb + p*ol_sp + l*ol_sl + c,
  * rotations (b,p,c<R) at rot + (b*P+p)*rot_s + c, translations likewise.  Ground truth dense fp32; num_edges int32 [B*P].

@@ -197,6 +197,110 @@ class Sparsemax(nn.Module):
         return _SparsemaxFn.apply(z).transpose(self.dim, -1)
 
 
+# ---- PointNet++ pieces (torch_geometric.nn.fps / radius / PointConv; call sites nn/net_blocks.py:16-24) ---------------
+def fps(pos, batch, ratio):
+    """Farthest point sampling per cloud -> GLOBAL indices, clouds in order, selection order inside a cloud.
+    Open upstream (random start point by default): fixed here to START AT THE CLOUD'S FIRST POINT; distances are the
+    fp32 fma chain of (a-b)^2 over the coordinates, argmax ties -> lower index."""
+    B = int(batch.max()) + 1
+    out = []
+    p32 = pos.detach().to(torch.float32)
+    for b in range(B):
+        ids = torch.nonzero(batch == b).view(-1)
+        P = p32[ids].numpy().astype(np.float32)
+        n = P.shape[0]
+        m = int(np.ceil(ratio * n))
+        sel = [0]
+        mind = np.full(n, np.inf, dtype=np.float32)
+        for _ in range(1, m):
+            d = np.zeros(n, dtype=np.float32)
+            for c in range(P.shape[1]):
+                diff = (P[:, c] - P[sel[-1], c]).astype(np.float32)
+                d = (diff.astype(np.float64) * diff.astype(np.float64) + d.astype(np.float64)).astype(np.float32)   # fmaf
+            mind = np.minimum(mind, d)
+            sel.append(int(np.argmax(mind)))              # first maximum
+        out.append(ids[torch.tensor(sel)])
+    return torch.cat(out)
+
+
+def radius(x, y, r, batch_x, batch_y, max_num_neighbors=32):
+    """torch_cluster.radius: for every row of y the points of x (same batch entry) within distance r.  Returns
+    (row = index into y, col = index into x).  Open upstream (which neighbours survive the cap): fixed here to the FIRST
+    max_num_neighbors in ascending x index with squared distance <= r^2 (fp32 fma chain)."""
+    x32, y32 = x.detach().to(torch.float32).numpy(), y.detach().to(torch.float32).numpy()
+    rows, cols = [], []
+    r2 = np.float32(r) * np.float32(r)
+    bx, by = batch_x.numpy(), batch_y.numpy()
+    for i in range(y32.shape[0]):
+        cand = np.nonzero(bx == by[i])[0]
+        d = np.zeros(cand.shape[0], dtype=np.float32)
+        for c in range(x32.shape[1]):
+            diff = (x32[cand, c] - y32[i, c]).astype(np.float32)
+            d = (diff.astype(np.float64) * diff.astype(np.float64) + d.astype(np.float64)).astype(np.float32)
+        keep = cand[d <= r2][:max_num_neighbors]
+        rows += [i] * len(keep)
+        cols += keep.tolist()
+    return torch.tensor(rows, dtype=torch.long), torch.tensor(cols, dtype=torch.long)
+
+
+class PointConv(nn.Module):
+    """PointNet set-abstraction convolution (Qi et al. 2017; PyG PointNetConv): out_i = max_j local_nn([x_j, pos_j - pos_i])
+    over the given edges (source j -> target i).  PyG's `add_self_loops` default re-indexes a BIPARTITE edge list as if both
+    sides shared one index space — an upstream quirk, not part of the published operator; not restated (the ball query
+    already contains every centroid itself)."""
+
+    def __init__(self, local_nn=None, global_nn=None):
+        super().__init__()
+        self.local_nn = local_nn
+        self.global_nn = global_nn
+
+    def forward(self, x, pos, edge_index):
+        pos_src, pos_dst = pos
+        src, dst = edge_index[0], edge_index[1]
+        msg = pos_src[src] - pos_dst[dst]
+        if x is not None:
+            msg = torch.cat([x[src], msg], dim=1)
+        msg = self.local_nn(msg)
+        out = torch.zeros(pos_dst.shape[0], msg.shape[1], dtype=msg.dtype)
+        out = out.scatter_reduce(0, dst[:, None].expand(-1, msg.shape[1]), msg, reduce='amax', include_self=False)
+        return out if self.global_nn is None else self.global_nn(out)
+
+
+class _SetAbstractionModule(nn.Module):
+    """nn/net_blocks.py:10-27."""
+
+    def __init__(self, ratio, conv_radius, per_point_nn):
+        super().__init__()
+        self.ratio = ratio
+        self.radius = conv_radius
+        self.conv = PointConv(per_point_nn)
+        self.trace = {}
+
+    def forward(self, features, pos, batch):
+        idx = fps(pos, batch, ratio=self.ratio)
+        row, col = radius(pos, pos[idx], self.radius, batch, batch[idx], max_num_neighbors=25)
+        self.trace = {'idx': idx, 'row': row, 'col': col}
+        edge_index = torch.stack([col, row], dim=0)
+        features = self.conv(features, (pos, pos[idx]), edge_index)
+        return features, pos[idx], batch[idx]
+
+
+class _GlobalSetAbstractionModule(nn.Module):
+    """nn/net_blocks.py:30-42."""
+
+    def __init__(self, per_point_net):
+        super().__init__()
+        self.nn = per_point_net
+
+    def forward(self, features, pos, batch):
+        features = torch.cat([features, pos], dim=1) if features is not None else pos
+        features = self.nn(features)
+        features = global_max_pool(features, batch)
+        pos = pos.new_zeros((features.size(0), 3))
+        batch = torch.arange(features.size(0))
+        return features, pos, batch
+
+
 # ---------------------------------------------------------------------------------------------
 # nn/net_blocks.py restated
 # ---------------------------------------------------------------------------------------------
@@ -315,6 +419,26 @@ class LSTMDecoderModule(nn.Module):
         out, _ = self.lstm(dec_input, (h0, c0))
         out = self.lin(out.contiguous().view(-1, self.hidden_size))
         return out.contiguous().view(bs, out_len, -1)
+
+
+class PointNetPlusPlus(nn.Module):
+    """nn/net_blocks.py:50-88."""
+
+    def __init__(self, out_size, config={}):
+        super().__init__()
+        self.config = {'r1': 0.3, 'r2': 0.4, 'r3': 5, 'r4': 7}
+        self.config.update(config)
+        H, F = self.config['EConv_hidden'], self.config['EConv_feature']
+        self.sa1_module = _SetAbstractionModule(0.2, self.config['r1'], MLP([3, H, H, F]))
+        self.sa_last_module = _GlobalSetAbstractionModule(MLP([3 + F, H, H, F]))
+        self.lin = nn.Linear(F, out_size)
+
+    def forward(self, positions):
+        pos_flat = positions.view(-1, positions.size(-1))
+        batch = torch.arange(positions.size(0)).repeat_interleave(positions.size(1))
+        sa_out = self.sa1_module(None, pos_flat, batch)
+        out, _, _ = self.sa_last_module(*sa_out)
+        return self.lin(out)
 
 
 class MLPDecoder(nn.Module):

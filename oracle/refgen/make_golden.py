@@ -107,6 +107,29 @@ def run_case(model_name, yaml_rel, nn_override, B, N, seed, tag, keep_state, los
                                                           os.path.getsize(out) / 1024))
 
 
+def run_pointnet_case():
+    """PointNetPlusPlus (nn/net_blocks.py:50-88) as the reference's own class, with fps / radius / PointConv from the stubs
+    (restated arithmetic, conventions fixed in oracle/ref_path.py).  Block level: the reference's model classes cannot use
+    this extractor (forward_encode indexes its output with [0], nn/nets.py:134-135)."""
+    import net_blocks as ref_blocks
+    cfg = {'EConv_hidden': 32, 'EConv_feature': 24}
+    torch.manual_seed(1100)
+    net = ref_blocks.PointNetPlusPlus(16, dict(cfg))
+    net.train()
+    g = torch.Generator().manual_seed(1101)
+    pos = torch.randn(2, 160, 3, generator=g) * 0.45
+    wgt = torch.randn(2, 16, generator=g)
+    state0 = copy.deepcopy(net.state_dict())
+    out = net(pos)
+    (out * wgt).sum().backward()
+    fx = {'config': cfg, 'out_size': 16, 'seed': 1100, 'positions': pos, 'wgt': wgt, 'out': out.detach().clone(),
+          'state_dict': state0, 'grads': {n: p.grad.clone() for n, p in net.named_parameters()},
+          'state_keys': [(k, tuple(v.shape)) for k, v in state0.items()], 'torch': torch.__version__, 'threads': 1}
+    path = os.path.join(REPO, 'tests', 'golden', 'pointnetpp_small.pt')
+    torch.save(fx, path)
+    print('%-28s |out| max %.4f  %.1f KB' % ('pointnetpp_small', out.abs().max().item(), os.path.getsize(path) / 1024))
+
+
 def run_stitch_known_answer():
     """The only trained weights the reference ships (models/att/neural_tailor_stitch_model.pth): StitchOnEdge3DPairs =
     MLP([16, 200, 200, 200, 1]) with real BatchNorm running statistics.  Eval-mode outputs of the reference's own class
@@ -188,3 +211,4 @@ if __name__ == '__main__':
     run_case('GarmentSegmentPattern3D', att_yaml, dict(SMALL_NN, global_pool='max'), 2, 64, 990, 'segment3d_poolmax', True)
     run_case('GarmentSegmentPattern3D', att_yaml, dict(SMALL_NN, global_pool='add'), 2, 64, 995, 'segment3d_pooladd', True)
     run_stitch_known_answer()
+    run_pointnet_case()

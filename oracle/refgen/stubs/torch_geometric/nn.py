@@ -1,5 +1,5 @@
 from oracle.ref_path import (DynamicEdgeConv, global_mean_pool, global_max_pool,  # noqa: F401
-                             global_add_pool)
+                             global_add_pool, PointConv, fps, radius)
 
 
 def knn(x, y, k, batch_x=None, batch_y=None):
@@ -10,4 +10,4 @@ def _outside(*a, **kw):
     raise NotImplementedError('outside the restated path')
 
 
-PointConv = ASAPooling = fps = radius = _outside
+ASAPooling = _outside

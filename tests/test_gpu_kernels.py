@@ -771,3 +771,39 @@ def test_lstm_encoder_module(gpe):
     assert relerr(xd.grad, xr.grad) < 1e-4
     for (n, p), (_, q) in zip(penc.lstm.named_parameters(), ref.named_parameters()):
         assert relerr(p.grad, q.grad) < 1e-4, n
+
+
+def test_pointnetpp_block(gpe, golden_dir):
+    """PointNetPlusPlus (nn/net_blocks.py:50-88): fps + ball query bit-exact vs the oracle's definitions, outputs within 1e-4
+    of the reference-generated fixture and of the fp64 oracle, parameter gradients vs fp64."""
+    import os
+    from oracle import ref_path as O
+    fx = torch.load(os.path.join(golden_dir, 'pointnetpp_small.pt'), weights_only=False)
+    torch.manual_seed(fx['seed'])
+    pnet = gpe.net_blocks.PointNetPlusPlus(fx['out_size'], dict(fx['config']))
+    assert [(k, tuple(v.shape)) for k, v in pnet.state_dict().items()] == [tuple(x) for x in fx['state_keys']]
+    pnet.load_state_dict(fx['state_dict'])
+    pnet = pnet.cuda().train()
+    pos = fx['positions']
+    out = pnet(pos.cuda())
+    (out * fx['wgt'].cuda()).sum().backward()
+    o64 = O.PointNetPlusPlus(fx['out_size'], dict(fx['config'])).double().train()
+    o64.load_state_dict({k: (v.double() if v.is_floating_point() else v) for k, v in fx['state_dict'].items()})
+    ref = o64(pos.double())
+    (ref * fx['wgt'].double()).sum().backward()
+    B, N = pos.shape[:2]
+    # integer work: bit-exact (fps selection order, ball-query neighbour lists)
+    tr = o64.sa1_module.trace
+    M = pnet.sa1_module.last['idx'].shape[1]
+    gidx = (pnet.sa1_module.last['idx'].cpu().long() + (torch.arange(B) * N)[:, None]).view(-1)
+    assert torch.equal(gidx, tr['idx'])
+    cnt = pnet.sa1_module.last['cnt'].cpu().long()
+    assert torch.equal(cnt, torch.bincount(tr['row'], minlength=B * M))
+    nbr = pnet.sa1_module.last['nbr'].cpu().long()
+    cols = torch.cat([nbr[s, :cnt[s]] + (s // M) * N for s in range(B * M)])
+    assert torch.equal(cols, tr['col'])
+    assert (out.detach().cpu() - fx['out']).abs().max().item() < 1e-4
+    assert relerr(out, ref) < 5e-5
+    pn = dict(pnet.named_parameters())
+    for n, p in o64.named_parameters():
+        assert relerr(pn[n].grad, p.grad) < 5e-3 if p.grad.dim() == 1 else relerr(pn[n].grad, p.grad) < 5e-4, n

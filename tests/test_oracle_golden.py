@@ -76,3 +76,20 @@ def test_oracle_fp64_mode_runs(golden_dir):
     # same graph as fp32 for layer 1 (positions are exactly representable), outputs close to fp32's
     assert torch.equal(model.feature_extractor.conv_layers[0].last_knn.to(torch.int32), fx['knn'][0])
     assert (preds['outlines'].float() - fx['preds']['outlines']).abs().max() < 5e-2
+
+
+def test_oracle_pointnetpp_matches_reference_fixture(golden_dir):
+    """PointNetPlusPlus: the reference's own class (stubs supply fps / radius / PointConv) vs the oracle's restatement."""
+    torch.set_num_threads(1)
+    fx = torch.load(os.path.join(golden_dir, 'pointnetpp_small.pt'), weights_only=False)
+    torch.manual_seed(fx['seed'])
+    net = O.PointNetPlusPlus(fx['out_size'], dict(fx['config'])).train()
+    sd = net.state_dict()
+    assert [(k, tuple(v.shape)) for k, v in sd.items()] == [tuple(x) for x in fx['state_keys']]
+    for k, v in fx['state_dict'].items():
+        assert torch.equal(sd[k], v), k
+    out = net(fx['positions'])
+    (out * fx['wgt']).sum().backward()
+    assert torch.equal(out, fx['out'])
+    for n, p in net.named_parameters():
+        torch.testing.assert_close(p.grad, fx['grads'][n], rtol=1e-5, atol=1e-8)
