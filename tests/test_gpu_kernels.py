@@ -807,3 +807,16 @@ def test_pointnetpp_block(gpe, golden_dir):
     pn = dict(pnet.named_parameters())
     for n, p in o64.named_parameters():
         assert relerr(pn[n].grad, p.grad) < 5e-3 if p.grad.dim() == 1 else relerr(pn[n].grad, p.grad) < 5e-4, n
+
+
+def test_batch_stager(gpe):
+    """Pinned, double-buffered H2D staging + on-device standardisation (nn/trainer.py:93; nn/data/transforms.py:35-50)."""
+    st = gpe.configs.data_config()['standardize']
+    stager = gpe.staging.BatchStager('cuda:0', st['f_shift'], st['f_scale'])
+    g = torch.Generator().manual_seed(9)
+    for _ in range(5):                                    # more batches than slots: buffers are reused safely
+        x = torch.randn(4, 300, 3, generator=g) * 20
+        y = stager.stage(x)
+        ref = (x - torch.tensor(st['f_shift'])) / torch.tensor(st['f_scale'])
+        assert y.is_cuda and y.shape == x.shape
+        assert torch.allclose(y.cpu(), ref, rtol=1e-6, atol=1e-6)
