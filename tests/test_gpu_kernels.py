@@ -820,3 +820,67 @@ def test_batch_stager(gpe):
         ref = (x - torch.tensor(st['f_shift'])) / torch.tensor(st['f_scale'])
         assert y.is_cuda and y.shape == x.shape
         assert torch.allclose(y.cpu(), ref, rtol=1e-6, atol=1e-6)
+
+
+def test_two_rank_exchange_on_shared_gpu(gpe, golden_dir, tmp_path):
+    """The N > 1 path with the REAL HIP model: two processes share cuda:0 (GPE_SHARE_DEVICE=1) and exchange gradients over
+    gloo (RCCL refuses two ranks on one device).  Attention variant: its `feature_extractor.lin` never gets a gradient, so
+    one bucket only completes in finish_gradient_sync().  Result must equal the mean of the two ranks' local gradients."""
+    import os, socket, subprocess, sys, textwrap
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / 'w2.py'
+    script.write_text(textwrap.dedent("""
+        import copy, os, sys
+        sys.path.insert(0, %r)
+        import torch, torch.distributed as dist
+        import gpe_amd
+        from gpe_amd import parallel
+        rank, local, world = parallel.init_distributed(backend='gloo')
+        assert world == 2 and torch.cuda.current_device() == 0
+        fx = torch.load(os.path.join(%r, 'segment3d_small.pt'), weights_only=False)
+        def build():
+            torch.manual_seed(fx['seed'])
+            return gpe_amd.nets.GarmentSegmentPattern3D(fx['data_config'], copy.deepcopy(fx['nn_config']),
+                                                        copy.deepcopy(fx['loss_config'])).cuda().train()
+        sl = slice(rank, rank + 1)                       # one garment per rank
+        def run(m, call):
+            torch.manual_seed(fx['seed'] + 2 + rank)
+            preds = call(fx['features'][sl].cuda(), log_step=0, epoch=0)
+            loss, _, _ = m.loss(preds, {k: v[sl].clone() for k, v in fx['gt'].items()}, epoch=0)
+            loss.backward()
+        plain = build(); run(plain, plain)
+        local_g = {n: (p.grad.clone() if p.grad is not None else None) for n, p in plain.named_parameters()}
+        model = build()
+        ddp = parallel.DistributedHotPath(model, device_ids=[torch.device('cuda', 0)], bucket_bytes=256 << 10)
+        assert len(ddp._buckets) > 2
+        run(model, ddp)
+        early = len(ddp._launched)
+        ddp.finish_gradient_sync()
+        torch.cuda.synchronize()
+        assert 0 < early < len(ddp._buckets)             # some buckets left during backward, the None-grad one at the end
+        for n, p in model.named_parameters():
+            g = local_g[n]
+            if g is None:
+                assert not p.grad.any(), n
+                continue
+            both = [torch.empty_like(g) for _ in range(2)]
+            dist.all_gather(both, g)
+            want = (both[0] + both[1]) / 2
+            assert torch.allclose(p.grad, want, rtol=1e-6, atol=1e-12), n
+        dist.barrier()
+        dist.destroy_process_group()
+        print('rank', rank, 'shared-gpu exchange ok', early, len(ddp._buckets))
+    """) % (repo, str(golden_dir)))
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE='2', MASTER_ADDR='127.0.0.1',
+                   MASTER_PORT=str(port), GPE_SHARE_DEVICE='1')
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    for rank, (p, out) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, out
+        assert 'rank %d shared-gpu exchange ok' % rank in out
