@@ -851,7 +851,7 @@ def test_two_rank_exchange_on_shared_gpu(gpe, golden_dir, tmp_path):
         plain = build(); run(plain, plain)
         local_g = {n: (p.grad.clone() if p.grad is not None else None) for n, p in plain.named_parameters()}
         model = build()
-        ddp = parallel.DistributedHotPath(model, device_ids=[torch.device('cuda', 0)], bucket_bytes=256 << 10)
+        ddp = parallel.DistributedHotPath(model, device_ids=[torch.device('cuda', 0)], bucket_bytes=16 << 10)
         assert len(ddp._buckets) > 2
         run(model, ddp)
         early = len(ddp._launched)
