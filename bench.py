@@ -49,7 +49,7 @@ def parse():
     ap.add_argument('--cpu-steps', type=int, default=3)
     ap.add_argument('--cpu-threads', type=int, default=0, help='0 = all host cores (nproc)')
     ap.add_argument('--no-kernel-timing', action='store_true')
-    ap.add_argument('--math', choices=['f32', 'mixed', 'bf16x3'], default='f32',
+    ap.add_argument('--math', choices=['f32', 'bf16x6', 'mixed', 'bf16x3'], default='f32',
                     help="arithmetic of the fused edge GEMMs for the timed region (gpe_math_set); 'f32' = exact")
     ap.add_argument('--no-fast-math-line', action='store_true', help='skip the extra mixed / bf16x3 measurements')
     ap.add_argument('--torch-adam', action='store_true', help='torch.optim.Adam instead of the fused arena optimizer')

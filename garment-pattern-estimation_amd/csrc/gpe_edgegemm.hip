@@ -546,23 +546,32 @@ static int eg_dispatch_m(int NT, int KCH, const RgParams& p, int stats_nblk, hip
     return GPE_EINVAL;
 }
 
-static int g_eg_math = 0;            // 0: exact fp32 MFMA, 1: bf16x3 (gpe_math_set)
+static int g_eg_math = 0;            // 0: exact fp32 MFMA, 1: bf16x3, 2: bf16x6 where it fits (gpe_math_set)
 void gpe_edgegemm_set_math(int m) { g_eg_math = m; }
 
 template <int AMODE, int EMODE>
-static int eg_dispatch(int NT, int KCH, const RgParams& p, int stats_nblk, hipStream_t s)
+static int eg_dispatch(int NT, int KCH, const RgParams& p, int stats_nblk, hipStream_t s, int math)
 {
-    return g_eg_math == 1 ? eg_dispatch_m<AMODE, EMODE, 1>(NT, KCH, p, stats_nblk, s)
-                          : eg_dispatch_m<AMODE, EMODE, 0>(NT, KCH, p, stats_nblk, s);
+    return math == 1 ? eg_dispatch_m<AMODE, EMODE, 1>(NT, KCH, p, stats_nblk, s)
+                     : eg_dispatch_m<AMODE, EMODE, 0>(NT, KCH, p, stats_nblk, s);
 }
 
 // Returns 1 and launches when the shape is on the register-stationary menu, 0 when the caller should use the generic
 // LDS-streamed kernel, < 0 on a launch error.
 int gpe_edgegemm_sr_try(const RgParams& p, int amode, int emode, int stats_nblk, hipStream_t s);   // gpe_edgegemm_sr.hip
+int gpe_edgegemm_x6_try(const RgParams& p, int amode, int emode, int stats_nblk, hipStream_t s);   // gpe_edgegemm_x6.hip
 
 int gpe_edgegemm_try(const RgParams& p, int amode, int emode, int stats_nblk, hipStream_t s)
 {
-    if (g_eg_math == 0 && !(p.dbg & 64)) {               // exact fp32: the single-role software-pipelined kernel first
+    // (r02: a "forward-only bf16x3" mode was measured and dropped — 1785 garments/s, but first-layer weight gradients are
+    // residuals of cancelling sums that amplify ANY 1e-5 perturbation of the stored activations ~1e3 times (1.5e-2 of
+    // max|grad|): nothing short of ~24-bit operands is parity-grade, forward or backward.)
+    const int math = g_eg_math;
+    if (g_eg_math == 2) {                                // bf16x6: three-term split-bf16 single-role kernel where it fits
+        const int r = gpe_edgegemm_x6_try(p, amode, emode, stats_nblk, s);
+        if (r != 0) return r;
+    }
+    if ((math == 0 || g_eg_math == 2) && !(p.dbg & 64)) {   // exact fp32: the single-role software-pipelined kernel
         const int r = gpe_edgegemm_sr_try(p, amode, emode, stats_nblk, s);
         if (r != 0) return r;
     }
@@ -576,11 +585,11 @@ int gpe_edgegemm_try(const RgParams& p, int amode, int emode, int stats_nblk, hi
     const int NT = (p.N <= 160) ? 10 : 13;
     const int KCH = (p.K <= 160) ? 10 : 13;
     int rc = GPE_EINVAL;
-    if (amode == A_GATHER && emode == E_EDGE_FWD) rc = eg_dispatch<A_GATHER, E_EDGE_FWD>(NT, KCH, p, stats_nblk, s);
-    else if (amode == A_DENSE && emode == E_EDGE_FWD) rc = eg_dispatch<A_DENSE, E_EDGE_FWD>(NT, KCH, p, stats_nblk, s);
+    if (amode == A_GATHER && emode == E_EDGE_FWD) rc = eg_dispatch<A_GATHER, E_EDGE_FWD>(NT, KCH, p, stats_nblk, s, math);
+    else if (amode == A_DENSE && emode == E_EDGE_FWD) rc = eg_dispatch<A_DENSE, E_EDGE_FWD>(NT, KCH, p, stats_nblk, s, math);
     else if (amode == A_DENSE && emode == E_BWD_INPLACE)
-        rc = eg_dispatch<A_DENSE, E_BWD_INPLACE>(NT, KCH, p, stats_nblk, s);
+        rc = eg_dispatch<A_DENSE, E_BWD_INPLACE>(NT, KCH, p, stats_nblk, s, math);
     else if (amode == A_DENSE && emode == E_BWD_GATHER)
-        rc = eg_dispatch<A_DENSE, E_BWD_GATHER>(NT, KCH, p, stats_nblk, s);
+        rc = eg_dispatch<A_DENSE, E_BWD_GATHER>(NT, KCH, p, stats_nblk, s, math);
     return rc == GPE_OK ? 1 : rc;
 }

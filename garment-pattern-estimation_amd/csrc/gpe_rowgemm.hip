@@ -215,10 +215,11 @@ static int g_gpe_math = 0;
 extern "C" int gpe_math_get(void) { return g_gpe_math; }
 extern "C" int gpe_math_set(int mode)
 {
-    if (mode < 0 || mode > 2) return GPE_EINVAL;
+    if (mode < 0 || mode > 3) return GPE_EINVAL;
     const int prev = g_gpe_math;
     g_gpe_math = mode;
-    gpe_edgegemm_set_math(mode != 0 ? 1 : 0);     // the row GEMMs (forward, input-gradient half) of modes 1 and 2
+    // row GEMMs (forward, input-gradient half): 0 exact fp32, 1 two-term split-bf16 (modes 1, 2), 2 three-term split (mode 3)
+    gpe_edgegemm_set_math(mode == 3 ? 2 : (mode != 0 ? 1 : 0));
     gpe_redgemm_set_math(mode == 1 ? 1 : 0);      // the weight-gradient reduce-GEMM: split-bf16 only in mode 1
     return prev;
 }

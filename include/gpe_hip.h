@@ -36,6 +36,9 @@ int gpe_debug_set(int flags);
  *                rounding errors are independent per element and average out), exact fp32 for the weight-gradient
  *                reduce-GEMM  G = dz^T (a - mean): G also feeds the BatchNorm-backward coefficients, residuals of large
  *                sums where a coherent 1e-5 product error would surface as a 1e-2 gradient error.
+ *   3 = "bf16x6" THREE-term split x = h + m + l (24 mantissa bits: exact), six bf16 MFMAs per product — the fp32 kernel's
+ *                accuracy class at 0.375 of its matrix time — for the row GEMMs whose shape fits the register file (10
+ *                output tiles; the others stay on the exact fp32 instruction); reduce-GEMM exact fp32.
  * Returns the previous mode, or -22 for an unknown one.  kNN, BatchNorm statistics, the LSTM decoder and every
  * elementwise op are fp32 (fp64 for reductions) in both modes. */
 int gpe_math_set(int mode);
