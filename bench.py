@@ -52,6 +52,7 @@ def parse():
     ap.add_argument('--math', choices=['f32', 'bf16x6', 'mixed', 'bf16x3'], default='f32',
                     help="arithmetic of the fused edge GEMMs for the timed region (gpe_math_set); 'f32' = exact")
     ap.add_argument('--no-fast-math-line', action='store_true', help='skip the extra mixed / bf16x3 measurements')
+    ap.add_argument('--call-shapes', default=None, metavar='FILE', help='write per-(entry, int args) launch counts and mean durations')
     ap.add_argument('--torch-adam', action='store_true', help='torch.optim.Adam instead of the fused arena optimizer')
     return ap.parse_args()
 
@@ -257,6 +258,16 @@ def main():
             d[3] += by
         breakdown = {n: {'launches_per_step': v[0] / nsteps, 'ms_per_step': v[1] / nsteps} for n, v in
                      sorted(agg.items(), key=lambda kv: -kv[1][1])}
+        if args.call_shapes:
+            # per (entry point, integer arguments): launches and mean duration — which SHAPES the time goes to
+            shp = {}
+            for name, ints, e0, e1 in rec:
+                d = shp.setdefault((name, ints), [0, 0.0])
+                d[0] += 1
+                d[1] += e0.elapsed_time(e1)
+            with open(args.call_shapes, 'w') as f:
+                for (name, ints), v in sorted(shp.items(), key=lambda kv: -kv[1][1]):
+                    f.write('%-24s x%-4d %8.1f us  %s\n' % (name, v[0] // nsteps, 1e3 * v[1] / v[0], ints))
         # dominant = the fused per-edge GEMM family (forward + backward + weight-gradient kernels)
         fam = ['gpe_edge_mlp_fwd', 'gpe_edge_mlp_bwd', 'gpe_edge_redgemm']
         dom = max(fam, key=lambda n: agg.get(n, [0, 0, 0, 0])[1])

@@ -762,6 +762,167 @@ __global__ __launch_bounds__(512, 2) void gpe_redgemm_b3_kernel(RdParams p)
 // partial groups: group q sums partials q, q+8, ... in fp64 (2 chains), the 8 group sums are combined through LDS in
 // index order.  8x the threads of a one-thread-per-element loop: with 256 partials of a 208 x 208 product (44 MB) the
 // serial version was latency-bound at ~0.4 TB/s.
+// ---------------------------------------------------------------------------------------------------------
+// Deep-reduction variant for ROW-POOR dense products (the LSTM / GRU weight gradients: 10 k rows against a 1000 x 250
+// output).  The big-block kernel above gives such a product ~6 row tiles per workgroup, a 58 MB partial image and the
+// guarded scalar loader (its rows are 2-level [sequence][step] descriptors): 150-175 us for 5 GFLOP.  Here the OUTPUT is
+// cut small instead — 64 x 64 per workgroup, grid (row split, M blocks, N blocks), 3 workgroups per CU — so the row
+// split stays <= 16 (partials <= 16 MB) and a workgroup still runs tens of row tiles.  Rows are addressed through the
+// 2-level descriptor with plain 16-B loads (aligned pitches, rows padded to 4 columns: every internal sequence buffer).
+// ---------------------------------------------------------------------------------------------------------
+#define RDD_B 64
+#define RDD_LD 80                     // == 16 (mod 32): conflict-free b32 operand reads
+#define RDD_MAX_GX 16
+
+__device__ __forceinline__ long rd_row_off(const GpeRows& a, unsigned r, double rcp_inner)
+{
+    if (a.inner <= 0) return (long)r * a.stride_outer;
+    const unsigned o = gpe_udiv(r, (unsigned)a.inner, rcp_inner);
+    return (long)o * a.stride_outer + (long)(r - o * (unsigned)a.inner) * a.stride_inner;
+}
+
+__global__ __launch_bounds__(256, 3) void gpe_redgemm_deep_kernel(RdParams p)
+{
+    extern __shared__ __align__(16) float smem[];
+    float* Us = smem;                              // [2][RD_RT * RDD_LD]
+    float* Vs = smem + 2 * RD_RT * RDD_LD;         // [2][RD_RT * RDD_LD]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 15, g = lane >> 4;
+    const int wm = wave & 1, wn = wave >> 1;
+    const int m0 = blockIdx.y * RDD_B, n0 = blockIdx.z * RDD_B;
+    const bool want_cs = p.part_cs != nullptr && blockIdx.z == 0;
+
+    // staging map: thread -> rows sr, sr + 16 of the tile, column quad cq of both operands
+    const int sr = tid >> 4, cq = (tid & 15) << 2;
+    const bool u_on = m0 + cq < p.Mg, v_on = n0 + cq < p.Ng;
+    const int ucol = u_on ? m0 + cq : 0, vcol = v_on ? n0 + cq : 0;      // clamped: the loads are unconditional
+    const double rcp_u = p.u.inner > 0 ? 1.0 / p.u.inner : 0.0, rcp_v = p.v.inner > 0 ? 1.0 / p.v.inner : 0.0;
+    float sh[4] = {0.f, 0.f, 0.f, 0.f};
+    if (p.v_shift && v_on) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) if (n0 + cq + t < p.Ng) sh[t] = p.v_shift[n0 + cq + t];
+    }
+    float4 ur[2], vr[2];
+    unsigned rmask = 0;
+    auto fetch = [&](int tile) {
+        const long row0 = (long)tile * RD_RT;
+        const int rv = (int)((p.rows - row0 < RD_RT) ? (p.rows - row0) : RD_RT);
+        rmask = 0;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int r = sr + 16 * h;
+            if (r < rv) rmask |= 1u << h;
+            const unsigned gr = (unsigned)(row0 + ((r < rv) ? r : rv - 1));
+            ur[h] = rd_ld4(p.u.base + rd_row_off(p.u, gr, rcp_u) + ucol);
+            vr[h] = rd_ld4(p.v.base + rd_row_off(p.v, gr, rcp_v) + vcol);
+        }
+    };
+    auto commit = [&](int buf) {
+        float* ub = Us + buf * RD_RT * RDD_LD;
+        float* vb = Vs + buf * RD_RT * RDD_LD;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int r = sr + 16 * h;
+            const bool ok = (rmask >> h) & 1u;
+            float4 u = ur[h], v = vr[h];
+            v.x -= sh[0]; v.y -= sh[1]; v.z -= sh[2]; v.w -= sh[3];
+            if (!(ok && u_on)) u = make_float4(0.f, 0.f, 0.f, 0.f);
+            else {                                                  // ragged last quad (padded columns are not data)
+                if (m0 + cq + 1 >= p.Mg) u.y = 0.f;
+                if (m0 + cq + 2 >= p.Mg) u.z = 0.f;
+                if (m0 + cq + 3 >= p.Mg) u.w = 0.f;
+            }
+            if (!(ok && v_on)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            else {
+                if (n0 + cq + 1 >= p.Ng) v.y = 0.f;
+                if (n0 + cq + 2 >= p.Ng) v.z = 0.f;
+                if (n0 + cq + 3 >= p.Ng) v.w = 0.f;
+            }
+            *reinterpret_cast<float4*>(&ub[r * RDD_LD + cq]) = u;
+            *reinterpret_cast<float4*>(&vb[r * RDD_LD + cq]) = v;
+        }
+    };
+
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) acc[q][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    double cs = 0.0;
+    const int cs_col = tid & 63, cs_rg = tid >> 6;     // column sums of U: thread = (column, group of 8 rows)
+
+    int tile = blockIdx.x;
+    if (tile < p.num_tiles) fetch(tile);
+    int buf = 0;
+    for (; tile < p.num_tiles; tile += gridDim.x) {
+        commit(buf);
+        __syncthreads();            // tile visible; every wave is past the MFMAs that read buffer buf^1
+        fetch(tile + (int)gridDim.x < p.num_tiles ? tile + (int)gridDim.x : tile);     // unconditional (see above)
+        const float* ub = Us + buf * RD_RT * RDD_LD;
+        const float* vb = Vs + buf * RD_RT * RDD_LD;
+        if (want_cs) {
+            const float* c = ub + (8 * cs_rg) * RDD_LD + cs_col;
+            const float s0 = (c[0] + c[RDD_LD]) + (c[2 * RDD_LD] + c[3 * RDD_LD]);
+            const float s1 = (c[4 * RDD_LD] + c[5 * RDD_LD]) + (c[6 * RDD_LD] + c[7 * RDD_LD]);
+            cs += (double)s0 + (double)s1;
+        }
+#pragma unroll
+        for (int r0 = 0; r0 < RD_RT; r0 += 4) {
+            float a[2], b[2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) a[q] = ub[(r0 + g) * RDD_LD + 16 * (2 * wm + q) + j];
+#pragma unroll
+            for (int n = 0; n < 2; ++n) b[n] = vb[(r0 + g) * RDD_LD + 16 * (2 * wn + n) + j];
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int n = 0; n < 2; ++n)
+                    acc[q][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q], b[n], acc[q][n], 0, 0, 0);
+        }
+        buf ^= 1;
+    }
+
+    // ---- one partial per workgroup (same image as the big-block kernel: gpe_redgemm_finish sums them) ------------
+    float* dst = p.part + (size_t)blockIdx.x * p.MgPad * p.NgPad;
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + 16 * (2 * wm + q) + 4 * g + r, nn = n0 + 16 * (2 * wn + n) + j;
+                dst[(size_t)m * p.NgPad + nn] = acc[q][n][r];
+            }
+    if (want_cs) {
+        __syncthreads();                                           // the operand tiles are dead
+        double* red = reinterpret_cast<double*>(smem);             // [4][64]
+        red[cs_rg * 64 + cs_col] = cs;
+        __syncthreads();
+        if (tid < RDD_B)
+            p.part_cs[(size_t)blockIdx.x * p.MgPad + m0 + tid] = (red[tid] + red[64 + tid]) + (red[128 + tid] + red[192 + tid]);
+    }
+}
+
+// rows a 16-B loader can take through the 2-level descriptor: aligned base and pitches, rows padded to 4 columns
+static bool rd_rows_vec2(const GpeRows& r, int cols)
+{
+    const long pitch = r.inner > 0 ? r.stride_inner : r.stride_outer;
+    if ((((uintptr_t)r.base) & 15) || (r.stride_outer & 3)) return false;
+    if (r.inner > 0 && (r.stride_inner & 3)) return false;
+    return pitch >= ((cols + 3) & ~3) || (cols & 3) == 0;
+}
+
+// row split of the deep kernel: ~3 workgroups per CU, at least 4 row tiles each, <= RDD_MAX_GX partial images
+static int rdd_gx(int Mg, int Ng, long num_tiles, int cus)
+{
+    const long blocks = (long)gpe_cdiv(Mg, RDD_B) * gpe_cdiv(Ng, RDD_B);
+    long gx = gpe_cdiv(3L * cus, blocks);
+    if (gx > RDD_MAX_GX) gx = RDD_MAX_GX;
+    if (num_tiles >= 0 && gx > num_tiles / 4) gx = num_tiles / 4;
+    return gx < 1 ? 1 : (int)gx;
+}
+
 #define RD_FIN_E 32
 #define RD_FIN_Q 8
 __global__ __launch_bounds__(RD_FIN_E * RD_FIN_Q) void gpe_redgemm_finish(
@@ -852,7 +1013,10 @@ extern "C" long gpe_redgemm_ws(int Mg, int Ng)
     rd_geometry(Mg, Ng, -1, &MH, &NH, &gy, &MgPad, &NgPad);
     if (NH < 0) return -1;
     const long gx = RD_MAX_GX / gy > 0 ? RD_MAX_GX / gy : 1;
-    return gx * MgPad * NgPad + 2L * gx * MgPad + 8;
+    const long big = gx * MgPad * NgPad + 2L * gx * MgPad + 8;
+    const long dM = gpe_round_up(Mg, RDD_B), dN = gpe_round_up(Ng, RDD_B);
+    const long deep = RDD_MAX_GX * dM * dN + 2L * RDD_MAX_GX * dM + 8;
+    return big > deep ? big : deep;
 }
 
 template <int MH, int NH, int VMODE>
@@ -921,6 +1085,25 @@ static int rd_run(RdParams& p, int vmode, float* G, int ldG, float* colsum, floa
     if (gx < 1) gx = 1;
     if (gx > p.num_tiles) gx = p.num_tiles > 0 ? p.num_tiles : 1;
     p.part = part;
+    // row-poor dense products (fewer than 8 row tiles per workgroup of the big-block grid) with 16-B loadable rows
+    if (vmode == V_DENSE && g_rd_math != 1 && p.num_tiles > 0 && p.num_tiles < 8L * gx && p.rows < (1L << 31) &&
+        rd_rows_vec2(p.u, p.Mg) && rd_rows_vec2(p.v, p.Ng)) {
+        const int dgx = rdd_gx(p.Mg, p.Ng, p.num_tiles, cus);
+        const int dgy = gpe_cdiv(p.Mg, RDD_B), dgz = gpe_cdiv(p.Ng, RDD_B);
+        p.MgPad = dgy * RDD_B; p.NgPad = dgz * RDD_B;
+        size_t doff = (size_t)dgx * p.MgPad * p.NgPad;
+        doff = (doff + 1) & ~(size_t)1;
+        p.part_cs = colsum ? reinterpret_cast<double*>(part + doff) : nullptr;
+        const size_t lds = (size_t)4 * RD_RT * RDD_LD * sizeof(float);
+        hipLaunchKernelGGL(gpe_redgemm_deep_kernel, dim3(dgx, dgy, dgz), dim3(256), lds, s, p);
+        GPE_CHECK_LAUNCH();
+        const long total_d = (long)p.Mg * p.Ng;
+        const long fin_d = gpe_cdiv(total_d, RD_FIN_E) + (colsum ? gpe_cdiv(p.Mg, RD_FIN_E) : 0);
+        hipLaunchKernelGGL(gpe_redgemm_finish, dim3(fin_d), dim3(RD_FIN_E * RD_FIN_Q), 0, s, p.part, p.part_cs, dgx, p.Mg,
+                           p.Ng, p.MgPad, p.NgPad, G, ldG, colsum, accumulate);
+        GPE_CHECK_LAUNCH();
+        return GPE_OK;
+    }
     size_t off = (size_t)gx * MgPad * NgPad;
     off = (off + 1) & ~(size_t)1;                                  // 8-B align the fp64 section
     p.part_cs = reinterpret_cast<double*>(part + off);

@@ -739,10 +739,12 @@ class RNNStackFn(torch.autograd.Function):
             redgemm_raw(gh_rows, _rows3d(hs[l][:, :T, :Hh]), Bn * T, GH, Hh, out=(d_whh, d_bhh))
             d_wih, d_bih = _gbuf(w_ih), _gbuf(b_ih)
             if l == 0 and not seq:
-                redgemm_raw(gx_rows, (x, x.stride(0), 0, T), Bn * T, GH, In, out=(d_wih, d_bih))
+                # the same input row feeds every step: sum the gate gradients over T first, then ONE Bn-row product
+                # (T times fewer rows than dG^T x over the repeated input)
+                dGs = torch.empty(Bn, GH, device=dev, dtype=F32)
+                L.call('gpe_reduce_inner', dgx[0], T * GHp, GHp, T, Bn, GH, dGs, GH, 0)
+                redgemm_raw(_rows2d(dGs), _rows2d(x), Bn, GH, In, out=(d_wih, d_bih))
                 if ctx.needs_input_grad[0]:
-                    dGs = torch.empty(Bn, GH, device=dev, dtype=F32)
-                    L.call('gpe_reduce_inner', dgx[0], T * GHp, GHp, T, Bn, GH, dGs, GH, 0)
                     d_x = torch.empty(Bn, In, device=dev, dtype=F32)
                     linear_raw(_rows2d(dGs), pack_weight(w_ih, transpose=True), None, Bn, In, GH, _rows2d(d_x))
             else:
