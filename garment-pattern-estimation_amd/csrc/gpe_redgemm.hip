@@ -767,12 +767,12 @@ __global__ __launch_bounds__(512, 2) void gpe_redgemm_b3_kernel(RdParams p)
 // output).  The big-block kernel above gives such a product ~6 row tiles per workgroup, a 58 MB partial image and the
 // guarded scalar loader (its rows are 2-level [sequence][step] descriptors): 150-175 us for 5 GFLOP.  Here the OUTPUT is
 // cut small instead — 64 x 64 per workgroup, grid (row split, M blocks, N blocks), 3 workgroups per CU — so the row
-// split stays <= 16 (partials <= 16 MB) and a workgroup still runs tens of row tiles.  Rows are addressed through the
+// split stays <= 32 and a workgroup still runs tens of row tiles.  Rows are addressed through the
 // 2-level descriptor with plain 16-B loads (aligned pitches, rows padded to 4 columns: every internal sequence buffer).
 // ---------------------------------------------------------------------------------------------------------
 #define RDD_B 64
 #define RDD_LD 80                     // == 16 (mod 32): conflict-free b32 operand reads
-#define RDD_MAX_GX 16
+#define RDD_MAX_GX 32
 
 __device__ __forceinline__ long rd_row_off(const GpeRows& a, unsigned r, double rcp_inner)
 {
@@ -781,6 +781,9 @@ __device__ __forceinline__ long rd_row_off(const GpeRows& a, unsigned r, double 
     return (long)o * a.stride_outer + (long)(r - o * (unsigned)a.inner) * a.stride_inner;
 }
 
+// VVEC: V rows take 16-B loads too; otherwise V (an external tensor such as the raw N x 3 positions) is read with clamped
+// scalar loads — U, the gradient operand, is always an internal aligned buffer.
+template <bool VVEC>
 __global__ __launch_bounds__(256, 3) void gpe_redgemm_deep_kernel(RdParams p)
 {
     extern __shared__ __align__(16) float smem[];
@@ -815,7 +818,15 @@ __global__ __launch_bounds__(256, 3) void gpe_redgemm_deep_kernel(RdParams p)
             if (r < rv) rmask |= 1u << h;
             const unsigned gr = (unsigned)(row0 + ((r < rv) ? r : rv - 1));
             ur[h] = rd_ld4(p.u.base + rd_row_off(p.u, gr, rcp_u) + ucol);
-            vr[h] = rd_ld4(p.v.base + rd_row_off(p.v, gr, rcp_v) + vcol);
+            const float* vp = p.v.base + rd_row_off(p.v, gr, rcp_v);
+            if constexpr (VVEC) vr[h] = rd_ld4(vp + vcol);
+            else {                                                  // clamped columns: masked at commit
+                const int last = p.Ng - 1;
+                vr[h].x = vp[vcol < last ? vcol : last];
+                vr[h].y = vp[vcol + 1 < last ? vcol + 1 : last];
+                vr[h].z = vp[vcol + 2 < last ? vcol + 2 : last];
+                vr[h].w = vp[vcol + 3 < last ? vcol + 3 : last];
+            }
         }
     };
     auto commit = [&](int buf) {
@@ -1085,9 +1096,9 @@ static int rd_run(RdParams& p, int vmode, float* G, int ldG, float* colsum, floa
     if (gx < 1) gx = 1;
     if (gx > p.num_tiles) gx = p.num_tiles > 0 ? p.num_tiles : 1;
     p.part = part;
-    // row-poor dense products (fewer than 8 row tiles per workgroup of the big-block grid) with 16-B loadable rows
-    if (vmode == V_DENSE && g_rd_math != 1 && p.num_tiles > 0 && p.num_tiles < 8L * gx && p.rows < (1L << 31) &&
-        rd_rows_vec2(p.u, p.Mg) && rd_rows_vec2(p.v, p.Ng)) {
+    // row-poor dense products (fewer than 64 row tiles per workgroup of the big-block grid) with a 16-B loadable U
+    if (vmode == V_DENSE && g_rd_math != 1 && p.num_tiles > 0 && p.num_tiles < 64L * gx && p.rows < (1L << 31) &&
+        rd_rows_vec2(p.u, p.Mg)) {
         const int dgx = rdd_gx(p.Mg, p.Ng, p.num_tiles, cus);
         const int dgy = gpe_cdiv(p.Mg, RDD_B), dgz = gpe_cdiv(p.Ng, RDD_B);
         p.MgPad = dgy * RDD_B; p.NgPad = dgz * RDD_B;
@@ -1095,7 +1106,8 @@ static int rd_run(RdParams& p, int vmode, float* G, int ldG, float* colsum, floa
         doff = (doff + 1) & ~(size_t)1;
         p.part_cs = colsum ? reinterpret_cast<double*>(part + doff) : nullptr;
         const size_t lds = (size_t)4 * RD_RT * RDD_LD * sizeof(float);
-        hipLaunchKernelGGL(gpe_redgemm_deep_kernel, dim3(dgx, dgy, dgz), dim3(256), lds, s, p);
+        if (rd_rows_vec2(p.v, p.Ng)) hipLaunchKernelGGL(gpe_redgemm_deep_kernel<true>, dim3(dgx, dgy, dgz), dim3(256), lds, s, p);
+        else hipLaunchKernelGGL(gpe_redgemm_deep_kernel<false>, dim3(dgx, dgy, dgz), dim3(256), lds, s, p);
         GPE_CHECK_LAUNCH();
         const long total_d = (long)p.Mg * p.Ng;
         const long fin_d = gpe_cdiv(total_d, RD_FIN_E) + (colsum ? gpe_cdiv(p.Mg, RD_FIN_E) : 0);

@@ -227,6 +227,67 @@ extern "C" int gpe_math_set(int mode)
 #define GPE_STATS_BLOCKS 512
 extern "C" int gpe_stats_blocks(void) { return GPE_STATS_BLOCKS; }
 
+// ---------------------------------------------------------------------------------------------------------
+// K <= 8 Linear (the layer-1 [P|Q] projection of the raw N x 3 positions: 65 536 x 400 outputs from 3 inputs).  Nothing
+// here is a GEMM: 105 MB of output against 0.8 MB of input, so the kernel is a streaming store — lane = one output
+// column quad with its K x 4 weights in registers, wave = one row at a time (row-uniform input loads).
+//   y = act(bias + sum_k a_k * W[k][:] (+ addend)),  k ascending fused multiply-adds.
+// ---------------------------------------------------------------------------------------------------------
+#define RG_SMALLK 8
+__global__ __launch_bounds__(256) void gpe_linear_smallk_kernel(RgParams p)
+{
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int c = (blockIdx.y * 64 + lane) << 2;
+    if (c >= p.N) return;                                  // N % 4 == 0 (dispatcher): whole quads only
+    float w[RG_SMALLK][4];
+    float b4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < RG_SMALLK; ++k) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            // packed weights: float4 ((k/16)*4 + (k/4)%4, n) holds W[4*(k/4) .. +3][n]
+            w[k][t] = (k < p.K) ? p.wp[((long)(((k >> 4) << 2) + ((k >> 2) & 3)) * p.Npad + c + t) * 4 + (k & 3)] : 0.f;
+        }
+    }
+    if (p.bias) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) b4[t] = p.bias[c + t];
+    }
+    const long nw = (long)gridDim.x * 4;
+    for (long r = (long)blockIdx.x * 4 + wave; r < p.M; r += nw) {
+        const float* ar = gpe_row_ptr(p.a, r);
+        float av[RG_SMALLK];
+#pragma unroll
+        for (int k = 0; k < RG_SMALLK; ++k) av[k] = ar[k < p.K ? k : 0];
+        float o[4] = {b4[0], b4[1], b4[2], b4[3]};
+#pragma unroll
+        for (int k = 0; k < RG_SMALLK; ++k) {
+            if (k < p.K) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) o[t] = __builtin_fmaf(av[k], w[k][t], o[t]);
+            }
+        }
+        if (p.addend.base) {
+            const float4 ad = ld4(gpe_row_ptr(p.addend, r) + c);
+            o[0] += ad.x; o[1] += ad.y; o[2] += ad.z; o[3] += ad.w;
+        }
+        if (p.act == 1) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) o[t] = fmaxf(o[t], 0.f);
+        }
+        float* dst;
+        if (p.y_inner <= 0) dst = p.y + r * p.y_so + c;
+        else { const long oo = r / p.y_inner; dst = p.y + oo * p.y_so + (r - oo * p.y_inner) * p.y_si + c; }
+        st4(dst, make_float4(o[0], o[1], o[2], o[3]));
+    }
+}
+
+static bool rg_rows_aligned16(const float* base, long so, long si, int inner)
+{
+    return !(((uintptr_t)base) & 15) && !(so & 3) && (inner <= 0 || !(si & 3));
+}
+
 extern "C" int gpe_linear(const float* a, long a_so, long a_si, int a_inner, const float* wp, const float* bias,
                           const float* addend, long ad_so, long ad_si, int ad_inner, float* y, long y_so,
                           long y_si, int y_inner, int M, int N, int K, int act, void* stream)
@@ -239,6 +300,14 @@ extern "C" int gpe_linear(const float* a, long a_so, long a_si, int a_inner, con
     p.wp = wp; p.Npad = gpe_round_up(N, 16); p.bias = bias;
     p.addend = GpeRows{addend, ad_so, ad_si, ad_inner};
     p.y = y; p.y_so = y_so; p.y_si = y_si; p.y_inner = y_inner; p.act = act;
+    if (K <= RG_SMALLK && !(N & 3) && M >= 4096 && rg_rows_aligned16(y, y_so, y_si, y_inner) &&
+        (!addend || rg_rows_aligned16(addend, ad_so, ad_si, ad_inner))) {
+        long gx = gpe_cdiv(M, 4 * 8);                      // >= 8 rows per wave
+        if (gx > 4096) gx = 4096;
+        hipLaunchKernelGGL(gpe_linear_smallk_kernel, dim3((unsigned)gx, gpe_cdiv(N, 256)), dim3(256), 0, (hipStream_t)stream, p);
+        GPE_CHECK_LAUNCH();
+        return GPE_OK;
+    }
     // latency-bound regime (the streaming kernel could not even put one workgroup on half the CUs): single-stage kernel
     if ((long)p.num_tiles * gpe_cdiv(N, 208) < 128) return gpe_smallgemm_linear(p, (hipStream_t)stream);
     // widest column block that still gives the chip >= 256 workgroups, else the narrowest

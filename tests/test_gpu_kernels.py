@@ -105,7 +105,9 @@ def test_knn_reverse(gpe):
 
 # --------------------------------------------------------------------------------------------------
 LIN_CASES = [(64, 200, 200), (100, 8, 250), (736, 1000, 250), (32, 250, 1000), (33, 7, 3), (1000, 400, 150),
-             (130, 23, 153), (65, 300, 520)]
+             (130, 23, 153), (65, 300, 520),
+             # K <= 8 streaming-store kernel / deep reduce-GEMM with an unaligned V (the layer-1 [P|Q] projection shapes)
+             (5000, 400, 3), (4100, 152, 6), (70000, 400, 3)]
 
 
 @pytest.mark.parametrize('M,N,K', LIN_CASES)
@@ -150,7 +152,7 @@ def test_linear_strided_addend_act(gpe):
 
 
 @pytest.mark.parametrize('rows,Mg,Ng', [(1000, 150, 200), (77, 8, 250), (5000, 1000, 250), (4096, 400, 3),
-                                        (300, 23, 153)])
+                                        (300, 23, 153), (65536, 400, 152), (10304, 1000, 252), (40000, 200, 7)])
 def test_redgemm(gpe, rows, Mg, Ng):
     ops = gpe.ops
     g = torch.Generator().manual_seed(rows + Mg)
@@ -159,6 +161,19 @@ def test_redgemm(gpe, rows, Mg, Ng):
     G, cs = ops.redgemm_raw(ops._rows2d(u.cuda()), ops._rows2d(v.cuda()), rows, Mg, Ng)
     assert relerr(G, u.double().t() @ v.double()) < 3e-6
     assert relerr(cs, u.double().sum(0)) < 3e-6
+
+
+def test_redgemm_two_level_rows(gpe):
+    """row-poor product over [sequence][step] descriptors (the LSTM weight gradients): the deep-reduction kernel."""
+    ops = gpe.ops
+    g = torch.Generator().manual_seed(3)
+    Bn, T, GH, H = 150, 7, 200, 50
+    dg = torch.randn(Bn, T, GH, generator=g).cuda()
+    hs = torch.randn(Bn, T + 1, 52, generator=g).cuda()              # padded pitch, one extra slot per sequence
+    G, cs = ops.redgemm_raw(ops._rows3d(dg), ops._rows3d(hs[:, :T, :H]), Bn * T, GH, H)
+    ref = dg.double().cpu().reshape(-1, GH).t() @ hs[:, :T, :H].double().cpu().reshape(-1, H)
+    assert relerr(G, ref) < 3e-6
+    assert relerr(cs, dg.double().cpu().reshape(-1, GH).sum(0)) < 3e-6
 
 
 # --------------------------------------------------------------------------------------------------
