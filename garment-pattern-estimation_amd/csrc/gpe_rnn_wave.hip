@@ -35,7 +35,7 @@ __device__ __forceinline__ float wv_sigmoid(float x) { return 1.f / (1.f + expf(
 template <int NT, int KS>
 __device__ __forceinline__ void wv_segment(const float* __restrict__ a, long stride, const float* __restrict__ wp, int K,
                                            int Npad, int row0, int rv, int n0, float* As, float* Ws, int lda,
-                                           f32x4 (&acc)[NT])
+                                           f32x4 (&acc)[NT], bool split = false)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 15, g = lane >> 4;
@@ -96,8 +96,13 @@ __device__ __forceinline__ void wv_segment(const float* __restrict__ a, long str
         }
         __syncthreads();
         const int nchunks = kp >> 4;
-        for (int kc = 0; kc < nchunks; ++kc) {
-            const float4 a4 = ld4(&As[(16 * wave + j) * lda + kc * 16 + 4 * g]);
+        // split: see wv_mma (defined below) — row tile (wave & 1), K half (wave >> 1)
+        const int rt = split ? (wave & 1) : wave;
+        const int half = (nchunks + 1) >> 1;
+        const int kc0 = (split && (wave >> 1)) ? half : 0;
+        const int kc1 = (split && !(wave >> 1)) ? half : nchunks;
+        for (int kc = kc0; kc < kc1; ++kc) {
+            const float4 a4 = ld4(&As[(16 * rt + j) * lda + kc * 16 + 4 * g]);
             const float av[4] = {a4.x, a4.y, a4.z, a4.w};
             float4 b4[NT];
 #pragma unroll
@@ -109,6 +114,107 @@ __device__ __forceinline__ void wv_segment(const float* __restrict__ a, long str
                     const float bv = (t == 0) ? b4[n].x : (t == 1) ? b4[n].y : (t == 2) ? b4[n].z : b4[n].w;
                     acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t], bv, acc[n], 0, 0, 0);
                 }
+            }
+        }
+    }
+}
+
+// ---- the same slab staging, split into fetch (global -> registers) / commit (registers -> LDS) / multiply, so that the
+// forward kernel can keep the NEXT slab's loads in flight under the current slab's MFMAs (a cell is 2-4 slabs: with the
+// loads exposed every slab cost ~2.5 us of L2 latency on top of ~2 us of matrix work) ----------------------------------------
+template <int NT, int KS>
+struct WvRegs {
+    float4 a[RG_BM / 4];
+    float4 w[(KS * NT + 63) / 64];           // (KS/4 planes) x (16*NT columns) float4 over 256 threads
+};
+
+template <int NT, int KS>
+__device__ __forceinline__ void wv_fetch(WvRegs<NT, KS>& R, const float* __restrict__ a, long stride,
+                                         const float* __restrict__ wp, int K, int Npad, int row0, int rv, int n0, int ks)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int kslab = (K - ks < KS) ? (K - ks) : KS;
+    const int kp = (kslab + 15) & ~15;
+    const int c = lane << 2;
+    const int cc = (c < kslab) ? c : 0;                       // clamped: every load below is unconditional
+#pragma unroll
+    for (int q = 0; q < RG_BM / 4; ++q) {
+        const int r = wave + 4 * q;
+        R.a[q] = ld4(a + (long)(row0 + (r < rv ? r : rv - 1)) * stride + ks + cc);
+    }
+    constexpr int per_plane = 16 * NT;
+    const int total = (kp >> 2) * per_plane;
+    const int chunk0 = ks >> 4;
+#pragma unroll
+    for (int u = 0; u < (KS * NT + 63) / 64; ++u) {
+        const int e = tid + 256 * u;
+        const int ec = (e < total) ? e : total - 1;
+        const int pl = ec / per_plane, n = ec - pl * per_plane;
+        const int nn = (n0 + n < Npad) ? n0 + n : Npad - 1;
+        R.w[u] = ld4(wp + (((long)(chunk0 * 4 + pl)) * Npad + nn) * 4);
+    }
+}
+
+template <int NT, int KS>
+__device__ __forceinline__ void wv_commit(const WvRegs<NT, KS>& R, int K, int Npad, int rv, int n0, int ks, float* As,
+                                          float* Ws, int lda)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int kslab = (K - ks < KS) ? (K - ks) : KS;
+    const int kp = (kslab + 15) & ~15;
+    const int c = lane << 2;
+    if (c < kp) {
+        const int nvalid = kslab - c;
+#pragma unroll
+        for (int q = 0; q < RG_BM / 4; ++q) {
+            const int r = wave + 4 * q;
+            float4 o = R.a[q];
+            if (r >= rv || nvalid <= 0) o = make_float4(0.f, 0.f, 0.f, 0.f);
+            else {
+                if (nvalid < 2) o.y = 0.f;
+                if (nvalid < 3) o.z = 0.f;
+                if (nvalid < 4) o.w = 0.f;
+            }
+            st4(&As[r * lda + c], o);
+        }
+    }
+    constexpr int per_plane = 16 * NT;
+    const int total = (kp >> 2) * per_plane;
+#pragma unroll
+    for (int u = 0; u < (KS * NT + 63) / 64; ++u) {
+        const int e = tid + 256 * u;
+        if (e < total) {
+            const int n = e % per_plane;
+            st4(&Ws[e * 4], (n0 + n < Npad) ? R.w[u] : make_float4(0.f, 0.f, 0.f, 0.f));
+        }
+    }
+}
+
+// split (a tile with <= 32 valid rows — the pattern decoders run Bn = 32): waves 2, 3 would only multiply zero rows, so
+// instead wave w takes row tile (w & 1) and HALF of the slab's K chunks (w >> 1); the halves meet in the C tile, where
+// rows 32..63 hold the second half's partial sums of rows 0..31 (the epilogues add them).
+template <int NT>
+__device__ __forceinline__ void wv_mma(const float* As, const float* Ws, int lda, int kp, f32x4 (&acc)[NT], bool split = false)
+{
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int j = lane & 15, g = lane >> 4;
+    const int nchunks = kp >> 4;
+    const int rt = split ? (wave & 1) : wave;
+    const int half = (nchunks + 1) >> 1;
+    const int kc0 = (split && (wave >> 1)) ? half : 0;
+    const int kc1 = (split && !(wave >> 1)) ? half : nchunks;
+    for (int kc = kc0; kc < kc1; ++kc) {
+        const float4 a4 = ld4(&As[(16 * rt + j) * lda + kc * 16 + 4 * g]);
+        const float av[4] = {a4.x, a4.y, a4.z, a4.w};
+        float4 b4[NT];
+#pragma unroll
+        for (int n = 0; n < NT; ++n) b4[n] = ld4(&Ws[(((kc * 4 + g) * 16 * NT) + 16 * n + j) * 4]);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                const float bv = (t == 0) ? b4[n].x : (t == 1) ? b4[n].y : (t == 2) ? b4[n].z : b4[n].w;
+                acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t], bv, acc[n], 0, 0, 0);
             }
         }
     }
@@ -133,13 +239,49 @@ __global__ __launch_bounds__(256) void gpe_rnn_wave_fwd_kernel(WvFwdParams p)
     const int rv = (p.Bn - row0 < RG_BM) ? (p.Bn - row0) : RG_BM;
     const int n0 = blockIdx.y * (16 * G);
 
+    const bool split = rv <= 32;                      // wave-pair K split (wv_mma)
     f32x4 accH[G], accX[G];
 #pragma unroll
     for (int n = 0; n < G; ++n) { accH[n] = (f32x4){0.f, 0.f, 0.f, 0.f}; accX[n] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
-    wv_segment<G, KS>(c.a0, c.a0_stride, c.w0, p.H, p.Npad, row0, rv, n0, As, Ws, lda, accH);
-    if (c.a1) {
-        if (G == 4) wv_segment<G, KS>(c.a1, c.a1_stride, c.w1, p.H, p.Npad, row0, rv, n0, As, Ws, lda, accH);
-        else wv_segment<G, KS>(c.a1, c.a1_stride, c.w1, p.H, p.Npad, row0, rv, n0, As, Ws, lda, accX);
+    // epilogue operands (addend rows, c_{t-1} / h_{t-1}) are fetched FIRST: their L2 latency hides under the slab loop
+    // instead of sitting between the last MFMA and the cell update
+    const int u = tid & 15;
+    const int unit = blockIdx.y * 16 + u;
+    const int unitc = (unit < p.H) ? unit : p.H - 1;
+    constexpr int IT = RG_BM / 16;
+    float e0[IT], e1[IT], e2[IT], e3[IT], e4[IT];
+    const float bhn = (G == 3) ? c.bhn[unitc] : 0.f;
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        const int r = (tid >> 4) + 16 * it;
+        const long gr = row0 + (r < rv ? r : rv - 1);
+        const float* xp = c.xproj + gr * c.xp_stride;
+        e0[it] = xp[unitc]; e1[it] = xp[p.H + unitc]; e2[it] = xp[2 * p.H + unitc];
+        if (G == 4) { e3[it] = xp[3 * p.H + unitc]; e4[it] = c.c_prev[gr * p.H + unitc]; }
+        else { e3[it] = c.a0[gr * c.a0_stride + unitc]; e4[it] = 0.f; }
+    }
+    // slab jobs: segment 0 = h_{l,t-1} x W_hh, segment 1 (layers > 0) = h_{l-1,t} x W_ih, each cdiv(H, KS) slabs
+    {
+        const int nslab = (p.H + KS - 1) / KS;
+        const int njobs = c.a1 ? 2 * nslab : nslab;
+        WvRegs<G, KS> R;
+        auto job_fetch = [&](int i) {
+            const int seg = (i >= nslab) ? 1 : 0, ks = (i - seg * nslab) * KS;
+            wv_fetch<G, KS>(R, seg ? c.a1 : c.a0, seg ? c.a1_stride : c.a0_stride, seg ? c.w1 : c.w0, p.H, p.Npad, row0, rv,
+                            n0, ks);
+        };
+        job_fetch(0);
+        for (int i = 0; i < njobs; ++i) {
+            const int seg = (i >= nslab) ? 1 : 0, ks = (i - seg * nslab) * KS;
+            const int kslab = (p.H - ks < KS) ? (p.H - ks) : KS;
+            __syncthreads();                               // the previous slab's MFMAs are done with As / Ws
+            wv_commit<G, KS>(R, p.H, p.Npad, rv, n0, ks, As, Ws, lda);
+            __syncthreads();
+            job_fetch(i + 1 < njobs ? i + 1 : i);          // unconditional (the last one re-fetches itself): a load under
+                                                           // a branch is waited for at the join
+            if (G == 4 || seg == 0) wv_mma<G>(As, Ws, lda, (kslab + 15) & ~15, accH, split);
+            else wv_mma<G>(As, Ws, lda, (kslab + 15) & ~15, accX, split);
+        }
     }
     __syncthreads();
 #pragma unroll
@@ -151,30 +293,23 @@ __global__ __launch_bounds__(256) void gpe_rnn_wave_fwd_kernel(WvFwdParams p)
         }
     __syncthreads();
 
-    const int u = tid & 15;
-    const int unit = blockIdx.y * 16 + u;
+    // C element (row, col) of the tile; with the wave-pair K split rows 32.. carry the second half of rows 0..31
+    auto cs_at = [&](int r, int col) -> float {
+        const float v = Cs[r * ldc + col];
+        return split ? v + Cs[(r + 32) * ldc + col] : v;
+    };
     if (unit >= p.H) return;
-    constexpr int IT = RG_BM / 16;
     if (G == 4) {
-        float xi[IT], xf[IT], xg[IT], xo[IT], cp[IT];
-#pragma unroll
-        for (int it = 0; it < IT; ++it) {
-            const int r = (tid >> 4) + 16 * it;
-            const long gr = row0 + (r < rv ? r : rv - 1);
-            const float* xp = c.xproj + gr * c.xp_stride;
-            xi[it] = xp[unit]; xf[it] = xp[p.H + unit]; xg[it] = xp[2 * p.H + unit]; xo[it] = xp[3 * p.H + unit];
-            cp[it] = c.c_prev[gr * p.H + unit];
-        }
 #pragma unroll
         for (int it = 0; it < IT; ++it) {
             const int r = (tid >> 4) + 16 * it;
             if (r < rv) {
                 const long gr = row0 + r;
-                const float ig = wv_sigmoid(Cs[r * ldc + u] + xi[it]);
-                const float fg = wv_sigmoid(Cs[r * ldc + 16 + u] + xf[it]);
-                const float gg = tanhf(Cs[r * ldc + 32 + u] + xg[it]);
-                const float og = wv_sigmoid(Cs[r * ldc + 48 + u] + xo[it]);
-                const float cn = fg * cp[it] + ig * gg;
+                const float ig = wv_sigmoid(cs_at(r, u) + e0[it]);
+                const float fg = wv_sigmoid(cs_at(r, 16 + u) + e1[it]);
+                const float gg = tanhf(cs_at(r, 32 + u) + e2[it]);
+                const float og = wv_sigmoid(cs_at(r, 48 + u) + e3[it]);
+                const float cn = fg * e4[it] + ig * gg;
                 float* go = c.saved + gr * 4 * p.H;
                 go[unit] = ig; go[p.H + unit] = fg; go[2 * p.H + unit] = gg; go[3 * p.H + unit] = og;
                 c.c_out[gr * p.H + unit] = cn;
@@ -182,28 +317,18 @@ __global__ __launch_bounds__(256) void gpe_rnn_wave_fwd_kernel(WvFwdParams p)
             }
         }
     } else {
-        float xr[IT], xz[IT], xn[IT], hp[IT];
-        const float bhn = c.bhn[unit];
-#pragma unroll
-        for (int it = 0; it < IT; ++it) {
-            const int r = (tid >> 4) + 16 * it;
-            const long gr = row0 + (r < rv ? r : rv - 1);
-            const float* xp = c.xproj + gr * c.xp_stride;
-            xr[it] = xp[unit]; xz[it] = xp[p.H + unit]; xn[it] = xp[2 * p.H + unit];
-            hp[it] = c.a0[gr * c.a0_stride + unit];
-        }
 #pragma unroll
         for (int it = 0; it < IT; ++it) {
             const int r = (tid >> 4) + 16 * it;
             if (r < rv) {
                 const long gr = row0 + r;
-                const float rg = wv_sigmoid(Cs[r * ldc + u] + Cs[r * ldc + 48 + u] + xr[it]);
-                const float zg = wv_sigmoid(Cs[r * ldc + 16 + u] + Cs[r * ldc + 64 + u] + xz[it]);
-                const float hn = Cs[r * ldc + 32 + u] + bhn;
-                const float ng = tanhf(Cs[r * ldc + 80 + u] + xn[it] + rg * hn);
+                const float rg = wv_sigmoid(cs_at(r, u) + cs_at(r, 48 + u) + e0[it]);
+                const float zg = wv_sigmoid(cs_at(r, 16 + u) + cs_at(r, 64 + u) + e1[it]);
+                const float hn = cs_at(r, 32 + u) + bhn;
+                const float ng = tanhf(cs_at(r, 80 + u) + e2[it] + rg * hn);
                 float* go = c.saved + gr * 4 * p.H;
                 go[unit] = rg; go[p.H + unit] = zg; go[2 * p.H + unit] = ng; go[3 * p.H + unit] = hn;
-                c.h_out[gr * c.h_stride + unit] = (1.f - zg) * ng + zg * hp[it];
+                c.h_out[gr * c.h_stride + unit] = (1.f - zg) * ng + zg * e3[it];
             }
         }
     }
@@ -217,7 +342,8 @@ static int wv_ks()
     static int ks = 0;
     if (!ks) {
         const char* e = getenv("GPE_WV_KS");
-        ks = (e && atoi(e) == 256) ? 256 : 128;
+        const int v = e ? atoi(e) : 0;
+        ks = (v == 256) ? 256 : 128;
     }
     return ks;
 }
@@ -239,7 +365,10 @@ static int wv_fwd_launch_ks(const WvFwdParams& p, hipStream_t s)
 template <int G>
 static int wv_fwd_launch(const WvFwdParams& p, hipStream_t s)
 {
-    return wv_ks() == 256 ? wv_fwd_launch_ks<G, 256>(p, s) : wv_fwd_launch_ks<G, 128>(p, s);
+    // a single row tile (the pattern decoders) is a pure latency chain: the wide slab halves its barrier pairs
+    // (a 96-wide slab — 50 KB, three workgroups per CU, the 576-workgroup panel diagonal in one round — measured slower:
+    // 686 vs 641 us per panel-decoder forward; three slabs per segment instead of two)
+    return (wv_ks() == 256 || p.Bn <= RG_BM) ? wv_fwd_launch_ks<G, 256>(p, s) : wv_fwd_launch_ks<G, 128>(p, s);
 }
 
 extern "C" int gpe_rnn_seq_fwd(int gates, int L, int T, int Bn, int H, const float* xproj0, long xp0_sb, long xp0_st,
@@ -337,8 +466,9 @@ __global__ __launch_bounds__(256) void gpe_rnn_wave_splitk_kernel(WvBwdParams p)
 #pragma unroll
     for (int n = 0; n < NT; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
     // one slab: reuse the forward's staging helper on the slab's column window
+    const bool split = rv <= 32;
     wv_segment<NT, KS>(c.a[seg] + ks, c.as[seg], c.w[seg] + (long)(ks >> 4) * 4 * p.Kpad_n * 4, kslab, p.Kpad_n, row0, rv, n0,
-                       As, Ws, lda, acc);
+                       As, Ws, lda, acc, split);
     __syncthreads();
 #pragma unroll
     for (int n = 0; n < NT; ++n)
@@ -350,7 +480,11 @@ __global__ __launch_bounds__(256) void gpe_rnn_wave_splitk_kernel(WvBwdParams p)
     if (cq < ncols) {
         float* dst0 = c.part + ((long)(seg * p.nz + z) * p.Bn) * p.H;
         for (int r = wave; r < rv; r += 4) {
-            const float4 v = ld4(&Cs[r * ldc + cq]);
+            float4 v = ld4(&Cs[r * ldc + cq]);
+            if (split) {
+                const float4 v2 = ld4(&Cs[(r + 32) * ldc + cq]);
+                v.x += v2.x; v.y += v2.y; v.z += v2.z; v.w += v2.w;
+            }
             float* dst = dst0 + (long)(row0 + r) * p.H + n0 + cq;
             const float o[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
