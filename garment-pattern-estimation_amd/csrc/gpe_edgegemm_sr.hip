@@ -235,7 +235,8 @@ __global__ __launch_bounds__(256, 1) void gpe_edgegemm_sr_kernel(RgParams p, int
             o.x = fmaxf(o.x + pv.x, 0.f); o.y = fmaxf(o.y + pv.y, 0.f);
             o.z = fmaxf(o.z + pv.z, 0.f); o.w = fmaxf(o.w + pv.w, 0.f);
         }
-        if (r >= s_rv) o = make_float4(0.f, 0.f, 0.f, 0.f);      // rows past the end of a partial last tile
+        // rows past the end of a partial last tile hold a copy of the last valid row (clamped loads): every output row
+        // depends on its own A row only and the epilogue skips rows >= e_rv, so they need no zeroing (4 v_cndmask per row)
         st4(&An[r * LDA + c], o);
     };
     // ---- epilogue of row u (compile-time u) of the tile being finished ------------------------------------------------

@@ -320,6 +320,17 @@ extern "C" int gpe_linear(const float* a, long a_so, long a_si, int a_inner, con
     // never use a block much wider than N
     const int single = rg_pick_nt_single(N);
     if (single > 0 && single < NT) NT = single;
+    // several column blocks: the width with the fewest padded columns (N = 400: two 208-wide blocks, 67 KB of LDS and
+    // two workgroups per CU, instead of 256 + 144 at 82 KB and one)
+    if (N > 256) {
+        int best = NT, best_pad = gpe_cdiv(N, 16 * NT) * 16 * NT;
+        const int wide[3] = {16, 13, 10};
+        for (int i = 0; i < 3; ++i) {
+            const int pad = gpe_cdiv(N, 16 * wide[i]) * 16 * wide[i];
+            if (pad < best_pad && (long)gpe_cdiv(N, 16 * wide[i]) * p.num_tiles >= 256) { best = wide[i]; best_pad = pad; }
+        }
+        NT = best;
+    }
     dim3 grid(p.num_tiles, gpe_cdiv(N, 16 * NT));
     return rg_dispatch_nt<A_DENSE, E_LINEAR>(NT, p, grid, (hipStream_t)stream);
 }
