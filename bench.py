@@ -44,6 +44,9 @@ def parse():
     ap.add_argument('--batch', type=int, default=32, help='garments per GPU')
     ap.add_argument('--points', type=int, default=2048)
     ap.add_argument('--k', type=int, default=16)
+    ap.add_argument('--model', choices=['lstm', 'att'], default='lstm',
+                    help="'lstm' = GarmentFullPattern3D (BASELINE cfg 1/2/3/5, the default line); 'att' = GarmentSegmentPattern3D "
+                         "(cfg 4: --model att --points 4096 --k 20) — an extra measurement, never the default")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-batch', type=int, default=8)
     ap.add_argument('--cpu-steps', type=int, default=3)
@@ -187,11 +190,12 @@ def main():
         raise SystemExit('launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)' % (args.gpus, world))
     dev = torch.device('cuda', local)
     data_config = configs.data_config()
-    nn_cfg = configs.lstm_model_config(k_neighbors=args.k)
+    nn_cfg = (configs.att_model_config if args.model == 'att' else configs.lstm_model_config)(k_neighbors=args.k)
 
     gpe_amd.set_math(args.math)
     torch.manual_seed(0)                               # identical replicas on every rank
-    model = nets.GarmentFullPattern3D(data_config, dict(nn_cfg), dict(nn_cfg['loss'])).to(dev).train()
+    model_cls = nets.GarmentSegmentPattern3D if args.model == 'att' else nets.GarmentFullPattern3D
+    model = model_cls(data_config, dict(nn_cfg), dict(nn_cfg['loss'])).to(dev).train()
     model.loss.with_quality_eval = False
     from gpe_amd import optim
     if args.torch_adam:
@@ -341,7 +345,7 @@ def main():
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(args, data_config, nn_cfg)
+        cpu = cpu_baseline(args, data_config, nn_cfg) if args.model == 'lstm' else None
 
     if rank == 0:
         garments = args.batch * world * args.steps
@@ -350,8 +354,10 @@ def main():
             'value': garments / elapsed, 'unit': 'garments/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': args.math, 'data': 'synthetic',
-            'config': {'workload': 'BASELINE cfg 2: GarmentFullPattern3D, N=%d, batch %d/GPU, k=%d, EdgeConv encoder'
-                                   ' + LSTM decoders' % (args.points, args.batch, args.k),
+            'config': {'workload': ('BASELINE cfg 4: GarmentSegmentPattern3D (attention), N=%d, batch %d/GPU, k=%d'
+                                    if args.model == 'att' else
+                                    'BASELINE cfg 2: GarmentFullPattern3D, N=%d, batch %d/GPU, k=%d, EdgeConv encoder'
+                                    ' + LSTM decoders') % (args.points, args.batch, args.k),
                        'global_batch': args.batch * world, 'parallelism': 'dp%d' % world,
                        'step': 'fwd + ComposedPatternLoss + bwd' + (' + RCCL grad all-reduce' if world > 1 else '')
                                + (' + Adam (torch)' if args.torch_adam else ' + fused Adam (flat arena)'),

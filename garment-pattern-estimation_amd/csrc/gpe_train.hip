@@ -338,49 +338,76 @@ extern "C" int gpe_order_match(const float* pred_feat, const float* gt_feat, int
 //   registers; the slab's w / feat rows are staged in LDS.  Partials [B][nslab][P][C] are combined in slab order by the
 //   second kernel (deterministic).  max keeps the argmax point for the backward pass.
 // =====================================================================================================================
-#define AP_ROWS 128
-#define AP_OUT 16        // outputs per thread: P*C <= 256*16
+#define AP_ROWS 64
+#define AP_TPT 2         // 4 x 4 output tiles per thread: ceil(P/4) * ceil(C/4) <= 256 * AP_TPT
 __global__ __launch_bounds__(256) void gpe_attn_pool_part_kernel(const float* __restrict__ w, int ldw,
                                                                  const float* __restrict__ feat, int ldf, int N, int P,
                                                                  int C, int mode, int nslab, float* __restrict__ part,
                                                                  int32_t* __restrict__ part_arg)
 {
-    extern __shared__ float sm[];
-    float* ws = sm;                       // [AP_ROWS][P]
-    float* fs = sm + AP_ROWS * P;         // [AP_ROWS][C]
-    const int b = blockIdx.y, slab = blockIdx.x, tid = threadIdx.x;
+    // register tiling: a thread owns 4 heads x 4 channels, so a slab row costs two ds_read_b128 per 16 products (one
+    // (p, c) output per register with two ds_read_b32 per product was LDS-issue bound: 0.72 ms at cfg 4)
+    extern __shared__ __align__(16) float sm[];
+    const int Pp = (P + 3) & ~3, Cp = (C + 3) & ~3;
+    float* ws = sm;                       // [AP_ROWS][Pp]  (pad columns zero)
+    float* fs = sm + AP_ROWS * Pp;        // [AP_ROWS][Cp]
+    const int b = blockIdx.y, slab = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n0 = slab * AP_ROWS;
     const int nr = (N - n0 < AP_ROWS) ? (N - n0) : AP_ROWS;
-    for (int e = tid; e < nr * P; e += 256) { const int r = e / P, c = e - r * P; ws[e] = w[((long)b * N + n0 + r) * ldw + c]; }
-    for (int e = tid; e < nr * C; e += 256) { const int r = e / C, c = e - r * C; fs[e] = feat[((long)b * N + n0 + r) * ldf + c]; }
-    __syncthreads();
-    const int total = P * C;
-    float acc[AP_OUT];
-    int arg[AP_OUT];
-    int op[AP_OUT], oc[AP_OUT];
-#pragma unroll
-    for (int q = 0; q < AP_OUT; ++q) {
-        const int o = tid + 256 * q;
-        const int oo = (o < total) ? o : 0;
-        op[q] = oo / C; oc[q] = oo - op[q] * C;
-        acc[q] = (mode == 1) ? -INFINITY : 0.f;
-        arg[q] = 0;
+    for (int r = wave; r < nr; r += 4) {
+        const long row = (long)b * N + n0 + r;
+        for (int c = lane; c < Pp; c += 64) ws[r * Pp + c] = (c < P) ? w[row * ldw + c] : 0.f;
+        for (int c = lane; c < Cp; c += 64) fs[r * Cp + c] = (c < C) ? feat[row * ldf + c] : 0.f;
     }
+    __syncthreads();
+    const int pq = Pp >> 2, cqn = Cp >> 2, tiles = pq * cqn;
+    float acc[AP_TPT][4][4];
+    int arg[AP_TPT][4][4];
+    int tp[AP_TPT], tc[AP_TPT];
+#pragma unroll
+    for (int q = 0; q < AP_TPT; ++q) {
+        const int t = tid + 256 * q;
+        const int tt = (t < tiles) ? t : 0;
+        tp[q] = tt / cqn; tc[q] = tt - tp[q] * cqn;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { acc[q][i][k] = (mode == 1) ? -INFINITY : 0.f; arg[q][i][k] = 0; }
+    }
+    const int ntq = (tiles + 255) >> 8;       // tile slots in use (uniform)
     for (int r = 0; r < nr; ++r) {
 #pragma unroll
-        for (int q = 0; q < AP_OUT; ++q) {
-            const float v = ws[r * P + op[q]] * fs[r * C + oc[q]];
-            if (mode == 1) { if (v > acc[q]) { acc[q] = v; arg[q] = n0 + r; } }
-            else acc[q] += v;
+        for (int q = 0; q < AP_TPT; ++q) {
+            if (q < ntq) {
+                const float4 wv = *reinterpret_cast<const float4*>(&ws[r * Pp + 4 * tp[q]]);
+                const float4 fv = *reinterpret_cast<const float4*>(&fs[r * Cp + 4 * tc[q]]);
+                const float wa[4] = {wv.x, wv.y, wv.z, wv.w}, fa[4] = {fv.x, fv.y, fv.z, fv.w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float v = wa[i] * fa[k];
+                        if (mode == 1) { if (v > acc[q][i][k]) { acc[q][i][k] = v; arg[q][i][k] = n0 + r; } }
+                        else acc[q][i][k] += v;
+                    }
+            }
         }
     }
+    const int total = P * C;
 #pragma unroll
-    for (int q = 0; q < AP_OUT; ++q) {
-        const int o = tid + 256 * q;
-        if (o < total) {
-            const size_t dst = ((size_t)b * nslab + slab) * total + o;
-            part[dst] = acc[q];
-            if (mode == 1) part_arg[dst] = arg[q];
+    for (int q = 0; q < AP_TPT; ++q) {
+        if (tid + 256 * q < tiles) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int p_ = 4 * tp[q] + i, c = 4 * tc[q] + k;
+                    if (p_ < P && c < C) {
+                        const size_t dst = ((size_t)b * nslab + slab) * total + (size_t)p_ * C + c;
+                        part[dst] = acc[q][i][k];
+                        if (mode == 1) part_arg[dst] = arg[q][i][k];
+                    }
+                }
         }
     }
 }
@@ -415,11 +442,11 @@ extern "C" int gpe_attn_pool_fwd(const float* w, int ldw, const float* feat, int
                                  int mode, float* out, int32_t* arg, float* part, int32_t* part_arg, void* stream)
 {
     if (!w || !feat || !out || !part || B <= 0 || N <= 0 || P <= 0 || C <= 0 || ldw < P || ldf < C || mode < 0 ||
-        mode > 2 || (long)P * C > 256L * AP_OUT)
+        mode > 2 || (long)gpe_cdiv(P, 4) * gpe_cdiv(C, 4) > 256L * AP_TPT)
         return GPE_EINVAL;
     if (mode == 1 && (!arg || !part_arg)) return GPE_EINVAL;
     const int nslab = gpe_cdiv(N, AP_ROWS);
-    const size_t lds = (size_t)AP_ROWS * (P + C) * sizeof(float);
+    const size_t lds = (size_t)AP_ROWS * (gpe_round_up(P, 4) + gpe_round_up(C, 4)) * sizeof(float);
     if (lds > 150 * 1024) return GPE_EINVAL;
     GPE_ENSURE_MAX_LDS_N((gpe_attn_pool_part_kernel), 150 * 1024);
     hipLaunchKernelGGL(gpe_attn_pool_part_kernel, dim3(nslab, B), dim3(256), lds, (hipStream_t)stream, w, ldw, feat, ldf, N,
@@ -431,32 +458,96 @@ extern "C" int gpe_attn_pool_fwd(const float* w, int ldw, const float* feat, int
 }
 
 // backward, mean / add: gw[n][p] = sc * sum_c feat[n][c] g[b][p][c] ; gf[n][c] = sc * sum_p w[n][p] g[b][p][c]
-// (sc = 1/N or 1).  One wave per point; the cloud's g matrix [P][C] sits in LDS.
+// (sc = 1/N or 1).  Workgroup = 64 points of a cloud; the cloud's (scaled) g matrix [P][C] and the 64 w / feat rows sit in
+// LDS, outputs are register tiles (gf: 4 points x 4 channels, p ascending; gw: 2 points x 4 heads, c ascending — the same
+// summation order as a plain per-output loop, so the result does not depend on the tiling).
+#define APB_ROWS 64
 __global__ __launch_bounds__(256) void gpe_attn_pool_bwd_kernel(const float* __restrict__ w, int ldw,
                                                                 const float* __restrict__ feat, int ldf,
                                                                 const float* __restrict__ g, int N, int P, int C,
-                                                                float sc, int chunk, float* __restrict__ gw, int ldgw,
+                                                                float sc, float* __restrict__ gw, int ldgw,
                                                                 float* __restrict__ gf, int ldgf)
 {
-    extern __shared__ float gs[];          // [P][C]
+    extern __shared__ __align__(16) float sm[];
+    const int Pp = (P + 3) & ~3, Cp = (C + 3) & ~3;
+    float* gs = sm;                          // [Pp][Cp]   (pad rows / columns zero)
+    float* ws = gs + Pp * Cp;                // [APB_ROWS][Pp]
+    float* fs = ws + APB_ROWS * Pp;          // [APB_ROWS][Cp]
     const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int e = tid; e < P * C; e += 256) gs[e] = g[(size_t)b * P * C + e] * sc;
+    const int n0 = blockIdx.x * APB_ROWS;
+    const int nr = (N - n0 < APB_ROWS) ? (N - n0) : APB_ROWS;
+    for (int p_ = wave; p_ < Pp; p_ += 4)
+        for (int c = lane; c < Cp; c += 64) gs[p_ * Cp + c] = (p_ < P && c < C) ? g[((size_t)b * P + p_) * C + c] * sc : 0.f;
+    for (int r = wave; r < APB_ROWS; r += 4) {
+        const long row = (long)b * N + n0 + (r < nr ? r : nr - 1);
+        for (int c = lane; c < Pp; c += 64) ws[r * Pp + c] = (c < P && r < nr) ? w[row * ldw + c] : 0.f;
+        for (int c = lane; c < Cp; c += 64) fs[r * Cp + c] = (c < C && r < nr) ? feat[row * ldf + c] : 0.f;
+    }
     __syncthreads();
-    const int n_begin = blockIdx.x * chunk;
-    const int n_end = (n_begin + chunk < N) ? n_begin + chunk : N;
-    for (int n = n_begin + wave; n < n_end; n += 4) {
-        const long row = (long)b * N + n;
-        // gf row: lanes over c
-        for (int c = lane; c < C; c += 64) {
-            float s = 0.f;
-            for (int p_ = 0; p_ < P; ++p_) s = __builtin_fmaf(w[row * ldw + p_], gs[p_ * C + c], s);
-            gf[row * ldgf + c] = s;
+    // gf: tiles of 4 points x 4 channels
+    const int cqn = Cp >> 2;
+    for (int t = tid; t < (APB_ROWS / 4) * cqn; t += 256) {
+        const int ng = t / cqn, cq = t - ng * cqn;
+        float acc[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc[i][k] = 0.f;
+        for (int p_ = 0; p_ < P; ++p_) {
+            const float4 gv = *reinterpret_cast<const float4*>(&gs[p_ * Cp + 4 * cq]);
+            const float ga[4] = {gv.x, gv.y, gv.z, gv.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float wv = ws[(4 * ng + i) * Pp + p_];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) acc[i][k] = __builtin_fmaf(wv, ga[k], acc[i][k]);
+            }
         }
-        // gw row: lanes over p, sequential over c (deterministic)
-        for (int p_ = lane; p_ < P; p_ += 64) {
-            float s = 0.f;
-            for (int c = 0; c < C; ++c) s = __builtin_fmaf(feat[row * ldf + c], gs[p_ * C + c], s);
-            gw[row * ldgw + p_] = s;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = 4 * ng + i;
+            if (r < nr) {
+                float* dst = gf + ((long)b * N + n0 + r) * ldgf + 4 * cq;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) if (4 * cq + k < C) dst[k] = acc[i][k];
+            }
+        }
+    }
+    // gw: tiles of 2 points x 4 heads, channels four at a time in ascending order
+    const int pq = Pp >> 2;
+    for (int t = tid; t < (APB_ROWS / 2) * pq; t += 256) {
+        const int ng = t / pq, pg = t - ng * pq;
+        float acc[2][4];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc[i][k] = 0.f;
+        for (int c4 = 0; c4 < Cp; c4 += 4) {
+            float4 fv[2], gv[4];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) fv[i] = *reinterpret_cast<const float4*>(&fs[(2 * ng + i) * Cp + c4]);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) gv[k] = *reinterpret_cast<const float4*>(&gs[(4 * pg + k) * Cp + c4]);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    float s_ = acc[i][k];
+                    s_ = __builtin_fmaf(fv[i].x, gv[k].x, s_);
+                    s_ = __builtin_fmaf(fv[i].y, gv[k].y, s_);
+                    s_ = __builtin_fmaf(fv[i].z, gv[k].z, s_);
+                    s_ = __builtin_fmaf(fv[i].w, gv[k].w, s_);
+                    acc[i][k] = s_;
+                }
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int r = 2 * ng + i;
+            if (r < nr) {
+                float* dst = gw + ((long)b * N + n0 + r) * ldgw + 4 * pg;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) if (4 * pg + k < P) dst[k] = acc[i][k];
+            }
         }
     }
 }
@@ -502,15 +593,12 @@ extern "C" int gpe_attn_pool_bwd(const float* w, int ldw, const float* feat, int
         hipLaunchKernelGGL(gpe_attn_pool_bwd_max_kernel, dim3(gpe_cdiv(P + C, 64), B), dim3(64), 0, (hipStream_t)stream, w,
                            ldw, feat, ldf, g, arg, N, P, C, gw, ldgw, gf, ldgf);
     } else {
-        const size_t lds = (size_t)P * C * sizeof(float);
+        const int Pp = gpe_round_up(P, 4), Cp = gpe_round_up(C, 4);
+        const size_t lds = ((size_t)Pp * Cp + (size_t)APB_ROWS * (Pp + Cp)) * sizeof(float);
         if (lds > 150 * 1024) return GPE_EINVAL;
         GPE_ENSURE_MAX_LDS_N((gpe_attn_pool_bwd_kernel), 150 * 1024);
-        int chunks = gpe_cdiv(2048, B);                    // ~2048 workgroups in total
-        if (chunks > gpe_cdiv(N, 4)) chunks = gpe_cdiv(N, 4);
-        if (chunks < 1) chunks = 1;
-        const int chunk = gpe_cdiv(N, chunks);
-        hipLaunchKernelGGL(gpe_attn_pool_bwd_kernel, dim3(gpe_cdiv(N, chunk), B), dim3(256), lds, (hipStream_t)stream, w, ldw,
-                           feat, ldf, g, N, P, C, mode == 0 ? 1.f / N : 1.f, chunk, gw, ldgw, gf, ldgf);
+        hipLaunchKernelGGL(gpe_attn_pool_bwd_kernel, dim3(gpe_cdiv(N, APB_ROWS), B), dim3(256), lds, (hipStream_t)stream, w, ldw,
+                           feat, ldf, g, N, P, C, mode == 0 ? 1.f / N : 1.f, gw, ldgw, gf, ldgf);
     }
     GPE_CHECK_LAUNCH();
     return GPE_OK;
