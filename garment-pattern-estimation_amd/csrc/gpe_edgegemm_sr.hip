@@ -53,6 +53,12 @@ __device__ __forceinline__ float4 sr_sel4(const float4 a0, const float4 a1, cons
     return r;
 }
 
+// row of the [P|Q] table that belongs to (pseudo-)point x: x itself, or x / f when a point is split into f pseudo-points
+__device__ __forceinline__ long sr_prow(int x, unsigned magic)
+{
+    return magic ? (long)__umulhi((unsigned)x, magic) : (long)x;
+}
+
 // K16: k == 16 (the benchmark configuration): every wave owns exactly ONE point per tile, so the slot index of a row is
 // its compile-time position u, a point completes exactly at u == 15, and row validity is one per-tile predicate — the
 // per-row bookkeeping (and the register copies its branches cost) disappears from the epilogue.
@@ -195,10 +201,10 @@ __global__ __launch_bounds__(256, 1) void gpe_edgegemm_sr_kernel(RgParams p, int
         }
         if (GATHER_ACT) {
             const int pt0 = tile * PT + wave * npw + vz, ptl = tile * PT + ((last * rkl) >> 16);
-            pve0 = ld4(p.pq + (long)((pt0 + 0 < ptl) ? pt0 + 0 : ptl) * p.ldpq + cn);
-            pve1 = ld4(p.pq + (long)((pt0 + 1 < ptl) ? pt0 + 1 : ptl) * p.ldpq + cn);
-            pve2 = ld4(p.pq + (long)((pt0 + 2 < ptl) ? pt0 + 2 : ptl) * p.ldpq + cn);
-            pve3 = ld4(p.pq + (long)((pt0 + 3 < ptl) ? pt0 + 3 : ptl) * p.ldpq + cn);
+            pve0 = ld4(p.pq + sr_prow((pt0 + 0 < ptl) ? pt0 + 0 : ptl, p.pmagic) * p.ldpq + cn);
+            pve1 = ld4(p.pq + sr_prow((pt0 + 1 < ptl) ? pt0 + 1 : ptl, p.pmagic) * p.ldpq + cn);
+            pve2 = ld4(p.pq + sr_prow((pt0 + 2 < ptl) ? pt0 + 2 : ptl, p.pmagic) * p.ldpq + cn);
+            pve3 = ld4(p.pq + sr_prow((pt0 + 3 < ptl) ? pt0 + 3 : ptl, p.pmagic) * p.ldpq + cn);
         }
     };
     auto issue_stage_loads = [&](int tile) {
@@ -219,10 +225,10 @@ __global__ __launch_bounds__(256, 1) void gpe_edgegemm_sr_kernel(RgParams p, int
         }
         if (AMODE == A_GATHER) {
             const int pt0 = tile * PT + wave * npw + vz, ptl = tile * PT + ((last * rkl) >> 16);
-            pvs0 = ld4(p.pq + (long)((pt0 + 0 < ptl) ? pt0 + 0 : ptl) * p.ldpq + ck);
-            pvs1 = ld4(p.pq + (long)((pt0 + 1 < ptl) ? pt0 + 1 : ptl) * p.ldpq + ck);
-            pvs2 = ld4(p.pq + (long)((pt0 + 2 < ptl) ? pt0 + 2 : ptl) * p.ldpq + ck);
-            pvs3 = ld4(p.pq + (long)((pt0 + 3 < ptl) ? pt0 + 3 : ptl) * p.ldpq + ck);
+            pvs0 = ld4(p.pq + sr_prow((pt0 + 0 < ptl) ? pt0 + 0 : ptl, p.pmagic) * p.ldpq + ck);
+            pvs1 = ld4(p.pq + sr_prow((pt0 + 1 < ptl) ? pt0 + 1 : ptl, p.pmagic) * p.ldpq + ck);
+            pvs2 = ld4(p.pq + sr_prow((pt0 + 2 < ptl) ? pt0 + 2 : ptl, p.pmagic) * p.ldpq + ck);
+            pvs3 = ld4(p.pq + sr_prow((pt0 + 3 < ptl) ? pt0 + 3 : ptl, p.pmagic) * p.ldpq + ck);
         }
     };
     // ---- LDS commit of staged row u (compile-time u) ------------------------------------------------------------------
@@ -509,6 +515,73 @@ static int sr_dispatch(int NT, int KCH, const RgParams& p, int stats_nblk, hipSt
     return GPE_EINVAL;
 }
 
+// ---- k > 16: merging the per-pseudo-point results ------------------------------------------------------------------------
+// A point with k > 16 neighbours is processed as f pseudo-points of kq = k / f rows (kq <= 16, so every wave still owns whole
+// pseudo-points).  The kernels then write one max / min / argmax / argmin row, or one dP row, per PSEUDO-point into a scratch
+// image; these two kernels fold the f rows of each point, in pseudo-point order (first maximum wins, fixed summation order).
+__global__ void gpe_sr_fold_agg_kernel(const float* __restrict__ tmx, const float* __restrict__ tmn,
+                                       const uint8_t* __restrict__ tamx, const uint8_t* __restrict__ tamn, long npts, int f,
+                                       int kq, int C, int ld, float* __restrict__ mx, float* __restrict__ mn,
+                                       uint8_t* __restrict__ amx, uint8_t* __restrict__ amn)
+{
+    const int cq = (C + 3) >> 2;
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= npts * cq) return;
+    const long pt = t / cq;
+    const int c = (int)(t - pt * cq) << 2;
+    float bx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY}, bn[4] = {INFINITY, INFINITY, INFINITY, INFINITY};
+    int ix[4] = {0, 0, 0, 0}, in_[4] = {0, 0, 0, 0};
+    for (int q = 0; q < f; ++q) {
+        const long o = (pt * f + q) * ld + c;
+        const float4 vx = ld4(tmx + o), vn = ld4(tmn + o);
+        const uchar4 ax = *reinterpret_cast<const uchar4*>(tamx + o), an = *reinterpret_cast<const uchar4*>(tamn + o);
+        const float x4[4] = {vx.x, vx.y, vx.z, vx.w}, n4[4] = {vn.x, vn.y, vn.z, vn.w};
+        const int ax4[4] = {ax.x, ax.y, ax.z, ax.w}, an4[4] = {an.x, an.y, an.z, an.w};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (x4[u] > bx[u]) { bx[u] = x4[u]; ix[u] = q * kq + ax4[u]; }
+            if (n4[u] < bn[u]) { bn[u] = n4[u]; in_[u] = q * kq + an4[u]; }
+        }
+    }
+    const long o = pt * ld + c;
+    st4(mx + o, make_float4(bx[0], bx[1], bx[2], bx[3]));
+    st4(mn + o, make_float4(bn[0], bn[1], bn[2], bn[3]));
+    *reinterpret_cast<uchar4*>(amx + o) = make_uchar4(ix[0], ix[1], ix[2], ix[3]);
+    *reinterpret_cast<uchar4*>(amn + o) = make_uchar4(in_[0], in_[1], in_[2], in_[3]);
+}
+
+__global__ void gpe_sr_fold_sum_kernel(const float* __restrict__ t, long npts, int f, int C, int ld, float* __restrict__ y)
+{
+    const int cq = (C + 3) >> 2;
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npts * cq) return;
+    const long pt = i / cq;
+    const int c = (int)(i - pt * cq) << 2;
+    float4 s = ld4(t + (pt * f) * ld + c);
+    for (int q = 1; q < f; ++q) {
+        const float4 v = ld4(t + (pt * f + q) * ld + c);
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    st4(y + pt * ld + c, s);
+}
+
+// grow-only scratch image per device (the fold inputs); hipFree synchronises the device, so regrowing is safe
+static void* sr_scratch(size_t bytes)
+{
+    constexpr int SR_MAX_DEVICES = 64;
+    static void* ptr[SR_MAX_DEVICES] = {};
+    static size_t cap[SR_MAX_DEVICES] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= SR_MAX_DEVICES) return nullptr;
+    if (bytes > cap[dev]) {
+        if (ptr[dev]) (void)hipFree(ptr[dev]);
+        ptr[dev] = nullptr; cap[dev] = 0;
+        if (hipMalloc(&ptr[dev], bytes) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        cap[dev] = bytes;
+    }
+    return ptr[dev];
+}
+
 // Returns 1 and launches when the shape is on this kernel's menu, 0 when the caller should try the next kernel,
 // < 0 on a launch error.  `p` comes with the generic tiling (R = (64/k)*k); this kernel re-tiles so that every wave
 // owns whole points: R = 4 * npw * k with npw * k <= 16.
@@ -521,9 +594,39 @@ int gpe_edgegemm_sr_try(const RgParams& p_in, int amode, int emode, int stats_nb
     if (amode == A_DENSE && (p.a.inner > 0 || (p.a.stride_outer & 3) || p.a.stride_outer < ((p.K + 3) & ~3) ||
                              (((uintptr_t)p.a.base) & 15)))
         return 0;                                        // dense rows must be aligned + padded for plain 16-B loads
-    if (p.k < 1 || p.k > SR_PB) return 0;
-    const int npw = SR_PB / p.k;                         // points per wave per tile
+    if (p.k < 1) return 0;
     const bool per_point = amode == A_GATHER || emode == E_BWD_GATHER || (emode == E_EDGE_FWD && p.agg);
+    // k > 16: rows that need nothing per point can be tiled any way (4 rows per "point": 64-row tiles); the per-point
+    // variants split a point into f pseudo-points of kq rows and fold the per-pseudo-point results afterwards
+    int fold_f = 1, fold_kq = 0;
+    float *fold_mx = nullptr, *fold_mn = nullptr, *fold_dp = nullptr;
+    uint8_t *fold_amx = nullptr, *fold_amn = nullptr;
+    const long npts = p.M / p.k;
+    if (p.k > SR_PB) {
+        if (!per_point) p.k = 4;
+        else {
+            int best = 0;
+            for (int kq = SR_PB; kq >= SR_PB / SR_NPW; --kq)
+                if (p.k % kq == 0 && (SR_PB / kq) * kq > (best ? (SR_PB / best) * best : 0)) best = kq;
+            if (!best || npts * (p.k / best) >= (1L << 31) || (p.oldagg & 3) || (p.lddp & 3)) return 0;
+            fold_f = p.k / best; fold_kq = best;
+            const long nps = npts * fold_f;                               // pseudo-points
+            const bool want_agg = emode == E_EDGE_FWD && p.agg, want_dp = emode == E_BWD_GATHER;
+            const size_t agg_f = want_agg ? (size_t)nps * p.oldagg : 0, dp_f = want_dp ? (size_t)nps * p.lddp : 0;
+            const size_t bytes = (2 * agg_f + dp_f) * sizeof(float) + 2 * agg_f + 256;
+            char* ws = (bytes > 256) ? (char*)sr_scratch(bytes) : nullptr;
+            if (bytes > 256 && !ws) return 0;                             // no scratch: the producer/consumer kernel runs it
+            if (want_agg) {
+                fold_mx = p.mx; fold_mn = p.mn; fold_amx = p.oamx; fold_amn = p.oamn;
+                p.mx = (float*)ws; p.mn = p.mx + agg_f;
+                p.oamx = (uint8_t*)(p.mn + agg_f); p.oamn = p.oamx + agg_f;
+            }
+            if (want_dp) { fold_dp = p.dP; p.dP = (float*)ws; }
+            p.k = best;
+            p.pmagic = (unsigned)(((1ull << 32) + fold_f - 1) / fold_f);  // x / f == umulhi(x, pmagic) for x < 2^31 / f
+        }
+    }
+    const int npw = SR_PB / p.k;                         // points per wave per tile
     if (per_point && npw > SR_NPW) return 0;
     p.R = 4 * npw * p.k;
     p.num_tiles = gpe_cdiv(p.M, p.R);
@@ -546,5 +649,19 @@ int gpe_edgegemm_sr_try(const RgParams& p_in, int amode, int emode, int stats_nb
     else if (amode == A_DENSE && emode == E_BWD_INPLACE) rc = sr_dispatch<A_DENSE, E_BWD_INPLACE>(NT, KCH, p, stats_nblk, s);
     else if (amode == A_DENSE && emode == E_BWD_GATHER) rc = sr_dispatch<A_DENSE, E_BWD_GATHER>(NT, KCH, p, stats_nblk, s);
     if (rc == GPE_ENOTSUP_SHAPE) return 0;
+    if (rc == GPE_OK && fold_f > 1) {
+        if (fold_mx) {
+            const long th = npts * ((p.N + 3) >> 2);
+            hipLaunchKernelGGL(gpe_sr_fold_agg_kernel, dim3((unsigned)gpe_cdiv(th, 256)), dim3(256), 0, s, p.mx, p.mn, p.oamx, p.oamn,
+                               npts, fold_f, fold_kq, p.N, p.oldagg, fold_mx, fold_mn, fold_amx, fold_amn);
+            GPE_CHECK_LAUNCH();
+        }
+        if (fold_dp) {
+            const long th = npts * ((p.N + 3) >> 2);
+            hipLaunchKernelGGL(gpe_sr_fold_sum_kernel, dim3((unsigned)gpe_cdiv(th, 256)), dim3(256), 0, s, p.dP, npts, fold_f, p.N,
+                               p.lddp, fold_dp);
+            GPE_CHECK_LAUNCH();
+        }
+    }
     return rc == GPE_OK ? 1 : rc;
 }

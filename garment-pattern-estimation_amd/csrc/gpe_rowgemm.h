@@ -35,6 +35,9 @@ struct RgParams {
     // of XCD c % 8.  tpc = tiles per cloud (N*k / R, exact); 0 = off.
     int pin_tpc;
     int pin_clouds;         // B when the caller's rows are B equal clouds (edge kernels), else 0
+    // k > 16 on the single-role kernels: a point's k rows are handled as f pseudo-points of k/f rows (gpe_edgegemm_sr.hip);
+    // the P row of pseudo-point x is then x / f = umulhi(x, pmagic).  0 = pseudo-points are points.
+    unsigned pmagic;
 };
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }

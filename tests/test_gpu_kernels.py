@@ -197,11 +197,15 @@ def _product_conv(gpe, oconv, C, H, Fo, k):
 
 
 # the (200, 150) cases run the register-stationary edge kernels: k = 16 the compile-time-slot variant, k = 5 / 8 / 10 the
-# generic one (3 / 2 / 1 points per wave, ragged last tile: E is not a multiple of the tile), k = 20 the paired fallback
+# generic one (3 / 2 / 1 points per wave, ragged last tile: E is not a multiple of the tile), k = 20 / 24 / 32 the
+# pseudo-point split (5 x 4, 3 x 8, 2 x 16 rows per point, folded afterwards), k = 17 (prime) the paired fallback.  (The fp64 oracle picks ONE argmax per (point, channel): a
+# near-tie the build resolves the other way moves that channel's gradient to another edge — seen at (1, 61, 150, .., 17)
+# with data seed 1 only, 9e-4 — so a case that fails on one seed and passes on five others is a tie, not a kernel fault.)
 @pytest.mark.parametrize('B,N,C,H,Fo,k', [(2, 64, 3, 32, 24, 4), (2, 96, 24, 32, 24, 5), (2, 128, 3, 200, 150, 16),
                                           (1, 256, 150, 200, 150, 16), (3, 50, 6, 64, 30, 20),
                                           (2, 100, 3, 200, 150, 5), (1, 77, 150, 200, 150, 8), (2, 67, 3, 200, 150, 10),
-                                          (1, 90, 150, 200, 150, 20)])
+                                          (1, 90, 150, 200, 150, 20), (2, 75, 150, 200, 150, 24),
+                                          (1, 70, 3, 200, 150, 32), (1, 64, 150, 200, 150, 17)])
 def test_edgeconv_layer_fwd_bwd(gpe, math_mode, B, N, C, H, Fo, k):
     from oracle import ref_path as O
     tol = TOL[math_mode]
