@@ -71,6 +71,9 @@ __device__ __forceinline__ unsigned gpe_udiv(unsigned n, unsigned d, double rcp)
 
 // compute units of the CURRENT device (cached per device ordinal); defined in gpe_pointwise.hip
 int gpe_num_cus();
+// grow-only device scratch of the CURRENT device, one image per `slot` (0: edge-kernel fold inputs, 1: kNN partial lists);
+// nullptr when the allocation fails.  hipFree synchronises the device, so regrowing is safe.  Defined in gpe_pointwise.hip.
+void* gpe_scratch(int slot, size_t bytes);
 
 // ---- cloud -> XCD pinning ---------------------------------------------------------------------------------------------
 // Workgroup b is dispatched to XCD b % 8 (observed placement; a wrong guess costs speed, never correctness), and every

@@ -565,23 +565,6 @@ __global__ void gpe_sr_fold_sum_kernel(const float* __restrict__ t, long npts, i
     st4(y + pt * ld + c, s);
 }
 
-// grow-only scratch image per device (the fold inputs); hipFree synchronises the device, so regrowing is safe
-static void* sr_scratch(size_t bytes)
-{
-    constexpr int SR_MAX_DEVICES = 64;
-    static void* ptr[SR_MAX_DEVICES] = {};
-    static size_t cap[SR_MAX_DEVICES] = {};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= SR_MAX_DEVICES) return nullptr;
-    if (bytes > cap[dev]) {
-        if (ptr[dev]) (void)hipFree(ptr[dev]);
-        ptr[dev] = nullptr; cap[dev] = 0;
-        if (hipMalloc(&ptr[dev], bytes) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-        cap[dev] = bytes;
-    }
-    return ptr[dev];
-}
-
 // Returns 1 and launches when the shape is on this kernel's menu, 0 when the caller should try the next kernel,
 // < 0 on a launch error.  `p` comes with the generic tiling (R = (64/k)*k); this kernel re-tiles so that every wave
 // owns whole points: R = 4 * npw * k with npw * k <= 16.
@@ -614,7 +597,7 @@ int gpe_edgegemm_sr_try(const RgParams& p_in, int amode, int emode, int stats_nb
             const bool want_agg = emode == E_EDGE_FWD && p.agg, want_dp = emode == E_BWD_GATHER;
             const size_t agg_f = want_agg ? (size_t)nps * p.oldagg : 0, dp_f = want_dp ? (size_t)nps * p.lddp : 0;
             const size_t bytes = (2 * agg_f + dp_f) * sizeof(float) + 2 * agg_f + 256;
-            char* ws = (bytes > 256) ? (char*)sr_scratch(bytes) : nullptr;
+            char* ws = (bytes > 256) ? (char*)gpe_scratch(0, bytes) : nullptr;
             if (bytes > 256 && !ws) return 0;                             // no scratch: the producer/consumer kernel runs it
             if (want_agg) {
                 fold_mx = p.mx; fold_mn = p.mn; fold_amx = p.oamx; fold_amn = p.oamn;

@@ -117,7 +117,8 @@ __device__ __forceinline__ void knn_select(bool first, float d, int lane, int ca
 template <int VEC, int PROBE>
 __global__ __launch_bounds__(256, 4) void gpe_knn_kernel(const float* __restrict__ x, int N, int C, int ldx, int k,
                                                          int32_t* __restrict__ idx, int32_t* __restrict__ idx_glob, int B,
-                                                         int tiles, int pin, int probe)
+                                                         int tiles, int pin, int probe, int nsplit,
+                                                         unsigned long long* __restrict__ part)
 {
     extern __shared__ __align__(16) float smem[];
     float* const qS = smem;                                // [64][KNN_LD]   query rows of this step's channels
@@ -130,18 +131,26 @@ __global__ __launch_bounds__(256, 4) void gpe_knn_kernel(const float* __restrict
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // 1-D grid.  pin: all 64-query tiles of cloud c run on XCD c % 8 (gpe_common.h), so the cloud's candidate table
     // (N x C floats, re-read by every tile) is fetched from HBM by one L2 instead of eight
-    int b, qt;
+    // nsplit > 1 (host: the tables of the clouds in flight on an XCD would not fit its L2): the candidate range of a query
+    // tile is cut into nsplit pieces, one workgroup each; every piece writes its own sorted k-list and gpe_knn_merge_kernel
+    // merges them.  All pieces of a cloud are consecutive work items, so nsplit x fewer clouds are streamed at a time.
+    int b, item;
+    const int ipc = tiles * nsplit;                        // work items per cloud
     if (pin) {
         const int xcd = blockIdx.x & (GPE_NXCD - 1), slot = blockIdx.x >> 3;
-        const int jc = slot / tiles;
+        const int jc = slot / ipc;
         b = xcd + GPE_NXCD * jc;
-        qt = slot - jc * tiles;
+        item = slot - jc * ipc;
         if (b >= B) return;
     } else {
-        b = blockIdx.x / tiles;
-        qt = blockIdx.x - b * tiles;
+        b = blockIdx.x / ipc;
+        item = blockIdx.x - b * ipc;
     }
+    const int qt = item / nsplit, piece = item - qt * nsplit;
     const int q0 = qt * KNN_TQ;
+    const int tps = (tiles + nsplit - 1) / nsplit;         // candidate tiles per piece (tiles == candidate tiles: TQ == TC)
+    const int c_first = piece * tps * KNN_TC;
+    const int c_stop = ((piece + 1) * tps * KNN_TC < N) ? (piece + 1) * tps * KNN_TC : N;
     const float* cloud = x + (size_t)b * N * ldx;
     float* const dW = dS + wave * 16 * KNN_LDD;
     unsigned long long* const mW = mS + wave * 64;
@@ -165,7 +174,7 @@ __global__ __launch_bounds__(256, 4) void gpe_knn_kernel(const float* __restrict
     const int nvec = KNN_TC * vpr;                         // vectors per operand tile (<= 2048 / VEC)
     constexpr int NPF = (KNN_TC * KNN_CCH) / (256 * VEC);
     float pre_c[NPF][VEC], pre_q[NPF][VEC];
-    int pf_c0 = 0, pf_ch = 0;                              // tile / chunk the NEXT prefetch loads
+    int pf_c0 = c_first, pf_ch = 0;                        // tile / chunk the NEXT prefetch loads
     auto prefetch = [&]() {
 #pragma unroll
         for (int i = 0; i < NPF; ++i) {
@@ -220,13 +229,13 @@ __global__ __launch_bounds__(256, 4) void gpe_knn_kernel(const float* __restrict
         }
     };
     prefetch();
-    const int nsteps = ((N + KNN_TC - 1) / KNN_TC) * nchunk;
+    const int nsteps = ((c_stop - c_first + KNN_TC - 1) / KNN_TC) * nchunk;
     int step = 0;
 
     const float* const qrow = &qS[(16 * wave + 4 * tq) * KNN_LD];
     const float* const crow = &cS[(4 * tc) * KNN_LD];
 
-    for (int c0 = 0; c0 < N; c0 += KNN_TC) {
+    for (int c0 = c_first; c0 < c_stop; c0 += KNN_TC) {
         float acc[4][4];
 #pragma unroll
         for (int a = 0; a < 4; ++a)
@@ -275,7 +284,7 @@ __global__ __launch_bounds__(256, 4) void gpe_knn_kernel(const float* __restrict
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 
         // ---- selection: lane = candidate of this tile ---------------------------------------------------------
-        if (PROBE && (probe & 1) && c0 > 0) continue;
+        if (PROBE && (probe & 1) && c0 > c_first) continue;
         const int cand = c0 + lane;
         const bool tail = c0 + KNN_TC > N;
 #pragma unroll
@@ -284,7 +293,7 @@ __global__ __launch_bounds__(256, 4) void gpe_knn_kernel(const float* __restrict
             if (tail && cand >= N) d = INFINITY;
             float ldv = ld_[i], t = thr[i];
             int liv = li_[i];
-            knn_select(c0 == 0, d, lane, cand, k, mW, ldv, liv, t);
+            knn_select(c0 == c_first, d, lane, cand, k, mW, ldv, liv, t);
             ld_[i] = ldv; li_[i] = liv; thr[i] = t;
             __builtin_amdgcn_sched_barrier(0);     // one query at a time: interleaving the 16 merges only spills
         }
@@ -295,23 +304,52 @@ __global__ __launch_bounds__(256, 4) void gpe_knn_kernel(const float* __restrict
     for (int i = 0; i < 16; ++i) {
         const int q = q0 + 16 * wave + i;
         if (q < N && lane < k) {
-            const size_t o = ((size_t)b * N + q) * k + lane;
-            idx[o] = li_[i];
-            if (idx_glob) idx_glob[o] = b * N + li_[i];
+            if (nsplit > 1) {          // this piece's sorted list (entries past the piece's candidates: +inf)
+                part[(((size_t)b * N + q) * nsplit + piece) * k + lane] =
+                    ((unsigned long long)(unsigned)__float_as_int(ld_[i]) << 32) | (unsigned)li_[i];
+            } else {
+                const size_t o = ((size_t)b * N + q) * k + lane;
+                idx[o] = li_[i];
+                if (idx_glob) idx_glob[o] = b * N + li_[i];
+            }
         }
+    }
+}
+
+// merge of the nsplit sorted k-lists of a query (one wave per query, lane = one of the nsplit*k <= 64 entries): the rank of
+// an entry among all of them in (dist, index) order is its output slot
+__global__ __launch_bounds__(256) void gpe_knn_merge_kernel(const unsigned long long* __restrict__ part, long nq, int N, int k,
+                                                            int nsplit, int32_t* __restrict__ idx, int32_t* __restrict__ idx_glob)
+{
+    const int lane = threadIdx.x & 63;
+    const long q = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= nq) return;
+    const int n = nsplit * k;
+    const unsigned long long key = (lane < n) ? part[q * n + lane] : ~0ull;
+    const unsigned lo = (unsigned)key, hi = (unsigned)(key >> 32);
+    int rank = 0;
+    for (int s2 = 0; s2 < n; ++s2) {
+        const unsigned long long other = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)hi, s2) << 32) |
+                                         (unsigned)__builtin_amdgcn_readlane((int)lo, s2);
+        rank += (other < key) ? 1 : 0;                   // keys are distinct (distinct candidate indices)
+    }
+    if (lane < n && rank < k) {
+        const long b = q / N;
+        idx[q * k + rank] = (int32_t)lo;
+        if (idx_glob) idx_glob[q * k + rank] = (int32_t)(b * N + lo);
     }
 }
 
 template <int VEC>
 static void knn_launch(long nblocks, size_t lds, hipStream_t s, int probe, const float* x, int N, int C, int ldx, int k,
-                       int32_t* idx, int32_t* idx_glob, int B, int tiles, int pin)
+                       int32_t* idx, int32_t* idx_glob, int B, int tiles, int pin, int nsplit, unsigned long long* part)
 {
     if (probe)
         hipLaunchKernelGGL((gpe_knn_kernel<VEC, 1>), dim3((unsigned)nblocks), dim3(256), lds, s, x, N, C, ldx, k, idx, idx_glob, B,
-                           tiles, pin, probe);
+                           tiles, pin, probe, nsplit, part);
     else
         hipLaunchKernelGGL((gpe_knn_kernel<VEC, 0>), dim3((unsigned)nblocks), dim3(256), lds, s, x, N, C, ldx, k, idx, idx_glob, B,
-                           tiles, pin, 0);
+                           tiles, pin, 0, nsplit, part);
 }
 
 extern "C" int gpe_knn(const float* x, int B, int N, int C, int ldx, int k, int32_t* idx, int32_t* idx_glob,
@@ -322,16 +360,47 @@ extern "C" int gpe_knn(const float* x, int B, int N, int C, int ldx, int k, int3
     const size_t lds = ((size_t)2 * KNN_TQ * KNN_LD + 4 * 16 * KNN_LDD) * sizeof(float) + 4 * 64 * sizeof(unsigned long long);
     static const int probe = getenv("GPE_KNN_PROBE") ? atoi(getenv("GPE_KNN_PROBE")) : 0;
     const int tiles = gpe_cdiv(N, KNN_TQ);
-    const int pin = gpe_pin_clouds(B) ? 1 : 0;
-    const long nblocks = pin ? (long)GPE_NXCD * gpe_cdiv(B, GPE_NXCD) * tiles : (long)B * tiles;
+    static const int dbg_pin = getenv("GPE_KNN_PIN") ? atoi(getenv("GPE_KNN_PIN")) : -1;      // measurement overrides
+    static const int dbg_vec = getenv("GPE_KNN_VEC") ? atoi(getenv("GPE_KNN_VEC")) : 0;
+    const int pin = (dbg_pin >= 0) ? (dbg_pin && B >= GPE_NXCD) : (gpe_pin_clouds(B) ? 1 : 0);
+    // Candidate split.  With every workgroup resident (4 per CU) an XCD works on 128 items at a time = 128 / (tiles * nsplit)
+    // clouds, whose tables (N x ldx floats each) are streamed once per item: they must fit the XCD's 4 MiB L2 together or the
+    // cyclic stream evicts every line before its next use (measured at cfg 2, layer 2: 4 x 1.25 MB -> 396-475 MB fetched for
+    // 39 MB; 3 tables -> 36 MB).  nsplit pieces per query tile put nsplit x fewer clouds in flight.
+    static const int dbg_split = getenv("GPE_KNN_SPLIT") ? atoi(getenv("GPE_KNN_SPLIT")) : 0;
+    int nsplit = 1;
+    if (pin) {
+        const double table = (double)N * ldx * sizeof(float), l2_budget = 3.2 * 1024 * 1024;
+        const int resident = 4 * gpe_num_cus() / GPE_NXCD;                 // items in flight per XCD
+        for (;;) {
+            const double clouds = (double)resident / ((double)tiles * nsplit);
+            if (table * (clouds > 1.0 ? clouds : 1.0) <= l2_budget) break;  // the tables in flight fit
+            if (clouds <= 1.0) break;                                      // one table alone is too big: no split helps
+            if (nsplit >= 4 || 2 * nsplit * k > 64 || 2 * nsplit > tiles) break;
+            nsplit *= 2;
+        }
+    }
+    if (dbg_split > 0 && dbg_split * k <= 64 && dbg_split <= tiles) nsplit = dbg_split;
+    unsigned long long* part = nullptr;
+    if (nsplit > 1) {
+        part = (unsigned long long*)gpe_scratch(1, (size_t)B * N * nsplit * k * sizeof(unsigned long long));
+        if (!part) nsplit = 1;                                             // no scratch: one piece, more HBM traffic
+    }
+    const long nblocks = (pin ? (long)GPE_NXCD * gpe_cdiv(B, GPE_NXCD) * tiles : (long)B * tiles) * nsplit;
     if (nblocks >= (1L << 31)) return GPE_EINVAL;
     // widest staging copy the rows allow (a C < 32 chunk is staged ((C + 3) & ~3) floats wide, so it must divide too)
     const uintptr_t xa = (uintptr_t)x;
-    const int vec = (C % 4 == 0 && ldx % 4 == 0 && xa % 16 == 0) ? 4 : (C % 2 == 0 && ldx % 2 == 0 && xa % 8 == 0) ? 2 : 1;
+    int vec = (C % 4 == 0 && ldx % 4 == 0 && xa % 16 == 0) ? 4 : (C % 2 == 0 && ldx % 2 == 0 && xa % 8 == 0) ? 2 : 1;
+    if (dbg_vec > 0 && dbg_vec < vec) vec = dbg_vec;
     hipStream_t s = (hipStream_t)stream;
-    if (vec == 4) knn_launch<4>(nblocks, lds, s, probe, x, N, C, ldx, k, idx, idx_glob, B, tiles, pin);
-    else if (vec == 2) knn_launch<2>(nblocks, lds, s, probe, x, N, C, ldx, k, idx, idx_glob, B, tiles, pin);
-    else knn_launch<1>(nblocks, lds, s, probe, x, N, C, ldx, k, idx, idx_glob, B, tiles, pin);
+    if (vec == 4) knn_launch<4>(nblocks, lds, s, probe, x, N, C, ldx, k, idx, idx_glob, B, tiles, pin, nsplit, part);
+    else if (vec == 2) knn_launch<2>(nblocks, lds, s, probe, x, N, C, ldx, k, idx, idx_glob, B, tiles, pin, nsplit, part);
+    else knn_launch<1>(nblocks, lds, s, probe, x, N, C, ldx, k, idx, idx_glob, B, tiles, pin, nsplit, part);
     GPE_CHECK_LAUNCH();
+    if (nsplit > 1) {
+        hipLaunchKernelGGL(gpe_knn_merge_kernel, dim3((unsigned)gpe_cdiv((long)B * N, 4)), dim3(256), 0, s, part, (long)B * N, N, k,
+                           nsplit, idx, idx_glob);
+        GPE_CHECK_LAUNCH();
+    }
     return GPE_OK;
 }

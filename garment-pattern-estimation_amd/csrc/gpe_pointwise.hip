@@ -21,6 +21,22 @@ int gpe_num_cus()
     return c;
 }
 
+void* gpe_scratch(int slot, size_t bytes)
+{
+    constexpr int SLOTS = 2, DEVS = 64;
+    static void* ptr[DEVS][SLOTS] = {};
+    static size_t cap[DEVS][SLOTS] = {};
+    int dev = 0;
+    if (slot < 0 || slot >= SLOTS || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= DEVS) return nullptr;
+    if (bytes > cap[dev][slot]) {
+        if (ptr[dev][slot]) (void)hipFree(ptr[dev][slot]);
+        ptr[dev][slot] = nullptr; cap[dev][slot] = 0;
+        if (hipMalloc(&ptr[dev][slot], bytes) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        cap[dev][slot] = bytes;
+    }
+    return ptr[dev][slot];
+}
+
 __device__ __forceinline__ float4 pw_ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void pw_st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 

@@ -5,7 +5,7 @@ import importlib, os, sys, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 gpe = importlib.import_module('garment-pattern-estimation_amd')
-B, N, k = 32, 2000, 16
+B, N, k = int(os.environ.get('KNN_PROBE_B', 32)), int(os.environ.get('KNN_PROBE_N', 2000)), 16
 for C in (3, 150):
     x = torch.randn(B * N, C, device='cuda')
     for _ in range(3): gpe.ops.knn(x, B, N, k)
