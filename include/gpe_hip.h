@@ -7,11 +7,14 @@
  * entry points below.  Each entry point names the reference line(s) whose arithmetic it replaces.
  *
  * Conventions (all functions):
- *   - plain C symbols; raw DEVICE pointers + dims + a hipStream_t passed as void*; caller owns every buffer,
- *     no hidden allocation; work is enqueued on `stream` of the CURRENT device and the call returns immediately;
+ *   - plain C symbols; raw DEVICE pointers + dims + a hipStream_t passed as void*; the caller owns every buffer it
+ *     passes; work is enqueued on `stream` of the CURRENT device and the call returns immediately;
  *     process-global state is limited to (a) the arithmetic mode (gpe_math_set) and the profiling switches
- *     (gpe_debug_set), which apply to every stream and device of the process, and (b) per-device caches of the
- *     CU count and of the >64 KB LDS opt-in (hipFuncSetAttribute), keyed by device ordinal;
+ *     (gpe_debug_set), which apply to every stream and device of the process, (b) per-device caches of the
+ *     CU count and of the >64 KB LDS opt-in (hipFuncSetAttribute), keyed by device ordinal, and (c) two grow-only
+ *     per-device scratch images (hipMalloc on first use / growth, never shared between streams by the library:
+ *     use ONE stream per device for these calls): the per-pseudo-point rows of gpe_edge_mlp_fwd / _bwd when
+ *     k > 16, and the partial k-lists of gpe_knn when it splits the candidate range (large clouds);
  *   - return 0 on success, -22 (EINVAL) on bad arguments, -5 (EIO) if the launch failed;
  *   - fp32 storage and arithmetic unless stated; matrix products run on v_mfma_f32_16x16x4_f32 (exact fp32);
  *     BatchNorm statistics are accumulated in fp64;
@@ -36,9 +39,11 @@ int gpe_debug_set(int flags);
  *                rounding errors are independent per element and average out), exact fp32 for the weight-gradient
  *                reduce-GEMM  G = dz^T (a - mean): G also feeds the BatchNorm-backward coefficients, residuals of large
  *                sums where a coherent 1e-5 product error would surface as a 1e-2 gradient error.
- *   3 = "bf16x6" THREE-term split x = h + m + l (24 mantissa bits: exact), six bf16 MFMAs per product — the fp32 kernel's
- *                accuracy class at 0.375 of its matrix time — for the row GEMMs whose shape fits the register file (10
- *                output tiles; the others stay on the exact fp32 instruction); reduce-GEMM exact fp32.
+ *   3 = "bf16x6" THREE-term split x = h + m + l, six bf16 MFMAs per product (every term down to 2^-24 except m*l, l*m,
+ *                l*l) for the row GEMMs whose shape fits the register file (10 output tiles; the others stay on the exact
+ *                fp32 instruction); reduce-GEMM exact fp32.  Each layer meets the exact mode's tolerances; end to end the
+ *                BatchNorm backward amplifies the dropped terms to ~1e-2 of max|grad|: APPROXIMATE, like
+ *                modes 1 and 2, and measured only 0.5 % faster than mode 0.
  * Returns the previous mode, or -22 for an unknown one.  kNN, BatchNorm statistics, the LSTM decoder and every
  * elementwise op are fp32 (fp64 for reductions) in both modes. */
 int gpe_math_set(int mode);
