@@ -16,6 +16,7 @@
 //   * one partial per workgroup at the end; a second kernel sums the partials in a fixed order (fp64), so results
 //     are run-to-run deterministic.
 #include "gpe_common.h"
+#include <stdlib.h>
 
 static int g_rd_math = 0;            // 0: exact fp32 MFMA, 1: bf16x3 (gpe_math_set)
 void gpe_redgemm_set_math(int m) { g_rd_math = m; }
@@ -1122,7 +1123,8 @@ static int rd_run(RdParams& p, int vmode, float* G, int ldG, float* colsum, floa
     dim3 grid(gx, gy);
     int rc = GPE_EINVAL;
     const int mt_all = gpe_cdiv(p.Mg, 16), nt_all = gpe_cdiv(p.Ng, 16);
-    const bool pc_ok = gy == 1 && nt_all == 13 && (mt_all == 13 || mt_all == 10) && rd_rows_vec(p.u, p.Mg) &&
+    static const int dbg_nopc = getenv("GPE_RD_NOPC") ? atoi(getenv("GPE_RD_NOPC")) : 0;     // measurement override
+    const bool pc_ok = !dbg_nopc && gy == 1 && nt_all == 13 && (mt_all == 13 || mt_all == 10) && rd_rows_vec(p.u, p.Mg) &&
                        (vmode == V_GATHER || rd_rows_vec(p.v, p.Ng)) && p.num_tiles >= 4 * gx;
     p.pin_tpc = 0;
     if (pc_ok && vmode == V_GATHER && p.pin_clouds > 0 && gpe_pin_clouds(p.pin_clouds) && p.pin_clouds % GPE_NXCD == 0) {
