@@ -387,7 +387,10 @@ extern "C" int gpe_rnn_seq_fwd(int gates, int L, int T, int Bn, int H, const flo
             WvFwdParams p = {};
             p.Bn = Bn; p.H = H; p.Npad = 16 * G * gpe_cdiv(H, 16);
             int n = 0;
-            for (int l = l0; l <= l_hi && n < WV_MAXCELL; ++l, ++n) {
+            // highest layer first: workgroups are dispatched in blockIdx.z order and a 3-cell panel diagonal is 576
+            // workgroups on 512 slots — the second round should be the cheap layer-0 cells (one K segment instead of two)
+            const int l_top = (l_hi < l0 + WV_MAXCELL - 1) ? l_hi : l0 + WV_MAXCELL - 1;
+            for (int l = l_top; l >= l0; --l, ++n) {
                 const int t = d - l;
                 WvFwdCell& c = p.cell[n];
                 c.a0 = hs + l * hs_sl + (long)t * hs_st;             // h_{l,t-1} lives at time slot t
