@@ -440,7 +440,8 @@ struct WvBwdCell {
     float* dgx; float* dgh; long dg_stride;        // pre-activation gradients of the cell, rows [Bn] pitch dg_stride
     int nseg_mask;                                 // bit s: segment s present
 };
-struct WvBwdParams { int Bn, H, K, Kpad_n, nz, ncell; WvBwdCell cell[WV_MAXCELL]; };   // nz = K slabs of the launch's slab size
+// nz = K-slab GROUPS of the launch (partials per segment); a workgroup multiplies `jslabs` consecutive slabs of its group
+struct WvBwdParams { int Bn, H, K, Kpad_n, nz, jslabs, ncell; WvBwdCell cell[WV_MAXCELL]; };
 
 // grid (row tiles, cdiv(H, 64), ncell * 2 * nz): block z -> (cell, segment, K slab)
 template <int KS>
@@ -463,15 +464,33 @@ __global__ __launch_bounds__(256) void gpe_rnn_wave_splitk_kernel(WvBwdParams p)
     const int row0 = blockIdx.x * RG_BM;
     const int rv = (p.Bn - row0 < RG_BM) ? (p.Bn - row0) : RG_BM;
     const int n0 = blockIdx.y * (16 * NT);
-    const int ks = z * KS;
-    const int kslab = (p.K - ks < KS) ? (p.K - ks) : KS;
     f32x4 acc[NT];
 #pragma unroll
     for (int n = 0; n < NT; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    // one slab: reuse the forward's staging helper on the slab's column window
     const bool split = rv <= 32;
-    wv_segment<NT, KS>(c.a[seg] + ks, c.as[seg], c.w[seg] + (long)(ks >> 4) * 4 * p.Kpad_n * 4, kslab, p.Kpad_n, row0, rv, n0,
-                       As, Ws, lda, acc, split);
+    // this workgroup's slabs ks = (z * jslabs + i) * KS, i < jslabs, while ks < K: the next slab's loads stay in flight
+    // under the current slab's MFMAs (same pipeline as the forward)
+    {
+        const int ks0 = z * p.jslabs * KS;
+        int njobs = (p.K - ks0 + KS - 1) / KS;
+        if (njobs > p.jslabs) njobs = p.jslabs;
+        WvRegs<NT, KS> R;
+        auto job_fetch = [&](int i) {
+            const int ks = ks0 + i * KS;
+            wv_fetch<NT, KS>(R, c.a[seg] + ks, c.as[seg], c.w[seg] + (long)(ks >> 4) * 4 * p.Kpad_n * 4, p.K - ks, p.Kpad_n, row0, rv,
+                             n0, 0);
+        };
+        job_fetch(0);
+        for (int i = 0; i < njobs; ++i) {
+            const int ks = ks0 + i * KS;
+            const int kslab = (p.K - ks < KS) ? (p.K - ks) : KS;
+            __syncthreads();
+            wv_commit<NT, KS>(R, p.K - ks, p.Kpad_n, rv, n0, 0, As, Ws, lda);
+            __syncthreads();
+            job_fetch(i + 1 < njobs ? i + 1 : i);
+            wv_mma<NT>(As, Ws, lda, (kslab + 15) & ~15, acc, split);
+        }
+    }
     __syncthreads();
 #pragma unroll
     for (int n = 0; n < NT; ++n)
@@ -558,7 +577,13 @@ extern "C" int gpe_rnn_seq_bwd(int gates, int L, int T, int Bn, int H, const flo
         return GPE_EINVAL;
     const int G = gates, K = G * H;
     const int KS = wv_ks();
-    const int nz = gpe_cdiv(K, KS);
+    // big batches: four slabs per workgroup (a 3-cell panel diagonal: 2304 single-slab workgroups in 4.5 rounds -> 480 in one,
+    // a quarter of the partial images; measured 804 / 717 / 621 / 689 us per backward at 1 / 2 / 4 / 8 slabs); a single row
+    // tile (the pattern decoders) stays at one slab per workgroup — it is a latency chain, not a throughput problem
+    static const int dbg_bj = getenv("GPE_WV_BJ") ? atoi(getenv("GPE_WV_BJ")) : 0;             // measurement override
+    int jslabs = (Bn > 3 * RG_BM) ? (gpe_cdiv(K, KS) < 4 ? gpe_cdiv(K, KS) : 4) : 1;
+    if (dbg_bj > 0 && Bn > 3 * RG_BM) jslabs = dbg_bj < gpe_cdiv(K, KS) ? dbg_bj : gpe_cdiv(K, KS);
+    const int nz = gpe_cdiv(gpe_cdiv(K, KS), jslabs);
     const long BH = (long)Bn * H;
     hipStream_t s = (hipStream_t)stream;
     const size_t lds = ((size_t)RG_BM * (KS + 4) + (size_t)KS * 64) * sizeof(float);
@@ -569,7 +594,7 @@ extern "C" int gpe_rnn_seq_bwd(int gates, int L, int T, int Bn, int H, const flo
         const int l_hi = (d < L - 1) ? d : L - 1;
         for (int l0 = l_lo; l0 <= l_hi; l0 += WV_MAXCELL) {
             WvBwdParams p = {};
-            p.Bn = Bn; p.H = H; p.K = K; p.Kpad_n = gpe_round_up(H, 16); p.nz = nz;
+            p.Bn = Bn; p.H = H; p.K = K; p.Kpad_n = gpe_round_up(H, 16); p.nz = nz; p.jslabs = jslabs;
             int n = 0, any_seg = 0;
             for (int l = l0; l <= l_hi && n < WV_MAXCELL; ++l, ++n) {
                 const int t = d - l;
