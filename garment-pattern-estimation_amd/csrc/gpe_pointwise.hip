@@ -102,9 +102,10 @@ __global__ __launch_bounds__(256) void gpe_pack_multi_kernel(const GpePackJob* _
     if (jb.kind == 6) { jb.out[e] = (e < jb.aux) ? jb.w[e] : 0.f; return; }       // [b1 | 0]
     if (jb.kind == 7) { jb.out[e] = jb.w[e] + ((e < jb.aux) ? jb.w2[e] : 0.f); return; }   // GRU: b_ih + [b_hr | b_hz | 0]
     const int t = (int)(e & 3);
-    const long r = e >> 2;
-    const int n = (int)(r % jb.Npad);
-    const int k = (int)((r / jb.Npad) * 4 + t);
+    const unsigned r = (unsigned)(e >> 2);                           // a job's output is far below 2^31 elements: 32-bit
+    const unsigned kq = r / (unsigned)jb.Npad;                       // division (the 64-bit form is ~100 instructions each)
+    const int n = (int)(r - kq * (unsigned)jb.Npad);
+    const int k = (int)(kq * 4 + t);
     float v = 0.f;
     const float* w = jb.w;
     const int ldw = jb.ldw;
