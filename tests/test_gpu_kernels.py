@@ -78,6 +78,26 @@ def test_knn_ties_lower_index_wins(gpe):
     assert torch.equal(got, ref)
 
 
+def test_knn_candidate_split_full_size(gpe):
+    """B = 32 clouds of 2048 x 150 features (the layer-2 shape of BASELINE cfg 2): four 1.25 MB tables per XCD do not fit the
+    4 MiB L2, so the launcher cuts the candidate range of every query tile in two and merges the partial k-lists.  The first
+    and the last cloud must still be bit-exact against the C oracle (near-duplicate points included)."""
+    from oracle import ref_path as O
+    B, N, C, k = 32, 2048, 150, 16
+    g = torch.Generator().manual_seed(123)
+    buf = torch.randn(B * N, 152, generator=g)
+    buf[5 * N + 7] = buf[5 * N + 3]                       # exact duplicates: equal distances across the two halves' merge
+    buf[31 * N + 1500] = buf[31 * N + 100]
+    x = buf[:, :C]
+    got = gpe.ops.knn(buf.cuda()[:, :C], B, N, k).cpu()
+    for b in (0, 5, 31):
+        ref = O.knn_local(x[b * N:(b + 1) * N].contiguous(), 1, k).to(torch.int32).view(N, k)
+        assert torch.equal(got[b], ref), b
+    # no duplicate neighbours anywhere
+    srt = got.sort(-1).values
+    assert (srt[..., 1:] != srt[..., :-1]).all()
+
+
 def test_knn_strided_rows(gpe):
     from oracle import ref_path as O
     g = torch.Generator().manual_seed(11)
