@@ -169,6 +169,17 @@ def test_linear_strided_addend_act(gpe):
     ops.linear_raw(ops._rows3d(add), ops.pack_weight(w, transpose=True), None, Bn * T, H, 4 * H, (y, H, 0, 0))
     ref2 = add.double().cpu().reshape(Bn * T, 4 * H) @ w.double().cpu()
     assert relerr(y, ref2) < 2e-6
+    # K <= 8 streaming-store kernel with bias, addend and ReLU, 2-level output rows
+    M, N, K = 5000, 24, 5
+    a = torch.randn(M, K, generator=g).cuda()
+    w3 = torch.randn(N, K, generator=g).cuda()
+    b3 = torch.randn(N, generator=g).cuda()
+    ad = torch.randn(M, N, generator=g).cuda()
+    y3 = torch.zeros(M // 100, 101, N).cuda()                    # row r = o * 100 + i lives at y3[o, i]; slot 100 unused
+    ops.linear_raw((a, K, 0, 0), ops.pack_weight(w3), b3, M, N, K, (y3, 101 * N, N, 100), 1, (ad, N, 0, 0))
+    ref3 = torch.relu(a.double().cpu() @ w3.double().cpu().t() + b3.double().cpu() + ad.double().cpu())
+    assert relerr(y3[:, :100].reshape(M, N), ref3) < 2e-6
+    assert float(y3[:, 100].abs().max()) == 0.0
 
 
 @pytest.mark.parametrize('rows,Mg,Ng', [(1000, 150, 200), (77, 8, 250), (5000, 1000, 250), (4096, 400, 3),
