@@ -316,27 +316,35 @@ __global__ __launch_bounds__(256, 4) void gpe_knn_kernel(const float* __restrict
     }
 }
 
-// merge of the nsplit sorted k-lists of a query (one wave per query, lane = one of the nsplit*k <= 64 entries): the rank of
-// an entry among all of them in (dist, index) order is its output slot
+// merge of the nsplit sorted k-lists of a query: one thread per entry.  The lists are sorted and all keys are distinct
+// (distinct candidate indices), so the output slot of an entry is its own position plus, for every other list, the number of
+// entries below it (a binary search over k sorted keys).
 __global__ __launch_bounds__(256) void gpe_knn_merge_kernel(const unsigned long long* __restrict__ part, long nq, int N, int k,
                                                             int nsplit, int32_t* __restrict__ idx, int32_t* __restrict__ idx_glob)
 {
-    const int lane = threadIdx.x & 63;
-    const long q = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (q >= nq) return;
     const int n = nsplit * k;
-    const unsigned long long key = (lane < n) ? part[q * n + lane] : ~0ull;
-    const unsigned lo = (unsigned)key, hi = (unsigned)(key >> 32);
-    int rank = 0;
-    for (int s2 = 0; s2 < n; ++s2) {
-        const unsigned long long other = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)hi, s2) << 32) |
-                                         (unsigned)__builtin_amdgcn_readlane((int)lo, s2);
-        rank += (other < key) ? 1 : 0;                   // keys are distinct (distinct candidate indices)
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nq * n) return;
+    const long q = t / n;
+    const int pos = (int)(t - q * n);
+    const int piece = pos / k, i = pos - piece * k;
+    const unsigned long long* base = part + q * n;
+    const unsigned long long key = base[pos];
+    int rank = i;
+    for (int p2 = 0; p2 < nsplit; ++p2) {
+        if (p2 == piece) continue;
+        const unsigned long long* lst = base + p2 * k;
+        int lo = 0, hi = k;                              // first entry of lst that is not below key
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (lst[mid] < key) lo = mid + 1; else hi = mid;
+        }
+        rank += lo;
     }
-    if (lane < n && rank < k) {
-        const long b = q / N;
-        idx[q * k + rank] = (int32_t)lo;
-        if (idx_glob) idx_glob[q * k + rank] = (int32_t)(b * N + lo);
+    if (rank < k) {
+        const unsigned lo32 = (unsigned)key;
+        idx[q * k + rank] = (int32_t)lo32;
+        if (idx_glob) idx_glob[q * k + rank] = (int32_t)((q / N) * N + lo32);
     }
 }
 
@@ -398,8 +406,8 @@ extern "C" int gpe_knn(const float* x, int B, int N, int C, int ldx, int k, int3
     else knn_launch<1>(nblocks, lds, s, probe, x, N, C, ldx, k, idx, idx_glob, B, tiles, pin, nsplit, part);
     GPE_CHECK_LAUNCH();
     if (nsplit > 1) {
-        hipLaunchKernelGGL(gpe_knn_merge_kernel, dim3((unsigned)gpe_cdiv((long)B * N, 4)), dim3(256), 0, s, part, (long)B * N, N, k,
-                           nsplit, idx, idx_glob);
+        hipLaunchKernelGGL(gpe_knn_merge_kernel, dim3((unsigned)gpe_cdiv((long)B * N * nsplit * k, 256)), dim3(256), 0, s, part,
+                           (long)B * N, N, k, nsplit, idx, idx_glob);
         GPE_CHECK_LAUNCH();
     }
     return GPE_OK;
