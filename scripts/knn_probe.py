@@ -7,7 +7,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 gpe = importlib.import_module('garment-pattern-estimation_amd')
 B, N, k = int(os.environ.get('KNN_PROBE_B', 32)), int(os.environ.get('KNN_PROBE_N', 2000)), 16
 for C in (3, 150):
-    x = torch.randn(B * N, C, device='cuda')
+    ld = (C + 3) // 4 * 4 if C >= 32 else C        # the training step's feature rows are padded to 4 columns
+    x = torch.randn(B * N, ld, device='cuda')[:, :C]
     for _ in range(3): gpe.ops.knn(x, B, N, k)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -68,6 +68,37 @@ def test_knn_bit_exact(gpe, B, N, C, k):
     assert bad == 0, '%d / %d queries differ' % (bad, B * N)
 
 
+MF_CASES = [(2, 300, 150, 152, 16), (1, 1000, 64, 64, 20), (3, 97, 32, 32, 5), (2, 513, 256, 256, 64), (1, 2048, 33, 36, 16),
+            (2, 130, 150, 152, 9)]
+
+
+@pytest.mark.parametrize('B,N,C,ld,k', MF_CASES)
+@pytest.mark.parametrize('data', ['gauss', 'offset', 'clusters', 'lattice'])
+def test_knn_wide_rows_hard_data(gpe, B, N, C, ld, k, data):
+    """padded wide rows (the float4 staging path) on data that is hard for a nearest-neighbour search: well-spread points,
+    features with a large common offset, tight clusters far from the origin (tiny distance differences on large norms) and
+    an integer lattice (exact ties).  (These cases were written for a bf16 matrix-pipe pre-filter with an exact recheck; it
+    passed them but was slower than the all-exact kernel and was dropped — DESIGN.md §9.)"""
+    from oracle import ref_path as O
+    g = torch.Generator().manual_seed(B * 7 + N + C + k)
+    if data == 'gauss':
+        x = torch.randn(B * N, C, generator=g)
+    elif data == 'offset':
+        x = torch.randn(B * N, C, generator=g).abs() * 0.3 + 5.0 + torch.randn(1, C, generator=g)
+    elif data == 'clusters':
+        cen = torch.randn(8, C, generator=g) * 20
+        x = cen[torch.randint(0, 8, (B * N,), generator=g)] + 1e-2 * torch.randn(B * N, C, generator=g)
+    else:
+        x = torch.randint(0, 3, (B * N, C), generator=g).float()
+        x[:, 8:] = 0                                        # few distinct points: many exactly equal distances
+    buf = torch.zeros(B * N, ld)
+    buf[:, :C] = x
+    ref = O.knn_local(x.contiguous(), B, k).to(torch.int32).view(B, N, k)
+    got = gpe.ops.knn(buf.cuda()[:, :C], B, N, k).cpu()
+    bad = (got != ref).any(-1).sum().item()
+    assert bad == 0, '%d / %d queries differ' % (bad, B * N)
+
+
 def test_knn_ties_lower_index_wins(gpe):
     from oracle import ref_path as O
     # integer lattice -> many exactly equal distances, plus duplicated points
