@@ -647,6 +647,9 @@ extern "C" int gpe_bn_bwd_from_G(const float* G, int ldG, const float* db, const
 // ---------------------------------------------------------------------------------------------------------
 // kNN graph transposition (one workgroup per cloud) and the pull-style scatter it enables
 // ---------------------------------------------------------------------------------------------------------
+// LDS_EDGES: the cloud's edge list is scattered and sorted in LDS and written out once, coalesced (it fits up to
+// N*k = 32 k edges, the benchmark shape); otherwise the buckets are sorted in place in global memory.
+template <bool LDS_EDGES>
 __global__ __launch_bounds__(1024) void gpe_knn_reverse_kernel(const int32_t* __restrict__ idx, int N, int k,
                                                                int32_t* __restrict__ rev_off,
                                                                int32_t* __restrict__ rev_edge)
@@ -658,7 +661,8 @@ __global__ __launch_bounds__(1024) void gpe_knn_reverse_kernel(const int32_t* __
     const int tid = threadIdx.x, b = blockIdx.x;
     const int32_t* id = idx + (size_t)b * N * k;
     int32_t* ro = rev_off + (size_t)b * (N + 1);
-    int32_t* re = rev_edge + (size_t)b * N * k;
+    int32_t* const re_g = rev_edge + (size_t)b * N * k;
+    int32_t* const re = LDS_EDGES ? reinterpret_cast<int32_t*>(sm + 2 * N + 1) : re_g;
     const int E = N * k;
     for (int i = tid; i < N; i += 1024) cnt[i] = 0;
     __syncthreads();
@@ -701,6 +705,10 @@ __global__ __launch_bounds__(1024) void gpe_knn_reverse_kernel(const int32_t* __
             re[h + 1] = v;
         }
     }
+    if (LDS_EDGES) {
+        __syncthreads();
+        for (int e = tid; e < E; e += 1024) re_g[e] = re[e];
+    }
 }
 
 extern "C" int gpe_knn_reverse(const int32_t* idx, int B, int N, int k, int32_t* rev_off, int32_t* rev_edge,
@@ -709,9 +717,16 @@ extern "C" int gpe_knn_reverse(const int32_t* idx, int B, int N, int k, int32_t*
     if (!idx || !rev_off || !rev_edge || B <= 0 || N <= 0 || k <= 0) return GPE_EINVAL;
     const size_t lds = (size_t)(2 * N + 1) * sizeof(int);
     if (lds > 150 * 1024) return GPE_EINVAL;
-    GPE_ENSURE_MAX_LDS_N((gpe_knn_reverse_kernel), 150 * 1024);
-    hipLaunchKernelGGL(gpe_knn_reverse_kernel, dim3(B), dim3(1024), lds, (hipStream_t)stream, idx, N, k, rev_off,
-                       rev_edge);
+    const size_t lds_e = lds + (size_t)N * k * sizeof(int);
+    if (lds_e <= 150 * 1024) {
+        GPE_ENSURE_MAX_LDS_N((gpe_knn_reverse_kernel<true>), 150 * 1024);
+        hipLaunchKernelGGL(gpe_knn_reverse_kernel<true>, dim3(B), dim3(1024), lds_e, (hipStream_t)stream, idx, N, k, rev_off,
+                           rev_edge);
+    } else {
+        GPE_ENSURE_MAX_LDS_N((gpe_knn_reverse_kernel<false>), 150 * 1024);
+        hipLaunchKernelGGL(gpe_knn_reverse_kernel<false>, dim3(B), dim3(1024), lds, (hipStream_t)stream, idx, N, k, rev_off,
+                           rev_edge);
+    }
     GPE_CHECK_LAUNCH();
     return GPE_OK;
 }
