@@ -62,7 +62,10 @@ __device__ __forceinline__ long sr_prow(int x, unsigned magic)
 // K16: k == 16 (the benchmark configuration): every wave owns exactly ONE point per tile, so the slot index of a row is
 // its compile-time position u, a point completes exactly at u == 15, and row validity is one per-tile predicate — the
 // per-row bookkeeping (and the register copies its branches cost) disappears from the epilogue.
-template <int AQ, int BQ, int KCH, int AMODE, int EMODE, bool K16>
+// HALF (with K16): K ends within the first 8 columns of the last 16-k chunk (K = 200, 150).  That chunk then runs as TWO k4
+// steps over its lower half — lane group g supplies k = 2g, 2g+1 instead of 4g..4g+3, for A and for the resident weights alike —
+// instead of four steps of which half the products multiply the zero padding (3.8-5 % of a tile's MFMAs).
+template <int AQ, int BQ, int KCH, int AMODE, int EMODE, bool K16, bool HALF = false>
 __global__ __launch_bounds__(256, 1) void gpe_edgegemm_sr_kernel(RgParams p, int stats_nblk)
 {
     constexpr int NT = 4 * AQ + BQ;
@@ -108,7 +111,16 @@ __global__ __launch_bounds__(256, 1) void gpe_edgegemm_sr_kernel(RgParams p, int
             const int cc = (col < p.Npad) ? col : p.Npad - 1;
             float4 t[KCH];
 #pragma unroll
-            for (int kc = 0; kc < KCH; ++kc) t[kc] = ld4(p.wp + (((long)(kc * 4 + g)) * p.Npad + cc) * 4);
+            for (int kc = 0; kc < KCH; ++kc) {
+                if (HALF && kc == KCH - 1) {
+                    // k = 16 kc + 2g + {0, 1}: packed element (plane (2g + t) / 4, component (2g + t) % 4)
+                    const int k0 = 2 * g, k1 = 2 * g + 1;
+                    t[kc].x = p.wp[(((long)(kc * 4 + (k0 >> 2))) * p.Npad + cc) * 4 + (k0 & 3)];
+                    t[kc].y = p.wp[(((long)(kc * 4 + (k1 >> 2))) * p.Npad + cc) * 4 + (k1 & 3)];
+                    t[kc].z = 0.f; t[kc].w = 0.f;
+                } else
+                    t[kc] = ld4(p.wp + (((long)(kc * 4 + g)) * p.Npad + cc) * 4);
+            }
 #pragma unroll
             for (int kc = 0; kc < KCH; ++kc)
                 dst[kc] = sr_pin_agpr4((col < p.Npad) ? t[kc] : make_float4(0.f, 0.f, 0.f, 0.f));
@@ -371,9 +383,21 @@ __global__ __launch_bounds__(256, 1) void gpe_edgegemm_sr_kernel(RgParams p, int
             for (int mt = 0; mt < 4; ++mt) { a[mt][0] = an[mt].x; a[mt][1] = an[mt].y; a[mt][2] = an[mt].z; a[mt][3] = an[mt].w; }
             aL[0] = anL.x; aL[1] = anL.y; aL[2] = anL.z; aL[3] = anL.w;
             if (kc + 1 < KCH) {
+                if (HALF && kc + 1 == KCH - 1) {         // half chunk: k = 2g, 2g+1 in .x, .y
 #pragma unroll
-                for (int mt = 0; mt < 4; ++mt) an[mt] = ld4(&As[(16 * mt + j) * LDA + 16 * (kc + 1) + 4 * g]);
-                if (BQ > 0) anL = ld4(&As[(16 * wave + j) * LDA + 16 * (kc + 1) + 4 * g]);
+                    for (int mt = 0; mt < 4; ++mt) {
+                        const float2 h2 = *reinterpret_cast<const float2*>(&As[(16 * mt + j) * LDA + 16 * (kc + 1) + 2 * g]);
+                        an[mt] = make_float4(h2.x, h2.y, 0.f, 0.f);
+                    }
+                    if (BQ > 0) {
+                        const float2 h2 = *reinterpret_cast<const float2*>(&As[(16 * wave + j) * LDA + 16 * (kc + 1) + 2 * g]);
+                        anL = make_float4(h2.x, h2.y, 0.f, 0.f);
+                    }
+                } else {
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt) an[mt] = ld4(&As[(16 * mt + j) * LDA + 16 * (kc + 1) + 4 * g]);
+                    if (BQ > 0) anL = ld4(&As[(16 * wave + j) * LDA + 16 * (kc + 1) + 4 * g]);
+                }
             }
             // ---- this chunk's slice of the memory pipeline ----
             if (kc == 0) {
@@ -411,6 +435,7 @@ __global__ __launch_bounds__(256, 1) void gpe_edgegemm_sr_kernel(RgParams p, int
             __builtin_amdgcn_sched_barrier(0);           // memory slice stays in front of this chunk's MFMAs
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
+                if (HALF && kc == KCH - 1 && t >= 2) continue;       // compile-time: the half chunk has two k4 steps
 #pragma unroll
                 for (int i = 0; i < AQ; ++i) {
                     const float bv = (t == 0) ? wA[i][kc].x : (t == 1) ? wA[i][kc].y : (t == 2) ? wA[i][kc].z : wA[i][kc].w;
@@ -480,17 +505,17 @@ __global__ __launch_bounds__(256, 1) void gpe_edgegemm_sr_kernel(RgParams p, int
 // ---------------------------------------------------------------------------------------------------------
 static int sr_num_cus() { return gpe_num_cus(); }
 
-template <int AQ, int BQ, int KCH, int AMODE, int EMODE, bool K16>
+template <int AQ, int BQ, int KCH, int AMODE, int EMODE, bool K16, bool HALF = false>
 static int sr_launch_k(const RgParams& p, int stats_nblk, hipStream_t s)
 {
     constexpr int NT = 4 * AQ + BQ;
     constexpr int LDA = 16 * KCH + 4, LDC = 16 * NT + 4;
     const size_t lds = (size_t)RG_BM * (2 * LDA + LDC) * sizeof(float);
-    GPE_ENSURE_MAX_LDS((gpe_edgegemm_sr_kernel<AQ, BQ, KCH, AMODE, EMODE, K16>));
+    GPE_ENSURE_MAX_LDS((gpe_edgegemm_sr_kernel<AQ, BQ, KCH, AMODE, EMODE, K16, HALF>));
     int gx = sr_num_cus();
     if (gx > p.num_tiles) gx = p.num_tiles;
     if (stats_nblk > 0 && gx > stats_nblk) gx = stats_nblk;
-    hipLaunchKernelGGL((gpe_edgegemm_sr_kernel<AQ, BQ, KCH, AMODE, EMODE, K16>), dim3(gx), dim3(256), lds, s, p, stats_nblk);
+    hipLaunchKernelGGL((gpe_edgegemm_sr_kernel<AQ, BQ, KCH, AMODE, EMODE, K16, HALF>), dim3(gx), dim3(256), lds, s, p, stats_nblk);
     GPE_CHECK_LAUNCH();
     return GPE_OK;
 }
@@ -498,6 +523,7 @@ static int sr_launch_k(const RgParams& p, int stats_nblk, hipStream_t s)
 template <int AQ, int BQ, int KCH, int AMODE, int EMODE>
 static int sr_launch(const RgParams& p, int stats_nblk, hipStream_t s)
 {
+    if (p.k == 16 && p.K <= 16 * (KCH - 1) + 8 && !(p.dbg & 128)) return sr_launch_k<AQ, BQ, KCH, AMODE, EMODE, true, true>(p, stats_nblk, s);
     return p.k == 16 ? sr_launch_k<AQ, BQ, KCH, AMODE, EMODE, true>(p, stats_nblk, s)
                      : sr_launch_k<AQ, BQ, KCH, AMODE, EMODE, false>(p, stats_nblk, s);
 }
