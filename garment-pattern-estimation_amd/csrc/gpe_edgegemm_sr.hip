@@ -62,7 +62,7 @@ __device__ __forceinline__ long sr_prow(int x, unsigned magic)
 // K16: k == 16 (the benchmark configuration): every wave owns exactly ONE point per tile, so the slot index of a row is
 // its compile-time position u, a point completes exactly at u == 15, and row validity is one per-tile predicate — the
 // per-row bookkeeping (and the register copies its branches cost) disappears from the epilogue.
-// HALF (with K16): K ends within the first 8 columns of the last 16-k chunk (K = 200, 150).  That chunk then runs as TWO k4
+// HALF: K ends within the first 8 columns of the last 16-k chunk (K = 200, 150).  That chunk then runs as TWO k4
 // steps over its lower half — lane group g supplies k = 2g, 2g+1 instead of 4g..4g+3, for A and for the resident weights alike —
 // instead of four steps of which half the products multiply the zero padding (3.8-5 % of a tile's MFMAs).
 template <int AQ, int BQ, int KCH, int AMODE, int EMODE, bool K16, bool HALF = false>
@@ -523,7 +523,9 @@ static int sr_launch_k(const RgParams& p, int stats_nblk, hipStream_t s)
 template <int AQ, int BQ, int KCH, int AMODE, int EMODE>
 static int sr_launch(const RgParams& p, int stats_nblk, hipStream_t s)
 {
-    if (p.k == 16 && p.K <= 16 * (KCH - 1) + 8 && !(p.dbg & 128)) return sr_launch_k<AQ, BQ, KCH, AMODE, EMODE, true, true>(p, stats_nblk, s);
+    if (p.K <= 16 * (KCH - 1) + 8 && !(p.dbg & 128))
+        return p.k == 16 ? sr_launch_k<AQ, BQ, KCH, AMODE, EMODE, true, true>(p, stats_nblk, s)
+                         : sr_launch_k<AQ, BQ, KCH, AMODE, EMODE, false, true>(p, stats_nblk, s);
     return p.k == 16 ? sr_launch_k<AQ, BQ, KCH, AMODE, EMODE, true>(p, stats_nblk, s)
                      : sr_launch_k<AQ, BQ, KCH, AMODE, EMODE, false>(p, stats_nblk, s);
 }
