@@ -5,7 +5,7 @@
 #include "gpe_common.h"
 #include <math.h>
 
-extern "C" int gpe_abi_version(void) { return 2; }
+extern "C" int gpe_abi_version(void) { return 3; }
 
 int gpe_num_cus()
 {
@@ -90,48 +90,61 @@ struct GpePackJob {
 };
 static_assert(sizeof(GpePackJob) == 64, "job layout is part of the ABI (ops.PackPlan builds it with numpy)");
 
+// one thread = one output quad (4 consecutive elements: the 4 k values of one packed float4); a block covers 1024 elements
+__device__ __forceinline__ float gpe_pack_elem(const GpePackJob& jb, int n, int k)
+{
+    const float* w = jb.w;
+    const int ldw = jb.ldw;
+    switch (jb.kind) {
+        case 0: return (n < jb.N && k < jb.K) ? w[(size_t)n * ldw + k] : 0.f;
+        case 1: return (n < jb.N && k < jb.K) ? w[(size_t)k * ldw + n] : 0.f;
+        case 2: {                                                   // gate-interleaved (LSTM G = 4, GRU G = 3), aux = H
+            const int H = jb.aux, G = jb.N / H;
+            const int b = n / (16 * G), gate = (n / 16) % G, u = (b << 4) + (n & 15);
+            return (u < H && k < jb.K) ? w[(size_t)(gate * H + u) * ldw + k] : 0.f;
+        }
+        case 3: {                                                   // [W1a - W1b ; W1b] (N = 2H rows, K = C), aux = H
+            const int H = jb.aux, C = jb.K;
+            if (!(n < jb.N && k < C)) return 0.f;
+            return (n < H) ? w[(size_t)n * ldw + k] - w[(size_t)n * ldw + C + k] : w[(size_t)(n - H) * ldw + C + k];
+        }
+        case 4: {                                                   // transpose of the above (N = C, K = 2H), aux = H
+            const int H = jb.aux, C = jb.N;
+            if (!(n < C && k < jb.K)) return 0.f;
+            return (k < H) ? w[(size_t)k * ldw + n] - w[(size_t)k * ldw + C + n] : w[(size_t)(k - H) * ldw + C + n];
+        }
+    }
+    return 0.f;
+}
+
 __global__ __launch_bounds__(256) void gpe_pack_multi_kernel(const GpePackJob* __restrict__ jobs, int njobs)
 {
     // wave-uniform job lookup: jobs are sorted by first_block
     int ji = 0;
     for (int q = 1; q < njobs; ++q) ji = ((long)blockIdx.x >= jobs[q].first_block) ? q : ji;
     const GpePackJob jb = jobs[ji];
-    const long e = ((long)blockIdx.x - jb.first_block) * 256 + threadIdx.x;
+    const long e = (((long)blockIdx.x - jb.first_block) * 256 + threadIdx.x) * 4;
     if (e >= jb.total) return;
-    if (jb.kind == 5) { jb.out[e] = jb.w[e] + jb.w2[e]; return; }                 // b_ih + b_hh
-    if (jb.kind == 6) { jb.out[e] = (e < jb.aux) ? jb.w[e] : 0.f; return; }       // [b1 | 0]
-    if (jb.kind == 7) { jb.out[e] = jb.w[e] + ((e < jb.aux) ? jb.w2[e] : 0.f); return; }   // GRU: b_ih + [b_hr | b_hz | 0]
-    const int t = (int)(e & 3);
-    const unsigned r = (unsigned)(e >> 2);                           // a job's output is far below 2^31 elements: 32-bit
-    const unsigned kq = r / (unsigned)jb.Npad;                       // division (the 64-bit form is ~100 instructions each)
-    const int n = (int)(r - kq * (unsigned)jb.Npad);
-    const int k = (int)(kq * 4 + t);
-    float v = 0.f;
-    const float* w = jb.w;
-    const int ldw = jb.ldw;
-    switch (jb.kind) {
-        case 0: if (n < jb.N && k < jb.K) v = w[(size_t)n * ldw + k]; break;
-        case 1: if (n < jb.N && k < jb.K) v = w[(size_t)k * ldw + n]; break;
-        case 2: {                                                   // gate-interleaved (LSTM G = 4, GRU G = 3), aux = H
-            const int H = jb.aux, G = jb.N / H;
-            const int b = n / (16 * G), gate = (n / 16) % G, u = (b << 4) + (n & 15);
-            if (u < H && k < jb.K) v = w[(size_t)(gate * H + u) * ldw + k];
-            break;
+    if (jb.kind >= 5) {                                              // vector jobs, element-wise
+        for (int t = 0; t < 4 && e + t < jb.total; ++t) {
+            const long i = e + t;
+            float v;
+            if (jb.kind == 5) v = jb.w[i] + jb.w2[i];                                   // b_ih + b_hh
+            else if (jb.kind == 6) v = (i < jb.aux) ? jb.w[i] : 0.f;                    // [b1 | 0]
+            else v = jb.w[i] + ((i < jb.aux) ? jb.w2[i] : 0.f);                         // GRU: b_ih + [b_hr | b_hz | 0]
+            jb.out[i] = v;
         }
-        case 3: {                                                   // [W1a - W1b ; W1b] (N = 2H rows, K = C), aux = H
-            const int H = jb.aux, C = jb.K;
-            if (n < jb.N && k < C)
-                v = (n < H) ? w[(size_t)n * ldw + k] - w[(size_t)n * ldw + C + k] : w[(size_t)(n - H) * ldw + C + k];
-            break;
-        }
-        case 4: {                                                   // transpose of the above (N = C, K = 2H), aux = H
-            const int H = jb.aux, C = jb.N;
-            if (n < C && k < jb.K)
-                v = (k < H) ? w[(size_t)k * ldw + n] - w[(size_t)k * ldw + C + n] : w[(size_t)(k - H) * ldw + C + n];
-            break;
-        }
+        return;
     }
-    jb.out[e] = v;
+    // matrix jobs: total = Npad * Kpad is a multiple of 4 and e = 4 * (kq * Npad + n)
+    const unsigned r = (unsigned)(e >> 2);                           // a job's output is far below 2^31 elements
+    const unsigned kq = r / (unsigned)jb.Npad;
+    const int n = (int)(r - kq * (unsigned)jb.Npad);
+    const int k0 = (int)(kq * 4);
+    float4 v;
+    v.x = gpe_pack_elem(jb, n, k0); v.y = gpe_pack_elem(jb, n, k0 + 1);
+    v.z = gpe_pack_elem(jb, n, k0 + 2); v.w = gpe_pack_elem(jb, n, k0 + 3);
+    *reinterpret_cast<float4*>(jb.out + e) = v;
 }
 
 extern "C" int gpe_pack_multi(const void* jobs_dev, int njobs, long total_blocks, void* stream)

@@ -127,7 +127,7 @@ class PackPlan:
             self.outs.append(out)
             tab[i] = (p.data_ptr(), p2.data_ptr() if p2 is not None else 0, out.data_ptr(), total, blk,
                       p.stride(0) if p.dim() == 2 else 0, N, K, kind, npad, aux)
-            blk += (total + 255) // 256
+            blk += (total + 1023) // 1024            # gpe_pack_multi_kernel: 256 threads x one output quad
             key = (p.data_ptr(), kind)
             _PACKS[key] = (self, out, i)
             self.keys.append(key)

@@ -70,7 +70,7 @@ int gpe_pack_weight(const float* w, int ldw, int N, int K, int transpose, const 
                     float* wp, void* stream);
 /* every weight-derived operand of a model refreshed by ONE launch (after an optimizer step): `jobs_dev` is a device array
  * of njobs 64-byte records {const float* w, w2; float* out; long total, first_block; int ldw, N, K, kind, Npad, aux}
- * sorted by first_block (256 outputs per block).  kind 0 plain pack, 1 transposed pack, 2 gate-interleaved pack (aux = H),
+ * sorted by first_block (1024 outputs per 256-thread block: one float4 per thread; ABI version 3 — version 2 had 256).  kind 0 plain pack, 1 transposed pack, 2 gate-interleaved pack (aux = H),
  * 3 pack of [W1a-W1b ; W1b] from W1 [H][2C] (gpe_w1_split + pack; aux = H), 4 its transpose, 5 out = w + w2 (N floats),
  * 6 out = [w[0:aux] | 0] (N floats), 7 out = w + [w2[0:aux] | 0] (N floats; GRU input-side bias b_ih + [b_hr | b_hz | 0]). */
 int gpe_pack_multi(const void* jobs_dev, int njobs, long total_blocks, void* stream);

@@ -43,7 +43,7 @@ def test_math_mode_switch_is_host_only():
 
 def test_host_only_queries():
     l = _lib.lib()
-    assert l.gpe_abi_version() == 2
+    assert l.gpe_abi_version() == 3
     assert l.gpe_packed_size(200, 200) == 208 * 208
     assert l.gpe_packed_size(7, 3) == 16 * 16
     assert l.gpe_packed_gates_size(250, 250) == 64 * 16 * 256
