@@ -336,10 +336,22 @@ __global__ __launch_bounds__(64 * BNF_WAVES) void gpe_bn_finalize_kernel(const d
     if (blockIdx.x == 0 && threadIdx.x == 0 && num_batches) *num_batches += 1;
     double s = 0, q = 0;
     if (c < C) {
-        for (int b = wave; b < nblk; b += BNF_WAVES) {
-            s += part[(size_t)b * 2 * C + c];
-            q += part[(size_t)b * 2 * C + C + c];
+        // four independent chains: the loads of a chain's next block do not wait for its add
+        double s4[4] = {0, 0, 0, 0}, q4[4] = {0, 0, 0, 0};
+        int b = wave;
+        for (; b + 3 * BNF_WAVES < nblk; b += 4 * BNF_WAVES) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                s4[u] += part[(size_t)(b + u * BNF_WAVES) * 2 * C + c];
+                q4[u] += part[(size_t)(b + u * BNF_WAVES) * 2 * C + C + c];
+            }
         }
+        for (; b < nblk; b += BNF_WAVES) {
+            s4[0] += part[(size_t)b * 2 * C + c];
+            q4[0] += part[(size_t)b * 2 * C + C + c];
+        }
+        s = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+        q = (q4[0] + q4[1]) + (q4[2] + q4[3]);
     }
     red[wave][0][lane] = s;
     red[wave][1][lane] = q;
@@ -427,7 +439,7 @@ extern "C" int gpe_edge_finish(const float* mx, const float* mn, int ldagg, cons
 // ---------------------------------------------------------------------------------------------------------
 // EdgeConv backward: per-point sums for the last BN (partials [PS_BLOCKS][2][C] fp64)
 // ---------------------------------------------------------------------------------------------------------
-#define PS_BLOCKS 128
+#define PS_BLOCKS 512          // (128 left half the CUs without a workgroup: 47 us for 118 MB)
 __global__ __launch_bounds__(256) void gpe_point_sums_kernel(const float* __restrict__ g, int ldg,
                                                              const float* __restrict__ mx,
                                                              const float* __restrict__ mn, int ldagg,
