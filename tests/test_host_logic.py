@@ -67,6 +67,31 @@ def test_every_fixture_config_constructs_with_reference_layout(tag, golden_dir):
     assert len(plan.specs) > 0
 
 
+def test_pack_plan_job_table():
+    """the 64-byte job records gpe_pack_multi reads (include/gpe_hip.h): one 256-thread block per 1024 outputs (ABI 3),
+    jobs sorted by first_block, every output buffer sized to its job"""
+    import numpy as np
+    ops = gpe_amd.ops
+    dc = configs.data_config()
+    cfg = configs.lstm_model_config(k_neighbors=5)
+    model = nets.GarmentFullPattern3D(dc, dict(cfg), dict(cfg['loss']))
+    plan = ops.PackPlan()
+    for m in model._pack_modules():
+        m.register_packs(plan)
+    model._register_own_packs(plan)
+    plan._build()
+    tab = plan.table.numpy().view(ops._JOB)
+    assert tab.dtype.itemsize == 64 and len(tab) == len(plan.specs)
+    blk = 0
+    for job, out in zip(tab, plan.outs):
+        assert int(job['first_block']) == blk
+        assert int(job['total']) == out.numel() and int(job['out']) == out.data_ptr()
+        if int(job['kind']) < 5:
+            assert int(job['total']) % 4 == 0                 # whole float4 quads
+        blk += (int(job['total']) + 1023) // 1024
+    assert plan.blocks == blk
+
+
 def test_stitch_model_layout(golden_dir):
     fx = torch.load(os.path.join(golden_dir, 'stitch_pairs_known_answer.pt'), weights_only=False)
     model = nets.StitchOnEdge3DPairs(fx['data_config'], dict(fx['nn_config']), {})
