@@ -29,7 +29,10 @@ void* gpe_scratch(int slot, size_t bytes)
     int dev = 0;
     if (slot < 0 || slot >= SLOTS || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= DEVS) return nullptr;
     if (bytes > cap[dev][slot]) {
-        if (ptr[dev][slot]) (void)hipFree(ptr[dev][slot]);
+        if (ptr[dev][slot]) {
+            (void)hipDeviceSynchronize();                  // queued kernels may still read the old image
+            (void)hipFree(ptr[dev][slot]);
+        }
         ptr[dev][slot] = nullptr; cap[dev][slot] = 0;
         if (hipMalloc(&ptr[dev][slot], bytes) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
         cap[dev][slot] = bytes;
