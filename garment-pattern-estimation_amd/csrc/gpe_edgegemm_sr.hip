@@ -65,9 +65,12 @@ __device__ __forceinline__ long sr_prow(int x, unsigned magic)
 // HALF: K ends within the first 8 columns of the last 16-k chunk (K = 200, 150).  That chunk then runs as TWO k4
 // steps over its lower half — lane group g supplies k = 2g, 2g+1 instead of 4g..4g+3, for A and for the resident weights alike —
 // instead of four steps of which half the products multiply the zero padding (3.8-5 % of a tile's MFMAs).
-template <int AQ, int BQ, int KCH, int AMODE, int EMODE, bool K16, bool HALF = false>
+// KC: compile-time rows per (pseudo-)point — 16 (above), 4 (k = 20, 24, ... as pseudo-points of four rows: four points per
+// wave and tile, slot = u % 4, P row = the (u / 4)-th of the wave's four — no per-row selects or counters), or 0 = generic.
+template <int AQ, int BQ, int KCH, int AMODE, int EMODE, int KC, bool HALF = false>
 __global__ __launch_bounds__(256, 1) void gpe_edgegemm_sr_kernel(RgParams p, int stats_nblk)
 {
+    constexpr bool K16 = KC == 16;
     constexpr int NT = 4 * AQ + BQ;
     constexpr int LDA = 16 * KCH + 4, LDC = 16 * NT + 4;
     // chunk schedule.  Chunk 0 issues every global load of the iteration.  The staged rows are committed to LDS FIRST
@@ -245,11 +248,12 @@ __global__ __launch_bounds__(256, 1) void gpe_edgegemm_sr_kernel(RgParams p, int
     };
     // ---- LDS commit of staged row u (compile-time u) ------------------------------------------------------------------
     auto commit_row = [&](float* An, int u) {
-        if ((!K16 && u >= rwl) || !k_on) return;
+        if ((!KC && u >= rwl) || !k_on) return;
         const int r = rbl + u;
         float4 o = v[u];
         if (AMODE == A_GATHER) {
-            const float4 pv = K16 ? pvs0 : sr_sel4(pvs0, pvs1, pvs2, pvs3, (u * rkl) >> 16);
+            const float4 pv = K16 ? pvs0 : (KC == 4) ? ((u >> 2) == 0 ? pvs0 : (u >> 2) == 1 ? pvs1 : (u >> 2) == 2 ? pvs2 : pvs3)
+                                                     : sr_sel4(pvs0, pvs1, pvs2, pvs3, (u * rkl) >> 16);
             o.x = fmaxf(o.x + pv.x, 0.f); o.y = fmaxf(o.y + pv.y, 0.f);
             o.z = fmaxf(o.z + pv.z, 0.f); o.w = fmaxf(o.w + pv.w, 0.f);
         }
@@ -259,10 +263,10 @@ __global__ __launch_bounds__(256, 1) void gpe_edgegemm_sr_kernel(RgParams p, int
     };
     // ---- epilogue of row u (compile-time u) of the tile being finished ------------------------------------------------
     auto epi_row = [&](int u, const float4 z) {
-        if (!K16 && u >= rwl) return;
+        if (!KC && u >= rwl) return;
         const int r = rbl + u;
         if (r >= e_rv) return;               // K16: all 16 rows of the wave's point are valid or none is (uniform)
-        const int slot = K16 ? u : es;
+        const int slot = KC ? (u % (KC ? KC : 1)) : es;
         if (n_on) {
             if (EMODE == E_EDGE_FWD) {
                 const float vv[4] = {fmaxf(z.x + bias4.x, 0.f), fmaxf(z.y + bias4.y, 0.f), fmaxf(z.z + bias4.z, 0.f),
@@ -281,7 +285,8 @@ __global__ __launch_bounds__(256, 1) void gpe_edgegemm_sr_kernel(RgParams p, int
             } else {
                 float4 av = act[u];
                 if (GATHER_ACT) {
-                    const float4 pv = K16 ? pve0 : sr_sel4(pve0, pve1, pve2, pve3, (u * rkl) >> 16);
+                    const float4 pv = K16 ? pve0 : (KC == 4) ? ((u >> 2) == 0 ? pve0 : (u >> 2) == 1 ? pve1 : (u >> 2) == 2 ? pve2 : pve3)
+                                                             : sr_sel4(pve0, pve1, pve2, pve3, (u * rkl) >> 16);
                     av.x = fmaxf(av.x + pv.x, 0.f); av.y = fmaxf(av.y + pv.y, 0.f);
                     av.z = fmaxf(av.z + pv.z, 0.f); av.w = fmaxf(av.w + pv.w, 0.f);
                 }
@@ -294,9 +299,9 @@ __global__ __launch_bounds__(256, 1) void gpe_edgegemm_sr_kernel(RgParams p, int
                 dp.x += o.x; dp.y += o.y; dp.z += o.z; dp.w += o.w;
             }
         }
-        if (K16 ? (u == SR_PB - 1) : (++es == p.k)) {        // a point is complete (K16: compile-time)
+        if (KC ? ((u % (KC ? KC : 1)) == KC - 1) : (++es == p.k)) {        // a point is complete (KC: compile-time)
             if (n_on) {
-                const long gpt = e_pt0 + (K16 ? 0 : ept);
+                const long gpt = e_pt0 + (KC ? (u / (KC ? KC : 1)) : ept);
                 if (EMODE == E_EDGE_FWD && p.agg) {
                     const long o = gpt * p.oldagg + c;
                     st4(p.mx + o, make_float4(vmx[0], vmx[1], vmx[2], vmx[3]));
@@ -505,17 +510,17 @@ __global__ __launch_bounds__(256, 1) void gpe_edgegemm_sr_kernel(RgParams p, int
 // ---------------------------------------------------------------------------------------------------------
 static int sr_num_cus() { return gpe_num_cus(); }
 
-template <int AQ, int BQ, int KCH, int AMODE, int EMODE, bool K16, bool HALF = false>
+template <int AQ, int BQ, int KCH, int AMODE, int EMODE, int KC, bool HALF = false>
 static int sr_launch_k(const RgParams& p, int stats_nblk, hipStream_t s)
 {
     constexpr int NT = 4 * AQ + BQ;
     constexpr int LDA = 16 * KCH + 4, LDC = 16 * NT + 4;
     const size_t lds = (size_t)RG_BM * (2 * LDA + LDC) * sizeof(float);
-    GPE_ENSURE_MAX_LDS((gpe_edgegemm_sr_kernel<AQ, BQ, KCH, AMODE, EMODE, K16, HALF>));
+    GPE_ENSURE_MAX_LDS((gpe_edgegemm_sr_kernel<AQ, BQ, KCH, AMODE, EMODE, KC, HALF>));
     int gx = sr_num_cus();
     if (gx > p.num_tiles) gx = p.num_tiles;
     if (stats_nblk > 0 && gx > stats_nblk) gx = stats_nblk;
-    hipLaunchKernelGGL((gpe_edgegemm_sr_kernel<AQ, BQ, KCH, AMODE, EMODE, K16, HALF>), dim3(gx), dim3(256), lds, s, p, stats_nblk);
+    hipLaunchKernelGGL((gpe_edgegemm_sr_kernel<AQ, BQ, KCH, AMODE, EMODE, KC, HALF>), dim3(gx), dim3(256), lds, s, p, stats_nblk);
     GPE_CHECK_LAUNCH();
     return GPE_OK;
 }
@@ -523,11 +528,16 @@ static int sr_launch_k(const RgParams& p, int stats_nblk, hipStream_t s)
 template <int AQ, int BQ, int KCH, int AMODE, int EMODE>
 static int sr_launch(const RgParams& p, int stats_nblk, hipStream_t s)
 {
-    if (p.K <= 16 * (KCH - 1) + 8 && !(p.dbg & 128))
-        return p.k == 16 ? sr_launch_k<AQ, BQ, KCH, AMODE, EMODE, true, true>(p, stats_nblk, s)
-                         : sr_launch_k<AQ, BQ, KCH, AMODE, EMODE, false, true>(p, stats_nblk, s);
-    return p.k == 16 ? sr_launch_k<AQ, BQ, KCH, AMODE, EMODE, true>(p, stats_nblk, s)
-                     : sr_launch_k<AQ, BQ, KCH, AMODE, EMODE, false>(p, stats_nblk, s);
+    const bool half = p.K <= 16 * (KCH - 1) + 8 && !(p.dbg & 128);
+    if (p.k == 16) return half ? sr_launch_k<AQ, BQ, KCH, AMODE, EMODE, 16, true>(p, stats_nblk, s)
+                               : sr_launch_k<AQ, BQ, KCH, AMODE, EMODE, 16>(p, stats_nblk, s);
+    // (the one KC = 4 instance the register allocator cannot fit without scratch runs as generic k)
+    constexpr bool k4_full_ok = !(EMODE == E_BWD_GATHER && AQ == 3 && KCH == 13);
+    if (p.k == 4 && !(p.dbg & 256) && (half || k4_full_ok))
+        return half ? sr_launch_k<AQ, BQ, KCH, AMODE, EMODE, 4, true>(p, stats_nblk, s)
+                    : sr_launch_k<AQ, BQ, KCH, AMODE, EMODE, k4_full_ok ? 4 : 0>(p, stats_nblk, s);
+    return half ? sr_launch_k<AQ, BQ, KCH, AMODE, EMODE, 0, true>(p, stats_nblk, s)
+                : sr_launch_k<AQ, BQ, KCH, AMODE, EMODE, 0>(p, stats_nblk, s);
 }
 
 template <int AMODE, int EMODE>
