@@ -32,6 +32,7 @@ struct RdParams {
     GpeRows u;
     GpeRows v;                                   // V_DENSE
     const float* pq; int ldpq; int H; const int32_t* jg; int k; double rcp_k;   // V_GATHER (global neighbour rows)
+    unsigned kmagic;                             // ceil(2^32 / k): row / k == umulhi(row, kmagic) while row * k < 2^32 (pc kernel)
     int pin_clouds;                              // B when the rows are B equal clouds (gpe_edge_redgemm), else 0
     const float* v_shift;                        // optional [Ng]: V := V - shift on valid rows (BN centring)
     int vec;                                     // rows aligned to 16 B and padded to 4 columns: plain 16-B loads
@@ -366,23 +367,28 @@ __global__ __launch_bounds__(512, 2) void gpe_redgemm_pc_kernel(RdParams p)
         float4 ur[RQ], vr[RQ], vr2[VMODE == V_GATHER ? RQ : 1];
 
         int jgv = 0;                                // V_GATHER: lane q <-> neighbour row of this wave's q-th row
-        auto load_jgv = [&](int tile) -> int {
+        // A partial last tile is fetched as the LAST 32 rows of the operands (rows - 32 ..: in bounds, the launcher guarantees
+        // rows >= 32): row order inside a tile is irrelevant to the sums, the rows that belong to the previous tile are
+        // zeroed by commit's slow path, and every tile's row addresses are base + q * (4 rows) with no per-row clamp.
+        const long us4 = 4L * p.u.stride_outer, vs4 = 4L * p.v.stride_outer;
+        auto tile_row0 = [&](int tile) -> long {
             const long row0 = (long)tile * RD_RT;
-            const int rv = (int)((p.rows - row0 < RD_RT) ? (p.rows - row0) : RD_RT);
-            const int r = w4 + 4 * ((lane < RQ) ? lane : RQ - 1);
-            return p.jg[row0 + ((r < rv) ? r : rv - 1)];
+            return (row0 + RD_RT <= p.rows) ? row0 : p.rows - RD_RT;
+        };
+        auto load_jgv = [&](int tile) -> int {
+            return p.jg[tile_row0(tile) + w4 + 4 * ((lane < RQ) ? lane : RQ - 1)];
         };
         auto fetch = [&](int tile) {
-            const long row0 = (long)tile * RD_RT;
-            const int rv = (int)((p.rows - row0 < RD_RT) ? (p.rows - row0) : RD_RT);
+            const long rb = tile_row0(tile) + w4;
+            const float* up = p.u.base + rb * p.u.stride_outer + cu;
+            const float* vp = p.v.base + rb * p.v.stride_outer + cv;
 #pragma unroll
             for (int q = 0; q < RQ; ++q) {
-                const int r = w4 + 4 * q;
-                const long gr = row0 + ((r < rv) ? r : rv - 1);
-                ur[q] = rd_ld4(p.u.base + gr * p.u.stride_outer + cu);
-                if (VMODE == V_DENSE) vr[q] = rd_ld4(p.v.base + gr * p.v.stride_outer + cv);
+                ur[q] = rd_ld4(up + q * us4);
+                if (VMODE == V_DENSE) vr[q] = rd_ld4(vp + q * vs4);
                 else {
-                    const long i = (long)gpe_udiv((unsigned)gr, (unsigned)p.k, p.rcp_k);
+                    // wave-uniform row: one s_mul_hi_u32 (the double-reciprocal gpe_udiv is ~8 VALU instructions per row here)
+                    const long i = (long)__umulhi((unsigned)(rb + 4 * q), p.kmagic);
                     // neighbour row: prefetched lane-distributed one tile ahead (load_jgv) — read here as p.jg[gr] it is
                     // a vector load whose result every later load of this fetch has to wait for (in-order vmcnt)
                     const long jj = __builtin_amdgcn_readlane(jgv, q);
@@ -397,35 +403,63 @@ __global__ __launch_bounds__(512, 2) void gpe_redgemm_pc_kernel(RdParams p)
             const long row0 = (long)tile * RD_RT;
             const int rv = (int)((p.rows - row0 < RD_RT) ? (p.rows - row0) : RD_RT);
             float c32[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int q = 0; q < RQ; ++q) {
-                const int r = w4 + 4 * q;
-                const bool ok = r < rv;
+            if (rv == RD_RT) {
+                // full tile (every tile but possibly the last): no masks at all.  Columns >= Mg / Ng of the LDS image then
+                // hold whatever the clamped loads delivered (pad columns of the rows, or a copy of columns 0..3): column m of
+                // U only ever reaches row m of the product and entry m of the column sums, column n of V only column n, and
+                // gpe_redgemm_finish reads m < Mg, n < Ng alone.  (112 v_cndmask + 16 exec branches per tile otherwise,
+                // each ~6 cycles of a SIMD that is otherwise issuing fp32 MFMAs.)
                 if (cq < UC) {
-                    float4 u = ur[q];
-                    if (!(ok && u_on)) u = make_float4(0.f, 0.f, 0.f, 0.f);
-                    else {
-                        if (cq + 1 >= p.Mg) u.y = 0.f;
-                        if (cq + 2 >= p.Mg) u.z = 0.f;
-                        if (cq + 3 >= p.Mg) u.w = 0.f;
+#pragma unroll
+                    for (int q = 0; q < RQ; ++q) {
+                        const float4 u = ur[q];
+                        c32[0] += u.x; c32[1] += u.y; c32[2] += u.z; c32[3] += u.w;
+                        *reinterpret_cast<float4*>(&ub[(w4 + 4 * q) * LDU + cq]) = u;
                     }
-                    c32[0] += u.x; c32[1] += u.y; c32[2] += u.z; c32[3] += u.w;
-                    *reinterpret_cast<float4*>(&ub[r * LDU + cq]) = u;
                 }
                 if (cq < VC) {
-                    float4 v = vr[q];
-                    if (VMODE == V_GATHER) {
-                        v.x = fmaxf(v.x + vr2[q].x, 0.f); v.y = fmaxf(v.y + vr2[q].y, 0.f);
-                        v.z = fmaxf(v.z + vr2[q].z, 0.f); v.w = fmaxf(v.w + vr2[q].w, 0.f);
+#pragma unroll
+                    for (int q = 0; q < RQ; ++q) {
+                        float4 v = vr[q];
+                        if (VMODE == V_GATHER) {
+                            v.x = fmaxf(v.x + vr2[q].x, 0.f); v.y = fmaxf(v.y + vr2[q].y, 0.f);
+                            v.z = fmaxf(v.z + vr2[q].z, 0.f); v.w = fmaxf(v.w + vr2[q].w, 0.f);
+                        }
+                        v.x -= sh[0]; v.y -= sh[1]; v.z -= sh[2]; v.w -= sh[3];
+                        *reinterpret_cast<float4*>(&vb[(w4 + 4 * q) * LDV + cq]) = v;
                     }
-                    v.x -= sh[0]; v.y -= sh[1]; v.z -= sh[2]; v.w -= sh[3];
-                    if (!(ok && v_on)) v = make_float4(0.f, 0.f, 0.f, 0.f);
-                    else {
-                        if (cq + 1 >= p.Ng) v.y = 0.f;
-                        if (cq + 2 >= p.Ng) v.z = 0.f;
-                        if (cq + 3 >= p.Ng) v.w = 0.f;
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < RQ; ++q) {
+                    const int r = w4 + 4 * q;
+                    const bool ok = r >= RD_RT - rv;           // (see fetch: a partial tile holds the operands' last 32 rows)
+                    if (cq < UC) {
+                        float4 u = ur[q];
+                        if (!(ok && u_on)) u = make_float4(0.f, 0.f, 0.f, 0.f);
+                        else {
+                            if (cq + 1 >= p.Mg) u.y = 0.f;
+                            if (cq + 2 >= p.Mg) u.z = 0.f;
+                            if (cq + 3 >= p.Mg) u.w = 0.f;
+                        }
+                        c32[0] += u.x; c32[1] += u.y; c32[2] += u.z; c32[3] += u.w;
+                        *reinterpret_cast<float4*>(&ub[r * LDU + cq]) = u;
                     }
-                    *reinterpret_cast<float4*>(&vb[r * LDV + cq]) = v;
+                    if (cq < VC) {
+                        float4 v = vr[q];
+                        if (VMODE == V_GATHER) {
+                            v.x = fmaxf(v.x + vr2[q].x, 0.f); v.y = fmaxf(v.y + vr2[q].y, 0.f);
+                            v.z = fmaxf(v.z + vr2[q].z, 0.f); v.w = fmaxf(v.w + vr2[q].w, 0.f);
+                        }
+                        v.x -= sh[0]; v.y -= sh[1]; v.z -= sh[2]; v.w -= sh[3];
+                        if (!(ok && v_on)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                        else {
+                            if (cq + 1 >= p.Ng) v.y = 0.f;
+                            if (cq + 2 >= p.Ng) v.z = 0.f;
+                            if (cq + 3 >= p.Ng) v.w = 0.f;
+                        }
+                        *reinterpret_cast<float4*>(&vb[r * LDV + cq]) = v;
+                    }
                 }
             }
 #pragma unroll
@@ -1125,7 +1159,8 @@ static int rd_run(RdParams& p, int vmode, float* G, int ldG, float* colsum, floa
     const int mt_all = gpe_cdiv(p.Mg, 16), nt_all = gpe_cdiv(p.Ng, 16);
     static const int dbg_nopc = getenv("GPE_RD_NOPC") ? atoi(getenv("GPE_RD_NOPC")) : 0;     // measurement override
     const bool pc_ok = !dbg_nopc && gy == 1 && nt_all == 13 && (mt_all == 13 || mt_all == 10) && rd_rows_vec(p.u, p.Mg) &&
-                       (vmode == V_GATHER || rd_rows_vec(p.v, p.Ng)) && p.num_tiles >= 4 * gx;
+                       (vmode == V_GATHER || rd_rows_vec(p.v, p.Ng)) && p.num_tiles >= 4 * gx &&
+                       (vmode != V_GATHER || (p.k > 1 && p.rows * p.k < (1L << 32)));   // umulhi row / k (kmagic)
     p.pin_tpc = 0;
     if (pc_ok && vmode == V_GATHER && p.pin_clouds > 0 && gpe_pin_clouds(p.pin_clouds) && p.pin_clouds % GPE_NXCD == 0) {
         const long rows_per_cloud = p.rows / p.pin_clouds;
@@ -1179,7 +1214,7 @@ extern "C" int gpe_edge_redgemm(const float* u, int ldu, int v_mode, const float
     p.rows = (long)B * N * k; p.Mg = Mg; p.Ng = Ng;
     p.u = GpeRows{u, ldu, 0, 0};
     p.v = GpeRows{v, ldv, 0, 0};
-    p.pq = pq; p.ldpq = ldpq; p.H = Ng; p.jg = jg; p.k = k; p.rcp_k = 1.0 / k; p.v_shift = v_shift;
+    p.pq = pq; p.ldpq = ldpq; p.H = Ng; p.jg = jg; p.k = k; p.rcp_k = 1.0 / k; p.kmagic = (unsigned)(((1ull << 32) + k - 1) / k); p.v_shift = v_shift;
     p.pin_clouds = B;
     return rd_run(p, v_mode == 0 ? V_GATHER : V_DENSE, G, ldG, colsum, part, 0, (hipStream_t)stream);
 }

@@ -225,6 +225,39 @@ def test_redgemm(gpe, rows, Mg, Ng):
     assert relerr(cs, u.double().sum(0)) < 3e-6
 
 
+@pytest.mark.parametrize('mode,B,N,k,Mg,Ng', [('dense', 1, 524288 + 13, 1, 200, 200), ('dense', 1, 524288 + 31, 1, 150, 200),
+                                              ('gather', 3, 12001, 15, 150, 200), ('gather', 5, 6563, 16, 200, 200),
+                                              ('gather', 32, 2048, 16, 200, 200)])
+def test_edge_redgemm_producer_consumer_tiles(gpe, mode, B, N, k, Mg, Ng):
+    """the producer/consumer reduce-GEMM (13 x 13 / 10 x 13 tile grids, >= 4 row tiles per CU) incl. a PARTIAL last row tile
+    (rows % 32 != 0), padded operand pitches with non-finite pad columns, and the V shift; fp64 reference on the device."""
+    ops, L = gpe.ops, gpe._lib
+    g = torch.Generator().manual_seed(B * N + Mg)
+    E = B * N * k
+    pu = (Mg + 3) // 4 * 4 + 4
+    ubuf = torch.full((E, pu), float('nan')).cuda()                    # pad columns must never reach a valid output
+    ubuf[:, :Mg] = torch.randn(E, Mg, generator=g).cuda()
+    shift = torch.randn(Ng, generator=g).cuda()
+    G = torch.empty(Mg, Ng).cuda()
+    cs = torch.empty(Mg).cuda()
+    ws = torch.empty(L.query('gpe_redgemm_ws', Mg, Ng)).cuda()
+    if mode == 'dense':
+        pv = Ng + 8
+        vbuf = torch.full((E, pv), float('nan')).cuda()
+        vbuf[:, :Ng] = torch.randn(E, Ng, generator=g).cuda()
+        L.call('gpe_edge_redgemm', ubuf, pu, 1, vbuf, pv, None, 0, None, shift, B, N, k, Mg, Ng, G, Ng, cs, ws)
+        vref = vbuf[:, :Ng].double() - shift.double()
+    else:
+        pq = torch.randn(B * N, 2 * Ng, generator=g).cuda()
+        jg = (torch.randint(0, N, (B, N, k), generator=g) + torch.arange(B).view(B, 1, 1) * N).int().cuda()
+        L.call('gpe_edge_redgemm', ubuf, pu, 0, None, 0, pq, 2 * Ng, jg, shift, B, N, k, Mg, Ng, G, Ng, cs, ws)
+        i = torch.arange(B * N, device='cuda').repeat_interleave(k)
+        vref = torch.relu(pq[i, :Ng].double() + pq[jg.view(-1).long(), Ng:].double()) - shift.double()
+    uref = ubuf[:, :Mg].double()
+    assert relerr(G, uref.t() @ vref) < 3e-6
+    assert relerr(cs, uref.sum(0)) < 3e-6
+
+
 def test_redgemm_two_level_rows(gpe):
     """row-poor product over [sequence][step] descriptors (the LSTM weight gradients): the deep-reduction kernel."""
     ops = gpe.ops
