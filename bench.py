@@ -101,7 +101,7 @@ def call_work(name, a):
 # HBM traffic per launch from the committed PMC passes (profiles/*_hbm_traffic.json, made by scripts/collect_profiles.sh
 # from two `rocprofv3 --pmc` runs of this same command); C-ABI entry -> device kernels it launches
 _TRAFFIC_KERNELS = {
-    # template tails: rowgemm <NT, AMODE, EMODE>; edgegemm (paired) <.., AMODE, EMODE, MATH>; edgegemm_sr <.., AMODE, EMODE, K16>
+    # template tails: rowgemm <NT, AMODE, EMODE>; edgegemm (paired) <.., AMODE, EMODE, MATH>; edgegemm_sr <.., AMODE, EMODE, KC, HALF>
     'gpe_edge_mlp_fwd': r'gpe_rowgemm_kernel<.*, 1>$|gpe_edgegemm(_sr)?_kernel<\d+, \d+, \d+, \d+, 1(, \w+)+>$',
     'gpe_edge_mlp_bwd': r'gpe_rowgemm_kernel<.*, [23]>$|gpe_edgegemm(_sr)?_kernel<\d+, \d+, \d+, \d+, [23](, \w+)+>$',
     'gpe_edge_redgemm': r'gpe_redgemm_pc_kernel<',
