@@ -51,7 +51,9 @@ int gpe_math_get(void);
 
 /* ---- kNN graph: torch_cluster.knn as called by DynamicEdgeConv (nn/net_blocks.py:127-135,174) ------------
  * x [B][N][ldx>=C]; idx [B][N][k] int32, LOCAL to the cloud, ascending (dist, index); self included.
- * dist = fp32 fma chain over channels of (x_c - y_c)^2, ties -> lower index (same rules as oracle/knn_ref.c). */
+ * dist = fp32 fma chain over channels of (x_c - y_c)^2, ties -> lower index (same rules as oracle/knn_ref.c).
+ * Limits: 1 <= k <= min(64, N) (the k-list of a query lives one entry per lane of its wavefront; torch_cluster's own device
+ * kernel stops at k = 100, the reference's configurations use k = 5 .. 20), B*N*k < 2^31; anything else returns -22. */
 int gpe_knn(const float* x, int B, int N, int C, int ldx, int k, int32_t* idx, int32_t* idx_glob, void* stream);
 /* idx_glob (may be NULL) [B][N][k] = b*N + idx: the GLOBAL row of each neighbour, which is what the gather kernels
  * below take as `jg` (B*N*k must be < 2^31). */
