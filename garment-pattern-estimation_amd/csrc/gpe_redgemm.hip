@@ -33,6 +33,7 @@ struct RdParams {
     GpeRows v;                                   // V_DENSE
     const float* pq; int ldpq; int H; const int32_t* jg; int k; double rcp_k;   // V_GATHER (global neighbour rows)
     unsigned kmagic;                             // ceil(2^32 / k): row / k == umulhi(row, kmagic) while row * k < 2^32 (pc kernel)
+    unsigned umagic, vmagic;                     // the same for u.inner / v.inner (2-level rows of the deep kernel)
     int pin_clouds;                              // B when the rows are B equal clouds (gpe_edge_redgemm), else 0
     const float* v_shift;                        // optional [Ng]: V := V - shift on valid rows (BN centring)
     int vec;                                     // rows aligned to 16 B and padded to 4 columns: plain 16-B loads
@@ -809,6 +810,14 @@ __global__ __launch_bounds__(512, 2) void gpe_redgemm_b3_kernel(RdParams p)
 #define RDD_LD 80                     // == 16 (mod 32): conflict-free b32 operand reads
 #define RDD_MAX_GX 32
 
+// 2-level row offset with the division as one v_mul_hi_u32 (host: r * inner < 2^32)
+__device__ __forceinline__ long rd_row_off_magic(const GpeRows& a, unsigned r, unsigned magic)
+{
+    if (a.inner <= 1) return (long)r * a.stride_outer;
+    const unsigned o = __umulhi(r, magic);
+    return (long)o * a.stride_outer + (long)(r - o * (unsigned)a.inner) * a.stride_inner;
+}
+
 __device__ __forceinline__ long rd_row_off(const GpeRows& a, unsigned r, double rcp_inner)
 {
     if (a.inner <= 0) return (long)r * a.stride_outer;
@@ -835,7 +844,6 @@ __global__ __launch_bounds__(256, 3) void gpe_redgemm_deep_kernel(RdParams p)
     const int sr = tid >> 4, cq = (tid & 15) << 2;
     const bool u_on = m0 + cq < p.Mg, v_on = n0 + cq < p.Ng;
     const int ucol = u_on ? m0 + cq : 0, vcol = v_on ? n0 + cq : 0;      // clamped: the loads are unconditional
-    const double rcp_u = p.u.inner > 0 ? 1.0 / p.u.inner : 0.0, rcp_v = p.v.inner > 0 ? 1.0 / p.v.inner : 0.0;
     float sh[4] = {0.f, 0.f, 0.f, 0.f};
     if (p.v_shift && v_on) {
 #pragma unroll
@@ -843,17 +851,19 @@ __global__ __launch_bounds__(256, 3) void gpe_redgemm_deep_kernel(RdParams p)
     }
     float4 ur[2], vr[2];
     unsigned rmask = 0;
+    bool tfull = false;                            // the staged tile has all 32 rows (uniform)
     auto fetch = [&](int tile) {
         const long row0 = (long)tile * RD_RT;
         const int rv = (int)((p.rows - row0 < RD_RT) ? (p.rows - row0) : RD_RT);
         rmask = 0;
+        tfull = rv == RD_RT;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int r = sr + 16 * h;
             if (r < rv) rmask |= 1u << h;
             const unsigned gr = (unsigned)(row0 + ((r < rv) ? r : rv - 1));
-            ur[h] = rd_ld4(p.u.base + rd_row_off(p.u, gr, rcp_u) + ucol);
-            const float* vp = p.v.base + rd_row_off(p.v, gr, rcp_v);
+            ur[h] = rd_ld4(p.u.base + rd_row_off_magic(p.u, gr, p.umagic) + ucol);
+            const float* vp = p.v.base + rd_row_off_magic(p.v, gr, p.vmagic);
             if constexpr (VVEC) vr[h] = rd_ld4(vp + vcol);
             else {                                                  // clamped columns: masked at commit
                 const int last = p.Ng - 1;
@@ -867,6 +877,20 @@ __global__ __launch_bounds__(256, 3) void gpe_redgemm_deep_kernel(RdParams p)
     auto commit = [&](int buf) {
         float* ub = Us + buf * RD_RT * RDD_LD;
         float* vb = Vs + buf * RD_RT * RDD_LD;
+        if (tfull) {
+            // full tile: no masks.  Columns past Mg / Ng of the 64-wide block carry whatever the clamped loads delivered:
+            // column m of U only reaches row m of the product and entry m of the column sums, column n of V only column
+            // n, and gpe_redgemm_finish reads m < Mg, n < Ng alone (same argument as gpe_redgemm_pc_kernel).
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int r = sr + 16 * h;
+                float4 v = vr[h];
+                v.x -= sh[0]; v.y -= sh[1]; v.z -= sh[2]; v.w -= sh[3];
+                *reinterpret_cast<float4*>(&ub[r * RDD_LD + cq]) = ur[h];
+                *reinterpret_cast<float4*>(&vb[r * RDD_LD + cq]) = v;
+            }
+            return;
+        }
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int r = sr + 16 * h;
@@ -1132,8 +1156,11 @@ static int rd_run(RdParams& p, int vmode, float* G, int ldG, float* colsum, floa
     if (gx > p.num_tiles) gx = p.num_tiles > 0 ? p.num_tiles : 1;
     p.part = part;
     // row-poor dense products (fewer than 64 row tiles per workgroup of the big-block grid) with a 16-B loadable U
-    if (vmode == V_DENSE && g_rd_math != 1 && p.num_tiles > 0 && p.num_tiles < 64L * gx && p.rows < (1L << 31) &&
-        rd_rows_vec2(p.u, p.Mg)) {
+    const long in_max = (p.u.inner > p.v.inner ? p.u.inner : p.v.inner) > 1 ? (p.u.inner > p.v.inner ? p.u.inner : p.v.inner) : 1;
+    if (vmode == V_DENSE && g_rd_math != 1 && p.num_tiles > 0 && p.num_tiles < 64L * gx && p.rows * in_max < (1L << 32) &&
+        p.rows < (1L << 31) && rd_rows_vec2(p.u, p.Mg)) {
+        p.umagic = p.u.inner > 1 ? (unsigned)(((1ull << 32) + p.u.inner - 1) / p.u.inner) : 0;
+        p.vmagic = p.v.inner > 1 ? (unsigned)(((1ull << 32) + p.v.inner - 1) / p.v.inner) : 0;
         const int dgx = rdd_gx(p.Mg, p.Ng, p.num_tiles, cus);
         const int dgy = gpe_cdiv(p.Mg, RDD_B), dgz = gpe_cdiv(p.Ng, RDD_B);
         p.MgPad = dgy * RDD_B; p.NgPad = dgz * RDD_B;
