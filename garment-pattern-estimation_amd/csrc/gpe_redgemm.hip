@@ -983,6 +983,102 @@ static bool rd_rows_vec2(const GpeRows& r, int cols)
     return pitch >= ((cols + 3) & ~3) || (cols & 3) == 0;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Thin products (Ng <= 4: the weight gradient of a Linear on raw xyz positions, 65 536 x 400 against 65 536 x 3): nothing for
+// the matrix pipe, the job is to stream U once.  Workgroup = a contiguous row range, wave w takes its rows w, w+4, ...,
+// lane = column quads lane, lane+64, ... of U (QL per lane); RDT_RB rows in flight per wave, fp32 fma chains of a few dozen
+// rows per wave, then the four waves are added in fp64 and one partial per workgroup goes to gpe_redgemm_finish.
+// HBM-bound (rows * Mg * 4 bytes): 80 -> ~25 us on the shape above, against the 224 x 256 big-block kernel.
+// ---------------------------------------------------------------------------------------------------------
+#define RDT_GX 512
+#define RDT_RB 4
+template <int QL>
+__global__ __launch_bounds__(256) void gpe_redgemm_thin_kernel(RdParams p)
+{
+    extern __shared__ __align__(16) float smem[];              // [4 waves][MgPad][5]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const long rpb = (p.rows + gridDim.x - 1) / gridDim.x;
+    const long r_begin = (long)blockIdx.x * rpb;
+    const long r_end = (r_begin + rpb < p.rows) ? r_begin + rpb : p.rows;
+    int cq[QL];
+#pragma unroll
+    for (int q = 0; q < QL; ++q) {
+        const int c = 4 * (lane + 64 * q);
+        cq[q] = (c < p.Mg) ? c : 0;                            // clamped: unconditional loads
+    }
+    float sh[4] = {0.f, 0.f, 0.f, 0.f};
+    if (p.v_shift) {
+#pragma unroll
+        for (int n = 0; n < 4; ++n) if (n < p.Ng) sh[n] = p.v_shift[n];
+    }
+    float acc[QL][4][4], cs[QL][4];
+#pragma unroll
+    for (int q = 0; q < QL; ++q)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            cs[q][c] = 0.f;
+#pragma unroll
+            for (int n = 0; n < 4; ++n) acc[q][c][n] = 0.f;
+        }
+    for (long r = r_begin + wave; r < r_end; r += 4 * RDT_RB) {
+        float4 u[RDT_RB][QL];
+        float v[RDT_RB][4];
+#pragma unroll
+        for (int j = 0; j < RDT_RB; ++j) {
+            const long rr = (r + 4 * j < r_end) ? r + 4 * j : r;            // clamped to a row of this wave (masked below)
+            const float* up = p.u.base + rr * p.u.stride_outer;
+            const float* vp = p.v.base + rr * p.v.stride_outer;
+#pragma unroll
+            for (int q = 0; q < QL; ++q) u[j][q] = rd_ld4(up + cq[q]);
+#pragma unroll
+            for (int n = 0; n < 4; ++n) v[j][n] = vp[(n < p.Ng) ? n : 0] - sh[n];
+        }
+#pragma unroll
+        for (int j = 0; j < RDT_RB; ++j) {
+            if (r + 4 * j < r_end) {                                        // uniform
+#pragma unroll
+                for (int q = 0; q < QL; ++q) {
+                    const float uu[4] = {u[j][q].x, u[j][q].y, u[j][q].z, u[j][q].w};
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        cs[q][c] += uu[c];
+#pragma unroll
+                        for (int n = 0; n < 4; ++n) acc[q][c][n] = __builtin_fmaf(uu[c], v[j][n], acc[q][c][n]);
+                    }
+                }
+            }
+        }
+    }
+    // ---- four waves -> one partial ------------------------------------------------------------------------------------
+    float* mine = smem + (size_t)wave * p.MgPad * 5;
+#pragma unroll
+    for (int q = 0; q < QL; ++q) {
+        const int c0 = 4 * (lane + 64 * q);
+        if (c0 < p.MgPad) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+#pragma unroll
+                for (int n = 0; n < 4; ++n) mine[(c0 + c) * 5 + n] = acc[q][c][n];
+                mine[(c0 + c) * 5 + 4] = cs[q][c];
+            }
+        }
+    }
+    __syncthreads();
+    float* dst = p.part + (size_t)blockIdx.x * p.MgPad * p.NgPad;            // NgPad == 4
+    const size_t wstride = (size_t)p.MgPad * 5;
+    for (int m = tid; m < p.MgPad; m += 256) {
+        const float* s0 = smem + (size_t)m * 5;
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+            dst[(size_t)m * 4 + n] = (float)(((double)s0[n] + (double)s0[wstride + n]) +
+                                             ((double)s0[2 * wstride + n] + (double)s0[3 * wstride + n]));
+        if (p.part_cs)
+            p.part_cs[(size_t)blockIdx.x * p.MgPad + m] = ((double)s0[4] + (double)s0[wstride + 4]) +
+                                                          ((double)s0[2 * wstride + 4] + (double)s0[3 * wstride + 4]);
+    }
+}
+
 // row split of the deep kernel: ~3 workgroups per CU, at least 4 row tiles each, <= RDD_MAX_GX partial images
 static int rdd_gx(int Mg, int Ng, long num_tiles, int cus)
 {
@@ -1086,7 +1182,10 @@ extern "C" long gpe_redgemm_ws(int Mg, int Ng)
     const long big = gx * MgPad * NgPad + 2L * gx * MgPad + 8;
     const long dM = gpe_round_up(Mg, RDD_B), dN = gpe_round_up(Ng, RDD_B);
     const long deep = RDD_MAX_GX * dM * dN + 2L * RDD_MAX_GX * dM + 8;
-    return big > deep ? big : deep;
+    const long mr = gpe_round_up(Mg, 4);
+    const long thin = Ng <= 4 ? (long)RDT_GX * mr * 4 + 2L * RDT_GX * mr + 8 : 0;      // gpe_redgemm_thin_kernel
+    const long m2 = big > deep ? big : deep;
+    return m2 > thin ? m2 : thin;
 }
 
 template <int MH, int NH, int VMODE>
@@ -1156,6 +1255,26 @@ static int rd_run(RdParams& p, int vmode, float* G, int ldG, float* colsum, floa
     if (gx > p.num_tiles) gx = p.num_tiles > 0 ? p.num_tiles : 1;
     p.part = part;
     // row-poor dense products (fewer than 64 row tiles per workgroup of the big-block grid) with a 16-B loadable U
+    // thin products: stream U once (Ng <= 4, plain 16-B loadable U rows, single-level rows on both sides)
+    if (vmode == V_DENSE && p.Ng <= 4 && p.Mg <= 1024 && p.rows >= 4096 && p.u.inner <= 0 && p.v.inner <= 0 &&
+        rd_rows_vec(p.u, p.Mg)) {
+        const int gxt = (int)(p.rows / 64 < RDT_GX ? p.rows / 64 : RDT_GX);
+        p.MgPad = gpe_round_up(p.Mg, 4); p.NgPad = 4;
+        size_t toff = (size_t)gxt * p.MgPad * 4;
+        toff = (toff + 1) & ~(size_t)1;
+        p.part_cs = colsum ? reinterpret_cast<double*>(part + toff) : nullptr;
+        const size_t lds = (size_t)4 * p.MgPad * 5 * sizeof(float);
+        const int ql = gpe_cdiv(p.MgPad, 256);
+        if (ql <= 1) { GPE_ENSURE_MAX_LDS((gpe_redgemm_thin_kernel<1>)); hipLaunchKernelGGL(gpe_redgemm_thin_kernel<1>, dim3(gxt), dim3(256), lds, s, p); }
+        else if (ql == 2) { GPE_ENSURE_MAX_LDS((gpe_redgemm_thin_kernel<2>)); hipLaunchKernelGGL(gpe_redgemm_thin_kernel<2>, dim3(gxt), dim3(256), lds, s, p); }
+        else { GPE_ENSURE_MAX_LDS((gpe_redgemm_thin_kernel<4>)); hipLaunchKernelGGL(gpe_redgemm_thin_kernel<4>, dim3(gxt), dim3(256), lds, s, p); }
+        GPE_CHECK_LAUNCH();
+        const long fin_t = gpe_cdiv((long)p.Mg * p.Ng, RD_FIN_E) + (colsum ? gpe_cdiv(p.Mg, RD_FIN_E) : 0);
+        hipLaunchKernelGGL(gpe_redgemm_finish, dim3(fin_t), dim3(RD_FIN_E * RD_FIN_Q), 0, s, p.part, p.part_cs, gxt, p.Mg,
+                           p.Ng, p.MgPad, p.NgPad, G, ldG, colsum, accumulate);
+        GPE_CHECK_LAUNCH();
+        return GPE_OK;
+    }
     const long in_max = (p.u.inner > p.v.inner ? p.u.inner : p.v.inner) > 1 ? (p.u.inner > p.v.inner ? p.u.inner : p.v.inner) : 1;
     if (vmode == V_DENSE && g_rd_math != 1 && p.num_tiles > 0 && p.num_tiles < 64L * gx && p.rows * in_max < (1L << 32) &&
         p.rows < (1L << 31) && rd_rows_vec2(p.u, p.Mg)) {

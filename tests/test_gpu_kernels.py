@@ -258,6 +258,23 @@ def test_edge_redgemm_producer_consumer_tiles(gpe, mode, B, N, k, Mg, Ng):
     assert relerr(cs, uref.sum(0)) < 3e-6
 
 
+@pytest.mark.parametrize('rows,Mg,Ng,pitch', [(65536, 400, 3, 400), (5000, 150, 1, 152), (20001, 1000, 4, 1000),
+                                             (4099, 37, 2, 40)])
+def test_redgemm_thin(gpe, rows, Mg, Ng, pitch):
+    """Ng <= 4 (the weight gradient of a Linear on raw positions): the streaming kernel, incl. padded U pitch with
+    non-finite pad columns, a ragged row split and the V shift."""
+    ops = gpe.ops
+    g = torch.Generator().manual_seed(rows + Mg + Ng)
+    ubuf = torch.full((rows, pitch), float('nan')).cuda()
+    ubuf[:, :Mg] = torch.randn(rows, Mg, generator=g).cuda()
+    u = ubuf[:, :Mg]
+    v = torch.randn(rows, Ng, generator=g).cuda()
+    shift = torch.randn(Ng, generator=g).cuda()
+    G, cs = ops.redgemm_raw(ops._rows2d(u), ops._rows2d(v), rows, Mg, Ng, v_shift=shift)
+    assert relerr(G, u.double().t() @ (v.double() - shift.double())) < 3e-6
+    assert relerr(cs, u.double().sum(0)) < 3e-6
+
+
 def test_redgemm_two_level_rows(gpe):
     """row-poor product over [sequence][step] descriptors (the LSTM weight gradients): the deep-reduction kernel."""
     ops = gpe.ops
