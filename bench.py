@@ -127,6 +127,16 @@ def pmc_traffic(entry):
     return (b / n, 'profiles/' + os.path.basename(files[-1])) if n else (None, None)
 
 
+
+def _workload_name(args):
+    """Names the BASELINE.json configuration the arguments amount to; anything else is labelled as a custom shape."""
+    shape = (args.model, args.points, args.batch, args.k)
+    named = {('lstm', 1024, 8, 5): 'BASELINE cfg 1', ('lstm', 2048, 32, 16): 'BASELINE cfg 2 (cfg 3 per GPU)',
+             ('att', 4096, 32, 20): 'BASELINE cfg 4', ('lstm', 8192, 64, 16): 'BASELINE cfg 5 per-GPU share (fp32)'}
+    model = ('GarmentSegmentPattern3D (attention)' if args.model == 'att'
+             else 'GarmentFullPattern3D, EdgeConv encoder + LSTM decoders')
+    return '%s: %s, N=%d, batch %d/GPU, k=%d' % (named.get(shape, 'custom shape'), model, args.points, args.batch, args.k)
+
 def _cpu_name():
     try:
         with open('/proc/cpuinfo') as f:
@@ -357,10 +367,7 @@ def main():
             'value': garments / elapsed, 'unit': 'garments/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': args.math, 'data': 'synthetic',
-            'config': {'workload': ('BASELINE cfg 4: GarmentSegmentPattern3D (attention), N=%d, batch %d/GPU, k=%d'
-                                    if args.model == 'att' else
-                                    'BASELINE cfg 2: GarmentFullPattern3D, N=%d, batch %d/GPU, k=%d, EdgeConv encoder'
-                                    ' + LSTM decoders') % (args.points, args.batch, args.k),
+            'config': {'workload': _workload_name(args),
                        'global_batch': args.batch * world, 'parallelism': 'dp%d' % world,
                        'step': 'fwd + ComposedPatternLoss + bwd' + (' + RCCL grad all-reduce' if world > 1 else '')
                                + (' + Adam (torch)' if args.torch_adam else ' + fused Adam (flat arena)'),
