@@ -114,7 +114,9 @@ __device__ __forceinline__ void knn_select(bool first, float d, int lane, int ca
 // PROBE != 0 compiles the phase switches of scripts/knn_probe.py in (GPE_KNN_PROBE bits: 1 skip the selection after the
 // first tile, 2 skip the staging after the first step, 4 skip the distance arithmetic); the shipped kernels have PROBE = 0.
 // VEC = floats per staging load (host: rows and channel count are multiples of VEC floats, base pointer VEC*4-aligned).
-template <int VEC, int PROBE>
+// SMALLC (host: C <= 4): a chunk is one 4-float column group, so a thread stages ONE vector per operand tile instead of up
+// to 32 / VEC — the scalar-load variant otherwise carries 16 staging registers it never fills and spills 16 others.
+template <int VEC, int PROBE, bool SMALLC = false>
 __global__ __launch_bounds__(256, 4) void gpe_knn_kernel(const float* __restrict__ x, int N, int C, int ldx, int k,
                                                          int32_t* __restrict__ idx, int32_t* __restrict__ idx_glob, int B,
                                                          int tiles, int pin, int probe, int nsplit,
@@ -172,7 +174,7 @@ __global__ __launch_bounds__(256, 4) void gpe_knn_kernel(const float* __restrict
     const int vpr = chw / VEC;                             // staging vectors per row
     const int rvpr = (65536 + vpr - 1) / vpr;              // e / vpr == (e * rvpr) >> 16 for e < 2048
     const int nvec = KNN_TC * vpr;                         // vectors per operand tile (<= 2048 / VEC)
-    constexpr int NPF = (KNN_TC * KNN_CCH) / (256 * VEC);
+    constexpr int NPF = SMALLC ? 1 : (KNN_TC * KNN_CCH) / (256 * VEC);
     float pre_c[NPF][VEC], pre_q[NPF][VEC];
     int pf_c0 = c_first, pf_ch = 0;                        // tile / chunk the NEXT prefetch loads
     auto prefetch = [&]() {
@@ -355,6 +357,9 @@ static void knn_launch(long nblocks, size_t lds, hipStream_t s, int probe, const
     if (probe)
         hipLaunchKernelGGL((gpe_knn_kernel<VEC, 1>), dim3((unsigned)nblocks), dim3(256), lds, s, x, N, C, ldx, k, idx, idx_glob, B,
                            tiles, pin, probe, nsplit, part);
+    else if (VEC == 1 && C <= 4)
+        hipLaunchKernelGGL((gpe_knn_kernel<1, 0, true>), dim3((unsigned)nblocks), dim3(256), lds, s, x, N, C, ldx, k, idx, idx_glob,
+                           B, tiles, pin, 0, nsplit, part);
     else
         hipLaunchKernelGGL((gpe_knn_kernel<VEC, 0>), dim3((unsigned)nblocks), dim3(256), lds, s, x, N, C, ldx, k, idx, idx_glob, B,
                            tiles, pin, 0, nsplit, part);
