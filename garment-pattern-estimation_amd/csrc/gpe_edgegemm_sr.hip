@@ -101,6 +101,7 @@ __global__ __launch_bounds__(256, 1) void gpe_edgegemm_sr_kernel(RgParams p, int
                                                          // share of tile t is t*PT + wave*npw — no per-tile division
     const int c = lane << 2;                             // this lane's column quad
     const bool k_on = c < p.K, n_on = c < p.N;
+    const bool track_agg = p.agg != 0;                   // wave-uniform
     const int ck = k_on ? c : 0, cn = n_on ? c : 0;      // clamped quads for the unconditional loads
 
     for (int e = tid; e < 2 * RG_BM * LDA; e += 256) smem[e] = 0.f;
@@ -279,8 +280,16 @@ __global__ __launch_bounds__(256, 1) void gpe_edgegemm_sr_kernel(RgParams p, int
                 for (int t = 0; t < 4; ++t) {
                     s32[t] += vv[t];
                     q32[t] = __builtin_fmaf(vv[t], vv[t], q32[t]);
-                    if (vv[t] > vmx[t]) { vmx[t] = vv[t]; imx[t] = slot; }
-                    if (vv[t] < vmn[t]) { vmn[t] = vv[t]; imn[t] = slot; }
+                }
+                // per-point max / min / argmax / argmin only where the block is aggregated (the last layer of an EdgeConv
+                // MLP): 6 VALU instructions per element — a fifth of a tile's non-MFMA instructions — that the inner
+                // layers never store (uniform branch)
+                if (track_agg) {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        if (vv[t] > vmx[t]) { vmx[t] = vv[t]; imx[t] = slot; }
+                        if (vv[t] < vmn[t]) { vmn[t] = vv[t]; imn[t] = slot; }
+                    }
                 }
             } else {
                 float4 av = act[u];
