@@ -206,3 +206,19 @@ def test_configs_equal_shipped_yamls():
         for k, v in configs.data_config().items():
             if k in y['dataset'] and k != 'max_pattern_len':
                 assert y['dataset'][k] == v, k
+
+
+def test_bench_workload_names():
+    """bench.py labels the BASELINE.json configuration its arguments amount to, and nothing else as one."""
+    import importlib.util
+    import types
+    spec = importlib.util.spec_from_file_location('bench_mod', os.path.join(os.path.dirname(os.path.dirname(__file__)), 'bench.py'))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    mk = lambda m, n, b, k: types.SimpleNamespace(model=m, points=n, batch=b, k=k)
+    assert bench._workload_name(mk('lstm', 2048, 32, 16)).startswith('BASELINE cfg 2')
+    assert bench._workload_name(mk('lstm', 1024, 8, 5)).startswith('BASELINE cfg 1')
+    assert bench._workload_name(mk('att', 4096, 32, 20)).startswith('BASELINE cfg 4')
+    assert bench._workload_name(mk('lstm', 8192, 64, 16)).startswith('BASELINE cfg 5')
+    assert bench._workload_name(mk('lstm', 1000, 3, 10)).startswith('custom shape')
+    assert 'N=1000, batch 3/GPU, k=10' in bench._workload_name(mk('lstm', 1000, 3, 10))
