@@ -140,6 +140,11 @@ class DynamicEdgeConv(nn.Module):
         self.aggr = aggr
         self.last_knn = None      # local indices used by the last forward (for stage-wise parity)
         self.knn_override = None  # inject a graph (LongTensor [B*N,k], local) instead of searching
+        # inject the winners of the max aggregation: (argmax, argmin) slots of the pre-BatchNorm activation, LongTensors
+        # [B*N, F] — the same role as knn_override at the other discontinuity of the layer (tests/relu_align.py).
+        # `argsel_gap` then holds the largest distance between the true maximum and the injected winner's message.
+        self.argsel_override = None
+        self.argsel_gap = 0.0
 
     def forward(self, x, batch):
         total = x.shape[0]
@@ -156,6 +161,13 @@ class DynamicEdgeConv(nn.Module):
         msg = self.nn(torch.cat([x_i, x_j - x_i], dim=-1).reshape(total * self.k, -1))
         msg = msg.view(total, self.k, -1)
         if self.aggr == 'max':
+            if self.argsel_override is not None:
+                amx, amn = self.argsel_override
+                gamma = self.nn[-1][2].weight.detach()           # BN after ReLU: max_j(s a_j + t) = s (s >= 0 ? max : min) a + t
+                sel = torch.where(gamma >= 0, amx, amn)
+                out = msg.gather(1, sel[:, None, :]).squeeze(1)
+                self.argsel_gap = (msg.max(dim=1).values - out).abs().max().item()
+                return out
             return msg.max(dim=1).values
         if self.aggr == 'mean':
             return msg.mean(dim=1)
