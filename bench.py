@@ -34,6 +34,7 @@ import torch  # noqa: E402
 
 PEAK_F32_TFLOPS = 157.3     # MI355X fp32 vector = fp32-input MFMA peak (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0
+PEAK_L2_GBS = 34500.0        # aggregate of the eight 4 MiB XCD L2s (MI355X_MICROARCH.md, 'L2 (per XCD)')
 
 
 def parse():
@@ -112,13 +113,32 @@ _TRAFFIC_KERNELS = {
 }
 
 
+def csrc_sha():
+    """sha1 over the kernel sources (csrc/*.hip, *.h): a PMC summary is only quoted for the code that produced it."""
+    import hashlib
+    d = os.path.join(REPO, 'garment-pattern-estimation_amd', 'csrc')
+    h = hashlib.sha1()
+    for f in sorted(os.listdir(d)):
+        if f.endswith(('.hip', '.h')):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), 'rb').read())
+    return h.hexdigest()[:16]
+
+
 def pmc_traffic(entry):
+    """HBM bytes per launch of the kernels behind a C-ABI entry, from the newest profiles/*_hbm_traffic.json — but only if
+    that file records the csrc hash of THIS tree (profiles/summarize_pmc.py writes it); a summary made from other kernel
+    sources is refused (traffic = null, the reason in traffic_source)."""
     import glob
     import re
-    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', '*_hbm_traffic.json')))
+    files = sorted(glob.glob(os.path.join(REPO, 'profiles', '*_hbm_traffic.json')))
     if not files or entry not in _TRAFFIC_KERNELS:
         return None, None
-    kern = json.load(open(files[-1]))['kernels']
+    doc = json.load(open(files[-1]))
+    if doc.get('csrc_sha') != csrc_sha():
+        return None, 'refused: profiles/%s was measured on csrc %s, this tree is %s' % (
+            os.path.basename(files[-1]), doc.get('csrc_sha'), csrc_sha())
+    kern = doc['kernels']
     n = b = 0.0
     for name, v in kern.items():
         if re.search(_TRAFFIC_KERNELS[entry], name):
@@ -170,13 +190,19 @@ def cpu_baseline(args, data_config, nn_cfg):
             times.append(time.perf_counter() - t0)
         return sum(times[1:]) / len(times[1:])
 
-    # Thread count: torch's intra-op pool does not scale to this host's core count on this op mix.  Measured on the GPU box
-    # (profiles/r02_b_bench.json, AMD EPYC 9575F, nproc = 256): B=2 step 0.77 s at 32 threads vs 91.7 s at 256 threads.  The
-    # baseline therefore runs at min(32, nproc) threads — the fastest configuration found — and reports nproc next to it;
-    # --cpu-threads overrides.
+    # Thread count: torch's intra-op pool does not scale to a 256-thread host on this op mix, so the baseline picks its
+    # thread count by MEASUREMENT inside this run: one timed step of a small sample (B=2 at the benchmarked N, k) at
+    # 16 / 32 / 64 threads (and nproc, under a time cap), then runs the baseline at the fastest.  --cpu-threads overrides.
     nproc = os.cpu_count() or 1
-    probe = {'32': 0.767, '256': 91.7, 'source': 'profiles/r02_b_bench.json (B=2, N=2048, k=16, s/step)'}
-    ncores = args.cpu_threads if args.cpu_threads > 0 else min(32, nproc)
+    probe = {}
+    if args.cpu_threads > 0:
+        ncores = args.cpu_threads
+    else:
+        for nt in sorted({min(n, nproc) for n in (16, 32, 64)}):
+            torch.set_num_threads(nt)
+            probe[str(nt)] = round(timed(2, args.points, args.k, 1), 3)
+        ncores = int(min(probe, key=probe.get))
+        probe['note'] = 's/step of a B=2 sample at N=%d, k=%d (1 warm-up + 1 timed), measured in this run' % (args.points, args.k)
     torch.set_num_threads(ncores)
     t2 = timed(args.cpu_batch, args.points, args.k, args.cpu_steps)
     t1 = timed(8, 1024, 5, max(args.cpu_steps, 5))          # BASELINE cfg 1: the reference's own CPU-runnable case
@@ -188,7 +214,7 @@ def cpu_baseline(args, data_config, nn_cfg):
                      'sample': 'BASELINE cfg 1 (N=1024, B=8, k=5), 1 warm-up + %d timed steps, %.3f s/step'
                                % (max(args.cpu_steps, 5), t1)},
             'cpu': _cpu_name(), 'nproc': nproc,
-            'thread_scaling_note': probe}
+            'thread_probe': probe}
 
 
 def main():
@@ -304,18 +330,29 @@ def main():
         roof_gather = {'definition': 'bytes_gather(layer) = N*k*(C_in*s+4) + N*C_in*s + N*F*s per garment (SURVEY.md 8d), '
                                      'x batch; layer 1 C_in=3, layer 2 C_in=%d; s=4' % F,
                        'bytes_layer1': bytes_gather(3), 'bytes_layer2': bytes_gather(F), 'peak': PEAK_HBM_GBS,
-                       'unit': 'GB/s'}
+                       'peak_l2': PEAK_L2_GBS, 'unit': 'GB/s', 'bound': 'hbm'}
         if 'gpe_edge_gather_stats' in agg:
+            # The stand-alone gather + BN-statistics pass is the only kernel whose time IS the gather.  Two honest roofs:
+            #   HBM side: counter bytes (FETCH+WRITE of the committed PMC pass of THIS csrc) / time / 8 TB/s
+            #   L2 side : algorithmic k-fold bytes (what the gather touches, served by the XCD L2s) / time / 34.5 TB/s
             n_l, ms, _, by = agg['gpe_edge_gather_stats']
-            ach = by / (ms * 1e-3) / 1e9
+            t = ms * 1e-3 / n_l
+            traffic, tsrc = pmc_traffic('gpe_edge_gather_stats')
+            l2_rate = by / n_l / t / 1e9
+            hbm_rate = traffic / t / 1e9 if traffic else None
             roof_gather['stats_pass'] = {
                 'kernel': 'gpe_edge_gather_stats (k-fold neighbour gather of the [P|Q] rows + fp64 BN statistics)',
-                'bound': 'hbm', 'algorithmic_bytes_per_launch': by / n_l, 'avg_launch_ms': ms / n_l,
-                'achieved': ach, 'frac': ach / PEAK_HBM_GBS,
-                'traffic': pmc_traffic('gpe_edge_gather_stats')[0],
-                'note': 'algorithmic bytes = N*k*(H*4+4) + N*H*4 per garment: what the gather touches; the Q table of a '
-                        'cloud is L2-resident by design, so achieved > HBM peak means the gather is served by L2 and the '
-                        'counter bytes (traffic) are the HBM side'}
+                'algorithmic_bytes_per_launch': by / n_l, 'avg_launch_ms': ms / n_l,
+                'l2_achieved': l2_rate, 'l2_frac': l2_rate / PEAK_L2_GBS,
+                'traffic': traffic, 'traffic_source': tsrc,
+                'hbm_achieved': hbm_rate, 'hbm_frac': hbm_rate / PEAK_HBM_GBS if hbm_rate else None,
+                'note': 'the Q table of a cloud is pinned to one XCD L2, so the k-fold gather is an L2 workload: l2_frac prices '
+                        'the algorithmic bytes against the L2 aggregate, hbm_frac the counter bytes against HBM.  Neither '
+                        'reaches 0.6: north_star\'s ">= 60 % of HBM roofline on the gather" is NOT met by this pass '
+                        '(0.1 ms of the step); the gather that matters is fused into the MFMA-bound forward below'}
+            roof_gather['achieved'] = hbm_rate
+            roof_gather['frac'] = roof_gather['stats_pass']['hbm_frac']
+            roof_gather['traffic'] = traffic
         # the kernel that carries the layer-2 gather into the matrix pipe (gather -> GEMM -> ReLU -> stats, fused)
         gl = [(ints, e0.elapsed_time(e1)) for name, ints, e0, e1 in rec if name == 'gpe_edge_mlp_fwd' and ints[0] == 0]
         if gl:
@@ -325,10 +362,6 @@ def main():
                 'kernel': 'gpe_edge_mlp_fwd a_mode=0 (gather -> LDS tile -> fp32 MFMA): MFMA-bound, the gather hides under '
                           'the matrix pipe', 'bound': 'mfma', 'gather_bytes_per_launch': by, 'avg_launch_ms': ms,
                 'gather_rate_GBs': by / (ms * 1e-3) / 1e9, 'traffic': pmc_traffic('gpe_edge_mlp_fwd:gather')[0]}
-        roof_gather['frac'] = roof_gather.get('stats_pass', {}).get('frac')
-        roof_gather['achieved'] = roof_gather.get('stats_pass', {}).get('achieved')
-        roof_gather['traffic'] = roof_gather.get('stats_pass', {}).get('traffic')
-        roof_gather['bound'] = 'hbm'
 
     # the opt-in fast mode, measured the same way on the same workload (reported beside `value`, never as `value`)
     fast = None
@@ -356,6 +389,12 @@ def main():
                           'ms_per_step': dt / n_f * 1e3, 'note': note}
         gpe_amd.set_math('f32')
 
+    # ---- the exchange step, for N > 1: what RCCL saw and what it costs -------------------------------------------------
+    exchange = None
+    if world > 1:
+        exchange = wrapped.measure_exchange(iters=10)      # every rank participates; rank 0 reports
+        exchange['exposed_ms_per_step'] = wrapped.exposed_ms()
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args, data_config, nn_cfg) if args.model == 'lstm' else None
@@ -373,6 +412,9 @@ def main():
                                + (' + Adam (torch)' if args.torch_adam else ' + fused Adam (flat arena)'),
                        'final_loss': final_loss},
             'roofline': roof, 'roofline_gather': roof_gather, 'cpu_baseline': cpu, 'fast_math': fast,
+            'dist_world': (torch.distributed.get_world_size() if world > 1 else 1),
+            'allreduce_ms_per_step': exchange and exchange['ms_per_step'],
+            'allreduce_bytes': exchange and exchange['bytes_per_step'], 'exchange': exchange,
             'kernel_ms_per_step': breakdown}
         print(json.dumps(out))
     if world > 1:

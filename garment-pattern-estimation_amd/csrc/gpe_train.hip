@@ -320,6 +320,28 @@ __global__ __launch_bounds__(256) void gpe_order_match_kernel(const float* __res
     int bad = 0;
     for (int e = tid; e < P * P; e += 256) bad |= isfinite(dm[e]) ? 1 : 0;
     if (bad) fail[0] = 1;
+    // Degenerate input (NaN / inf predictions: every distance +inf, the rounds above keep hitting entry 0): rows would stay
+    // at -1 and the gathers that consume `perm` would index out of bounds (a device-side assert that poisons the context,
+    // where the reference raises a clean ValueError).  Keep the output in bounds — unmatched rows take the unused columns
+    // in ascending order — and report the failure through `fail` (thread 0 wrote every perm entry itself).
+    if (tid == 0) {
+        unsigned long long used = 0ull;
+        bool open_rows = false;
+        for (int r = 0; r < P; ++r) {
+            const int64_t c = perm[(size_t)b * P + r];
+            if (c >= 0) used |= 1ull << c; else open_rows = true;
+        }
+        if (open_rows) {
+            fail[0] = 1;
+            int c = 0;
+            for (int r = 0; r < P; ++r) {
+                if (perm[(size_t)b * P + r] >= 0) continue;
+                while (c < P - 1 && ((used >> c) & 1ull)) ++c;
+                perm[(size_t)b * P + r] = c;
+                used |= 1ull << c;
+            }
+        }
+    }
 }
 
 extern "C" int gpe_order_match(const float* pred_feat, const float* gt_feat, int B, int P, int D, int64_t* perm,

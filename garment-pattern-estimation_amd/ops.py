@@ -14,6 +14,8 @@ Two per-model services live here as well (both optional; without them every Func
                 straight into the arena's gradient buffer (no per-parameter tensors, no cat/copy for the all-reduce
                 buckets, one fused Adam launch).
 """
+import weakref
+
 import numpy as np
 import torch
 
@@ -49,7 +51,7 @@ def round_up(a, b):
 # PackPlan: weight-derived operands refreshed by one launch
 # -------------------------------------------------------------------------------------------------
 WEIGHTS_EPOCH = 0          # bumped by optimizers that update parameters through raw pointers (optim.FusedAdam)
-_PACKS = {}                # (param data_ptr, kind) -> (plan, output tensor)
+_PACKS = {}                # (param data_ptr, kind) -> (plan, output tensor); a plan's entries die with the plan (weakref.finalize)
 
 K_PLAIN, K_TRANS, K_GATES, K_PQ, K_PQT, K_VADD, K_BPQ, K_GRUB = 0, 1, 2, 3, 4, 5, 6, 7
 _JOB = np.dtype([('w', '<u8'), ('w2', '<u8'), ('out', '<u8'), ('total', '<i8'), ('first_block', '<i8'),
@@ -76,6 +78,8 @@ class PackPlan:
         self.epoch = -1
         self.home = None
         self.keys = []
+        self._keys_box = box = []              # shared with the finalizer: the keys this plan currently owns in _PACKS
+        weakref.finalize(self, lambda: [_PACKS.pop(k, None) for k in box])
 
     def _add(self, p, kind, N, K, aux=0, p2=None, out_numel=None):
         self.specs.append((p, p2, kind, N, K, aux, out_numel))
@@ -111,6 +115,7 @@ class PackPlan:
         for k in self.keys:
             _PACKS.pop(k, None)
         self.keys, self.outs = [], []
+        del self._keys_box[:]
         dev = self.specs[0][0].device
         tab = np.zeros(len(self.specs), dtype=_JOB)
         blk = 0
@@ -129,20 +134,25 @@ class PackPlan:
                       p.stride(0) if p.dim() == 2 else 0, N, K, kind, npad, aux)
             blk += (total + 1023) // 1024            # gpe_pack_multi_kernel: 256 threads x one output quad
             key = (p.data_ptr(), kind)
-            _PACKS[key] = (self, out, i)
+            _PACKS[key] = (weakref.ref(self), out, i)
             self.keys.append(key)
+            self._keys_box.append(key)
         self.blocks = blk
         self.table = torch.from_numpy(tab.view(np.uint8).copy()).to(dev)
-        self.home = (self.specs[0][0].data_ptr(), dev)
+        self.home = self._home()
+
+    def _home(self):
+        """where every source parameter lives right now: the job table holds raw pointers, so ANY parameter that moved
+        (a partial re-homing, `p.data = ...` on a subset) must rebuild it"""
+        return tuple((p.data_ptr(), p2.data_ptr() if p2 is not None else 0, p.device) for p, p2, *_ in self.specs)
 
     def refresh(self):
         """Called at the start of a model forward: one gpe_pack_multi launch if any parameter changed since the last."""
         if not self.specs:
             return
         vers = self._versions()
-        first = self.specs[0][0]
-        if self.table is None or self.home != (first.data_ptr(), first.device):
-            self._build()                      # first use, or the parameters moved (.to(device), arena re-homing)
+        if self.table is None or self.home != self._home():
+            self._build()                      # first use, or a parameter moved (.to(device), arena re-homing)
         elif self.vers == vers and self.epoch == WEIGHTS_EPOCH:
             return
         L.call('gpe_pack_multi', self.table, len(self.specs), self.blocks)
@@ -155,7 +165,8 @@ def _planned(t, kind, t2=None):
     if hit is None:
         return None
     plan, out, i = hit
-    if plan.vers is None or plan.epoch != WEIGHTS_EPOCH:
+    plan = plan()
+    if plan is None or plan.vers is None or plan.epoch != WEIGHTS_EPOCH:
         return None
     if plan.vers[i] != t._version + (t2._version if t2 is not None else 0):
         return None
@@ -165,13 +176,13 @@ def _planned(t, kind, t2=None):
 # -------------------------------------------------------------------------------------------------
 # gradient sink (optim.FlatArena): weight gradients are written straight into the arena
 # -------------------------------------------------------------------------------------------------
-_SINK = {}                 # param data_ptr -> (arena, flat gradient view shaped like the parameter)
+_SINK = {}                 # param data_ptr -> (weakref to the arena, flat gradient view shaped like the parameter)
 
 
 def _gbuf(param, shape=None):
     """Output buffer for the gradient of `param`: the arena view if the parameter is registered, else a new tensor."""
     hit = _SINK.get(param.data_ptr())
-    if hit is not None:
+    if hit is not None and hit[0]() is not None:
         return hit[1]
     return torch.empty(param.shape if shape is None else shape, device=param.device, dtype=F32)
 
@@ -180,9 +191,10 @@ def _gret(param, buf):
     """What backward returns for `param`: None when the gradient already sits in the arena (and the arena is told, so that
     a gradient bucket can leave for the all-reduce), else the tensor itself."""
     hit = _SINK.get(param.data_ptr())
-    if hit is None:
+    arena = hit[0]() if hit is not None else None
+    if arena is None:
         return buf
-    hit[0].mark_written(param)
+    arena.mark_written(param)
     return None
 
 

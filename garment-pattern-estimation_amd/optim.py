@@ -49,6 +49,12 @@ class FlatArena:
         self.index = {p.data_ptr(): i for i, p in enumerate(self.params)}
         self.listeners = []            # callables(param index) run when a gradient has been written by a kernel
         self.written = set()
+        # parameters that received a gradient since the last optimizer step, through either route (kernel-written:
+        # mark_written; autograd-accumulated: the hook below).  FusedAdam skips the others, like torch.optim.Adam skips
+        # parameters whose .grad is None.
+        self.touched = set()
+        for i, p in enumerate(self.params):
+            p.register_post_accumulate_grad_hook(lambda _p, i=i: self.touched.add(i))
         self.is_sink = False
         if register_sink and dev.type == 'cuda':
             self.register_sink()
@@ -56,8 +62,13 @@ class FlatArena:
 
     # ---- gradient sink protocol (ops._gbuf / ops._gret) ---------------------------------------------------
     def register_sink(self):
-        for p in self.params:
-            ops._SINK[p.data_ptr()] = (self, p.grad)
+        import weakref
+        me = weakref.ref(self)
+        keys = [p.data_ptr() for p in self.params]
+        for k, p in zip(keys, self.params):
+            ops._SINK[k] = (me, p.grad)
+        # the registry must not keep a dead model's arena (2 x 11 MB) alive, nor answer for recycled addresses
+        weakref.finalize(self, lambda: [ops._SINK.pop(k, None) for k in keys if (ops._SINK.get(k) or (None,))[0] is me])
         self.is_sink = True
 
     def unregister_sink(self):
@@ -68,16 +79,19 @@ class FlatArena:
     def mark_written(self, param):
         i = self.index[param.data_ptr()]
         if i in self.written:
-            raise RuntimeError('FlatArena: a second gradient for the same parameter in one backward pass — the in-place '
-                               'gradient sink needs every parameter to be used once per step (unregister_sink() for '
-                               'weight sharing / gradient accumulation)')
+            raise RuntimeError('FlatArena: a second gradient for the same parameter since the last begin_step() — either the '
+                               'optimizer step was not taken through FusedAdam.step() / arena.zero_grad() (torch optimizers: '
+                               'call arena.zero_grad() instead of optimizer.zero_grad()), or a parameter is used twice per '
+                               'step (weight sharing / gradient accumulation: unregister_sink())')
         self.written.add(i)
+        self.touched.add(i)
         for fn in self.listeners:
             fn(i)
 
     def begin_step(self):
         """Forget which gradients were written (call after the optimizer consumed them)."""
         self.written.clear()
+        self.touched.clear()
 
     def zero_grad(self):
         self.grad.zero_()
@@ -102,6 +116,26 @@ class OneCycle:
     @staticmethod
     def _cos(start, end, pct):
         return end + (start - end) / 2.0 * (math.cos(math.pi * pct) + 1)
+
+    def state_dict(self):
+        """What a resumed run needs (FusedAdam owns the step counter): the schedule's shape."""
+        return {'max_lr': self.max_lr, 'total_steps': self.total, 'initial_lr': self.initial, 'min_lr': self.min_lr,
+                'end1': self.end1, 'end2': self.end2}
+
+    def load_state_dict(self, sd):
+        """Accepts this class's own dict, or torch's OneCycleLR.state_dict() (nn/trainer.py:283 saves that one): of the
+        latter `total_steps` and, through `_schedule_phases`, the phase boundaries and rates are taken; `last_epoch`
+        (the step counter) is returned so that the caller can hand it to FusedAdam."""
+        if 'total_steps' in sd and 'max_lr' in sd:
+            self.max_lr, self.total = float(sd['max_lr']), int(sd['total_steps'])
+            self.initial, self.min_lr = float(sd['initial_lr']), float(sd['min_lr'])
+            self.end1, self.end2 = float(sd['end1']), float(sd['end2'])
+            return None
+        self.total = int(sd['total_steps'])
+        ph = sd.get('_schedule_phases')
+        if ph:
+            self.end1, self.end2 = float(ph[0]['end_step']), float(ph[1]['end_step'])
+        return sd.get('last_epoch')
 
     def lr(self, step):
         """learning rate used BY optimizer step number `step` (0-based: step 0 runs at the initial rate)."""
@@ -135,8 +169,28 @@ class FusedAdam:
         a = self.arena
         lr = self.lr if self.schedule is None else self.schedule.lr(self.t)
         self.t += 1
-        L.call('gpe_adam_step', a.flat, a.grad, self.m, self.v, a.numel, float(lr), float(self.betas[0]),
-               float(self.betas[1]), self.eps, self.weight_decay, self.t, float(grad_scale), 1)
+        # torch.optim.Adam leaves a parameter alone in a step in which it received no gradient (grad None): no moment decay,
+        # no weight decay, no move.  Same here: the launch covers the maximal runs of arena segments that were touched
+        # (normally ONE run = the whole arena; the attention model's unused feature_extractor.lin splits it in two).
+        # Nothing recorded at all (gradients written by hand into arena.grad) = everything is live.
+        runs = [(0, a.numel)]
+        if a.touched and len(a.touched) < len(a.params):
+            runs, start = [], None
+            for i in range(len(a.params)):
+                if i in a.touched:
+                    if start is None:
+                        start = a.offsets[i]
+                    end = a.offsets[i] + (a.params[i].numel() + 3) // 4 * 4
+                elif start is not None:
+                    runs.append((start, end))
+                    start = None
+            if start is not None:
+                runs.append((start, end))
+        for lo, hi in runs:
+            L.call('gpe_adam_step', a.flat[lo:hi], a.grad[lo:hi], self.m[lo:hi], self.v[lo:hi], hi - lo, float(lr),
+                   float(self.betas[0]), float(self.betas[1]), self.eps, self.weight_decay, self.t, float(grad_scale), 1)
+        if len(runs) != 1 or runs[0] != (0, a.numel):
+            a.grad.zero_()             # untouched segments may still hold stale values written by hand
         self.last_lr = lr
         a.begin_step()
         ops.bump_weights_epoch()       # parameters changed through raw pointers: torch's version counters did not move
@@ -145,11 +199,71 @@ class FusedAdam:
         """Gradients are cleared inside step(); this only exists for trainer loops that call it unconditionally."""
         self.arena.begin_step()
 
+    # ---- checkpoints: torch.optim.Adam's format (nn/trainer.py:281-285 saves optimizer.state_dict(), _restore_run loads it) ----
+    def _module_order(self):
+        """arena index of the i-th parameter in `[p for p in module.parameters() if p.requires_grad]` order — the order
+        torch.optim.Adam(model.parameters()) numbers its state by (the arena stores the reverse)."""
+        n = len(self.arena.params)
+        return [n - 1 - i for i in range(n)]
+
     def state_dict(self):
-        return {'t': self.t, 'm': self.m.clone(), 'v': self.v.clone(), 'lr': self.lr, 'betas': self.betas,
-                'eps': self.eps, 'weight_decay': self.weight_decay}
+        """torch.optim.Adam.state_dict() layout: state[i] = {step, exp_avg, exp_avg_sq} per parameter (index = position in
+        model.parameters()), param_groups[0] with the hyper-parameters.  A checkpoint written here loads into
+        torch.optim.Adam over the same model and vice versa."""
+        a = self.arena
+        state = {}
+        for i, ai in enumerate(self._module_order()):
+            o, n = a.segment(ai)
+            shape = a.params[ai].shape
+            state[i] = {'step': torch.tensor(float(self.t)),
+                        'exp_avg': self.m[o:o + n].view(shape).clone(),
+                        'exp_avg_sq': self.v[o:o + n].view(shape).clone()}
+        group = {'lr': self.last_lr if self.schedule is not None else self.lr, 'betas': tuple(self.betas), 'eps': self.eps,
+                 'weight_decay': self.weight_decay, 'amsgrad': False, 'maximize': False, 'foreach': None,
+                 'capturable': False, 'differentiable': False, 'fused': None, 'decoupled_weight_decay': False,
+                 'params': list(range(len(a.params)))}
+        if self.schedule is not None:
+            group['initial_lr'] = self.schedule.initial
+        return {'state': state, 'param_groups': [group]}
 
     def load_state_dict(self, sd):
-        self.t = sd['t']
-        self.m.copy_(sd['m'])
-        self.v.copy_(sd['v'])
+        """Loads torch.optim.Adam's layout (this class's own output, or a checkpoint of the reference trainer).  Validates the
+        parameter count and every shape; parameters without an entry (torch keeps none for a parameter that never received
+        a gradient) start from zero moments.  Hyper-parameters come from param_groups[0]."""
+        a = self.arena
+        if 't' in sd and 'm' in sd:                    # round-2 private format: flat buffers in arena order
+            if sd['m'].numel() != self.m.numel():
+                raise ValueError('FusedAdam: flat moment buffer of %d elements does not fit this arena (%d)'
+                                 % (sd['m'].numel(), self.m.numel()))
+            self.t = int(sd['t'])
+            self.m.copy_(sd['m'])
+            self.v.copy_(sd['v'])
+            return
+        groups = sd['param_groups']
+        if len(groups) != 1:
+            raise ValueError('FusedAdam: expected ONE param group (nn/trainer.py:172 builds one), got %d' % len(groups))
+        g = groups[0]
+        if len(g['params']) != len(a.params):
+            raise ValueError('FusedAdam: checkpoint has %d parameters, the model %d' % (len(g['params']), len(a.params)))
+        if g.get('amsgrad') or g.get('maximize'):
+            raise ValueError('FusedAdam: amsgrad / maximize checkpoints are not supported')
+        order = self._module_order()
+        self.m.zero_()
+        self.v.zero_()
+        t = 0
+        for key, st in sd['state'].items():
+            i = g['params'].index(key) if key in g['params'] else int(key)
+            ai = order[i]
+            o, n = a.segment(ai)
+            shape = a.params[ai].shape
+            for name, dst in (('exp_avg', self.m), ('exp_avg_sq', self.v)):
+                if tuple(st[name].shape) != tuple(shape):
+                    raise ValueError('FusedAdam: %s of parameter %d has shape %s, the model\'s is %s'
+                                     % (name, i, tuple(st[name].shape), tuple(shape)))
+                dst[o:o + n].copy_(st[name].reshape(-1))
+            t = max(t, int(float(st['step'])))
+        self.t = t
+        self.lr = float(g['lr']) if self.schedule is None else self.lr
+        self.betas = tuple(float(b) for b in g['betas'])
+        self.eps, self.weight_decay = float(g['eps']), float(g['weight_decay'])
+        self.last_lr = float(g['lr'])

@@ -50,10 +50,48 @@ class DistributedHotPath(nn.Module):
             a.listeners.append(self._on_written)
             for i, p in enumerate(a.params):
                 p.register_post_accumulate_grad_hook(lambda _p, i=i: self._on_hook(_p, i))
+        self._exposed = []
         self._reset()
 
     def forward(self, *args, **kwargs):
         return self.module(*args, **kwargs)
+
+    def measure_exchange(self, iters=10):
+        """The exchange step on its own (collective on every rank): all buckets all-reduced back to back on a scratch copy
+        of the gradient arena, `iters` times between two synchronisations.  -> {dist_world (what the process group
+        reports), backend, buckets, bytes_per_step, ms_per_step}.  bench.py prints it so that a reader can check that RCCL
+        really connected N ranks and what the un-overlapped exchange costs; the step itself overlaps it with backward."""
+        import time
+        scratch = torch.zeros_like(self.arena.grad)
+        sync = torch.cuda.synchronize if scratch.is_cuda else (lambda: None)
+        nbytes = sum((hi - lo) * scratch.element_size() for _, _, lo, hi in self._buckets)
+        out = {'dist_world': self.world, 'backend': dist.get_backend(self.group) if dist.is_initialized() else None,
+               'buckets': len(self._buckets), 'bytes_per_step': nbytes, 'ms_per_step': 0.0}
+        if self.world == 1:
+            return out
+        for it in range(iters + 2):
+            if it == 2:
+                dist.barrier(group=self.group)
+                sync()
+                t0 = time.perf_counter()
+            works = [dist.all_reduce(scratch[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                     for _, _, lo, hi in self._buckets]
+            for w in works:
+                w.wait()
+        sync()
+        out['ms_per_step'] = (time.perf_counter() - t0) / iters * 1e3
+        return out
+
+    def exposed_ms(self):
+        """Mean time finish_gradient_sync() spent between the end of backward and the arrival of the last bucket (event
+        pair on the compute stream around the waits), over the steps since construction: the part of the exchange that
+        backward did NOT hide."""
+        if not self._exposed:
+            return None
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+        ms = [a.elapsed_time(b) if not isinstance(a, float) else (b - a) * 1e3 for a, b in self._exposed]
+        return sum(ms) / len(ms)
 
     def _reset(self):
         self._pending = [e - s for s, e, _, _ in self._buckets]
@@ -94,8 +132,22 @@ class DistributedHotPath(nn.Module):
             for bi in range(len(self._buckets)):
                 if bi not in self._launched:
                     self._launch(bi)
+            cuda = self.arena.grad.is_cuda
+            if cuda:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            else:
+                import time
+                e0 = time.perf_counter()
             for work in self._inflight:
                 work.wait()
+            if cuda:
+                e1.record()
+            else:
+                e1 = time.perf_counter()
+            self._exposed.append((e0, e1))
+            if len(self._exposed) > 64:
+                del self._exposed[0]
         self._reset()
 
 

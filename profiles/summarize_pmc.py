@@ -35,5 +35,18 @@ for name in sorted(set(fetch) | set(write)):
     fb = 2.0 * 1024.0 * kf / max(nf, 1)
     wb = 1024.0 * kw / max(nw, 1)
     out[name] = {'launches': max(nf, nw), 'fetch_bytes': fb, 'write_bytes': wb, 'hbm_bytes': fb + wb}
-json.dump({'source': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), reads x2 (gfx950 correction), per launch',
+def csrc_sha():
+    """sha1 over the kernel sources of this tree (same definition as bench.py csrc_sha): bench.py quotes a traffic file only
+    for the code that produced it."""
+    import hashlib
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'garment-pattern-estimation_amd', 'csrc')
+    h = hashlib.sha1()
+    for f in sorted(os.listdir(d)):
+        if f.endswith(('.hip', '.h')):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), 'rb').read())
+    return h.hexdigest()[:16]
+
+
+json.dump({'csrc_sha': csrc_sha(), 'source': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), reads x2 (gfx950 correction), per launch',
            'kernels': out}, sys.stdout, indent=1)

@@ -715,6 +715,107 @@ def test_fused_adam_onecycle_vs_torch(gpe):
         assert relerr(p, q) < 1e-5
 
 
+def test_fused_adam_checkpoint_exchanges_with_torch_adam(gpe):
+    """nn/trainer.py:281-285 saves optimizer.state_dict() and _restore_run loads it: FusedAdam speaks torch.optim.Adam's
+    format in both directions — a run stepped by torch Adam continues under FusedAdam and vice versa, to fp32 round-off."""
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(21, 30), torch.nn.Tanh(), torch.nn.Linear(30, 5)).cuda()
+    twin = copy.deepcopy(net)
+    g = torch.Generator().manual_seed(2)
+    xs = [torch.randn(8, 21, generator=g).cuda() for _ in range(6)]
+    topt = torch.optim.Adam(twin.parameters(), lr=3e-3, weight_decay=1e-4)
+    for x in xs[:3]:                                           # three steps under torch Adam ...
+        topt.zero_grad()
+        twin(x).square().mean().backward()
+        topt.step()
+    net.load_state_dict(twin.state_dict())
+    opt = gpe.optim.FusedAdam(net, lr=1.0, weight_decay=0.5)   # wrong hyper-parameters on purpose: the checkpoint's win
+    opt.load_state_dict(topt.state_dict())
+    assert opt.t == 3 and opt.lr == 3e-3 and opt.weight_decay == 1e-4
+    for x in xs[3:]:                                           # ... three more under FusedAdam and under torch
+        net(x).square().mean().backward()
+        opt.step()
+        topt.zero_grad()
+        twin(x).square().mean().backward()
+        topt.step()
+    for p, q in zip(net.parameters(), twin.parameters()):
+        assert relerr(p, q) < 1e-5
+    # and back: FusedAdam's state loads into a fresh torch Adam (same keys, shapes, step count)
+    sd = opt.state_dict()
+    ref_sd = topt.state_dict()
+    assert set(sd['state'].keys()) == set(ref_sd['state'].keys())
+    assert sd['param_groups'][0]['params'] == ref_sd['param_groups'][0]['params']
+    for k, st in sd['state'].items():
+        assert float(st['step']) == float(ref_sd['state'][k]['step']) == 6.0
+        assert relerr(st['exp_avg'], ref_sd['state'][k]['exp_avg']) < 1e-5
+        assert relerr(st['exp_avg_sq'], ref_sd['state'][k]['exp_avg_sq']) < 1e-5
+    fresh = torch.optim.Adam(twin.parameters(), lr=1.0)
+    fresh.load_state_dict(sd)
+    assert fresh.param_groups[0]['lr'] == 3e-3
+    # a checkpoint of another model is refused instead of loading misaligned moments
+    other = gpe.optim.FusedAdam(torch.nn.Linear(21, 31).cuda())
+    with pytest.raises(ValueError):
+        other.load_state_dict(sd)
+    # the schedule: torch's OneCycleLR state carries the step count
+    sched = gpe.optim.OneCycle(2e-3, 40)
+    rs = torch.optim.lr_scheduler.OneCycleLR(torch.optim.Adam(twin.parameters(), lr=2e-3), max_lr=2e-3, epochs=4,
+                                             steps_per_epoch=10, cycle_momentum=False)
+    assert gpe.optim.OneCycle(1.0, 7).load_state_dict(sched.state_dict()) is None
+    assert sched.load_state_dict(rs.state_dict()) == rs.last_epoch
+
+
+def test_fused_adam_skips_parameters_without_gradient(gpe):
+    """torch.optim.Adam leaves a parameter whose grad is None alone (no weight decay, no moment decay); FusedAdam does the
+    same for arena segments that received no gradient in the step."""
+    torch.manual_seed(1)
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.a = torch.nn.Linear(9, 12)
+            self.unused = torch.nn.Linear(12, 4)
+            self.b = torch.nn.Linear(12, 3)
+
+        def forward(self, x):
+            return self.b(torch.relu(self.a(x)))
+
+    net = Net().cuda()
+    twin = copy.deepcopy(net)
+    opt = gpe.optim.FusedAdam(net, lr=1e-2, weight_decay=0.1)
+    topt = torch.optim.Adam(twin.parameters(), lr=1e-2, weight_decay=0.1)
+    w0 = net.unused.weight.detach().clone()
+    g = torch.Generator().manual_seed(3)
+    for _ in range(4):
+        x = torch.randn(6, 9, generator=g).cuda()
+        net(x).square().mean().backward()
+        opt.step()
+        topt.zero_grad()
+        twin(x).square().mean().backward()
+        topt.step()
+    assert torch.equal(net.unused.weight, w0)                  # untouched, although weight_decay > 0
+    for p, q in zip(net.parameters(), twin.parameters()):
+        assert relerr(p, q) < 1e-5
+    assert not opt.arena.grad.any()
+
+
+def test_order_match_degenerate_input_stays_in_bounds(gpe):
+    """NaN predictions: the reference raises ValueError inside the loss; the device matching reports through its flag and
+    keeps the permutation a valid index (the gathers that consume it must not trip a device-side assert)."""
+    from gpe_amd import ops
+    B, P, D = 3, 23, 7
+    g = torch.Generator().manual_seed(4)
+    pf = torch.randn(B, P, D, generator=g).cuda()
+    gf = torch.randn(B, P, D, generator=g).cuda()
+    pf[1] = float('nan')
+    perm, fail = ops.order_match(pf, gf)
+    assert int(fail.item()) == 1
+    assert perm.min().item() >= 0 and perm.max().item() < P
+    for b in (0, 2):                                           # healthy patterns: a true permutation
+        assert sorted(perm[b].tolist()) == list(range(P))
+    torch.gather(gf, 1, perm[:, :, None].expand(-1, -1, D))    # in bounds
+    torch.cuda.synchronize()
+
+
 def test_pack_plan_and_grad_sink_are_transparent(gpe, golden_dir):
     """One pack launch per weight change + in-place gradient sink: same outputs and gradients as the plain path; stale
     packs are never used after an in-place weight change."""
