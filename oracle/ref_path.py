@@ -556,6 +556,63 @@ class PanelLoopLoss:
         return sq.sum() / (sq.shape[0] * sq.shape[1])
 
 
+class PatternStitchLoss:
+    """nn/metrics/losses.py:54-180 — stitch tags of the two sides of a stitch are pulled together (mean squared distance
+    per stitch, averaged per pattern, then over the batch) and tags of different stitches pushed `triplet_margin` apart,
+    either against every other tag (:112-146) or only against the closest one (HardNet, :148-180).  A pattern without
+    stitches divides by zero exactly as the reference does (NaN)."""
+
+    def __init__(self, triplet_margin=0.1, use_hardnet=True):
+        self.triplet_margin = triplet_margin
+        self.neg_loss = self._hardnet_neg if use_hardnet else self._all_pairs_neg
+
+    @staticmethod
+    def _pattern_tags(both_sides, n):
+        half = len(both_sides) // 2
+        return torch.cat([both_sides[:n, :], both_sides[half:half + n, :]])
+
+    def __call__(self, stitch_tags, gt_stitches, gt_stitches_nums):
+        gt_stitches = gt_stitches.long()
+        B = stitch_tags.shape[0]
+        flat = stitch_tags.reshape(B, -1, stitch_tags.shape[-1])              # pattern-level edge id = panel * L + edge
+        rows = torch.arange(B).unsqueeze(-1)
+        left, right = flat[rows, gt_stitches[:, 0, :]], flat[rows, gt_stitches[:, 1, :]]
+        both = torch.cat([left, right], dim=1)
+        sq = (left - right) ** 2
+        similarity = 0.
+        for b in range(B):
+            n = gt_stitches_nums[b]
+            similarity = similarity + sq[b][:n, :].sum() / n
+        similarity = similarity / B
+        neg = self.neg_loss(both, gt_stitches_nums)
+        return similarity + neg, dict(stitch_similarity_loss=similarity, stitch_neg_loss=neg)
+
+    def _all_pairs_neg(self, both, nums):
+        per_tag = []
+        for b, sides in enumerate(both):
+            n = nums[b]
+            tags = self._pattern_tags(sides, n)
+            for i, tag in enumerate(tags):
+                gap = self.triplet_margin - ((tag - tags) ** 2).sum(dim=-1)
+                gap[i] = 0
+                gap[i + n if i < n else i - n] = 0                            # the other side of the same stitch
+                gap = torch.max(gap, torch.zeros_like(gap))
+                per_tag.append(gap.sum() / len(gap))
+        return sum(per_tag) / len(per_tag)
+
+    def _hardnet_neg(self, both, nums):
+        per_tag = []
+        for b, sides in enumerate(both):
+            n = nums[b]
+            tags = self._pattern_tags(sides, n)
+            for i, tag in enumerate(tags):
+                d = ((tag - tags) ** 2).sum(dim=-1)
+                d[i] = float('inf')
+                d[i + n if i < n else i - n] = float('inf')
+                per_tag.append(max(self.triplet_margin - d.min(), 0))
+        return sum(per_tag) / len(per_tag)
+
+
 def eval_pad_vector(data_stats):
     """nn/metrics/eval_utils.py (pad vector = -shift/scale when GT is standardised, zeros otherwise)."""
     if data_stats:
@@ -566,10 +623,11 @@ def eval_pad_vector(data_stats):
 
 
 class ComposedPatternLoss:
-    """nn/metrics/composed_loss.py:129-334 restricted to the components the shipped YAMLs evaluate before
-    `epoch_with_stitches` (shape / loop / rotation / translation), INCLUDING the ground-truth pre-processing in front of
-    them: panel-order matching (:428-590) and panel-origin matching (:593-703), restated with the reference's own loops.
-    Stitch / segmentation terms raise, so a silent mismatch is impossible."""
+    """nn/metrics/composed_loss.py:129-362: shape / loop / rotation / translation terms, from `epoch_with_stitches` on
+    also the stitch terms (:336-362 — PatternStitchLoss, supervised stitch tags, free-edge classification), INCLUDING the
+    ground-truth pre-processing in front of them: panel-order matching (:428-590) and panel-origin matching (:593-755) with
+    the re-numbering of the stitched edges and the per-panel shift of the free-edge mask, restated with the reference's own
+    loops.  The segmentation term raises, so a silent mismatch is impossible."""
 
     def __init__(self, data_config, in_config={}):
         self.config = {
@@ -588,6 +646,9 @@ class ComposedPatternLoss:
         stats = data_config.get('standardize')
         outl = {'shift': stats['gt_shift']['outlines'], 'scale': stats['gt_scale']['outlines']} if stats else {}
         self.loop_loss = PanelLoopLoss(eval_pad_vector(outl))
+        if 'stitch' in self.l_components:
+            self.stitch_loss = PatternStitchLoss(self.config['stitch_tags_margin'],
+                                                 use_hardnet=self.config['stitch_hardnet_version'])
         self.last_permutation = None
         self.last_leading_edges = None
 
@@ -631,6 +692,13 @@ class ComposedPatternLoss:
                 B, P = preds['outlines'].shape[:2]
                 pf = torch.cat([preds['translations'], preds['outlines'].contiguous().view(B, P, -1)], dim=-1)
                 gf = torch.cat([gt['translations'], gt['outlines'].contiguous().view(B, P, -1)], dim=-1)
+            elif by == 'stitches':
+                pf = torch.cat([preds['translations'], preds['rotations']], dim=-1)
+                gf = torch.cat([gt['translations'], gt['rotations']], dim=-1)
+                if self.epoch >= self.config['epoch_with_stitches']:        # :464-477: the free-edge mask joins the feature
+                    B, P = preds['free_edges_mask'].shape[:2]
+                    pf = torch.cat([pf, torch.round(torch.sigmoid(preds['free_edges_mask'])).view(B, P, -1)], dim=-1)
+                    gf = torch.cat([gf, gt['free_edges_mask'].view(B, P, -1).to(gf.dtype)], dim=-1)
             else:
                 raise NotImplementedError(by)
             perm = self._panel_order_match(pf.detach().to(gf.dtype), gf)
@@ -644,6 +712,59 @@ class ComposedPatternLoss:
                 out['rotations'] = self._feature_permute(gt['rotations'], perm)
             if 'translation' in self.l_components:
                 out['translations'] = self._feature_permute(gt['translations'], perm)
+            if self._stitch_terms_active():                                    # :505-517
+                out['stitches'] = self._stitch_after_permute(gt['stitches'], gt['num_stitches'], perm, self.max_panel_len)
+                out['free_edges_mask'] = self._feature_permute(gt['free_edges_mask'], perm)
+                if 'stitch_supervised' in self.l_components:
+                    out['stitch_tags'] = self._feature_permute(gt['stitch_tags'], perm)
+        return out
+
+    def _stitch_terms_active(self):
+        return self.epoch >= self.config['epoch_with_stitches'] and any(
+            c in self.l_components for c in ('stitch', 'stitch_supervised', 'free_class'))
+
+    # -- composed_loss.py:592-620: where did each panel go? (a panel named twice by the permutation keeps its LAST slot)
+    @staticmethod
+    def _stitch_after_permute(stitches, nums, perm, L):
+        out = stitches.clone()
+        for b in range(len(stitches)):
+            slot_of = [-1] * perm.shape[1]
+            for slot in range(perm.shape[1]):
+                slot_of[int(perm[b][slot])] = slot
+            for side in (0, 1):
+                for i in range(int(nums[b])):
+                    e = int(stitches[b][side][i])
+                    panel = e // L
+                    out[b][side][i] = slot_of[panel] * L + (e - panel * L)
+        return out
+
+    # -- composed_loss.py:705-725: the loop of a panel now starts at `lead`; padding stays where it is
+    @staticmethod
+    def _per_panel_shift(feat, leads, num_edges):
+        out = feat.clone()
+        P = feat.shape[1]
+        for b in range(len(feat)):
+            for p in range(P):
+                lead, n = int(leads[b * P + p]), int(num_edges[b * P + p])
+                if n < 3 or not lead:
+                    continue
+                cur = feat[b][p]
+                out[b][p] = torch.cat((cur[lead:n], cur[:lead], cur[n:]))
+        return out
+
+    # -- composed_loss.py:727-755: the same shift applied to the edge numbers the stitches refer to
+    @staticmethod
+    def _gt_stitches_shift(stitches, nums, leads, num_edges, P, L):
+        out = stitches.clone()
+        for b in range(len(stitches)):
+            for side in (0, 1):
+                for i in range(int(nums[b])):
+                    e = int(stitches[b][side][i])
+                    panel = e // L
+                    g = b * P + panel
+                    lead, n = int(leads[g]), int(num_edges[g])
+                    inner = e - panel * L
+                    out[b][side][i] = panel * L + (inner - lead if inner >= lead else n - (lead - inner))
         return out
 
     # -- composed_loss.py:656-703,757-765: per panel, try every edge-loop origin, keep the first best
@@ -670,13 +791,16 @@ class ComposedPatternLoss:
             out = dict(gt)
             out['outlines'] = torch.stack(chosen).view(B, -1, g.shape[-2], g.shape[-1])
             self.last_leading_edges = torch.tensor(leads, dtype=torch.int32)
+            if self._stitch_terms_active():                                    # :604-617
+                out['stitches'] = self._gt_stitches_shift(gt['stitches'], gt['num_stitches'], leads, gt_num_edges,
+                                                          self.max_pattern_size, self.max_panel_len)
+                out['free_edges_mask'] = self._per_panel_shift(gt['free_edges_mask'], leads, gt_num_edges)
+                if 'stitch_supervised' in self.l_components:
+                    out['stitch_tags'] = self._per_panel_shift(gt['stitch_tags'], leads, gt_num_edges)
         return out
 
     def __call__(self, preds, ground_truth, names=None, epoch=1000):
         self.epoch = epoch
-        if epoch >= self.config['epoch_with_stitches'] and any(
-                c in self.l_components for c in ('stitch', 'stitch_supervised', 'free_class')):
-            raise NotImplementedError('stitch losses are outside the restated path')
         if 'segmentation' in self.l_components:
             raise NotImplementedError('segmentation loss is outside the restated path')
         gt = ground_truth
@@ -700,7 +824,23 @@ class ComposedPatternLoss:
         if 'translation' in self.l_components:
             d['translation_loss'] = mse(preds['translations'], gt['translations'].to(dt))
             loss = loss + d['translation_loss']
-        update = (epoch == self.config['epoch_with_order_matching'] and self.config['panel_order_inariant_loss'])
+        if self._stitch_terms_active():                                        # :259-266, 336-362
+            extra = 0.
+            if 'stitch' in self.l_components:
+                st, parts = self.stitch_loss(preds['stitch_tags'], gt['stitches'], gt['num_stitches'])
+                d.update(parts)
+                extra = extra + st
+            if 'stitch_supervised' in self.l_components:
+                d['stitch_supervised_loss'] = mse(preds['stitch_tags'], gt['stitch_tags'].to(dt))
+                extra = extra + self.config['stitch_supervised_weight'] * d['stitch_supervised_loss']
+            if 'free_class' in self.l_components:
+                d['free_edges_loss'] = nn.functional.binary_cross_entropy_with_logits(
+                    preds['free_edges_mask'], gt['free_edges_mask'].to(dt))
+                extra = extra + d['free_edges_loss']
+            loss = loss + extra
+        update = (epoch == self.config['epoch_with_stitches'] and any(
+            c in self.l_components for c in ('stitch', 'stitch_supervised', 'free_class'))
+            or epoch == self.config['epoch_with_order_matching'] and self.config['panel_order_inariant_loss'])
         return loss, d, update
 
     def train(self, mode=True):

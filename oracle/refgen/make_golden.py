@@ -40,7 +40,13 @@ def load_cfg(rel):
     return data_config, cfg['NN']
 
 
-def run_case(model_name, yaml_rel, nn_override, B, N, seed, tag, keep_state, loss_override=None, gt_extra=False):
+ONLY = set(sys.argv[1:])      # `make_golden.py tag [tag ...]` regenerates just those fixtures
+
+
+def run_case(model_name, yaml_rel, nn_override, B, N, seed, tag, keep_state, loss_override=None, gt_extra=False, epoch=0,
+             stitch_gt=False):
+    if ONLY and tag not in ONLY:
+        return
     data_config, nn_cfg = load_cfg(yaml_rel)
     nn_cfg = copy.deepcopy(nn_cfg)
     nn_cfg.update(nn_override)
@@ -60,15 +66,35 @@ def run_case(model_name, yaml_rel, nn_override, B, N, seed, tag, keep_state, los
           'num_edges': torch.randint(0, L + 1, (B, P), generator=g)}   # includes < 3 (skipped panels)
     if gt_extra:   # keys the order matching permutes (nn/metrics/composed_loss.py:497-499)
         gt['empty_panels_mask'] = gt['num_edges'] < 3
+    if stitch_gt:
+        # what the dataset hands over for the stitch terms (nn/data/datasets.py:805-819, pattern_converter.py:81-91):
+        # `stitches` [B, 2, max_num_stitches] pattern-level edge ids (panel * max_panel_len + edge), zero-padded;
+        # `num_stitches` [B]; `free_edges_mask` [B, P, L] bool = edges no stitch refers to; `stitch_tags` [B, P, L, 3]
+        S = data_config['max_num_stitches']
+        st = torch.zeros(B, 2, S, dtype=torch.long)
+        nst = torch.zeros(B, dtype=torch.long)
+        free = torch.ones(B, P, L, dtype=torch.bool)
+        for b in range(B):
+            edges = [(p, e) for p in range(P) for e in range(int(gt['num_edges'][b, p]))]
+            order = torch.randperm(len(edges), generator=g).tolist()
+            n = min(int(torch.randint(3, S + 1, (1,), generator=g)), len(edges) // 2)
+            nst[b] = n
+            for i in range(n):
+                for side in (0, 1):
+                    p_, e_ = edges[order[2 * i + side]]
+                    st[b, side, i] = p_ * L + e_
+                    free[b, p_, e_] = False
+        gt['stitches'], gt['num_stitches'], gt['free_edges_mask'] = st, nst, free
+        gt['stitch_tags'] = torch.randn(B, P, L, 3, generator=g)
     state0 = copy.deepcopy(model.state_dict())
     torch.manual_seed(seed + 2)            # fixes the random LSTM h0/c0 draw
-    preds = model(feats, log_step=0, epoch=0)
-    loss, loss_dict, _ = model.loss(preds, {k: v.clone() for k, v in gt.items()}, epoch=0)
+    preds = model(feats, log_step=0, epoch=epoch)
+    loss, loss_dict, _ = model.loss(preds, {k: v.clone() for k, v in gt.items()}, epoch=epoch)
     loss.backward()
     knn = [c.last_knn.to(torch.int32) for c in model.feature_extractor.conv_layers]
     fx = {
         'model': model_name, 'yaml': yaml_rel, 'nn_override': nn_override, 'data_config': data_config,
-        'nn_config': nn_cfg, 'loss_config': loss_cfg, 'B': B, 'N': N, 'seed': seed,
+        'nn_config': nn_cfg, 'loss_config': loss_cfg, 'B': B, 'N': N, 'seed': seed, 'epoch': epoch,
         'features': feats, 'gt': gt,
         'preds': {k: v.detach().clone() for k, v in preds.items()},
         'loss': loss.detach().clone(), 'loss_dict': {k: v.detach().clone() for k, v in loss_dict.items()},
@@ -85,7 +111,7 @@ def run_case(model_name, yaml_rel, nn_override, B, N, seed, tag, keep_state, los
         # what the matching decided, re-derived with the reference's own helpers on the same predictions
         with torch.no_grad():
             L_ = model.loss
-            L_.epoch = 0
+            L_.epoch = epoch
             L_.device = feats.device
             gt2 = {k: v.clone() for k, v in gt.items()}
             if loss_cfg.get('panel_order_inariant_loss'):
@@ -96,8 +122,14 @@ def run_case(model_name, yaml_rel, nn_override, B, N, seed, tag, keep_state, los
                 rot, lead = L_._batch_edge_order_match(preds['outlines'], gt2['outlines'], ne)
                 fx['gt_outlines_matched'] = rot.clone()
                 fx['leading_edges'] = torch.tensor([int(v) for v in lead], dtype=torch.int32)
+                if stitch_gt and epoch >= loss_cfg['epoch_with_stitches']:
+                    gt2 = L_._rotate_gt(preds, gt2, ne, epoch)
             else:
                 fx['gt_outlines_matched'] = gt2['outlines'].clone()
+            if stitch_gt and epoch >= loss_cfg['epoch_with_stitches']:
+                # the re-numbered stitches / shifted free-edge mask the stitch terms were evaluated on
+                fx['gt_stitches_matched'] = gt2['stitches'].clone()
+                fx['gt_free_mask_matched'] = gt2['free_edges_mask'].clone()
     if keep_state:
         fx['state_dict'] = state0
         fx['grads'] = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
@@ -210,5 +242,20 @@ if __name__ == '__main__':
              2, 64, 980, 'full3d_lstm2rev', True)
     run_case('GarmentSegmentPattern3D', att_yaml, dict(SMALL_NN, global_pool='max'), 2, 64, 990, 'segment3d_poolmax', True)
     run_case('GarmentSegmentPattern3D', att_yaml, dict(SMALL_NN, global_pool='add'), 2, 64, 995, 'segment3d_pooladd', True)
-    run_stitch_known_answer()
-    run_pointnet_case()
+    # ---- round 3: the stitch terms of the benchmarked model's own YAML (active from epoch_with_stitches = 40 on:
+    # nn/metrics/composed_loss.py:259-266,336-362; nn/metrics/losses.py:54-180) and the re-numbering of the stitched edges by
+    # the order / origin matching (:505-517,604-617,705-755)
+    run_case('GarmentFullPattern3D', lstm_yaml, SMALL_NN, 3, 64, 1200, 'full3d_stitch', True, epoch=40, stitch_gt=True)
+    run_case('GarmentFullPattern3D', lstm_yaml, SMALL_NN, 3, 64, 1210, 'full3d_stitch_match', True, epoch=40, stitch_gt=True,
+             loss_override={'panel_origin_invariant_loss': True, 'panel_order_inariant_loss': True,
+                            'order_by': 'shape_translation'}, gt_extra=True)
+    run_case('GarmentFullPattern3D', lstm_yaml, SMALL_NN, 3, 64, 1220, 'full3d_stitch_hardnet', False, epoch=41,
+             stitch_gt=True, gt_extra=True,
+             loss_override={'stitch_hardnet_version': True, 'panel_order_inariant_loss': True, 'order_by': 'stitches',
+                            'stitch_supervised_weight': 0.1,
+                            'loss_components': ['shape', 'loop', 'rotation', 'translation', 'stitch', 'stitch_supervised',
+                                                'free_class']})
+    if not ONLY or 'stitch_pairs_known_answer' in ONLY:
+        run_stitch_known_answer()
+    if not ONLY or 'pointnetpp_small' in ONLY:
+        run_pointnet_case()

@@ -18,7 +18,9 @@ CASES = ['full3d_small', 'segment3d_small', 'full3d_shipped', 'segment3d_shipped
          'segment3d_k20', 'segment3d_globalatt', 'segment3d_globalatt_small', 'full3d_originmatch', 'full3d_ordermatch',
          'full3d_ordermatch_placement', 'full3d_poolmax', 'full3d_pooladd', 'full3d_aggrmean', 'full3d_aggradd',
          'full3d_depth1', 'full3d_depth3', 'full3d_mlpdec', 'full3d_gru', 'full3d_lstm2rev', 'segment3d_poolmax',
-         'segment3d_pooladd']
+         'segment3d_pooladd',
+         # round 3: the stitch terms (epoch >= epoch_with_stitches) incl. the re-numbering of stitched edges by the matching
+         'full3d_stitch', 'full3d_stitch_match', 'full3d_stitch_hardnet']
 
 
 def _build(fx):
@@ -41,8 +43,9 @@ def test_oracle_matches_reference_fixture(tag, golden_dir):
         for k, v in fx['state_dict'].items():
             assert torch.equal(sd[k], v), k
     torch.manual_seed(fx['seed'] + 2)
-    preds = model(fx['features'], log_step=0, epoch=0)
-    loss, loss_dict, upd = model.loss(preds, {k: v.clone() for k, v in fx['gt'].items()}, epoch=0)
+    epoch = fx.get('epoch', 0)
+    preds = model(fx['features'], log_step=0, epoch=epoch)
+    loss, loss_dict, upd = model.loss(preds, {k: v.clone() for k, v in fx['gt'].items()}, epoch=epoch)
     loss.backward()
     for i, conv in enumerate(model.feature_extractor.conv_layers):
         assert torch.equal(conv.last_knn.to(torch.int32), fx['knn'][i])
@@ -52,6 +55,8 @@ def test_oracle_matches_reference_fixture(tag, golden_dir):
         assert torch.equal(preds[k], v), k           # same ops, same order, 1 thread -> bit-equal
     assert torch.equal(loss, fx['loss'])
     assert set(loss_dict.keys()) == set(fx['loss_dict'].keys())
+    for k, v in fx['loss_dict'].items():
+        assert torch.equal(torch.as_tensor(loss_dict[k]), v), k
     assert sorted(n for n, p in model.named_parameters() if p.grad is None) == sorted(fx['none_grads'])
     for n, p in model.named_parameters():
         if p.grad is not None:
@@ -65,6 +70,17 @@ def test_oracle_matches_reference_fixture(tag, golden_dir):
     # the ground-truth matching in front of the loss: same decisions as the reference's own helpers
     if 'leading_edges' in fx:
         assert torch.equal(model.loss.last_leading_edges, fx['leading_edges'])
+    if 'gt_stitches_matched' in fx:
+        # re-derive the matched ground truth with the oracle's helpers on the fixture's (bit-equal) predictions
+        L_ = model.loss
+        with torch.no_grad():
+            gt2 = {k: v.clone() for k, v in fx['gt'].items()}
+            if L_.config['panel_order_inariant_loss']:
+                gt2 = L_._gt_order_match(preds, gt2)
+            if L_.config['panel_origin_invariant_loss']:
+                gt2 = L_._rotate_gt(preds, gt2, gt2['num_edges'].int().view(-1))
+        assert torch.equal(gt2['stitches'], fx['gt_stitches_matched'])
+        assert torch.equal(gt2['free_edges_mask'], fx['gt_free_mask_matched'])
 
 
 def test_oracle_fp64_mode_runs(golden_dir):
