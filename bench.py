@@ -48,6 +48,9 @@ def parse():
     ap.add_argument('--model', choices=['lstm', 'att'], default='lstm',
                     help="'lstm' = GarmentFullPattern3D (BASELINE cfg 1/2/3/5, the default line); 'att' = GarmentSegmentPattern3D "
                          "(cfg 4: --model att --points 4096 --k 20) — an extra measurement, never the default")
+    ap.add_argument('--epoch', type=int, default=0,
+                    help='epoch handed to the loss: 0 (default, SURVEY.md 8d) = the four main terms; >= 40 = the shipped YAML\'s '
+                         'stitch + free-class terms are active as well (synthetic stitches) — an extra measurement')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-batch', type=int, default=8)
     ap.add_argument('--cpu-steps', type=int, default=3)
@@ -69,6 +72,17 @@ def synthetic(B, N, data_config, seed, device):
     gt = {'outlines': torch.randn(B, P, Lp, 4, generator=g), 'rotations': torch.randn(B, P, 4, generator=g),
           'translations': torch.randn(B, P, 3, generator=g),
           'num_edges': torch.randint(3, Lp + 1, (B, P), generator=g)}
+    # ground truth of the stitch terms (only read when --epoch >= epoch_with_stitches): S stitches per pattern between distinct
+    # real edges (every panel has >= 3), the free-edge mask derived from them as the dataset does
+    S = data_config['max_num_stitches']
+    st = torch.zeros(B, 2, S, dtype=torch.long)
+    free = torch.ones(B, P, Lp, dtype=torch.bool)
+    for b in range(B):
+        pick = torch.randperm(P * 3, generator=g)[:2 * S]            # edges 0..2 of every panel exist
+        ids = (pick // 3) * Lp + pick % 3
+        st[b, 0], st[b, 1] = ids[:S], ids[S:]
+        free[b].view(-1)[ids] = False
+    gt.update(stitches=st, num_stitches=torch.full((B,), S, dtype=torch.long), free_edges_mask=free)
     return feats.to(device), {k: v.to(device) for k, v in gt.items()}
 
 
@@ -250,8 +264,8 @@ def main():
 
     def step(i):
         torch.manual_seed(i * 131 + rank)              # the decoder draws random LSTM states every forward
-        preds = wrapped(feats, log_step=i, epoch=0)
-        loss, _, _ = model.loss(preds, gt, epoch=0)
+        preds = wrapped(feats, log_step=i, epoch=args.epoch)
+        loss, _, _ = model.loss(preds, gt, epoch=args.epoch)
         loss.backward()
         wrapped.finish_gradient_sync()
         opt.step()
@@ -408,6 +422,7 @@ def main():
             'scaling': 'weak', 'vs_baseline': None, 'dtype': args.math, 'data': 'synthetic',
             'config': {'workload': _workload_name(args),
                        'global_batch': args.batch * world, 'parallelism': 'dp%d' % world,
+                       'loss_epoch': args.epoch,
                        'step': 'fwd + ComposedPatternLoss + bwd' + (' + RCCL grad all-reduce' if world > 1 else '')
                                + (' + Adam (torch)' if args.torch_adam else ' + fused Adam (flat arena)'),
                        'final_loss': final_loss},

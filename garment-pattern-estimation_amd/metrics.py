@@ -9,11 +9,15 @@ On device tensors (the only thing a model of this package can produce) everythin
     panel instead of a Python loop over panels x edge shifts;
   * `panel_order_inariant_loss`: ops.order_match, the greedy assignment of composed_loss.py:530-570 as one workgroup per
     pattern; the random pre-matching permutation (epoch < epoch_with_order_matching) and the gathers stay torch calls.
-CPU tensors (host-logic tests feed hand-made predictions) take a batched torch restatement of the same formulas.
+  * from `epoch_with_stitches` on, the stitch terms of the shipped YAMLs (composed_loss.py:336-362): PatternStitchLoss
+    (losses.py:54-180, both negative-term variants), supervised stitch tags, free-edge classification — ops.StitchLossFn,
+    one forward and one backward launch — and the re-numbering of the stitched edges / shift of the free-edge mask that the
+    two matchings imply (ops.stitch_renumber, ops.panel_shift).
+CPU tensors (host-logic tests feed hand-made predictions) take a batched torch restatement of the main terms; the stitch
+terms exist on the device only (a CPU tensor raises).
 
-Not built (raise): stitch / free_class / segmentation terms — off the hot path and inactive before
-`epoch_with_stitches`.  Quality components are evaluation-side bookkeeping: `with_quality_eval` is accepted and ignored,
-no quality keys are added to the loss dict."""
+Not built (raise): the segmentation term (entmax.SparsemaxLoss; no shipped config trains with it).  Quality components are
+evaluation-side bookkeeping: `with_quality_eval` is accepted and ignored, no quality keys are added to the loss dict."""
 import torch
 import torch.nn as nn
 
@@ -153,10 +157,17 @@ class ComposedPatternLoss:
             return (torch.cat([preds['translations'], preds['outlines'].contiguous().view(B, P, -1)], dim=-1),
                     torch.cat([gt['translations'], gt['outlines'].contiguous().view(B, P, -1)], dim=-1))
         if by == 'stitches':
-            if self.epoch >= self.config['epoch_with_stitches']:
-                raise NotImplementedError("order_by='stitches' with active stitch terms is outside the built path")
-            return (torch.cat([preds['translations'], preds['rotations']], dim=-1),
-                    torch.cat([gt['translations'], gt['rotations']], dim=-1))
+            if 'free_edges_mask' not in preds or 'translations' not in preds or 'rotations' not in preds:
+                raise ValueError('ComposedPatternLoss::Error::Ordering by stitches requested but free edges mask or placement are not predicted')
+            pf = torch.cat([preds['translations'], preds['rotations']], dim=-1)
+            gf = torch.cat([gt['translations'], gt['rotations']], dim=-1)
+            if self.epoch >= self.config['epoch_with_stitches']:          # composed_loss.py:464-477
+                B, P = preds['free_edges_mask'].shape[:2]
+                pf = torch.cat([pf, torch.round(torch.sigmoid(preds['free_edges_mask'])).reshape(B, P, -1)], dim=-1)
+                gf = torch.cat([gf, gt['free_edges_mask'].reshape(B, P, -1).to(gf.dtype)], dim=-1)
+            else:
+                print('ComposedPatternLoss::Warning::skipped order match by stitch tags as stitch loss is not enabled')
+            return pf, gf
         raise NotImplementedError(
             'ComposedPatternLoss::Error::Ordering by requested feature <{}> is not implemented'.format(by))
 
@@ -193,7 +204,7 @@ class ComposedPatternLoss:
             raise ValueError('ComposedPatternLoss::Error::Failed to match panel order')
 
     def _gt_order_match(self, preds, gt):
-        """composed_loss.py:428-528 without the stitch re-numbering (stitch terms raise before this point)."""
+        """composed_loss.py:428-528."""
         with torch.no_grad():
             pf, gf = self._order_features(preds, gt)
             perm = self._panel_order_match(pf, gf)
@@ -207,17 +218,39 @@ class ComposedPatternLoss:
                 out['rotations'] = self._feature_permute(gt['rotations'], perm)
             if 'translation' in self.l_components:
                 out['translations'] = self._feature_permute(gt['translations'], perm)
+            if self._stitch_terms_active(self.epoch):                      # composed_loss.py:505-517
+                from . import ops
+                self._need_device(gt['stitches'])
+                out['stitches'] = ops.stitch_renumber(gt['stitches'].long().contiguous(),
+                                                      gt['num_stitches'].long().contiguous(), self.max_pattern_size,
+                                                      self.max_panel_len, perm=perm.contiguous())
+                out['free_edges_mask'] = self._feature_permute(gt['free_edges_mask'], perm)
+                if 'stitch_supervised' in self.l_components:
+                    out['stitch_tags'] = self._feature_permute(gt['stitch_tags'], perm)
         return out
 
+    @staticmethod
+    def _need_device(t):
+        if not t.is_cuda:
+            raise RuntimeError('the stitch terms of ComposedPatternLoss run on the MI355X only (got a %s tensor)' % t.device)
+
     def _rotate_gt(self, preds, gt, gt_num_edges):
-        """composed_loss.py:593-623,656-703 without the stitch shifts."""
+        """composed_loss.py:593-623,656-755."""
         with torch.no_grad():
             out = dict(gt)
             ol, gto = preds['outlines'], gt['outlines']
             if ol.is_cuda:
                 from . import ops
-                out['outlines'], lead = ops.origin_match(ol, gto.float().contiguous(), gt_num_edges.contiguous())
+                ne = gt_num_edges.contiguous()
+                out['outlines'], lead = ops.origin_match(ol, gto.float().contiguous(), ne)
                 self.last_leading_edges = lead
+                if self._stitch_terms_active(self.epoch):                  # composed_loss.py:604-617
+                    out['stitches'] = ops.stitch_renumber(gt['stitches'].long().contiguous(),
+                                                          gt['num_stitches'].long().contiguous(), self.max_pattern_size,
+                                                          self.max_panel_len, lead=lead, num_edges=ne)
+                    out['free_edges_mask'] = ops.panel_shift(gt['free_edges_mask'].float(), lead, ne)
+                    if 'stitch_supervised' in self.l_components:
+                        out['stitch_tags'] = ops.panel_shift(gt['stitch_tags'].float(), lead, ne)
             else:
                 B, P, L, D = gto.shape
                 pr, g = ol.detach().reshape(B * P, L, D), gto.reshape(B * P, L, D)
@@ -246,7 +279,7 @@ class ComposedPatternLoss:
         if 'segmentation' in self.l_components:
             raise NotImplementedError('segmentation loss (entmax.SparsemaxLoss) is outside the built path')
         if self._stitch_terms_active(epoch):
-            raise NotImplementedError('stitch losses (epoch >= epoch_with_stitches) are outside the built path')
+            self._need_device(preds['outlines'])
         for key in ground_truth:
             ground_truth[key] = ground_truth[key].to(self.device)
         gt = ground_truth
@@ -256,11 +289,42 @@ class ComposedPatternLoss:
         if self.config['panel_origin_invariant_loss']:
             gt = self._rotate_gt(preds, gt, gt_num_edges)
         full_loss, loss_dict = self._main_losses(preds, gt, gt_num_edges)
+        if self._stitch_terms_active(epoch):
+            self.last_matched_stitch_gt = {k: gt[k] for k in ('stitches', 'free_edges_mask') if k in gt}   # diagnostics / tests
+            extra, extra_dict = self._stitch_losses(preds, gt)
+            full_loss = full_loss + extra
+            loss_dict.update(extra_dict)
         loss_update_ind = (
             epoch == self.config['epoch_with_stitches'] and any(
                 el in self.l_components for el in ['stitch', 'stitch_supervised', 'free_class'])
             or epoch == self.config['epoch_with_order_matching'] and self.config['panel_order_inariant_loss'])
         return full_loss, loss_dict, loss_update_ind
+
+    def _stitch_losses(self, preds, gt):
+        """composed_loss.py:336-362 through ops.StitchLossFn."""
+        from . import ops
+        comps = self.l_components
+        flags = (ops.STITCH_MAIN if 'stitch' in comps else 0) | (ops.STITCH_FREE if 'free_class' in comps else 0) | \
+                (ops.STITCH_SUP if 'stitch_supervised' in comps else 0)
+        if 'stitch' in comps and self.config['stitch_hardnet_version']:
+            flags |= ops.STITCH_HARDNET
+        tags = preds['stitch_tags'] if flags & (ops.STITCH_MAIN | ops.STITCH_SUP) else None
+        logits = preds['free_edges_mask'] if flags & ops.STITCH_FREE else None
+        out = ops.StitchLossFn.apply(
+            tags, logits,
+            gt['stitches'].long().contiguous() if flags & ops.STITCH_MAIN else None,
+            gt['num_stitches'].long().contiguous() if flags & ops.STITCH_MAIN else None,
+            gt['free_edges_mask'].float().contiguous() if flags & ops.STITCH_FREE else None,
+            gt['stitch_tags'].float().contiguous() if flags & ops.STITCH_SUP else None,
+            flags, float(self.config['stitch_tags_margin']), float(self.config['stitch_supervised_weight']))
+        loss_dict = {}
+        if 'stitch' in comps:
+            loss_dict.update(stitch_similarity_loss=out[1], stitch_neg_loss=out[2])
+        if 'stitch_supervised' in comps:
+            loss_dict.update(stitch_supervised_loss=out[3])
+        if 'free_class' in comps:
+            loss_dict.update(free_edges_loss=out[4])
+        return out[0], loss_dict
 
     def _main_losses(self, preds, gt, gt_num_edges):
         """composed_loss.py:294-321."""

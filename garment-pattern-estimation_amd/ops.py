@@ -1017,6 +1017,66 @@ class PatternLossFn(torch.autograd.Function):
         return g_ol, g_rot, g_tr, None, None, None, None, None, None, None, None
 
 
+STITCH_MAIN, STITCH_HARDNET, STITCH_FREE, STITCH_SUP = 1, 2, 4, 8
+
+
+class StitchLossFn(torch.autograd.Function):
+    """ComposedPatternLoss._stitch_losses (nn/metrics/composed_loss.py:336-362): PatternStitchLoss (nn/metrics/losses.py:54-180,
+    both negative-term variants), the supervised stitch-tag MSE and the free-edge BCE-with-logits in one forward and one
+    backward launch.  Returns a [5] tensor {total, similarity, negative, supervised, free}; only element 0 carries gradient.
+    stitch_tags [B,P,L,D] and free_logits [B,P,L] are the strided views of the panel decoder's output."""
+
+    @staticmethod
+    def forward(ctx, stitch_tags, free_logits, stitches, nums, gt_mask, gt_tags, flags, margin, sup_w):
+        ref = stitch_tags if stitch_tags is not None else free_logits
+        _dev_check(ref)
+        dev = ref.device
+        B, P, Lp = ref.shape[:3]
+        D = stitch_tags.shape[3] if stitch_tags is not None else 0
+        ts = _view_strides(stitch_tags) if stitch_tags is not None else (0, 0, 0)
+        ms = (free_logits.stride(0), free_logits.stride(1), free_logits.stride(2)) if free_logits is not None else (0, 0, 0)
+        S = stitches.shape[2] if stitches is not None else 0
+        part = torch.empty(B, 6, device=dev, dtype=torch.float64)
+        out = torch.empty(5, device=dev, dtype=F32)
+        args = (stitch_tags, ts[0], ts[1], ts[2], D, free_logits, ms[0], ms[1], ms[2], stitches, nums, S, gt_mask, gt_tags,
+                B, P, Lp, flags, float(margin), float(sup_w))
+        L.call('gpe_stitch_loss_fwd', *args, part, out)
+        ctx.args, ctx.part, ctx.shape = args, part, (B, P, Lp, D)
+        ctx.need = (stitch_tags is not None and bool(flags & (STITCH_MAIN | STITCH_SUP)),
+                    free_logits is not None and bool(flags & STITCH_FREE))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        B, P, Lp, D = ctx.shape
+        dev = g.device
+        g = g.contiguous()
+        g_tags = torch.empty(B, P, Lp, D, device=dev, dtype=F32) if ctx.need[0] else None
+        g_mask = torch.empty(B, P, Lp, device=dev, dtype=F32) if ctx.need[1] else None
+        L.call('gpe_stitch_loss_bwd', *ctx.args, ctx.part, g, g_tags, g_mask)
+        return g_tags, g_mask, None, None, None, None, None, None, None
+
+
+def stitch_renumber(stitches, nums, P, Lp, perm=None, lead=None, num_edges=None):
+    """composed_loss.py:592-620 (`perm`: the panel-order permutation) and :727-755 (`lead` / `num_edges`: the panel-origin
+    shift) applied to the ground-truth stitches [B,2,S] int64 -> a new tensor."""
+    B, _, S = stitches.shape
+    out = torch.empty_like(stitches)
+    L.call('gpe_stitch_renumber', stitches, nums, B, S, P, Lp, perm, lead, num_edges, out)
+    return out
+
+
+def panel_shift(feat, lead, num_edges):
+    """composed_loss.py:705-725 `_per_panel_shift` on per-edge ground truth [B,P,L] or [B,P,L,D] (fp32) -> a new tensor."""
+    _dev_check(feat)
+    feat = feat.contiguous()
+    Lp = feat.shape[2]
+    D = feat.shape[3] if feat.dim() == 4 else 1
+    out = torch.empty_like(feat)
+    L.call('gpe_panel_shift', feat, D, lead, num_edges, feat.shape[0] * feat.shape[1], Lp, out)
+    return out
+
+
 def origin_match(outlines, gt_ol, num_edges):
     """composed_loss.py:656-703 `_batch_edge_order_match`: -> (gt outlines with every panel's edge loop shifted to the
     origin that best matches the prediction, leading edge per panel int32 [B*P])."""

@@ -327,6 +327,37 @@ int gpe_origin_match(const float* ol, long ol_sb, long ol_sp, long ol_sl, const 
 int gpe_order_match(const float* pred_feat, const float* gt_feat, int B, int P, int D, int64_t* perm, int32_t* fail,
                     void* stream);
 
+/* ---- stitch terms, active from `epoch_with_stitches` on (nn/metrics/composed_loss.py:336-362; PatternStitchLoss
+ * nn/metrics/losses.py:54-180) --------------------------------------------------------------------------------------------
+ * tags (b,p,l,d<D) at tags + b*t_sb + p*t_sp + l*t_sl + d and free-edge logits (b,p,l) at logit + b*m_sb + p*m_sp + l*m_sl
+ * are strided views of the panel decoder's [B,P,L,8] output.  stitches int64 [B][2][S]: pattern-level edge ids
+ * (panel * L + edge) of the two sides of every stitch, the first nums[b] (int64 [B]) of them valid; S <= 64, D <= 8.
+ * gt_mask fp32 [B,P,L] (1 = free edge), gt_tags fp32 [B,P,L,D] (supervised variant only).
+ * flags: 1 stitch (similarity + negative term) | 2 HardNet negative (closest other tag only, losses.py:148-180; default:
+ * every other tag, :112-146) | 4 free-edge BCE-with-logits | 8 supervised tag MSE.
+ * fwd: part [B][6] fp64 workspace (re-used by bwd); out5 = {total, similarity, negative, supervised, free} with
+ *      total = (similarity + negative) + sup_w * supervised + free.  A pattern without stitches gives NaN (the reference
+ *      divides by its zero stitch count as well).
+ * bwd: gradient of `total` times the device scalar *gscale (NULL = 1), dense: g_tags [B,P,L,D], g_mask [B,P,L]. */
+int gpe_stitch_loss_fwd(const float* tags, long t_sb, long t_sp, long t_sl, int D, const float* logit, long m_sb, long m_sp,
+                        long m_sl, const int64_t* stitches, const int64_t* nums, int S, const float* gt_mask,
+                        const float* gt_tags, int B, int P, int L, int flags, float margin, float sup_w, double* part,
+                        float* out5, void* stream);
+int gpe_stitch_loss_bwd(const float* tags, long t_sb, long t_sp, long t_sl, int D, const float* logit, long m_sb, long m_sp,
+                        long m_sl, const int64_t* stitches, const int64_t* nums, int S, const float* gt_mask,
+                        const float* gt_tags, int B, int P, int L, int flags, float margin, float sup_w, const double* part,
+                        const float* gscale, float* g_tags, float* g_mask, void* stream);
+/* stitched-edge re-numbering of the ground truth (composed_loss.py:592-620 after the panel-order permutation `perm` int64
+ * [B][P], then :727-755 for the panel-origin shift `lead` int32 [B*P] with `num_edges` int32 [B*P] of the permuted panels);
+ * either step is skipped when its pointer is NULL.  out int64 [B][2][S]; entries past nums[b] are copied. */
+int gpe_stitch_renumber(const int64_t* stitches, const int64_t* nums, int B, int S, int P, int L, const int64_t* perm,
+                        const int32_t* lead, const int32_t* num_edges, int64_t* out, void* stream);
+/* per-edge ground truth [npanels][L][D] follows its panel's new loop origin (composed_loss.py:705-725 `_per_panel_shift`):
+ * rows l < n of a panel with n >= 3 edges and lead != 0 become feat[(l + lead) mod n], everything else is copied. */
+int gpe_panel_shift(const float* feat, int D, const int32_t* lead, const int32_t* num_edges, long npanels, int L, float* out,
+                    void* stream);
+
+
 /* ---- optimizer / input side (nn/trainer.py:162-185; nn/data/transforms.py:35-50) ----------------------------------- */
 /* one torch.optim.Adam step (amsgrad off) over a flat arena of n floats (16-B aligned p, g, m, v); `step` counts from 1;
  * the gradient is read as g*gscale; zero_grad != 0 clears g afterwards.  The OneCycleLR value is passed in as lr. */

@@ -689,6 +689,92 @@ def test_pattern_loss_and_matching(gpe, origin, order):
     assert upd == bool(order)
 
 
+def _stitch_gt(B, P, Lp, S, num_edges, seed, duplicate=False):
+    """what the dataset hands over for the stitch terms (nn/data/datasets.py:805-819): pattern-level edge ids of the two sides
+    of every stitch (zero-padded), their count, the free-edge mask, supervised tags."""
+    g = torch.Generator().manual_seed(seed)
+    st = torch.zeros(B, 2, S, dtype=torch.long)
+    nst = torch.zeros(B, dtype=torch.long)
+    free = torch.ones(B, P, Lp, dtype=torch.bool)
+    for b in range(B):
+        edges = [(p, e) for p in range(P) for e in range(int(num_edges[b, p]))]
+        order = torch.randperm(len(edges), generator=g).tolist()
+        n = min(int(torch.randint(2, S + 1, (1,), generator=g)), len(edges) // 2)
+        nst[b] = n
+        for i in range(n):
+            for side in (0, 1):
+                p_, e_ = edges[order[2 * i + side]]
+                st[b, side, i] = p_ * Lp + e_
+                free[b, p_, e_] = False
+        if duplicate and n >= 2:
+            st[b, 1, 1] = st[b, 0, 0]                           # one edge on two stitches: its gradient accumulates
+    return {'stitches': st, 'num_stitches': nst, 'free_edges_mask': free,
+            'stitch_tags': torch.randn(B, P, Lp, 3, generator=g)}
+
+
+@pytest.mark.parametrize('hardnet,origin,order,supervised', [(False, False, False, False), (True, False, False, True),
+                                                             (False, True, 'shape_translation', False),
+                                                             (True, True, 'stitches', True), (False, False, 'placement', True)])
+def test_stitch_losses_and_renumbering(gpe, hardnet, origin, order, supervised):
+    """The stitch terms of ComposedPatternLoss at epoch >= epoch_with_stitches (HIP kernels) vs the oracle's restatement of
+    nn/metrics/composed_loss.py:336-362,505-517,592-620,604-617,705-755 and nn/metrics/losses.py:54-180: value, every entry
+    of the loss dict, gradients of all three prediction views, the re-numbered stitches and the shifted free-edge mask."""
+    from oracle import ref_path as O
+    dc = gpe.configs.data_config()
+    B, P, Lp, S = 4, dc['max_pattern_len'], dc['max_panel_len'], dc['max_num_stitches']
+    comps = ['shape', 'loop', 'rotation', 'translation', 'stitch', 'free_class'] + (['stitch_supervised'] if supervised else [])
+    cfg = dict(loss_components=comps, quality_components=[], panel_origin_invariant_loss=origin,
+               panel_order_inariant_loss=bool(order), order_by=order if order else 'placement', epoch_with_order_matching=0,
+               epoch_with_stitches=40, stitch_hardnet_version=hardnet, stitch_tags_margin=0.3, stitch_supervised_weight=0.1)
+    ours = gpe.metrics.ComposedPatternLoss(dc, dict(cfg))
+    theirs = O.ComposedPatternLoss(dc, dict(cfg))
+    panels, place, gt = _loss_inputs(B, P, Lp, 7)
+    panels[..., 4:7] *= 0.4                                      # tags closer than the margin: the negative term is active
+    gt.update(_stitch_gt(B, P, Lp, S, gt['num_edges'], 8, duplicate=True))
+
+    def views(pn, pl):
+        v = _views(pn, pl, B, P)
+        v['stitch_tags'] = pn[..., 4:7]
+        v['free_edges_mask'] = pn[..., 7]
+        return v
+
+    pr, qr = panels.double().requires_grad_(), place.double().requires_grad_()
+    lr_, dr, ur = theirs(views(pr, qr), {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in gt.items()},
+                         epoch=40)
+    lr_.backward()
+    pd, qd = panels.cuda().requires_grad_(), place.cuda().requires_grad_()
+    lo, do, upd = ours(views(pd, qd), {k: v.clone() for k, v in gt.items()}, epoch=40)
+    lo.backward()
+    assert upd == ur and upd                                     # epoch == epoch_with_stitches: the loss structure changed
+    assert set(do.keys()) == set(dr.keys()) and 'stitch_neg_loss' in do and 'free_edges_loss' in do
+    assert float(dr['stitch_neg_loss']) > 0                      # the test exercises the active branch
+    assert abs(lo.item() - lr_.item()) < 2e-6 * max(1, abs(lr_.item()))
+    for k_ in dr:
+        assert abs(float(do[k_]) - float(dr[k_])) < 2e-6 * max(1, abs(float(dr[k_]))), k_
+    assert relerr(pd.grad, pr.grad) < 2e-6
+    assert relerr(pd.grad[..., 4:], pr.grad[..., 4:]) < 2e-6     # the tag / free-edge columns on their own scale
+    assert relerr(qd.grad, qr.grad) < 2e-6
+    if order:
+        ours.check_order_match()
+        assert torch.equal(ours.last_permutation.cpu(), theirs.last_permutation)
+    if origin:
+        assert torch.equal(ours.last_leading_edges.cpu(), theirs.last_leading_edges)
+    # the ground truth the stitch terms saw: re-derive it with the oracle's helpers
+    with torch.no_grad():
+        gt2 = {k: v.clone() for k, v in gt.items()}
+        theirs.epoch = 40
+        if order:
+            gt2 = theirs._gt_order_match(views(pr, qr), gt2)
+        if origin:
+            gt2 = theirs._rotate_gt(views(pr, qr), gt2, gt2['num_edges'].int().view(-1))
+    got = ours.last_matched_stitch_gt
+    assert torch.equal(got['stitches'].cpu(), gt2['stitches'])
+    assert torch.equal(got['free_edges_mask'].cpu().bool(), gt2['free_edges_mask'].bool())
+    # before the switch-over epoch nothing of this runs and the dict has the four main keys only
+    lo0, do0, upd0 = ours(views(pd.detach(), qd.detach()), {k: v.clone() for k, v in gt.items()}, epoch=39)
+    assert set(do0.keys()) == {'pattern_loss', 'loop_loss', 'rotation_loss', 'translation_loss'} and upd0 == bool(order and 0 == 39)
+
+
 def test_fused_adam_onecycle_vs_torch(gpe):
     """gpe_adam_step over a flat arena + the OneCycle schedule vs torch.optim.Adam + OneCycleLR in fp64
     (nn/trainer.py:162-185)."""
