@@ -365,11 +365,9 @@ static void knn_launch(long nblocks, size_t lds, hipStream_t s, int probe, const
                            tiles, pin, 0, nsplit, part);
 }
 
-extern "C" int gpe_knn(const float* x, int B, int N, int C, int ldx, int k, int32_t* idx, int32_t* idx_glob,
-                       void* stream)
+// all-exact path: every distance by the defined chain (C < 16, k > 48, or GPE_KNN_EXACT=1)
+static int knn_exact(const float* x, int B, int N, int C, int ldx, int k, int32_t* idx, int32_t* idx_glob, void* stream)
 {
-    if (!x || !idx || B < 0 || N <= 0 || C <= 0 || ldx < C || k <= 0 || k > 64 || k > N || (long)B * N * k >= (1L << 31)) return GPE_EINVAL;
-    if (B == 0) return GPE_OK;
     const size_t lds = ((size_t)2 * KNN_TQ * KNN_LD + 4 * 16 * KNN_LDD) * sizeof(float) + 4 * 64 * sizeof(unsigned long long);
     static const int probe = getenv("GPE_KNN_PROBE") ? atoi(getenv("GPE_KNN_PROBE")) : 0;
     const int tiles = gpe_cdiv(N, KNN_TQ);
@@ -415,5 +413,558 @@ extern "C" int gpe_knn(const float* x, int B, int N, int C, int ldx, int k, int3
                            (long)B * N, N, k, nsplit, idx, idx_glob);
         GPE_CHECK_LAUNCH();
     }
+    return GPE_OK;
+}
+
+// =====================================================================================================================
+// C >= 16: the distance arithmetic on the fp32 matrix pipe, bit-exact result through a bounded exact recheck
+// =====================================================================================================================
+// The sub + fma chain above costs 2 VALU lane-ops per (query, candidate, channel); d~ = |q|^2 + |p|^2 - 2 q.p costs one fp32
+// MFMA multiply-add (v_mfma_f32_16x16x4_f32: exact products, fp32 accumulation) — half the issue slots.  d~ is NOT the
+// defined distance (oracle/knn_ref.c: the fmaf chain of (q_c - p_c)^2), so it only FILTERS:
+//   1. gpe_knn_norms_kernel    |x|^2 per point, max per cloud;
+//   2. gpe_knn_mfma_kernel     per query the K2 = min(64, N, 2k + 8) best candidates by (d~, index), streamed like above;
+//                              a candidate is inserted only below min(K2-th best, k-th best + 2E): nothing further out can
+//                              be needed (the k-th best only decreases);
+//   3. gpe_knn_rerank_kernel   one wave per query: every candidate of the exact top-k has d~ <= T = d~[k-th] + 2E (proof
+//                              below), list neighbours further than 2E apart are in their exact order already, so only runs
+//                              of entries closer than 2E are re-evaluated with the exact chain and sorted by (d, index).
+//                              If K2 entries lie below T the list may have lost a needed candidate: that query is redone
+//                              exactly by its wave (lattices, duplicated points: correct, just slower).
+// E bounds |d~ - d| + |d_chain - d| for the real-valued d = sum (q_c - p_c)^2 of the fp32 inputs (u = 2^-24):
+//   d_chain: every term is >= 0, C + 2 roundings deep                        ->  <= (C + 2) u d <= 2 (C + 2) u (|q|^2 + |p|^2)
+//   d~     : |q|^2, |p|^2 chains (C u each), the dot product (at most two roundings per element: 2 C u |q||p|, doubled by the
+//            factor 2), three more roundings                                 ->  <= (3 C + 4) u (|q|^2 + |p|^2)
+// so E = (5 C + 8) u (|q|^2 + max_p |p|^2) suffices; the kernels use (6 C + 16) u and 1 % on top.
+// Why T suffices: let p be in the exact top-k with d~(p) > kth~ + 2E.  The k list entries r with d~(r) <= kth~ have
+// d_chain(r) <= d~(r) + E <= kth~ + E < d~(p) - E <= d_chain(p): k candidates strictly closer than p — contradiction.
+#define KNN_MF_MINC 16
+
+#define KNN_NORM_ROWS 16
+__global__ __launch_bounds__(256) void gpe_knn_norms_kernel(const float* __restrict__ x, long rows, int N, int C, int ldx,
+                                                            float* __restrict__ norms, int* __restrict__ cmax)
+{
+    // wave = KNN_NORM_ROWS consecutive rows, all of their loads of a 64-channel slab in flight together (a row at a time was a
+    // chain of dependent round trips)
+    const int lane = threadIdx.x & 63;
+    const long r0 = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * KNN_NORM_ROWS;
+    if (r0 >= rows) return;
+    const long last = rows - 1;
+    float s[KNN_NORM_ROWS];
+#pragma unroll
+    for (int u = 0; u < KNN_NORM_ROWS; ++u) s[u] = 0.f;
+    for (int c0 = 0; c0 < C; c0 += 64) {
+        const int c = c0 + lane;
+        const int cc = (c < C) ? c : 0;
+        float v[KNN_NORM_ROWS];
+#pragma unroll
+        for (int u = 0; u < KNN_NORM_ROWS; ++u) v[u] = x[((r0 + u < last) ? r0 + u : last) * ldx + cc];
+#pragma unroll
+        for (int u = 0; u < KNN_NORM_ROWS; ++u) s[u] = (c < C) ? __builtin_fmaf(v[u], v[u], s[u]) : s[u];
+    }
+#pragma unroll
+    for (int u = 0; u < KNN_NORM_ROWS; ++u) {
+        float t = s[u];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) t += __int_as_float(__builtin_amdgcn_ds_bpermute((lane ^ o) << 2, __float_as_int(t)));
+        if (lane == 0 && r0 + u <= last) norms[r0 + u] = t;
+    }
+}
+
+// max_p |p|^2 of every cloud (one workgroup per cloud; per-wave atomics on 32 addresses cost 40 us)
+__global__ __launch_bounds__(256) void gpe_knn_cmax_kernel(const float* __restrict__ norms, int N, int* __restrict__ cmax)
+{
+    __shared__ float red[256];
+    const float* p = norms + (size_t)blockIdx.x * N;
+    float m = 0.f;
+    for (int i = threadIdx.x; i < N; i += 256) m = fmaxf(m, p[i]);
+    red[threadIdx.x] = m;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + st]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) cmax[blockIdx.x] = __float_as_int(red[0]);
+}
+
+// the selection step of knn_select with a list of K2 entries of which only the first kk matter for the insertion bound
+__device__ __forceinline__ float knn_select_mf(bool first, float d, int lane, int cand, int K2, int kk, float m2e,
+                                               float thr, unsigned long long* mW, float& ldv, int& liv)
+{
+    const int db = __float_as_int(d);
+    const unsigned long long key = ((unsigned long long)(unsigned)db << 32) | (unsigned)lane;
+    if (first) {
+        int rank = 0;
+#pragma unroll 8
+        for (int s2 = 0; s2 < 64; ++s2) {
+            const unsigned long long keyn = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(db, s2) << 32) | (unsigned)s2;
+            rank += (keyn < key) ? 1 : 0;
+        }
+        const int dperm = __builtin_amdgcn_ds_permute(rank << 2, db);
+        const int iperm = __builtin_amdgcn_ds_permute(rank << 2, cand);
+        ldv = (lane < K2) ? __int_as_float(dperm) : INFINITY;
+        liv = (lane < K2) ? iperm : -1;
+        return fminf(knn_readlane_f(ldv, K2 - 1), knn_readlane_f(ldv, kk - 1) + m2e);
+    }
+    const unsigned long long m = __ballot(d < thr);
+    if (m == 0) return thr;
+    int shift = 0, rank = 0, pos = 0;
+    unsigned long long mm = m;
+    do {
+        const int src = __builtin_ctzll(mm);
+        mm &= mm - 1;
+        const int dnb = __builtin_amdgcn_readlane(db, src);
+        const float dn = __int_as_float(dnb);
+        shift += (dn < ldv) ? 1 : 0;
+        const unsigned long long keyn = ((unsigned long long)(unsigned)dnb << 32) | (unsigned)src;
+        rank += (keyn < key) ? 1 : 0;
+        const int front = __builtin_popcountll(__ballot(ldv <= dn));
+        pos = (lane == src) ? front : pos;
+    } while (mm);
+    asm volatile("" ::: "memory");
+    if (lane < K2) {
+        const int np = lane + shift;
+        if (np < K2) mW[np] = ((unsigned long long)(unsigned)__float_as_int(ldv) << 32) | (unsigned)liv;
+    }
+    if ((m >> lane) & 1ull) {
+        const int np = pos + rank;
+        if (np < K2) mW[np] = ((unsigned long long)(unsigned)db << 32) | (unsigned)cand;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const unsigned long long got = mW[lane];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    ldv = (lane < K2) ? __int_as_float((int)(got >> 32)) : INFINITY;
+    liv = (lane < K2) ? (int)(unsigned)got : -1;
+    // the insertion bound of this query from now on: min(K2-th best, kk-th best + 2E)
+    return fminf(knn_readlane_f(ldv, K2 - 1), knn_readlane_f(ldv, kk - 1) + m2e);
+}
+
+// Same work decomposition as gpe_knn_kernel (64 queries x 64 candidates per step, wave w owns queries 16w..16w+15, operand
+// tiles point-major in LDS).  Matrix roles: A = the tile's 64 candidates (4 row blocks), B = the wave's 16 queries, so lane
+// (j = lane % 16, g = lane / 16) ends up with the dot products of query j against candidates 16 mt + 4g .. + 3 — one float4
+// of the wave's query-major distance strip per row block.  In MFMA t of a 16-channel block lane group g supplies channel
+// 4g + t of both operands (one ds_read_b128 per operand row and block).
+template <int VEC>
+__global__ __launch_bounds__(256, 4) void gpe_knn_mfma_kernel(const float* __restrict__ x, int N, int C, int ldx, int kk,
+                                                              int K2, const float* __restrict__ norms,
+                                                              const int* __restrict__ cmax, float ce, int B, int tiles,
+                                                              int pin, int nsplit, unsigned long long* __restrict__ part,
+                                                              int probe)
+{
+    extern __shared__ __align__(16) float smem[];
+    float* const qS = smem;
+    float* const cS = qS + KNN_TQ * KNN_LD;
+    float* const dS = cS + KNN_TC * KNN_LD;
+    unsigned long long* const mS = reinterpret_cast<unsigned long long*>(dS + 4 * 16 * KNN_LDD);
+    float* const npS = reinterpret_cast<float*>(mS + 4 * 64);       // [64] |p|^2 of the candidate tile
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int b, item;
+    const int ipc = tiles * nsplit;
+    if (pin) {
+        const int xcd = blockIdx.x & (GPE_NXCD - 1), slot = blockIdx.x >> 3;
+        const int jc = slot / ipc;
+        b = xcd + GPE_NXCD * jc;
+        item = slot - jc * ipc;
+        if (b >= B) return;
+    } else {
+        b = blockIdx.x / ipc;
+        item = blockIdx.x - b * ipc;
+    }
+    const int qt = item / nsplit, piece = item - qt * nsplit;
+    const int q0 = qt * KNN_TQ;
+    const int tps = (tiles + nsplit - 1) / nsplit;
+    const int c_first = piece * tps * KNN_TC;
+    const int c_stop = ((piece + 1) * tps * KNN_TC < N) ? (piece + 1) * tps * KNN_TC : N;
+    const float* cloud = x + (size_t)b * N * ldx;
+    const float* cnorm = norms + (size_t)b * N;
+    float* const dW = dS + wave * 16 * KNN_LDD;
+    unsigned long long* const mW = mS + wave * 64;
+
+    float ld_[16];
+    int li_[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { ld_[i] = INFINITY; li_[i] = -1; }
+    float thrq = INFINITY;           // lane L: the insertion bound of query L % 16 (what its tile minimum is tested against)
+
+    const int j = lane & 15, g = lane >> 4;
+    const int myq = (q0 + 16 * wave + j < N) ? q0 + 16 * wave + j : N - 1;
+    const float nq = cnorm[myq];
+    const float cm = __int_as_float(cmax[b]);
+    // 2E of each of the wave's 16 queries (uniform per query; lane i of the first 16 holds query i's norm)
+    float m2e_of;
+    {
+        const int qi = (q0 + 16 * wave + (lane & 15) < N) ? q0 + 16 * wave + (lane & 15) : N - 1;
+        m2e_of = 2.02f * ce * (cnorm[qi] + cm);
+    }
+
+    // ---- staging (as in gpe_knn_kernel) ----------------------------------------------------------------------------
+    const int nchunk = (C + KNN_CCH - 1) / KNN_CCH;
+    const int chw = (C < KNN_CCH) ? ((C + 15) & ~15) : KNN_CCH;        // whole 16-channel blocks
+    const int vpr = chw / VEC;
+    const int rvpr = (65536 + vpr - 1) / vpr;
+    const int nvec = KNN_TC * vpr;
+    constexpr int NPF = (KNN_TC * KNN_CCH) / (256 * VEC);
+    float pre_c[NPF][VEC], pre_q[NPF][VEC];
+    float pre_n = 0.f;
+    int pf_c0 = c_first, pf_ch = 0;
+    auto prefetch = [&]() {
+#pragma unroll
+        for (int i = 0; i < NPF; ++i) {
+            const int e = tid + 256 * i;
+            if (e < nvec) {
+                const int row = (e * rvpr) >> 16, cv = e - row * vpr;
+                const int ch = pf_ch + cv * VEC;
+                const bool on = ch < C;                    // a vector may straddle C (row pitch padded): zeroed per element below
+                const int chc = on ? ch : 0;
+                const int pr = (pf_c0 + row < N) ? pf_c0 + row : N - 1;
+                const int qr = (q0 + row < N) ? q0 + row : N - 1;
+                const float* pc = cloud + (size_t)pr * ldx + chc;
+                const float* pq = cloud + (size_t)qr * ldx + chc;
+                if constexpr (VEC == 4) {
+                    const float4 v = *reinterpret_cast<const float4*>(pc), w = *reinterpret_cast<const float4*>(pq);
+                    pre_c[i][0] = v.x; pre_c[i][1] = v.y; pre_c[i][2] = v.z; pre_c[i][3] = v.w;
+                    pre_q[i][0] = w.x; pre_q[i][1] = w.y; pre_q[i][2] = w.z; pre_q[i][3] = w.w;
+                } else if constexpr (VEC == 2) {
+                    const float2 v = *reinterpret_cast<const float2*>(pc), w = *reinterpret_cast<const float2*>(pq);
+                    pre_c[i][0] = v.x; pre_c[i][1] = v.y;
+                    pre_q[i][0] = w.x; pre_q[i][1] = w.y;
+                } else {
+                    pre_c[i][0] = *pc; pre_q[i][0] = *pq;
+                }
+#pragma unroll
+                for (int t = 0; t < VEC; ++t)
+                    if (ch + t >= C) { pre_c[i][t] = 0.f; pre_q[i][t] = 0.f; }
+            }
+        }
+        if (pf_ch == 0 && tid < KNN_TC) pre_n = cnorm[(pf_c0 + tid < N) ? pf_c0 + tid : N - 1];
+        pf_ch += KNN_CCH;
+        if (pf_ch >= C) { pf_ch = 0; pf_c0 += KNN_TC; }
+    };
+    auto commit = [&](bool first_chunk) {
+#pragma unroll
+        for (int i = 0; i < NPF; ++i) {
+            const int e = tid + 256 * i;
+            if (e < nvec) {
+                const int row = (e * rvpr) >> 16, cv = e - row * vpr;
+                float* dc = &cS[row * KNN_LD + cv * VEC];
+                float* dq = &qS[row * KNN_LD + cv * VEC];
+                if constexpr (VEC == 4) {
+                    *reinterpret_cast<float4*>(dc) = make_float4(pre_c[i][0], pre_c[i][1], pre_c[i][2], pre_c[i][3]);
+                    *reinterpret_cast<float4*>(dq) = make_float4(pre_q[i][0], pre_q[i][1], pre_q[i][2], pre_q[i][3]);
+                } else if constexpr (VEC == 2) {
+                    *reinterpret_cast<float2*>(dc) = make_float2(pre_c[i][0], pre_c[i][1]);
+                    *reinterpret_cast<float2*>(dq) = make_float2(pre_q[i][0], pre_q[i][1]);
+                } else {
+                    *dc = pre_c[i][0]; *dq = pre_q[i][0];
+                }
+            }
+        }
+        if (first_chunk && tid < KNN_TC) npS[tid] = pre_n;
+    };
+    prefetch();
+    const int nsteps = ((c_stop - c_first + KNN_TC - 1) / KNN_TC) * nchunk;
+    int step = 0;
+
+    const float* const brow = &qS[(16 * wave + j) * KNN_LD + 4 * g];
+    const float* const arow = &cS[j * KNN_LD + 4 * g];
+
+    for (int c0 = c_first; c0 < c_stop; c0 += KNN_TC) {
+        f32x4 acc[4];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int ch = 0; ch < C; ch += KNN_CCH, ++step) {
+            __syncthreads();
+            if (!((probe & 2) && step > 0)) commit(ch == 0);
+            __syncthreads();
+            if (step + 1 < nsteps && !(probe & 2)) prefetch();
+            int nblk = ((C - ch < KNN_CCH) ? (C - ch + 15) : KNN_CCH) >> 4;   // channels past C are staged as zeros
+            if (probe & 4) nblk = 0;
+            for (int blk = 0; blk < nblk; ++blk) {
+                const float4 bq = *reinterpret_cast<const float4*>(&brow[16 * blk]);
+                float4 aq[4];
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) aq[mt] = *reinterpret_cast<const float4*>(&arow[16 * mt * KNN_LD + 16 * blk]);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const float bv = (t == 0) ? bq.x : (t == 1) ? bq.y : (t == 2) ? bq.z : bq.w;
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt) {
+                        const float av = (t == 0) ? aq[mt].x : (t == 1) ? aq[mt].y : (t == 2) ? aq[mt].z : aq[mt].w;
+                        acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[mt], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        // d~ = |q|^2 + |p|^2 - 2 q.p, clamped at +0 (the bit pattern must order like the value)
+        const bool tail = c0 + KNN_TC > N;
+        float4 dq[4];
+        float dmin = INFINITY;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const float4 np = *reinterpret_cast<const float4*>(&npS[16 * mt + 4 * g]);
+            float4 d;
+            d.x = __builtin_fmaf(-2.f, acc[mt][0], nq + np.x); d.y = __builtin_fmaf(-2.f, acc[mt][1], nq + np.y);
+            d.z = __builtin_fmaf(-2.f, acc[mt][2], nq + np.z); d.w = __builtin_fmaf(-2.f, acc[mt][3], nq + np.w);
+            d.x = d.x > 0.f ? d.x : 0.f; d.y = d.y > 0.f ? d.y : 0.f; d.z = d.z > 0.f ? d.z : 0.f; d.w = d.w > 0.f ? d.w : 0.f;
+            if (tail) {                                  // candidates past the cloud never qualify
+                const int cb = c0 + 16 * mt + 4 * g;
+                d.x = (cb + 0 < N) ? d.x : INFINITY; d.y = (cb + 1 < N) ? d.y : INFINITY;
+                d.z = (cb + 2 < N) ? d.z : INFINITY; d.w = (cb + 3 < N) ? d.w : INFINITY;
+            }
+            dq[mt] = d;
+            dmin = fminf(fminf(dmin, fminf(d.x, d.y)), fminf(d.z, d.w));
+        }
+        // which of the wave's 16 queries have a candidate below their insertion bound in this tile?  (lane (j, g) tested the
+        // 16 candidates it holds of query j.)  The others skip the tile without touching the strip.
+        unsigned qm = 0xffffu;
+        if (c0 != c_first) {
+            const unsigned long long hm = __ballot(dmin < thrq);
+            qm = (unsigned)((hm | (hm >> 16) | (hm >> 32) | (hm >> 48)) & 0xffffull);
+        }
+        if ((probe & 1) && c0 > c_first) qm = 0;
+        if (qm == 0) continue;
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) *reinterpret_cast<float4*>(&dW[j * KNN_LDD + 16 * mt + 4 * g]) = dq[mt];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+
+        const int cand = c0 + lane;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            if (!((qm >> i) & 1u)) continue;
+            const float d = dW[i * KNN_LDD + lane];
+            float ldv = ld_[i];
+            int liv = li_[i];
+            const float t = knn_select_mf(c0 == c_first, d, lane, cand, K2, kk, knn_readlane_f(m2e_of, i),
+                                          knn_readlane_f(thrq, i), mW, ldv, liv);
+            ld_[i] = ldv; li_[i] = liv;
+            thrq = ((lane & 15) == i) ? t : thrq;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int q = q0 + 16 * wave + i;
+        if (q < N && lane < K2)
+            part[(((size_t)b * N + q) * nsplit + piece) * K2 + lane] =
+                ((unsigned long long)(unsigned)__float_as_int(ld_[i]) << 32) | (unsigned)li_[i];
+    }
+}
+
+// exact chain distance of one (query row, candidate row) pair per lane — oracle/knn_ref.c's arithmetic
+// (16-byte loads when both rows allow it: a lane walks its own row, so the loads of the next channels must be in flight under
+// the dependent fma chain — one dword load per step was a full L2 round trip per channel, 12 us per re-evaluated candidate)
+__device__ __forceinline__ float knn_exact_chain(const float* __restrict__ q, const float* __restrict__ p, int C, bool vec4)
+{
+    float acc = 0.f;
+    int c = 0;
+    if (vec4) {
+        // 32 channels per batch: all 16 loads are issued before the first dependent fma
+        for (; c + 32 <= C; c += 32) {
+            float4 qv[8], pv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                qv[u] = *reinterpret_cast<const float4*>(q + c + 4 * u);
+                pv[u] = *reinterpret_cast<const float4*>(p + c + 4 * u);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                acc = knn_sqacc(knn_sub(qv[u].x, pv[u].x), acc);
+                acc = knn_sqacc(knn_sub(qv[u].y, pv[u].y), acc);
+                acc = knn_sqacc(knn_sub(qv[u].z, pv[u].z), acc);
+                acc = knn_sqacc(knn_sub(qv[u].w, pv[u].w), acc);
+            }
+        }
+        for (; c + 4 <= C; c += 4) {
+            const float4 qv = *reinterpret_cast<const float4*>(q + c), pv = *reinterpret_cast<const float4*>(p + c);
+            acc = knn_sqacc(knn_sub(qv.x, pv.x), acc);
+            acc = knn_sqacc(knn_sub(qv.y, pv.y), acc);
+            acc = knn_sqacc(knn_sub(qv.z, pv.z), acc);
+            acc = knn_sqacc(knn_sub(qv.w, pv.w), acc);
+        }
+    }
+#pragma unroll 4
+    for (; c < C; ++c) acc = knn_sqacc(knn_sub(q[c], p[c]), acc);
+    return acc;
+}
+
+__global__ __launch_bounds__(256) void gpe_knn_rerank_kernel(const float* __restrict__ x, long nq_total, int N, int C, int ldx,
+                                                             int k, int K2, int nsplit,
+                                                             const unsigned long long* __restrict__ part,
+                                                             const float* __restrict__ norms, const int* __restrict__ cmax,
+                                                             float ce, int32_t* __restrict__ idx,
+                                                             int32_t* __restrict__ idx_glob)
+{
+    __shared__ unsigned long long strip[4][64];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long q = (long)blockIdx.x * 4 + wave;
+    if (q >= nq_total) return;
+    const int b = (int)(q / N);
+    const float* cloud = x + (size_t)b * N * ldx;
+    const float* qrow = x + q * ldx;
+    const bool vec4 = (ldx % 4 == 0) && ((uintptr_t)x % 16 == 0);      // every row starts 16-byte aligned
+    unsigned long long* const mW = strip[wave];
+    const int nk = nsplit * K2;                                       // <= 64
+    // ---- merge the pieces' sorted lists: rank of every key among all of them (keys are distinct: distinct candidates) ----
+    unsigned long long key = (lane < nk) ? part[q * nk + lane] : ~0ull;
+    if (nsplit > 1) {
+        int rank = 0;
+        const unsigned klo = (unsigned)key, khi = (unsigned)(key >> 32);
+        for (int s2 = 0; s2 < nk; ++s2) {
+            const unsigned long long kn = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)khi, s2) << 32) |
+                                          (unsigned)__builtin_amdgcn_readlane((int)klo, s2);
+            rank += (kn < key || (kn == key && s2 < lane)) ? 1 : 0;
+        }
+        if (lane < nk) mW[rank] = key;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        key = (lane < nk) ? mW[lane] : ~0ull;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    float da = __int_as_float((int)(key >> 32));                      // approximate distance (lanes >= nk: NaN pattern, unused)
+    int id = (int)(unsigned)key;
+    const float m2e = 2.02f * ce * (norms[q] + __int_as_float(cmax[b]));
+    const float T = knn_readlane_f(da, k - 1) + m2e;
+    const unsigned long long below = __ballot(lane < nk && da <= T);
+    const int m = __builtin_popcountll(below);                        // a prefix of the sorted list
+    const bool overflow = (m >= K2) && (K2 < N);
+    if (overflow) {
+        // the list may have lost a needed candidate: this query exactly, by this wave (candidates 64 at a time)
+        float ldv = INFINITY, thr = INFINITY;
+        int liv = -1;
+        for (int c0 = 0; c0 < N; c0 += 64) {
+            const int cand = c0 + lane;
+            float d = INFINITY;
+            if (cand < N) d = knn_exact_chain(qrow, cloud + (size_t)cand * ldx, C, vec4);
+            knn_select(c0 == 0, d, lane, cand, k, mW, ldv, liv, thr);
+        }
+        if (lane < k) {
+            idx[q * k + lane] = liv;
+            if (idx_glob) idx_glob[q * k + lane] = b * N + liv;
+        }
+        return;
+    }
+    // ---- runs of entries closer than 2E to their neighbour: exact distances, sorted inside the run by (d, index) ----------
+    const bool in_s = lane < m;
+    const float dnext = __int_as_float(__builtin_amdgcn_ds_bpermute(((lane + 1) & 63) << 2, __float_as_int(da)));
+    const bool near_next = (lane + 1 < m) && (dnext - da <= m2e);
+    const unsigned long long nn = __ballot(near_next);
+    const bool near_prev = (lane > 0) && ((nn >> (lane - 1)) & 1ull);
+    const bool flagged = in_s && (near_next || near_prev);
+    const unsigned long long fl = __ballot(flagged);
+    int newpos = lane;
+#ifdef KNN_DEBUG_DUMP
+    float dbg_dex0 = -1.f, dbg_dex1 = -1.f; int dbg_r0 = -1, dbg_r1 = -1, dbg_s0 = -1;
+#endif
+    if (fl) {
+        const unsigned long long starts = __ballot(in_s && !near_prev);
+        const unsigned long long le = (lane == 63) ? ~0ull : ((1ull << (lane + 1)) - 1ull);
+        const int start = 63 - __builtin_clzll((starts & le) | 1ull);
+        float dex = da;
+        if (flagged) dex = knn_exact_chain(qrow, cloud + (size_t)id * ldx, C, vec4);
+        int r = 0;
+        for (int s2 = 0; s2 < m; ++s2) {
+            const float dj = knn_readlane_f(dex, s2);
+            const int ij = __builtin_amdgcn_readlane(id, s2);
+            const int sj = __builtin_amdgcn_readlane(start, s2);
+            r += (sj == start && (dj < dex || (dj == dex && ij < id))) ? 1 : 0;
+        }
+        if (flagged) newpos = start + r;
+#ifdef KNN_DEBUG_DUMP
+        dbg_dex0 = knn_readlane_f(dex, 0); dbg_dex1 = knn_readlane_f(dex, 1);
+        dbg_r0 = __builtin_amdgcn_readlane(r, 0); dbg_r1 = __builtin_amdgcn_readlane(r, 1); dbg_s0 = __builtin_amdgcn_readlane(start, 0);
+#endif
+    }
+    if (in_s && newpos < k) {
+        idx[q * k + newpos] = id;
+        if (idx_glob) idx_glob[q * k + newpos] = b * N + id;
+    }
+#ifdef KNN_DEBUG_DUMP
+    if (idx_glob && lane < k) {
+        int v = 0;
+        if (lane == 0) v = m;
+        if (lane == 1) v = (int)(unsigned)fl;
+        if (lane == 2) v = __float_as_int(m2e);
+        if (lane == 3) v = __float_as_int(knn_readlane_f(da, 0));
+        if (lane == 4) v = __float_as_int(knn_readlane_f(da, 1));
+        if (lane == 5) v = __float_as_int(T);
+        if (lane == 6) v = __float_as_int(dbg_dex0);
+        if (lane == 7) v = __float_as_int(dbg_dex1);
+        if (lane == 8) v = dbg_r0;
+        if (lane == 9) v = dbg_r1;
+        if (lane == 10) v = dbg_s0;
+        if (lane == 11) v = __builtin_amdgcn_readlane(id, 0);
+        if (lane == 12) v = __builtin_amdgcn_readlane(newpos, 0);
+        idx_glob[q * k + lane] = v;
+    }
+#endif
+}
+
+extern "C" int gpe_knn(const float* x, int B, int N, int C, int ldx, int k, int32_t* idx, int32_t* idx_glob,
+                       void* stream)
+{
+    if (!x || !idx || B < 0 || N <= 0 || C <= 0 || ldx < C || k <= 0 || k > 64 || k > N || (long)B * N * k >= (1L << 31)) return GPE_EINVAL;
+    if (B == 0) return GPE_OK;
+    static const int force_exact = getenv("GPE_KNN_EXACT") ? atoi(getenv("GPE_KNN_EXACT")) : 0;
+    if (C < KNN_MF_MINC || k > 48 || force_exact) return knn_exact(x, B, N, C, ldx, k, idx, idx_glob, stream);
+    // ---- matrix-pipe filter + exact recheck ----
+    int K2 = (2 * k < 32) ? 2 * k : 32;
+    if (K2 < k + 8) K2 = k + 8;
+    if (K2 > 64) K2 = 64;
+    if (K2 > N) K2 = N;
+    const int tiles = gpe_cdiv(N, KNN_TQ);
+    static const int dbg_pin = getenv("GPE_KNN_PIN") ? atoi(getenv("GPE_KNN_PIN")) : -1;
+    static const int dbg_vec = getenv("GPE_KNN_VEC") ? atoi(getenv("GPE_KNN_VEC")) : 0;
+    static const int dbg_split = getenv("GPE_KNN_SPLIT") ? atoi(getenv("GPE_KNN_SPLIT")) : 0;
+    static const int mprobe = getenv("GPE_KNN_PROBE") ? atoi(getenv("GPE_KNN_PROBE")) : 0;   // timing aid (wrong results)
+    const int pin = (dbg_pin >= 0) ? (dbg_pin && B >= GPE_NXCD) : (gpe_pin_clouds(B) ? 1 : 0);
+    // No candidate split here.  knn_exact cuts the candidate range in pieces so that the tables in flight fit an L2; for this
+    // path every piece would pay its own first-tile ranking and its own list build-up (selection work x 1.7 at two pieces) plus
+    // a 64-key merge per query in the rerank: measured at cfg 2, layer 2: 0.99 ms with two pieces, 0.86 ms with one (the extra
+    // ~360 MB of L2 misses per launch are 0.5 TB/s of HBM traffic under a kernel that is not memory-bound).  GPE_KNN_SPLIT
+    // still forces pieces (the merge code stays tested).
+    int nsplit = 1;
+    if (dbg_split > 0 && dbg_split * K2 <= 64 && dbg_split <= tiles) nsplit = dbg_split;
+    const size_t nq = (size_t)B * N;
+    const size_t part_bytes = nq * nsplit * K2 * sizeof(unsigned long long);
+    const size_t norm_bytes = (nq * sizeof(float) + 255) & ~(size_t)255;
+    char* scratch = (char*)gpe_scratch(1, part_bytes + norm_bytes + (size_t)B * sizeof(int) + 256);
+    if (!scratch) return knn_exact(x, B, N, C, ldx, k, idx, idx_glob, stream);
+    unsigned long long* part = (unsigned long long*)scratch;
+    float* norms = (float*)(scratch + part_bytes);
+    int* cmax = (int*)(scratch + part_bytes + norm_bytes);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(gpe_knn_norms_kernel, dim3((unsigned)gpe_cdiv((long)nq, 4 * KNN_NORM_ROWS)), dim3(256), 0, s, x, (long)nq, N, C, ldx, norms,
+                       cmax);
+    GPE_CHECK_LAUNCH();
+    hipLaunchKernelGGL(gpe_knn_cmax_kernel, dim3(B), dim3(256), 0, s, norms, N, cmax);
+    GPE_CHECK_LAUNCH();
+    const float ce = (6.f * C + 16.f) * 5.9604645e-8f;     // (6C + 16) * 2^-24, see the bound above
+    const size_t lds = ((size_t)2 * KNN_TQ * KNN_LD + 4 * 16 * KNN_LDD) * sizeof(float) + 4 * 64 * sizeof(unsigned long long) +
+                       KNN_TC * sizeof(float);
+    const long nblocks = (pin ? (long)GPE_NXCD * gpe_cdiv(B, GPE_NXCD) * tiles : (long)B * tiles) * nsplit;
+    if (nblocks >= (1L << 31)) return GPE_EINVAL;
+    const uintptr_t xa = (uintptr_t)x;
+    // widest staging copy: a vector may run into the row's pad columns (their contents are replaced by zeros), so only the
+    // pitch and the base address have to allow it
+    int vec = (ldx % 4 == 0 && xa % 16 == 0 && ((C + 3) & ~3) <= ldx) ? 4
+            : (ldx % 2 == 0 && xa % 8 == 0 && ((C + 1) & ~1) <= ldx) ? 2 : 1;
+    if (dbg_vec > 0 && dbg_vec < vec) vec = dbg_vec;
+    if (vec == 4)
+        hipLaunchKernelGGL((gpe_knn_mfma_kernel<4>), dim3((unsigned)nblocks), dim3(256), lds, s, x, N, C, ldx, k, K2, norms, cmax, ce,
+                           B, tiles, pin, nsplit, part, mprobe);
+    else if (vec == 2)
+        hipLaunchKernelGGL((gpe_knn_mfma_kernel<2>), dim3((unsigned)nblocks), dim3(256), lds, s, x, N, C, ldx, k, K2, norms, cmax, ce,
+                           B, tiles, pin, nsplit, part, mprobe);
+    else
+        hipLaunchKernelGGL((gpe_knn_mfma_kernel<1>), dim3((unsigned)nblocks), dim3(256), lds, s, x, N, C, ldx, k, K2, norms, cmax, ce,
+                           B, tiles, pin, nsplit, part, mprobe);
+    GPE_CHECK_LAUNCH();
+    hipLaunchKernelGGL(gpe_knn_rerank_kernel, dim3((unsigned)gpe_cdiv((long)nq, 4)), dim3(256), 0, s, x, (long)nq, N, C, ldx, k, K2,
+                       nsplit, part, norms, cmax, ce, idx, idx_glob);
+    GPE_CHECK_LAUNCH();
     return GPE_OK;
 }

@@ -99,6 +99,40 @@ def test_knn_wide_rows_hard_data(gpe, B, N, C, ld, k, data):
     assert bad == 0, '%d / %d queries differ' % (bad, B * N)
 
 
+_KNN_ALT_WORKER = '''
+import sys, torch
+sys.path.insert(0, %r)
+import gpe_amd
+from oracle import ref_path as O
+g = torch.Generator().manual_seed(5)
+for (B, N, C, ld, k) in [(8, 256, 150, 152, 16), (9, 200, 33, 36, 5), (8, 130, 64, 64, 20)]:
+    for kind in ('gauss', 'clusters', 'lattice'):
+        if kind == 'gauss':
+            x = torch.randn(B * N, C, generator=g)
+        elif kind == 'clusters':
+            x = (torch.randn(8, C, generator=g) * 20)[torch.randint(0, 8, (B * N,), generator=g)] + 1e-2 * torch.randn(B * N, C, generator=g)
+        else:
+            x = torch.randint(0, 3, (B * N, C), generator=g).float(); x[:, 8:] = 0
+        buf = torch.zeros(B * N, ld); buf[:, :C] = x
+        ref = O.knn_local(x.contiguous(), B, k).to(torch.int32).view(B, N, k)
+        got = gpe_amd.ops.knn(buf.cuda()[:, :C], B, N, k).cpu()
+        assert torch.equal(got, ref), (B, N, C, k, kind, (got != ref).any(-1).sum().item())
+print('alt path ok')
+'''
+
+
+@pytest.mark.parametrize('env', [{'GPE_KNN_EXACT': '1'}, {'GPE_KNN_SPLIT': '2'}, {'GPE_KNN_EXACT': '1', 'GPE_KNN_SPLIT': '2'}])
+def test_knn_alternative_paths(gpe, env, tmp_path):
+    """The paths the dispatcher no longer takes by default on wide rows — the all-exact kernel's float4 / float2 staging
+    (C >= 16 now goes through the matrix-pipe filter) and the candidate split with its list merge (forced: B >= 8 pins clouds
+    to XCDs, which is what enables pieces) — stay bit-exact.  The overrides are read once per process, hence the subprocess."""
+    import os, subprocess, sys
+    script = tmp_path / 'w.py'
+    script.write_text(_KNN_ALT_WORKER % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    r = subprocess.run([sys.executable, str(script)], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and 'alt path ok' in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 def test_knn_ties_lower_index_wins(gpe):
     from oracle import ref_path as O
     # integer lattice -> many exactly equal distances, plus duplicated points
@@ -110,9 +144,9 @@ def test_knn_ties_lower_index_wins(gpe):
 
 
 def test_knn_candidate_split_full_size(gpe):
-    """B = 32 clouds of 2048 x 150 features (the layer-2 shape of BASELINE cfg 2): four 1.25 MB tables per XCD do not fit the
-    4 MiB L2, so the launcher cuts the candidate range of every query tile in two and merges the partial k-lists.  The first
-    and the last cloud must still be bit-exact against the C oracle (near-duplicate points included)."""
+    """B = 32 clouds of 2048 x 150 features (the layer-2 shape of BASELINE cfg 2) through the default dispatch (matrix-pipe
+    filter + exact rerank; the all-exact kernel would cut the candidate range in two here).  The first and the last cloud
+    must be bit-exact against the C oracle (exact duplicates included)."""
     from oracle import ref_path as O
     B, N, C, k = 32, 2048, 150, 16
     g = torch.Generator().manual_seed(123)
