@@ -1200,3 +1200,31 @@ extern "C" int gpe_add(const float* a, const float* b, float* out, long n, void*
     GPE_CHECK_LAUNCH();
     return GPE_OK;
 }
+
+// out[(b*T + t)*H + h] = x[b*x_sb + t*x_st + h] * mask[(b*T + t)*H + h] — the inter-layer dropout of nn.LSTM / nn.GRU
+// (/root/reference/nn/net_blocks.py:346,374,418-420,469 pass `dropout` to torch's recurrent modules, which multiply the
+// output sequence of every layer but the last by a Bernoulli(1-p)/(1-p) mask).  x is a strided [Bn, T, H] view (the h history
+// of a recurrent stack, or a dense gradient); mask and out are dense.
+__global__ void gpe_mul_rows_kernel(const float* __restrict__ x, long x_sb, long x_st, const float* __restrict__ mask, int T,
+                                    int H, long n, float* __restrict__ out)
+{
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    const int h = (int)(e % H);
+    const long q = e / H;
+    const int t = (int)(q % T);
+    const long b = q / T;
+    out[e] = x[b * x_sb + t * x_st + h] * mask[e];
+}
+
+extern "C" int gpe_mul_rows(const float* x, long x_sb, long x_st, const float* mask, long Bn, int T, int H, float* out,
+                            void* stream)
+{
+    if (!x || !mask || !out || Bn < 0 || T <= 0 || H <= 0) return GPE_EINVAL;
+    const long n = Bn * T * H;
+    if (n == 0) return GPE_OK;
+    hipLaunchKernelGGL(gpe_mul_rows_kernel, dim3(gpe_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, x, x_sb, x_st, mask, T, H,
+                       n, out);
+    GPE_CHECK_LAUNCH();
+    return GPE_OK;
+}

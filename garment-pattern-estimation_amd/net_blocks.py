@@ -282,8 +282,7 @@ class LSTMEncoderModule(nn.Module):
 
     def __init__(self, elem_len, encoding_size, n_layers, dropout=0, custom_init='kaiming_normal'):
         super().__init__()
-        if dropout:
-            raise NotImplementedError('LSTM dropout > 0 has no kernel (shipped configs use 0)')
+        self.dropout = float(dropout)
         self.custom_init = custom_init
         self.n_layers = n_layers
         self.encoding_size = encoding_size
@@ -300,7 +299,7 @@ class LSTMEncoderModule(nn.Module):
         c0 = _init_tenzor(self.n_layers, bs, self.encoding_size, device=device, init_type=self.custom_init)
         seq = batch_sequence if batch_sequence.stride(-1) == 1 else batch_sequence.contiguous()
         _, hN, _ = ops.rnn_stack(seq, h0, c0, seq.size(1), self.n_layers, 'lstm', _rnn_params(self.lstm, self.n_layers),
-                                 want_state=True)
+                                 want_state=True, dropout=self.dropout, training=self.training)
         return hN[-1]
 
 
@@ -311,8 +310,7 @@ class LSTMDecoderModule(nn.Module):
     def __init__(self, encoding_size, hidden_size, out_elem_size, n_layers, dropout=0,
                  custom_init='kaiming_normal', **kwargs):
         super().__init__()
-        if dropout:
-            raise NotImplementedError('LSTM dropout > 0 has no kernel (shipped configs use 0)')
+        self.dropout = float(dropout)
         self.custom_init = custom_init
         self.n_layers = n_layers
         self.encoding_size = encoding_size
@@ -335,7 +333,8 @@ class LSTMDecoderModule(nn.Module):
         c0 = _init_tenzor(self.n_layers, bs, self.hidden_size, device=device, init_type=self.custom_init)
         self.last_states = (h0, c0)
         enc = batch_enc if batch_enc.is_contiguous() else batch_enc.contiguous()
-        top, _, _ = ops.rnn_stack(enc, h0, c0, out_len, self.n_layers, 'lstm', _rnn_params(self.lstm, self.n_layers))
+        top, _, _ = ops.rnn_stack(enc, h0, c0, out_len, self.n_layers, 'lstm', _rnn_params(self.lstm, self.n_layers),
+                                  dropout=self.dropout, training=self.training)
         return ops.linear(top, self.lin.weight, self.lin.bias).view(bs, out_len, -1)
 
 
@@ -346,8 +345,7 @@ class LSTMDoubleReverseDecoderModule(nn.Module):
     def __init__(self, encoding_size, hidden_size, out_elem_size, n_layers, dropout=0,
                  custom_init='kaiming_normal', **kwargs):
         super().__init__()
-        if dropout:
-            raise NotImplementedError('LSTM dropout > 0 has no kernel (shipped configs use 0)')
+        self.dropout = float(dropout)
         self.custom_init = custom_init
         self.n_layers = n_layers
         self.encoding_size = encoding_size
@@ -374,11 +372,13 @@ class LSTMDoubleReverseDecoderModule(nn.Module):
         self.last_states = (h0, c0)
         enc = batch_enc if batch_enc.is_contiguous() else batch_enc.contiguous()
         out, hN, cN = ops.rnn_stack(enc, h0, c0, out_len, self.n_layers, 'lstm',
-                                    _rnn_params(self.lstm_reverse, self.n_layers), want_state=True)
+                                    _rnn_params(self.lstm_reverse, self.n_layers), want_state=True,
+                                    dropout=self.dropout, training=self.training)
         dec_input = enc.unsqueeze(1).expand(-1, out_len, -1)
         seq = torch.cat([torch.flip(out, [1]), dec_input], -1)            # skip connection with the original input
         top, _, _ = ops.rnn_stack(seq, hN, cN, out_len, self.n_layers, 'lstm',
-                                  _rnn_params(self.lstm_forward, self.n_layers))
+                                  _rnn_params(self.lstm_forward, self.n_layers), dropout=self.dropout,
+                                  training=self.training)
         return ops.linear(top, self.lin.weight, self.lin.bias).view(bs, out_len, -1)
 
 
@@ -388,8 +388,7 @@ class GRUDecoderModule(nn.Module):
     def __init__(self, encoding_size, hidden_size, out_elem_size, n_layers, dropout=0,
                  custom_init='kaiming_normal', **kwargs):
         super().__init__()
-        if dropout:
-            raise NotImplementedError('GRU dropout > 0 has no kernel (shipped configs use 0)')
+        self.dropout = float(dropout)
         self.custom_init = custom_init
         self.n_layers = n_layers
         self.encoding_size = encoding_size
@@ -411,7 +410,8 @@ class GRUDecoderModule(nn.Module):
         self.last_states = (h0,)
         enc = batch_enc if batch_enc.is_contiguous() else batch_enc.contiguous()
         top, _, _ = ops.rnn_stack(enc, h0, None, out_len, self.n_layers, 'gru',
-                                  _rnn_params(self.recurrent_cell, self.n_layers))
+                                  _rnn_params(self.recurrent_cell, self.n_layers), dropout=self.dropout,
+                                  training=self.training)
         return ops.linear(top, self.lin.weight, self.lin.bias).view(bs, out_len, -1)
 
 

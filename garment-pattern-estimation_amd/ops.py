@@ -778,9 +778,60 @@ class RNNStackFn(torch.autograd.Function):
         return (d_x, d_h0, d_c0, None, None, None, None, *grads)
 
 
-def rnn_stack(x, h0, c0, T, n_layers, kind, params, want_state=False):
-    out = RNNStackFn.apply(x, h0, c0, T, n_layers, kind, want_state, *params)
-    return out if kind == 'lstm' else (out[0], out[1], None)
+class DropoutMulFn(torch.autograd.Function):
+    """y = x * mask on a (strided) [Bn, T, H] sequence: the dropout torch's recurrent modules apply between layers."""
+
+    @staticmethod
+    def forward(ctx, x, mask):
+        _dev_check(x)
+        assert x.dim() == 3 and x.stride(2) == 1 and mask.is_contiguous() and mask.shape == x.shape
+        Bn, T, H = x.shape
+        out = torch.empty(Bn, T, H, device=x.device, dtype=F32)
+        L.call('gpe_mul_rows', x, x.stride(0), x.stride(1), mask, Bn, T, H, out)
+        ctx.save_for_backward(mask)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        mask, = ctx.saved_tensors
+        if g.stride(2) != 1:
+            g = g.contiguous()
+        Bn, T, H = mask.shape
+        gx = torch.empty(Bn, T, H, device=g.device, dtype=F32)
+        L.call('gpe_mul_rows', g, g.stride(0), g.stride(1), mask, Bn, T, H, gx)
+        return gx, None
+
+
+def _dropout_mask(T, Bn, H, p, device):
+    """The mask at::dropout draws for a recurrent layer's output: torch's nn.LSTM / nn.GRU work time-major, so the noise tensor
+    is [T, Bn, H] (ATen RNN.cpp apply_layer_stack -> dropout -> empty_like(input).bernoulli_(1 - p).div_(1 - p)).  Drawn on the
+    CPU generator in that shape — the stream the reference's CPU run consumes, like the random start states — and handed over
+    batch-major."""
+    noise = torch.empty(T, Bn, H).bernoulli_(1 - p).div_(1 - p)
+    return noise.transpose(0, 1).contiguous().to(device, non_blocking=True)
+
+
+def rnn_stack(x, h0, c0, T, n_layers, kind, params, want_state=False, dropout=0.0, training=False):
+    """nn.LSTM / nn.GRU(batch_first=True, num_layers, dropout).  Without dropout (or in eval mode, or with one layer) the whole
+    stack runs in wavefront order (RNNStackFn).  With dropout the layers run one after the other — the mask sits between them —
+    each as a one-layer RNNStackFn over the masked output sequence of the layer below."""
+    if not (dropout > 0 and training and n_layers > 1):
+        out = RNNStackFn.apply(x, h0, c0, T, n_layers, kind, want_state, *params)
+        return out if kind == 'lstm' else (out[0], out[1], None)
+    lstm = kind == 'lstm'
+    inp, hs, cs = x, [], []
+    for l in range(n_layers):
+        out = RNNStackFn.apply(inp, h0[l:l + 1], c0[l:l + 1] if lstm else None, T, 1, kind, want_state, *params[4 * l:4 * l + 4])
+        top = out[0]
+        if want_state:
+            hs.append(out[1])
+            if lstm:
+                cs.append(out[2])
+        if l < n_layers - 1:
+            inp = DropoutMulFn.apply(top, _dropout_mask(T, top.shape[0], top.shape[2], float(dropout), top.device))
+    hN = torch.cat(hs, 0) if want_state else None
+    cN = torch.cat(cs, 0) if (want_state and lstm) else None
+    return top, hN, cN
 
 
 # -------------------------------------------------------------------------------------------------

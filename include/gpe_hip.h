@@ -384,6 +384,9 @@ int gpe_w1_split(const float* w1, int ldw1, const float* b1, int H, int C, float
 int gpe_scale(const float* x, float alpha, float* out, long n, void* stream);
 /* out = a + b (n floats) */
 int gpe_add(const float* a, const float* b, float* out, long n, void* stream);
+/* inter-layer dropout of nn.LSTM / nn.GRU (nn/net_blocks.py:346,374,418-420,469): out [Bn,T,H] dense = x (strided [Bn,T,H] view:
+ * element (b,t,h) at x + b*x_sb + t*x_st + h) * mask [Bn,T,H] dense (Bernoulli(1-p)/(1-p), drawn by the caller). */
+int gpe_mul_rows(const float* x, long x_sb, long x_st, const float* mask, long Bn, int T, int H, float* out, void* stream);
 
 #ifdef __cplusplus
 }

@@ -255,6 +255,12 @@ if __name__ == '__main__':
                             'stitch_supervised_weight': 0.1,
                             'loss_components': ['shape', 'loop', 'rotation', 'translation', 'stitch', 'stitch_supervised',
                                                 'free_class']})
+    # recurrent dropout (nn/nets.py:67,113,123 -> nn.LSTM / nn.GRU(dropout=p): a Bernoulli mask between the layers, drawn on
+    # the CPU generator after the random start states)
+    run_case('GarmentFullPattern3D', lstm_yaml, dict(SMALL_NN, dropout=0.25), 2, 64, 1300, 'full3d_dropout', True)
+    run_case('GarmentFullPattern3D', lstm_yaml, dict(SMALL_NN, dropout=0.4, panel_decoder='GRUDecoderModule',
+                                                     pattern_decoder='LSTMDoubleReverseDecoderModule'),
+             2, 64, 1310, 'full3d_dropout_gru_2rev', True)
     if not ONLY or 'stitch_pairs_known_answer' in ONLY:
         run_stitch_known_answer()
     if not ONLY or 'pointnetpp_small' in ONLY:

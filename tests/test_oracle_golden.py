@@ -20,7 +20,9 @@ CASES = ['full3d_small', 'segment3d_small', 'full3d_shipped', 'segment3d_shipped
          'full3d_depth1', 'full3d_depth3', 'full3d_mlpdec', 'full3d_gru', 'full3d_lstm2rev', 'segment3d_poolmax',
          'segment3d_pooladd',
          # round 3: the stitch terms (epoch >= epoch_with_stitches) incl. the re-numbering of stitched edges by the matching
-         'full3d_stitch', 'full3d_stitch_match', 'full3d_stitch_hardnet']
+         'full3d_stitch', 'full3d_stitch_match', 'full3d_stitch_hardnet',
+         # recurrent dropout between the layers of the LSTM / GRU decoders
+         'full3d_dropout', 'full3d_dropout_gru_2rev']
 
 
 def _build(fx):
