@@ -1058,6 +1058,12 @@ def test_rccl_world1_gradient_exchange(gpe, golden_dir, tmp_path):
         for (n, p), (_, q) in zip(model.named_parameters(), plain.named_parameters()):
             # "world 2" average of a 1-rank sum = grad / 2
             assert torch.allclose(p.grad, q.grad / 2, rtol=1e-6, atol=1e-12), n
+        # what bench.py prints for N > 1: the exchange on its own over RCCL (async all-reduce of every bucket on a scratch
+        # arena, barrier, synchronisation) and the exposed part measured around the waits of finish_gradient_sync
+        ex = ddp.measure_exchange(iters=3)
+        assert ex['backend'] == 'nccl' and ex['buckets'] == len(ddp._buckets) and ex['ms_per_step'] > 0, ex
+        assert ex['bytes_per_step'] == sum((hi - lo) * 4 for _, _, lo, hi in ddp._buckets)
+        assert ddp.exposed_ms() is not None and ddp.exposed_ms() >= 0
         dist.destroy_process_group()
         print('rccl ok', len(ddp._buckets), 'buckets')
     """) % (repo, str(golden_dir)))
