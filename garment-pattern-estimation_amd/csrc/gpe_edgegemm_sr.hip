@@ -446,7 +446,10 @@ __global__ __launch_bounds__(256, 1) void gpe_edgegemm_sr_kernel(RgParams p, int
                     zq[q] = ld4(&Cs[((rr < RG_BM) ? rr : RG_BM - 1) * LDC + cn]);
                 }
             }
-            __builtin_amdgcn_sched_barrier(0);           // memory slice stays in front of this chunk's MFMAs
+            // memory slice stays in front of this chunk's MFMAs — except in the in-place backward variant, where letting the
+            // scheduler sink the next chunk's operand reads into the MFMA block measured faster (771 -> 729 us per launch at
+            // cfg 2; the same freedom costs the other three variants 1-3 %: scripts/sr_probe.py, round 3)
+            if (EMODE != E_BWD_INPLACE) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 if (HALF && kc == KCH - 1 && t >= 2) continue;       // compile-time: the half chunk has two k4 steps

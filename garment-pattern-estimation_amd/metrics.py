@@ -13,8 +13,8 @@ On device tensors (the only thing a model of this package can produce) everythin
     (losses.py:54-180, both negative-term variants), supervised stitch tags, free-edge classification — ops.StitchLossFn,
     one forward and one backward launch — and the re-numbering of the stitched edges / shift of the free-edge mask that the
     two matchings imply (ops.stitch_renumber, ops.panel_shift).
-CPU tensors (host-logic tests feed hand-made predictions) take a batched torch restatement of the main terms; the stitch
-terms exist on the device only (a CPU tensor raises).
+There is no CPU or torch-math path in `ComposedPatternLoss`: predictions must be fp32 device tensors (what the models of
+this package produce); anything else raises, like the model path itself.
 
 Not built (raise): the segmentation term (entmax.SparsemaxLoss; no shipped config trains with it).  Quality components are
 evaluation-side bookkeeping: `with_quality_eval` is accepted and ignored, no quality keys are added to the loss dict."""
@@ -183,18 +183,7 @@ class ComposedPatternLoss:
             perm, fail = ops.order_match(pf, gf)
             self._order_fail = fail              # device flag; checked lazily (no host sync on the hot path)
             return perm
-        dist = torch.cdist(pf, gf)
-        perm = torch.full((B, P), -1, dtype=torch.long)
-        for _ in range(P):
-            flat = dist.view(B, -1).argmin(dim=1)
-            rows, cols = flat // P, flat % P
-            for i in range(B):
-                perm[i, rows[i]] = cols[i]
-                dist[i, rows[i], :] = float('inf')
-                dist[i, :, cols[i]] = float('inf')
-        if torch.isfinite(dist).any():
-            raise ValueError('ComposedPatternLoss::Error::Failed to match panel order')
-        return perm
+        raise RuntimeError('ComposedPatternLoss runs on the MI355X only (got %s predictions); there is no CPU path' % pf.device)
 
     def check_order_match(self):
         """Host-side check of the last device order matching (the reference raises inside the loss; here the flag is read
@@ -232,7 +221,7 @@ class ComposedPatternLoss:
     @staticmethod
     def _need_device(t):
         if not t.is_cuda:
-            raise RuntimeError('the stitch terms of ComposedPatternLoss run on the MI355X only (got a %s tensor)' % t.device)
+            raise RuntimeError('ComposedPatternLoss runs on the MI355X only (got a %s tensor); there is no CPU path' % t.device)
 
     def _rotate_gt(self, preds, gt, gt_num_edges):
         """composed_loss.py:593-623,656-755."""
@@ -252,24 +241,7 @@ class ComposedPatternLoss:
                     if 'stitch_supervised' in self.l_components:
                         out['stitch_tags'] = ops.panel_shift(gt['stitch_tags'].float(), lead, ne)
             else:
-                B, P, L, D = gto.shape
-                pr, g = ol.detach().reshape(B * P, L, D), gto.reshape(B * P, L, D)
-                n = gt_num_edges.view(-1).long().clamp(0, L)
-                l_idx = torch.arange(L)
-                best = torch.full((B * P,), float('inf'))
-                lead = torch.zeros(B * P, dtype=torch.long)
-                chosen = g.clone()
-                for r in range(L):
-                    src = torch.where(l_idx[None, :] < n[:, None],
-                                      (l_idx[None, :] + r) % n.clamp(min=1)[:, None], l_idx[None, :].expand(B * P, L))
-                    cand = torch.gather(g, 1, src[:, :, None].expand(-1, -1, D))
-                    d = ((pr - cand) ** 2).sum(dim=(1, 2))
-                    ok = (d < best) & ((r < n) | (r == 0))
-                    best = torch.where(ok, d, best)
-                    lead = torch.where(ok, torch.full_like(lead, r), lead)
-                    chosen = torch.where(ok[:, None, None], cand, chosen)
-                out['outlines'] = chosen.view(B, P, L, D)
-                self.last_leading_edges = lead.int()
+                self._need_device(ol)
         return out
 
     # ---- main entry ------------------------------------------------------------------------------------------
@@ -278,8 +250,7 @@ class ComposedPatternLoss:
         self.epoch = epoch
         if 'segmentation' in self.l_components:
             raise NotImplementedError('segmentation loss (entmax.SparsemaxLoss) is outside the built path')
-        if self._stitch_terms_active(epoch):
-            self._need_device(preds['outlines'])
+        self._need_device(preds['outlines'])
         for key in ground_truth:
             ground_truth[key] = ground_truth[key].to(self.device)
         gt = ground_truth
@@ -356,24 +327,8 @@ class ComposedPatternLoss:
             if 'translation' in comps:
                 loss_dict.update(translation_loss=out[4])
             return out[0], loss_dict
-        full_loss, loss_dict = 0., {}
-        if 'shape' in comps:
-            v = self.regression_loss(ol, gt['outlines'])
-            full_loss = full_loss + v
-            loss_dict.update(pattern_loss=v)
-        if 'loop' in comps:
-            v = self.loop_loss(ol, gt_num_edges)
-            full_loss = full_loss + self.config['loop_loss_weight'] * v
-            loss_dict.update(loop_loss=v)
-        if 'rotation' in comps:
-            v = self.regression_loss(preds['rotations'], gt['rotations'])
-            full_loss = full_loss + v
-            loss_dict.update(rotation_loss=v)
-        if 'translation' in comps:
-            v = self.regression_loss(preds['translations'], gt['translations'])
-            full_loss = full_loss + v
-            loss_dict.update(translation_loss=v)
-        return full_loss, loss_dict
+        raise RuntimeError('ComposedPatternLoss runs on fp32 device tensors only (got %s / %s); there is no CPU path'
+                           % (ol.device, ol.dtype))
 
     def eval(self):
         self.training = False
