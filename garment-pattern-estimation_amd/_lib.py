@@ -8,7 +8,8 @@ import re
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libgpe_hip.so')
+# GPE_HIP_LIB selects another build of the same ABI (A/B measurements of kernel variants: scripts/ab_probe.sh)
+LIB_PATH = os.environ.get('GPE_HIP_LIB') or os.path.join(_HERE, 'libgpe_hip.so')
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), 'include', 'gpe_hip.h')
 
 _CT = {'p': ctypes.c_void_p, 'i': ctypes.c_int, 'l': ctypes.c_long, 'f': ctypes.c_float, 'd': ctypes.c_double}

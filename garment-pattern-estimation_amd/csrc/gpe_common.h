@@ -71,7 +71,8 @@ __device__ __forceinline__ unsigned gpe_udiv(unsigned n, unsigned d, double rcp)
 
 // compute units of the CURRENT device (cached per device ordinal); defined in gpe_pointwise.hip
 int gpe_num_cus();
-// grow-only device scratch of the CURRENT device, one image per `slot` (0: edge-kernel fold inputs, 1: kNN partial lists);
+// grow-only device scratch of the CURRENT device, one image per `slot` (0: edge-kernel fold inputs, 1: kNN lists / norms,
+// 2: the dummy store image of the straight-line edge kernels);
 // nullptr when the allocation fails.  hipFree synchronises the device, so regrowing is safe.  Defined in gpe_pointwise.hip.
 void* gpe_scratch(int slot, size_t bytes);
 

@@ -67,10 +67,21 @@ __device__ __forceinline__ long sr_prow(int x, unsigned magic)
 // instead of four steps of which half the products multiply the zero padding (3.8-5 % of a tile's MFMAs).
 // KC: compile-time rows per (pseudo-)point — 16 (above), 4 (k = 20, 24, ... as pseudo-points of four rows: four points per
 // wave and tile, slot = u % 4, P row = the (u / 4)-th of the wave's four — no per-row selects or counters), or 0 = generic.
-template <int AQ, int BQ, int KCH, int AMODE, int EMODE, int KC, bool HALF = false>
+// AGG >= 0 (k == 16 instances of the forward / gathered-backward variants): STRAIGHT-LINE slices.  The memory / epilogue slice of
+// a chunk then contains no branch and no exec-masked region, so it shares a basic block with the chunk's MFMAs and the
+// scheduler weaves the two (measured: 171 non-MFMA runs of <= 14 instructions instead of 11 runs of 47-268, and fewer of
+// them — 511 VALU + 260 SALU per tile instead of 813 + 410 on the gather forward; 5-6 % per launch):
+//   * `do_stage`: the rows of the next tile are always committed (their loads are clamped anyway; a tile past the end is
+//     never multiplied);
+//   * `do_epi` / a wave whose rows lie past the end of a partial last tile: the epilogue always runs, but its global stores
+//     are redirected to a 64 KB dummy image (p.dummy) and its statistics are not flushed;
+//   * lanes past the last column quad repeat the last valid quad (same addresses, same data) instead of being masked;
+//   * AGG = the compile-time value of p.agg (the per-point max / min / arg tracking of the aggregated last block).
+template <int AQ, int BQ, int KCH, int AMODE, int EMODE, int KC, bool HALF = false, int AGG = -1>
 __global__ __launch_bounds__(256, 1) void gpe_edgegemm_sr_kernel(RgParams p, int stats_nblk)
 {
     constexpr bool K16 = KC == 16;
+    constexpr bool SL = K16 && AGG >= 0 && EMODE != E_BWD_INPLACE;
     constexpr int NT = 4 * AQ + BQ;
     constexpr int LDA = 16 * KCH + 4, LDC = 16 * NT + 4;
     // chunk schedule.  Chunk 0 issues every global load of the iteration.  The staged rows are committed to LDS FIRST
@@ -100,9 +111,12 @@ __global__ __launch_bounds__(256, 1) void gpe_edgegemm_sr_kernel(RgParams p, int
     const int PT = p.R / p.k, npw = PT >> 2;             // points per tile / per wave: first point of this wave's
                                                          // share of tile t is t*PT + wave*npw — no per-tile division
     const int c = lane << 2;                             // this lane's column quad
-    const bool k_on = c < p.K, n_on = c < p.N;
-    const bool track_agg = p.agg != 0;                   // wave-uniform
-    const int ck = k_on ? c : 0, cn = n_on ? c : 0;      // clamped quads for the unconditional loads
+    const bool k_real = c < p.K, n_real = c < p.N;
+    const bool k_on = SL || k_real, n_on = SL || n_real; // SL: no lane is masked, lanes past the end repeat the last quad
+    const bool track_agg = (AGG >= 0) ? (AGG != 0) : (p.agg != 0);   // wave-uniform (compile-time for AGG >= 0)
+    // clamped quads for the unconditional loads; SL: also for the stores (the last valid quad: same address, same data)
+    const int ck = k_real ? c : (SL ? ((p.K - 1) & ~3) : 0), cn = n_real ? c : (SL ? ((p.N - 1) & ~3) : 0);
+    const int cs_k = SL ? ck : c, cs_n = SL ? cn : c;    // column quad of the LDS commit / of the global stores
 
     for (int e = tid; e < 2 * RG_BM * LDA; e += 256) smem[e] = 0.f;
 
@@ -142,14 +156,14 @@ __global__ __launch_bounds__(256, 1) void gpe_edgegemm_sr_kernel(RgParams p, int
     if (n_on) {
         if (EMODE == E_EDGE_FWD) {
             if (p.bias) {
-                bias4.x = p.bias[c];
-                if (c + 1 < p.N) bias4.y = p.bias[c + 1];
-                if (c + 2 < p.N) bias4.z = p.bias[c + 2];
-                if (c + 3 < p.N) bias4.w = p.bias[c + 3];
+                bias4.x = p.bias[cs_n];
+                if (cs_n + 1 < p.N) bias4.y = p.bias[cs_n + 1];
+                if (cs_n + 2 < p.N) bias4.z = p.bias[cs_n + 2];
+                if (cs_n + 3 < p.N) bias4.w = p.bias[cs_n + 3];
             }
         } else {                                         // N % 4 == 0 guaranteed by the dispatcher
-            cs4 = ld4(p.coef_out + c); c14 = ld4(p.coef_out + p.N + c);
-            k24 = ld4(p.coef_out + 2 * p.N + c); mu4 = ld4(p.coef_out + 3 * p.N + c);
+            cs4 = ld4(p.coef_out + cs_n); c14 = ld4(p.coef_out + p.N + cs_n);
+            k24 = ld4(p.coef_out + 2 * p.N + cs_n); mu4 = ld4(p.coef_out + 3 * p.N + cs_n);
         }
     }
     float s32[4], q32[4], vmx[4], vmn[4];
@@ -157,6 +171,12 @@ __global__ __launch_bounds__(256, 1) void gpe_edgegemm_sr_kernel(RgParams p, int
     float4 dp;
     int es = 0, ept = 0;                                 // row inside the current point, point inside this wave's share
     long e_row0 = 0, e_pt0 = 0; int e_rv = 0;            // tile being finished
+    // SL: where the epilogue of the tile being finished stores — the real rows, or the dummy image when this wave has nothing
+    // valid to finish (first iteration, rows past the end of a partial last tile)
+    bool e_live = true;
+    float* e_out = p.out;                                // row r of the tile at e_out + r * ldo
+    float *e_mx = p.mx, *e_mn = p.mn, *e_dp = p.dP;      // the wave's point of the tile
+    uint8_t *e_amx = p.oamx, *e_amn = p.oamn;
 
     float4 v[SR_PB];                                     // rows staged for the next tile
     float4 pvs0, pvs1, pvs2, pvs3;                       // P rows of the points being staged (gather)
@@ -193,7 +213,7 @@ __global__ __launch_bounds__(256, 1) void gpe_edgegemm_sr_kernel(RgParams p, int
     int jgv_s = 0, jgv_e = 0;            // neighbour rows for the NEXT stage (A_GATHER) / the NEXT epilogue (E_BWD_GATHER)
 
     // ---- VMEM issue: everything this iteration will need --------------------------------------------------------------
-    auto issue_epi_loads = [&](int tile) {
+    auto issue_epi_loads = [&](int tile, bool live) {
         e_row0 = (long)tile * p.R;
         e_pt0 = (long)tile * PT + wave * npw;
         e_rv = (int)((p.M - e_row0 < p.R) ? (p.M - e_row0) : p.R);
@@ -201,6 +221,17 @@ __global__ __launch_bounds__(256, 1) void gpe_edgegemm_sr_kernel(RgParams p, int
 #pragma unroll
         for (int t = 0; t < 4; ++t) { s32[t] = 0.f; q32[t] = 0.f; vmx[t] = -INFINITY; vmn[t] = INFINITY; imx[t] = 0; imn[t] = 0; }
         dp = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (SL) {
+            e_live = live && rbl < e_rv;                 // K16: all 16 rows of the wave's point are valid or none is
+            e_out = e_live ? p.out + e_row0 * p.ldo : p.dummy;
+            if (EMODE == E_EDGE_FWD && track_agg) {
+                e_mx = e_live ? p.mx + e_pt0 * p.oldagg : p.dummy;
+                e_mn = e_live ? p.mn + e_pt0 * p.oldagg : p.dummy;
+                e_amx = e_live ? p.oamx + e_pt0 * p.oldagg : reinterpret_cast<uint8_t*>(p.dummy);
+                e_amn = e_live ? p.oamn + e_pt0 * p.oldagg : reinterpret_cast<uint8_t*>(p.dummy);
+            }
+            if (EMODE == E_BWD_GATHER) e_dp = e_live ? p.dP + e_pt0 * p.lddp : p.dummy;
+        }
         if (EMODE == E_EDGE_FWD) return;
         // NOTE: every load below is unconditional (clamped rows, clamped column quad): a register that is loaded under a
         // branch needs a copy at the join, and that copy waits for the load right there — no pipelining left
@@ -260,13 +291,13 @@ __global__ __launch_bounds__(256, 1) void gpe_edgegemm_sr_kernel(RgParams p, int
         }
         // rows past the end of a partial last tile hold a copy of the last valid row (clamped loads): every output row
         // depends on its own A row only and the epilogue skips rows >= e_rv, so they need no zeroing (4 v_cndmask per row)
-        st4(&An[r * LDA + c], o);
+        st4(&An[r * LDA + cs_k], o);
     };
     // ---- epilogue of row u (compile-time u) of the tile being finished ------------------------------------------------
     auto epi_row = [&](int u, const float4 z) {
         if (!KC && u >= rwl) return;
         const int r = rbl + u;
-        if (r >= e_rv) return;               // K16: all 16 rows of the wave's point are valid or none is (uniform)
+        if (!SL && r >= e_rv) return;        // K16: all 16 rows of the wave's point are valid or none is (uniform)
         const int slot = KC ? (u % (KC ? KC : 1)) : es;
         if (n_on) {
             if (EMODE == E_EDGE_FWD) {
@@ -274,8 +305,9 @@ __global__ __launch_bounds__(256, 1) void gpe_edgegemm_sr_kernel(RgParams p, int
                                      fmaxf(z.w + bias4.w, 0.f)};
                 // gather variant: the activation rows stream out past L2 so that they do not evict the cloud's Q table
                 // (counter fetch of this kernel 199 -> <145 MB against 109 MB compulsory, same run time: profiles/r02_b)
-                if (AMODE == A_GATHER) st4_stream(p.out + (e_row0 + r) * p.ldo + c, make_float4(vv[0], vv[1], vv[2], vv[3]));
-                else st4(p.out + (e_row0 + r) * p.ldo + c, make_float4(vv[0], vv[1], vv[2], vv[3]));
+                float* const orow = SL ? e_out + (long)r * p.ldo + cs_n : p.out + (e_row0 + r) * p.ldo + c;
+                if (AMODE == A_GATHER) st4_stream(orow, make_float4(vv[0], vv[1], vv[2], vv[3]));
+                else st4(orow, make_float4(vv[0], vv[1], vv[2], vv[3]));
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
                     s32[t] += vv[t];
@@ -304,21 +336,28 @@ __global__ __launch_bounds__(256, 1) void gpe_edgegemm_sr_kernel(RgParams p, int
                 o.y = (av.y > 0.f) ? z.y * cs4.y - c14.y - (av.y - mu4.y) * k24.y : 0.f;
                 o.z = (av.z > 0.f) ? z.z * cs4.z - c14.z - (av.z - mu4.z) * k24.z : 0.f;
                 o.w = (av.w > 0.f) ? z.w * cs4.w - c14.w - (av.w - mu4.w) * k24.w : 0.f;
-                st4(p.out + (e_row0 + r) * p.ldo + c, o);
+                st4(SL ? e_out + (long)r * p.ldo + cs_n : p.out + (e_row0 + r) * p.ldo + c, o);
                 dp.x += o.x; dp.y += o.y; dp.z += o.z; dp.w += o.w;
             }
         }
         if (KC ? ((u % (KC ? KC : 1)) == KC - 1) : (++es == p.k)) {        // a point is complete (KC: compile-time)
             if (n_on) {
                 const long gpt = e_pt0 + (KC ? (u / (KC ? KC : 1)) : ept);
-                if (EMODE == E_EDGE_FWD && p.agg) {
-                    const long o = gpt * p.oldagg + c;
-                    st4(p.mx + o, make_float4(vmx[0], vmx[1], vmx[2], vmx[3]));
-                    st4(p.mn + o, make_float4(vmn[0], vmn[1], vmn[2], vmn[3]));
-                    *reinterpret_cast<uchar4*>(p.oamx + o) = make_uchar4(imx[0], imx[1], imx[2], imx[3]);
-                    *reinterpret_cast<uchar4*>(p.oamn + o) = make_uchar4(imn[0], imn[1], imn[2], imn[3]);
+                if (EMODE == E_EDGE_FWD && track_agg) {
+                    if (SL) {                            // K16: the wave's one point of the tile
+                        st4(e_mx + cs_n, make_float4(vmx[0], vmx[1], vmx[2], vmx[3]));
+                        st4(e_mn + cs_n, make_float4(vmn[0], vmn[1], vmn[2], vmn[3]));
+                        *reinterpret_cast<uchar4*>(e_amx + cs_n) = make_uchar4(imx[0], imx[1], imx[2], imx[3]);
+                        *reinterpret_cast<uchar4*>(e_amn + cs_n) = make_uchar4(imn[0], imn[1], imn[2], imn[3]);
+                    } else {
+                        const long o = gpt * p.oldagg + c;
+                        st4(p.mx + o, make_float4(vmx[0], vmx[1], vmx[2], vmx[3]));
+                        st4(p.mn + o, make_float4(vmn[0], vmn[1], vmn[2], vmn[3]));
+                        *reinterpret_cast<uchar4*>(p.oamx + o) = make_uchar4(imx[0], imx[1], imx[2], imx[3]);
+                        *reinterpret_cast<uchar4*>(p.oamn + o) = make_uchar4(imn[0], imn[1], imn[2], imn[3]);
+                    }
                 }
-                if (EMODE == E_BWD_GATHER) st4(p.dP + gpt * p.lddp + c, dp);
+                if (EMODE == E_BWD_GATHER) st4(SL ? e_dp + cs_n : p.dP + gpt * p.lddp + c, dp);
             }
 #pragma unroll
             for (int t = 0; t < 4; ++t) { vmx[t] = -INFINITY; vmn[t] = INFINITY; imx[t] = 0; imn[t] = 0; }
@@ -372,7 +411,7 @@ __global__ __launch_bounds__(256, 1) void gpe_edgegemm_sr_kernel(RgParams p, int
         const float* As = buf ? Abuf1 : Abuf0;
         float* An = buf ? Abuf0 : Abuf1;
         const bool do_epi = prev >= 0 && !(p.dbg & 2);
-        const bool do_stage = next < p.num_tiles && !(p.dbg & 1);
+        const bool do_stage = SL || (next < p.num_tiles && !(p.dbg & 1));   // SL: always (clamped loads, harmless LDS rows)
 
         f32x4 acc[4][AQ], accL[BQ > 0 ? BQ : 1];
 #pragma unroll
@@ -415,7 +454,7 @@ __global__ __launch_bounds__(256, 1) void gpe_edgegemm_sr_kernel(RgParams p, int
             }
             // ---- this chunk's slice of the memory pipeline ----
             if (kc == 0) {
-                issue_epi_loads(prev >= 0 ? prev : tile);            // clamped: results unused when !do_epi
+                issue_epi_loads(prev >= 0 ? prev : tile, do_epi);    // clamped: results unused when !do_epi
                 issue_stage_loads(next < p.num_tiles ? next : tile); // clamped: results unused when !do_stage
                 if (GATHER_ACT) jgv_e = load_jgv(tile);              // this tile is finished in the next iteration
                 if (AMODE == A_GATHER) jgv_s = load_jgv(next2 < p.num_tiles ? next2 : tile);
@@ -430,7 +469,7 @@ __global__ __launch_bounds__(256, 1) void gpe_edgegemm_sr_kernel(RgParams p, int
                 }
             }
             if (kc >= EP_START) {
-                if (do_epi) {
+                if (SL || do_epi) {
 #pragma unroll
                     for (int q = 0; q < EPC; ++q) {
                         const int u = (kc - EP_START) * EPC + q;
@@ -448,8 +487,9 @@ __global__ __launch_bounds__(256, 1) void gpe_edgegemm_sr_kernel(RgParams p, int
             }
             // memory slice stays in front of this chunk's MFMAs — except in the in-place backward variant, where letting the
             // scheduler sink the next chunk's operand reads into the MFMA block measured faster (771 -> 729 us per launch at
-            // cfg 2; the same freedom costs the other three variants 1-3 %: scripts/sr_probe.py, round 3)
-            if (EMODE != E_BWD_INPLACE) __builtin_amdgcn_sched_barrier(0);
+            // cfg 2; the same freedom costs the other three variants 1-3 % while their slices sit in blocks of their own),
+            // and in the straight-line instances, whose slice is woven into the MFMA stream: scripts/sr_probe.py, round 3
+            if (EMODE != E_BWD_INPLACE && !SL) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 if (HALF && kc == KCH - 1 && t >= 2) continue;       // compile-time: the half chunk has two k4 steps
@@ -468,7 +508,7 @@ __global__ __launch_bounds__(256, 1) void gpe_edgegemm_sr_kernel(RgParams p, int
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (do_epi) epi_flush_stats();
+        if (SL ? e_live : do_epi) epi_flush_stats();
         __syncthreads();                                 // (1) every wave is done with C (epilogue of the previous tile)
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
@@ -487,18 +527,18 @@ __global__ __launch_bounds__(256, 1) void gpe_edgegemm_sr_kernel(RgParams p, int
     }
     // ---- tail: epilogue of the last tile -------------------------------------------------------------------------------
     if (prev >= 0 && !(p.dbg & 2)) {
-        issue_epi_loads(prev);
+        issue_epi_loads(prev, true);
 #pragma unroll
         for (int u = 0; u < SR_PB; ++u) {
             const int rr = rbl + u;
             epi_row(u, ld4(&Cs[((rr < RG_BM) ? rr : RG_BM - 1) * LDC + cn]));
         }
-        epi_flush_stats();
+        if (!SL || e_live) epi_flush_stats();
     }
     __syncthreads();
     if (EMODE == E_EDGE_FWD && p.stats_part) {
         double* red = reinterpret_cast<double*>(smem);          // [4 waves][2][16*NT]
-        if (n_on) {
+        if (n_real) {
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 red[(wave * 2 + 0) * (16 * NT) + c + t] = stS[t];
@@ -522,17 +562,18 @@ __global__ __launch_bounds__(256, 1) void gpe_edgegemm_sr_kernel(RgParams p, int
 // ---------------------------------------------------------------------------------------------------------
 static int sr_num_cus() { return gpe_num_cus(); }
 
-template <int AQ, int BQ, int KCH, int AMODE, int EMODE, int KC, bool HALF = false>
+template <int AQ, int BQ, int KCH, int AMODE, int EMODE, int KC, bool HALF = false, int AGG = -1>
 static int sr_launch_k(const RgParams& p, int stats_nblk, hipStream_t s)
 {
     constexpr int NT = 4 * AQ + BQ;
     constexpr int LDA = 16 * KCH + 4, LDC = 16 * NT + 4;
     const size_t lds = (size_t)RG_BM * (2 * LDA + LDC) * sizeof(float);
-    GPE_ENSURE_MAX_LDS((gpe_edgegemm_sr_kernel<AQ, BQ, KCH, AMODE, EMODE, KC, HALF>));
+    GPE_ENSURE_MAX_LDS((gpe_edgegemm_sr_kernel<AQ, BQ, KCH, AMODE, EMODE, KC, HALF, AGG>));
     int gx = sr_num_cus();
     if (gx > p.num_tiles) gx = p.num_tiles;
     if (stats_nblk > 0 && gx > stats_nblk) gx = stats_nblk;
-    hipLaunchKernelGGL((gpe_edgegemm_sr_kernel<AQ, BQ, KCH, AMODE, EMODE, KC, HALF>), dim3(gx), dim3(256), lds, s, p, stats_nblk);
+    hipLaunchKernelGGL((gpe_edgegemm_sr_kernel<AQ, BQ, KCH, AMODE, EMODE, KC, HALF, AGG>), dim3(gx), dim3(256), lds, s, p,
+                       stats_nblk);
     GPE_CHECK_LAUNCH();
     return GPE_OK;
 }
@@ -541,8 +582,19 @@ template <int AQ, int BQ, int KCH, int AMODE, int EMODE>
 static int sr_launch(const RgParams& p, int stats_nblk, hipStream_t s)
 {
     const bool half = p.K <= 16 * (KCH - 1) + 8 && !(p.dbg & 128);
-    if (p.k == 16) return half ? sr_launch_k<AQ, BQ, KCH, AMODE, EMODE, 16, true>(p, stats_nblk, s)
-                               : sr_launch_k<AQ, BQ, KCH, AMODE, EMODE, 16>(p, stats_nblk, s);
+    if (p.k == 16) {
+        // the benchmark's neighbourhood size: straight-line instances (AGG = p.agg at compile time) for every variant but the
+        // in-place backward; they need the dummy image for redirected stores (p.dbg & 512: the branchy form, for A/B timing)
+        if (EMODE != E_BWD_INPLACE && p.dummy && !(p.dbg & 512)) {
+            const bool agg = EMODE == E_EDGE_FWD && p.agg;
+            if (agg) return half ? sr_launch_k<AQ, BQ, KCH, AMODE, EMODE, 16, true, 1>(p, stats_nblk, s)
+                                 : sr_launch_k<AQ, BQ, KCH, AMODE, EMODE, 16, false, 1>(p, stats_nblk, s);
+            return half ? sr_launch_k<AQ, BQ, KCH, AMODE, EMODE, 16, true, 0>(p, stats_nblk, s)
+                        : sr_launch_k<AQ, BQ, KCH, AMODE, EMODE, 16, false, 0>(p, stats_nblk, s);
+        }
+        return half ? sr_launch_k<AQ, BQ, KCH, AMODE, EMODE, 16, true>(p, stats_nblk, s)
+                    : sr_launch_k<AQ, BQ, KCH, AMODE, EMODE, 16>(p, stats_nblk, s);
+    }
     // (the one KC = 4 instance the register allocator cannot fit without scratch runs as generic k)
     constexpr bool k4_full_ok = !(EMODE == E_BWD_GATHER && AQ == 3 && KCH == 13);
     if (p.k == 4 && !(p.dbg & 256) && (half || k4_full_ok))
@@ -676,6 +728,8 @@ int gpe_edgegemm_sr_try(const RgParams& p_in, int amode, int emode, int stats_nb
     }
     const int NT = (p.N <= 160) ? 10 : 13;
     const int KCH = (p.K <= 160) ? 10 : 13;
+    // dummy image of the straight-line instances: 64 rows x 512 floats (row pitches here are <= 256 floats)
+    p.dummy = (p.ldo <= 512 && p.oldagg <= 512 && p.lddp <= 512) ? (float*)gpe_scratch(2, (size_t)64 * 512 * sizeof(float)) : nullptr;
     int rc = GPE_EINVAL;
     if (amode == A_GATHER && emode == E_EDGE_FWD) rc = sr_dispatch<A_GATHER, E_EDGE_FWD>(NT, KCH, p, stats_nblk, s);
     else if (amode == A_DENSE && emode == E_EDGE_FWD) rc = sr_dispatch<A_DENSE, E_EDGE_FWD>(NT, KCH, p, stats_nblk, s);

@@ -23,7 +23,7 @@ int gpe_num_cus()
 
 void* gpe_scratch(int slot, size_t bytes)
 {
-    constexpr int SLOTS = 2, DEVS = 64;
+    constexpr int SLOTS = 3, DEVS = 64;
     static void* ptr[DEVS][SLOTS] = {};
     static size_t cap[DEVS][SLOTS] = {};
     int dev = 0;

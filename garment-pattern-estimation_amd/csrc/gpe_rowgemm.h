@@ -38,6 +38,9 @@ struct RgParams {
     // k > 16 on the single-role kernels: a point's k rows are handled as f pseudo-points of k/f rows (gpe_edgegemm_sr.hip);
     // the P row of pseudo-point x is then x / f = umulhi(x, pmagic).  0 = pseudo-points are points.
     unsigned pmagic;
+    // 64 KB+ scratch image that absorbs the epilogue stores of a wave with nothing valid to finish (straight-line instances of
+    // gpe_edgegemm_sr_kernel); NULL = use the branchy instances
+    float* dummy;
 };
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
