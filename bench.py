@@ -117,11 +117,11 @@ def call_work(name, a):
 # from two `rocprofv3 --pmc` runs of this same command); C-ABI entry -> device kernels it launches
 _TRAFFIC_KERNELS = {
     # template tails: rowgemm <NT, AMODE, EMODE>; edgegemm (paired) <.., AMODE, EMODE, MATH>; edgegemm_sr <.., AMODE, EMODE, KC, HALF>
-    'gpe_edge_mlp_fwd': r'gpe_rowgemm_kernel<.*, 1>$|gpe_edgegemm(_sr)?_kernel<\d+, \d+, \d+, \d+, 1(, \w+)+>$',
-    'gpe_edge_mlp_bwd': r'gpe_rowgemm_kernel<.*, [23]>$|gpe_edgegemm(_sr)?_kernel<\d+, \d+, \d+, \d+, [23](, \w+)+>$',
+    'gpe_edge_mlp_fwd': r'gpe_rowgemm_kernel<.*, 1>$|gpe_edgegemm(_sr)?_kernel<\d+, \d+, \d+, \d+, 1(, [-\w]+)+>$',
+    'gpe_edge_mlp_bwd': r'gpe_rowgemm_kernel<.*, [23]>$|gpe_edgegemm(_sr)?_kernel<\d+, \d+, \d+, \d+, [23](, [-\w]+)+>$',
     'gpe_edge_redgemm': r'gpe_redgemm_pc_kernel<',
     'gpe_edge_gather_stats': r'gpe_gather_stats_kernel',
-    'gpe_edge_mlp_fwd:gather': r'gpe_edgegemm(_sr)?_kernel<\d+, \d+, \d+, 1, 1(, \w+)+>$',     # AMODE = A_GATHER, EMODE = fwd
+    'gpe_edge_mlp_fwd:gather': r'gpe_edgegemm(_sr)?_kernel<\d+, \d+, \d+, 1, 1(, [-\w]+)+>$',     # AMODE = A_GATHER, EMODE = fwd
     'gpe_knn': r'gpe_knn_kernel',
     'gpe_edge_pull_dq': r'gpe_pull_dq_kernel',
 }
