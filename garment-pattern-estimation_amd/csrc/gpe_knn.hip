@@ -439,6 +439,11 @@ static int knn_exact(const float* x, int B, int N, int C, int ldx, int k, int32_
 // Why T suffices: let p be in the exact top-k with d~(p) > kth~ + 2E.  The k list entries r with d~(r) <= kth~ have
 // d_chain(r) <= d~(r) + E <= kth~ + E < d~(p) - E <= d_chain(p): k candidates strictly closer than p — contradiction.
 #define KNN_MF_MINC 16
+#ifndef KNN_MF_CCH
+#define KNN_MF_CCH 32          // channels staged per step by the matrix-pipe filter
+#endif
+#define KNN_MF_LD (KNN_MF_CCH + 4)
+#define KNN_MF_WGS ((KNN_MF_CCH <= 32) ? 4 : (KNN_MF_CCH <= 48) ? 3 : 2)
 
 #define KNN_NORM_ROWS 16
 __global__ __launch_bounds__(256) void gpe_knn_norms_kernel(const float* __restrict__ x, long rows, int N, int C, int ldx,
@@ -545,7 +550,7 @@ __device__ __forceinline__ float knn_select_mf(bool first, float d, int lane, in
 // of the wave's query-major distance strip per row block.  In MFMA t of a 16-channel block lane group g supplies channel
 // 4g + t of both operands (one ds_read_b128 per operand row and block).
 template <int VEC>
-__global__ __launch_bounds__(256, 4) void gpe_knn_mfma_kernel(const float* __restrict__ x, int N, int C, int ldx, int kk,
+__global__ __launch_bounds__(256, KNN_MF_WGS) void gpe_knn_mfma_kernel(const float* __restrict__ x, int N, int C, int ldx, int kk,
                                                               int K2, const float* __restrict__ norms,
                                                               const int* __restrict__ cmax, float ce, int B, int tiles,
                                                               int pin, int nsplit, unsigned long long* __restrict__ part,
@@ -553,8 +558,8 @@ __global__ __launch_bounds__(256, 4) void gpe_knn_mfma_kernel(const float* __res
 {
     extern __shared__ __align__(16) float smem[];
     float* const qS = smem;
-    float* const cS = qS + KNN_TQ * KNN_LD;
-    float* const dS = cS + KNN_TC * KNN_LD;
+    float* const cS = qS + KNN_TQ * KNN_MF_LD;
+    float* const dS = cS + KNN_TC * KNN_MF_LD;
     unsigned long long* const mS = reinterpret_cast<unsigned long long*>(dS + 4 * 16 * KNN_LDD);
     float* const npS = reinterpret_cast<float*>(mS + 4 * 64);       // [64] |p|^2 of the candidate tile
 
@@ -601,12 +606,12 @@ __global__ __launch_bounds__(256, 4) void gpe_knn_mfma_kernel(const float* __res
     }
 
     // ---- staging (as in gpe_knn_kernel) ----------------------------------------------------------------------------
-    const int nchunk = (C + KNN_CCH - 1) / KNN_CCH;
-    const int chw = (C < KNN_CCH) ? ((C + 15) & ~15) : KNN_CCH;        // whole 16-channel blocks
+    const int nchunk = (C + KNN_MF_CCH - 1) / KNN_MF_CCH;
+    const int chw = (C < KNN_MF_CCH) ? ((C + 15) & ~15) : KNN_MF_CCH;        // whole 16-channel blocks
     const int vpr = chw / VEC;
     const int rvpr = (65536 + vpr - 1) / vpr;
     const int nvec = KNN_TC * vpr;
-    constexpr int NPF = (KNN_TC * KNN_CCH) / (256 * VEC);
+    constexpr int NPF = (KNN_TC * KNN_MF_CCH) / (256 * VEC);
     float pre_c[NPF][VEC], pre_q[NPF][VEC];
     float pre_n = 0.f;
     int pf_c0 = c_first, pf_ch = 0;
@@ -640,7 +645,7 @@ __global__ __launch_bounds__(256, 4) void gpe_knn_mfma_kernel(const float* __res
             }
         }
         if (pf_ch == 0 && tid < KNN_TC) pre_n = cnorm[(pf_c0 + tid < N) ? pf_c0 + tid : N - 1];
-        pf_ch += KNN_CCH;
+        pf_ch += KNN_MF_CCH;
         if (pf_ch >= C) { pf_ch = 0; pf_c0 += KNN_TC; }
     };
     auto commit = [&](bool first_chunk) {
@@ -649,8 +654,8 @@ __global__ __launch_bounds__(256, 4) void gpe_knn_mfma_kernel(const float* __res
             const int e = tid + 256 * i;
             if (e < nvec) {
                 const int row = (e * rvpr) >> 16, cv = e - row * vpr;
-                float* dc = &cS[row * KNN_LD + cv * VEC];
-                float* dq = &qS[row * KNN_LD + cv * VEC];
+                float* dc = &cS[row * KNN_MF_LD + cv * VEC];
+                float* dq = &qS[row * KNN_MF_LD + cv * VEC];
                 if constexpr (VEC == 4) {
                     *reinterpret_cast<float4*>(dc) = make_float4(pre_c[i][0], pre_c[i][1], pre_c[i][2], pre_c[i][3]);
                     *reinterpret_cast<float4*>(dq) = make_float4(pre_q[i][0], pre_q[i][1], pre_q[i][2], pre_q[i][3]);
@@ -668,25 +673,25 @@ __global__ __launch_bounds__(256, 4) void gpe_knn_mfma_kernel(const float* __res
     const int nsteps = ((c_stop - c_first + KNN_TC - 1) / KNN_TC) * nchunk;
     int step = 0;
 
-    const float* const brow = &qS[(16 * wave + j) * KNN_LD + 4 * g];
-    const float* const arow = &cS[j * KNN_LD + 4 * g];
+    const float* const brow = &qS[(16 * wave + j) * KNN_MF_LD + 4 * g];
+    const float* const arow = &cS[j * KNN_MF_LD + 4 * g];
 
     for (int c0 = c_first; c0 < c_stop; c0 += KNN_TC) {
         f32x4 acc[4];
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        for (int ch = 0; ch < C; ch += KNN_CCH, ++step) {
+        for (int ch = 0; ch < C; ch += KNN_MF_CCH, ++step) {
             __syncthreads();
             if (!((probe & 2) && step > 0)) commit(ch == 0);
             __syncthreads();
             if (step + 1 < nsteps && !(probe & 2)) prefetch();
-            int nblk = ((C - ch < KNN_CCH) ? (C - ch + 15) : KNN_CCH) >> 4;   // channels past C are staged as zeros
+            int nblk = ((C - ch < KNN_MF_CCH) ? (C - ch + 15) : KNN_MF_CCH) >> 4;   // channels past C are staged as zeros
             if (probe & 4) nblk = 0;
             for (int blk = 0; blk < nblk; ++blk) {
                 const float4 bq = *reinterpret_cast<const float4*>(&brow[16 * blk]);
                 float4 aq[4];
 #pragma unroll
-                for (int mt = 0; mt < 4; ++mt) aq[mt] = *reinterpret_cast<const float4*>(&arow[16 * mt * KNN_LD + 16 * blk]);
+                for (int mt = 0; mt < 4; ++mt) aq[mt] = *reinterpret_cast<const float4*>(&arow[16 * mt * KNN_MF_LD + 16 * blk]);
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
                     const float bv = (t == 0) ? bq.x : (t == 1) ? bq.y : (t == 2) ? bq.z : bq.w;
@@ -943,7 +948,7 @@ extern "C" int gpe_knn(const float* x, int B, int N, int C, int ldx, int k, int3
     hipLaunchKernelGGL(gpe_knn_cmax_kernel, dim3(B), dim3(256), 0, s, norms, N, cmax);
     GPE_CHECK_LAUNCH();
     const float ce = (6.f * C + 16.f) * 5.9604645e-8f;     // (6C + 16) * 2^-24, see the bound above
-    const size_t lds = ((size_t)2 * KNN_TQ * KNN_LD + 4 * 16 * KNN_LDD) * sizeof(float) + 4 * 64 * sizeof(unsigned long long) +
+    const size_t lds = ((size_t)2 * KNN_TQ * KNN_MF_LD + 4 * 16 * KNN_LDD) * sizeof(float) + 4 * 64 * sizeof(unsigned long long) +
                        KNN_TC * sizeof(float);
     const long nblocks = (pin ? (long)GPE_NXCD * gpe_cdiv(B, GPE_NXCD) * tiles : (long)B * tiles) * nsplit;
     if (nblocks >= (1L << 31)) return GPE_EINVAL;
