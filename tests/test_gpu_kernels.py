@@ -351,7 +351,10 @@ def _product_conv(gpe, oconv, C, H, Fo, k):
                                           (1, 256, 150, 200, 150, 16), (3, 50, 6, 64, 30, 20),
                                           (2, 100, 3, 200, 150, 5), (1, 77, 150, 200, 150, 8), (2, 67, 3, 200, 150, 10),
                                           (1, 90, 150, 200, 150, 20), (2, 75, 150, 200, 150, 24),
-                                          (1, 70, 3, 200, 150, 32), (1, 64, 150, 200, 150, 17)])
+                                          (1, 70, 3, 200, 150, 32), (1, 64, 150, 200, 150, 17),
+                                          # k = 16 with a RAGGED last tile (130 points = 32 tiles of 4 points + 2): the straight-line
+                                          # instances finish the tile's two absent points into their dummy image
+                                          (1, 130, 150, 200, 150, 16), (3, 43, 3, 200, 150, 16)])
 def test_edgeconv_layer_fwd_bwd(gpe, math_mode, B, N, C, H, Fo, k):
     from oracle import ref_path as O
     tol = TOL[math_mode]
