@@ -67,7 +67,8 @@ template <int AQ, int BQ, int KCH, int AMODE, int EMODE, int KC, bool HALF = fal
 __global__ __launch_bounds__(256, 1) void gpe_edgegemm_sr_kernel(RgParams p, int stats_nblk)
 {
     constexpr bool K16 = KC == 16;
-    constexpr bool SL = K16 && AGG >= 0 && EMODE != E_BWD_INPLACE;    // (in place: the woven schedule measured 1.5x SLOWER)
+    // (in place: the woven schedule measured 1.5x SLOWER; KC = 4: the host only picks these instances when no tile is partial)
+    constexpr bool SL = (K16 || KC == 4) && AGG >= 0 && EMODE != E_BWD_INPLACE;
     constexpr int NT = 4 * AQ + BQ;
     constexpr int LDA = 16 * KCH + 4, LDC = 16 * NT + 4;
     // chunk schedule.  Chunk 0 issues every global load of the iteration.  The staged rows are committed to LDS FIRST
@@ -330,11 +331,12 @@ __global__ __launch_bounds__(256, 1) void gpe_edgegemm_sr_kernel(RgParams p, int
             if (n_on) {
                 const long gpt = e_pt0 + (KC ? (u / (KC ? KC : 1)) : ept);
                 if (EMODE == E_EDGE_FWD && track_agg) {
-                    if (SL) {                            // K16: the wave's one point of the tile
-                        st4(e_mx + cs_n, make_float4(vmx[0], vmx[1], vmx[2], vmx[3]));
-                        st4(e_mn + cs_n, make_float4(vmn[0], vmn[1], vmn[2], vmn[3]));
-                        *reinterpret_cast<uchar4*>(e_amx + cs_n) = make_uchar4(imx[0], imx[1], imx[2], imx[3]);
-                        *reinterpret_cast<uchar4*>(e_amn + cs_n) = make_uchar4(imn[0], imn[1], imn[2], imn[3]);
+                    if (SL) {                            // the (u / KC)-th point of the wave's share of the tile
+                        const long po = (long)(u / (KC ? KC : 1)) * p.oldagg + cs_n;
+                        st4(e_mx + po, make_float4(vmx[0], vmx[1], vmx[2], vmx[3]));
+                        st4(e_mn + po, make_float4(vmn[0], vmn[1], vmn[2], vmn[3]));
+                        *reinterpret_cast<uchar4*>(e_amx + po) = make_uchar4(imx[0], imx[1], imx[2], imx[3]);
+                        *reinterpret_cast<uchar4*>(e_amn + po) = make_uchar4(imn[0], imn[1], imn[2], imn[3]);
                     } else {
                         const long o = gpt * p.oldagg + c;
                         st4(p.mx + o, make_float4(vmx[0], vmx[1], vmx[2], vmx[3]));
@@ -343,7 +345,7 @@ __global__ __launch_bounds__(256, 1) void gpe_edgegemm_sr_kernel(RgParams p, int
                         *reinterpret_cast<uchar4*>(p.oamn + o) = make_uchar4(imn[0], imn[1], imn[2], imn[3]);
                     }
                 }
-                if (EMODE == E_BWD_GATHER) st4(SL ? e_dp + cs_n : p.dP + gpt * p.lddp + c, dp);
+                if (EMODE == E_BWD_GATHER) st4(SL ? e_dp + (long)(u / (KC ? KC : 1)) * p.lddp + cs_n : p.dP + gpt * p.lddp + c, dp);
             }
 #pragma unroll
             for (int t = 0; t < 4; ++t) { vmx[t] = -INFINITY; vmn[t] = INFINITY; imx[t] = 0; imn[t] = 0; }
@@ -586,9 +588,16 @@ static int sr_launch(const RgParams& p, int stats_nblk, hipStream_t s)
     }
     // (the one KC = 4 instance the register allocator cannot fit without scratch runs as generic k)
     constexpr bool k4_full_ok = !(EMODE == E_BWD_GATHER && AQ == 3 && KCH == 13);
-    if (p.k == 4 && !(p.dbg & 256) && (half || k4_full_ok))
+    if (p.k == 4 && !(p.dbg & 256) && (half || k4_full_ok)) {
+        // four-row pseudo-points (k = 20, 24, ...): straight-line instances when no tile is partial
+        if (EMODE != E_BWD_INPLACE && p.dummy && !(p.dbg & 512) && p.M % p.R == 0 && half) {
+            const bool agg = EMODE == E_EDGE_FWD && p.agg;
+            return agg ? sr_launch_k<AQ, BQ, KCH, AMODE, EMODE, 4, true, 1>(p, stats_nblk, s)
+                       : sr_launch_k<AQ, BQ, KCH, AMODE, EMODE, 4, true, 0>(p, stats_nblk, s);
+        }
         return half ? sr_launch_k<AQ, BQ, KCH, AMODE, EMODE, 4, true>(p, stats_nblk, s)
                     : sr_launch_k<AQ, BQ, KCH, AMODE, EMODE, k4_full_ok ? 4 : 0>(p, stats_nblk, s);
+    }
     return half ? sr_launch_k<AQ, BQ, KCH, AMODE, EMODE, 0, true>(p, stats_nblk, s)
                 : sr_launch_k<AQ, BQ, KCH, AMODE, EMODE, 0>(p, stats_nblk, s);
 }

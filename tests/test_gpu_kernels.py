@@ -354,7 +354,9 @@ def _product_conv(gpe, oconv, C, H, Fo, k):
                                           (1, 70, 3, 200, 150, 32), (1, 64, 150, 200, 150, 17),
                                           # k = 16 with a RAGGED last tile (130 points = 32 tiles of 4 points + 2): the straight-line
                                           # instances finish the tile's two absent points into their dummy image
-                                          (1, 130, 150, 200, 150, 16), (3, 43, 3, 200, 150, 16)])
+                                          (1, 130, 150, 200, 150, 16), (3, 43, 3, 200, 150, 16),
+                                          # k = 20 / 24 with E a multiple of 64: the straight-line four-row pseudo-point instances
+                                          (2, 64, 150, 200, 150, 20), (1, 32, 3, 200, 150, 24)])
 def test_edgeconv_layer_fwd_bwd(gpe, math_mode, B, N, C, H, Fo, k):
     from oracle import ref_path as O
     tol = TOL[math_mode]
