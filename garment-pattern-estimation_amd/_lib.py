@@ -95,6 +95,16 @@ def _conv(a):
 TIMING = None
 
 
+# One kernel stream per device.  The library keeps a little per-DEVICE state next to the process-global arithmetic mode — the
+# grow-only scratch images of include/gpe_hip.h (kNN candidate lists, pseudo-point folds, the edge kernels' dummy image) — so
+# two streams of one device running the path concurrently would share them.  The first stream that launches on a device
+# becomes that device's kernel stream; a launch from another stream raises instead of racing.  (Copy-only side streams —
+# staging.BatchStager, the start-state uploader — never come through here.)  GPE_MULTI_STREAM=1 lifts the check for callers
+# that serialise their streams themselves.
+_KERNEL_STREAM = {}
+_MULTI_STREAM_OK = os.environ.get('GPE_MULTI_STREAM') == '1'
+
+
 def call(name, *args):
     """Invoke a C-ABI entry point on torch's current HIP stream (appended as the trailing `stream` argument)."""
     fn = getattr(lib(), name)
@@ -109,6 +119,10 @@ def call(name, *args):
                                    % (name, a.device, cur))
             break
     stream = torch.cuda.current_stream()
+    if _KERNEL_STREAM.setdefault(cur, stream.cuda_stream) != stream.cuda_stream and not _MULTI_STREAM_OK:
+        raise RuntimeError('%s: launched from a second stream of cuda:%d — the library keeps per-device scratch images, so one '
+                           'process drives ONE kernel stream per device (set GPE_MULTI_STREAM=1 if you serialise the streams '
+                           'yourself)' % (name, cur))
     if TIMING is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(stream)

@@ -814,6 +814,19 @@ def test_stitch_losses_and_renumbering(gpe, hardnet, origin, order, supervised):
     assert set(do0.keys()) == {'pattern_loss', 'loop_loss', 'rotation_loss', 'translation_loss'} and upd0 == bool(order and 0 == 39)
 
 
+def test_second_kernel_stream_is_refused(gpe):
+    """include/gpe_hip.h: per-device scratch images -> one kernel stream per device; a launch from another stream raises
+    instead of racing on them."""
+    x = torch.randn(2 * 64, 3, device='cuda')
+    gpe.ops.knn(x, 2, 64, 4)                                   # the default stream becomes this device's kernel stream
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        with pytest.raises(RuntimeError, match='second stream'):
+            gpe.ops.knn(x, 2, 64, 4)
+    gpe.ops.knn(x, 2, 64, 4)                                   # the first stream keeps working
+    torch.cuda.synchronize()
+
+
 def test_fused_adam_onecycle_vs_torch(gpe):
     """gpe_adam_step over a flat arena + the OneCycle schedule vs torch.optim.Adam + OneCycleLR in fp64
     (nn/trainer.py:162-185)."""
