@@ -31,28 +31,33 @@ def eval_pad_vector(data_stats={}):
 
 
 class PanelLoopLoss:
-    """nn/metrics/losses.py:8-51, batched: panels with < 3 edges contribute zero (the reference `continue`s)."""
+    """nn/metrics/losses.py:8-51 (panels with < 3 edges contribute zero: the reference `continue`s) through the HIP loss
+    kernel (ops.PatternLossFn with only the loop term switched on).  ComposedPatternLoss evaluates the loop term inside its one
+    fused launch; this class exists for callers that use the reference's class on its own.  Device tensors only."""
 
     def __init__(self, max_edges_in_panel, data_stats={}):
         self.data_stats = data_stats
         self.pad_vector = eval_pad_vector(data_stats)
 
     def __call__(self, predicted_panels, gt_panel_num_edges=None):
-        if predicted_panels.dim() > 3:
-            predicted_panels = predicted_panels.reshape(-1, predicted_panels.shape[-2], predicted_panels.shape[-1])
-        n_panels, L = predicted_panels.shape[0], predicted_panels.shape[1]
-        dev = predicted_panels.device
+        from . import ops
         if self.pad_vector is None:
             raise ValueError('PanelLoopLoss needs data_stats (the reference would fail on a None pad vector too)')
-        pad = self.pad_vector.to(dev)[:2]
+        if not predicted_panels.is_cuda or predicted_panels.dtype != torch.float32:
+            raise RuntimeError('PanelLoopLoss runs on fp32 device tensors only (got %s / %s); there is no CPU path'
+                               % (predicted_panels.device, predicted_panels.dtype))
+        x = predicted_panels if predicted_panels.dim() > 3 else predicted_panels.unsqueeze(1)      # [B, P, L, D]
+        if x.dim() != 4 or x.shape[-1] < 4:
+            raise ValueError('PanelLoopLoss expects panels of [.., L, >= 4] edge features (got %s)' % (tuple(predicted_panels.shape),))
+        x = x[..., :4]
+        B, P, L = x.shape[:3]
         if gt_panel_num_edges is None:
-            n = torch.full((n_panels,), L, device=dev, dtype=torch.long)
+            n = torch.full((B * P,), L, device=x.device, dtype=torch.int32)
         else:
-            n = gt_panel_num_edges.to(dev).long().view(-1)
-        mask = (torch.arange(L, device=dev)[None, :] < n[:, None]) & (n[:, None] >= 3)
-        sums = ((predicted_panels[:, :, :2] - pad) * mask[:, :, None].to(predicted_panels.dtype)).sum(dim=1)
-        sq = sums ** 2
-        return sq.sum() / (sq.shape[0] * sq.shape[1])
+            n = gt_panel_num_edges.to(x.device).int().reshape(-1).contiguous()
+        out = ops.PatternLossFn.apply(x, None, None, x.detach(), None, None, n, ops.LOSS_LOOP,
+                                      float(self.pad_vector[0]), float(self.pad_vector[1]), 1.0)
+        return out[0]                      # loop weight 1: the total IS the loop term (element 0 carries the gradient)
 
 
 class ComposedLoss:

@@ -827,6 +827,32 @@ def test_second_kernel_stream_is_refused(gpe):
     torch.cuda.synchronize()
 
 
+def test_panel_loop_loss_standalone(gpe):
+    """metrics.PanelLoopLoss used on its own (the reference's class, nn/metrics/losses.py:8-51) == the oracle's per-panel loop:
+    value and gradient, batched [B, P, L, 4] view of the decoder output and flat [n_panels, L, 4] input."""
+    from oracle import ref_path as O
+    dc = gpe.configs.data_config()
+    stats = {'shift': dc['standardize']['gt_shift']['outlines'], 'scale': dc['standardize']['gt_scale']['outlines']}
+    ours = gpe.metrics.PanelLoopLoss(dc['max_panel_len'], data_stats=stats)
+    theirs = O.PanelLoopLoss(O.eval_pad_vector(stats))
+    g = torch.Generator().manual_seed(3)
+    B, P, Lp = 3, 23, 14
+    panels = torch.randn(B, P, Lp, 8, generator=g)
+    n = torch.randint(0, Lp + 1, (B, P), generator=g)
+    pr = panels.double().requires_grad_()
+    lr_ = theirs(pr[..., :4], n.view(-1))
+    lr_.backward()
+    pd = panels.cuda().requires_grad_()
+    lo = ours(pd[..., :4], n.cuda())
+    lo.backward()
+    assert abs(lo.item() - lr_.item()) < 2e-6 * max(1, abs(lr_.item()))
+    assert relerr(pd.grad, pr.grad) < 2e-6
+    flat = panels[..., :4].reshape(B * P, Lp, 4).contiguous().cuda()
+    assert abs(ours(flat, n.view(-1).cuda()).item() - lr_.item()) < 2e-6 * max(1, abs(lr_.item()))
+    with pytest.raises(RuntimeError, match='no CPU path'):
+        ours(panels[..., :4], n)
+
+
 def test_fused_adam_onecycle_vs_torch(gpe):
     """gpe_adam_step over a flat arena + the OneCycle schedule vs torch.optim.Adam + OneCycleLR in fp64
     (nn/trainer.py:162-185)."""
