@@ -1228,3 +1228,71 @@ extern "C" int gpe_mul_rows(const float* x, long x_sb, long x_st, const float* m
     GPE_CHECK_LAUNCH();
     return GPE_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------
+// explicit EdgeConv message inputs — the general formulation behind DynamicEdgeConv (nn/net_blocks.py:124-135):
+//   out[e][0:C] = x_i, out[e][C:2C] = x_j - x_i   for edge e = i*k + s, j = jg[e]  (row pitch ldo >= 2C, pad columns zeroed)
+// Used only for first-block widths the fused P|Q path does not take (EConv_hidden not a multiple of 4, or > 256): the edge MLP
+// then runs as a dense MLP over the E message rows.  Backward: gx_i = sum_s (g1 - g2)[i*k+s] + sum_{e : jg[e] = i} g2[e],
+// the second sum pulled through the transposed graph in ascending edge order (deterministic, no atomics).
+// ---------------------------------------------------------------------------------------------------------
+__global__ void gpe_edge_inputs_fwd_kernel(const float* __restrict__ x, int ldx, int C, const int32_t* __restrict__ jg, int k,
+                                           long E, float* __restrict__ out, int ldo)
+{
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= E * ldo) return;
+    const long e = t / ldo;
+    const int c = (int)(t - e * ldo);
+    float v = 0.f;
+    if (c < 2 * C) {
+        const long i = e / k;
+        const float xi = x[i * ldx + (c < C ? c : c - C)];
+        v = (c < C) ? xi : x[(long)jg[e] * ldx + (c - C)] - xi;
+    }
+    out[t] = v;
+}
+
+extern "C" int gpe_edge_inputs_fwd(const float* x, int ldx, int C, const int32_t* jg, long npts, int k, float* out, int ldo,
+                                   void* stream)
+{
+    if (!x || !jg || !out || C <= 0 || ldx < C || npts <= 0 || k <= 0 || ldo < 2 * C) return GPE_EINVAL;
+    const long total = npts * k * ldo;
+    hipLaunchKernelGGL(gpe_edge_inputs_fwd_kernel, dim3((unsigned)gpe_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, x, ldx,
+                       C, jg, k, npts * k, out, ldo);
+    GPE_CHECK_LAUNCH();
+    return GPE_OK;
+}
+
+// rev_off [B][N+1], rev_edge [B][N*k]: the transposed graph of gpe_knn_reverse (edge numbers LOCAL to the cloud)
+__global__ void gpe_edge_inputs_bwd_kernel(const float* __restrict__ g, int ldg, int C, const int32_t* __restrict__ rev_off,
+                                           const int32_t* __restrict__ rev_edge, int N, int k, long npts,
+                                           float* __restrict__ gx, int ldgx)
+{
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= npts * C) return;
+    const long i = t / C;
+    const int c = (int)(t - i * C);
+    const long b = i / N;
+    const int il = (int)(i - b * N);
+    float s = 0.f;
+    for (int sl = 0; sl < k; ++sl) {
+        const float* row = g + (i * k + sl) * ldg;
+        s += row[c] - row[C + c];
+    }
+    const int32_t* off = rev_off + b * (N + 1);
+    const int32_t* ed = rev_edge + b * (long)N * k;
+    const long ebase = b * (long)N * k;
+    for (int q = off[il]; q < off[il + 1]; ++q) s += g[(ebase + ed[q]) * ldg + C + c];
+    gx[i * ldgx + c] = s;
+}
+
+extern "C" int gpe_edge_inputs_bwd(const float* g, int ldg, int C, const int32_t* rev_off, const int32_t* rev_edge, int B,
+                                   int N, int k, float* gx, int ldgx, void* stream)
+{
+    if (!g || !rev_off || !rev_edge || !gx || C <= 0 || ldg < 2 * C || B <= 0 || N <= 0 || k <= 0 || ldgx < C) return GPE_EINVAL;
+    const long total = (long)B * N * C;
+    hipLaunchKernelGGL(gpe_edge_inputs_bwd_kernel, dim3((unsigned)gpe_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, g, ldg,
+                       C, rev_off, rev_edge, N, k, (long)B * N, gx, ldgx);
+    GPE_CHECK_LAUNCH();
+    return GPE_OK;
+}

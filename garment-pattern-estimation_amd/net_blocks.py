@@ -49,7 +49,12 @@ class DynamicEdgeConv(nn.Module):
             args += [l.weight, l.bias, b.weight, b.bias]
         for b in bn:
             args += [b.running_mean, b.running_var, b.num_batches_tracked]
-        out, idx = ops.EdgeConvFn.apply(x, n_clouds, n_points, self.k, self.training, eps, mom, nb, self.aggr, *args)
+        H0 = lin[0].weight.shape[0]
+        if H0 % 4 or H0 > 256:
+            # a first-block width the fused P|Q kernels do not take: the general (explicit-message) formulation
+            out, idx = ops.edge_conv_general(x, n_clouds, n_points, self.k, self.training, eps, mom, nb, self.aggr, args)
+        else:
+            out, idx = ops.EdgeConvFn.apply(x, n_clouds, n_points, self.k, self.training, eps, mom, nb, self.aggr, *args)
         self.last_knn = idx
         return out
 

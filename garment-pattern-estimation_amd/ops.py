@@ -473,7 +473,8 @@ class EdgeConvFn(torch.autograd.Function):
         H0 = widths[0]
         assert Ws[0].shape[1] == 2 * C
         if H0 % 4 or H0 > 256:
-            raise ValueError('EConv_hidden must be a multiple of 4 and <= 256 (got %d)' % H0)
+            raise ValueError('EdgeConvFn (the fused P|Q path) needs a first-block width that is a multiple of 4 and <= 256 '
+                             '(got %d): use ops.edge_conv_general' % H0)
         E = BN * k
         nblk = L.query('gpe_stats_blocks')
         idx, jg = knn(x, B, N, k, want_global=True)
@@ -639,6 +640,51 @@ class EdgeConvFn(torch.autograd.Function):
             gx = torch.empty(BN, C, device=dev, dtype=F32)
             linear_raw(_rows2d(dPQ), wpq_t, None, BN, C, 2 * H0, _rows2d(gx))
         return (gx, None, None, None, None, None, None, None, None, *grads, *([None] * (3 * nb)))
+
+
+class EdgeInputsFn(torch.autograd.Function):
+    """cat[x_i, x_j - x_i] per edge of the kNN graph, materialised [E, 2C] — the general formulation of the DynamicEdgeConv
+    message input (nn/net_blocks.py:124-135), used by edge_conv_general for first-block widths the fused P|Q path does not
+    take."""
+
+    @staticmethod
+    def forward(ctx, x, idx, jg, B, N, k):
+        _dev_check(x)
+        C = x.shape[1]
+        ld = round_up(2 * C, 4)
+        out = torch.empty(B * N * k, ld, device=x.device, dtype=F32)
+        L.call('gpe_edge_inputs_fwd', x, x.stride(0), C, jg, B * N, k, out, ld)
+        ctx.save_for_backward(idx)
+        ctx.dims = (B, N, k, C)
+        return out[:, :2 * C]
+
+    @staticmethod
+    def backward(ctx, g):
+        idx, = ctx.saved_tensors
+        B, N, k, C = ctx.dims
+        if g.stride(1) != 1:
+            g = g.contiguous()
+        rev_off, rev_edge = knn_reverse(idx)
+        gx = torch.empty(B * N, C, device=g.device, dtype=F32)
+        L.call('gpe_edge_inputs_bwd', g, g.stride(0), C, rev_off, rev_edge, B, N, k, gx, C)
+        return gx, None, None, None, None, None
+
+
+def edge_conv_general(x, B, N, k, training, eps, momentum, nb, aggr, tensors):
+    """DynamicEdgeConv for first-block widths outside the fused path's menu (EConv_hidden % 4 != 0 or > 256): kNN graph ->
+    explicit [x_i, x_j - x_i] rows -> the edge MLP as a dense MLP over the E message rows (DenseMLPFn: the same kernels, every
+    BatchNorm incl. the last applied per message) -> max / mean / add over each point's k messages.  Same arithmetic as the
+    reference formulation; several times slower than EdgeConvFn (no P|Q split, E-row first block, stored per-edge outputs)."""
+    idx, jg = knn(x, B, N, k, want_global=True)
+    msg_in = EdgeInputsFn.apply(x, idx, jg, B, N, k)
+    msg = DenseMLPFn.apply(msg_in, training, eps, momentum, nb, *tensors)
+    if aggr == 'max':
+        out = SegmentPoolFn.apply(msg, B * N, k, 1)
+    elif aggr == 'add':
+        out = SegmentPoolFn.apply(msg, B * N, k, 2)
+    else:
+        out = SegmentMeanFn.apply(msg, B * N, k)
+    return out, idx
 
 
 # -------------------------------------------------------------------------------------------------

@@ -263,6 +263,14 @@ int gpe_bn_apply_scaled(const float* a, int lda, const float* stats, long rows, 
                         float* y, int ldy, void* stream);
 /* out[i][c] = sum over the k messages of point i of a[i*k+s][c] */
 int gpe_edge_sum_k(const float* a, int lda, long npts, int k, int F, float* out, int ldo, void* stream);
+/* explicit message inputs of DynamicEdgeConv (nn/net_blocks.py:124-135: cat[x_i, x_j - x_i]) for first-block widths the fused
+ * P|Q path does not take (EConv_hidden not a multiple of 4, or > 256): out [npts*k][ldo >= 2C], row e = i*k + s holds
+ * [x_i | x_{jg[e]} - x_i] (pad columns zero).  bwd: gx [B*N][C] from g [B*N*k][ldg >= 2C] through the transposed graph of
+ * gpe_knn_reverse (rev_off [B][N+1], rev_edge [B][N*k]) — a deterministic pull, no atomics. */
+int gpe_edge_inputs_fwd(const float* x, int ldx, int C, const int32_t* jg, long npts, int k, float* out, int ldo,
+                        void* stream);
+int gpe_edge_inputs_bwd(const float* g, int ldg, int C, const int32_t* rev_off, const int32_t* rev_edge, int B, int N, int k,
+                        float* gx, int ldgx, void* stream);
 /* gpe_edge_dz3 for aggr 'add' / 'mean': every message of a point receives gscale * g[i] (no arg-slot selection) */
 int gpe_edge_dz3_all(float* a3, int lda3, const float* g, int ldg, float gscale, const float* coef, int B, int N, int k,
                      int F, void* stream);

@@ -261,6 +261,10 @@ if __name__ == '__main__':
     run_case('GarmentFullPattern3D', lstm_yaml, dict(SMALL_NN, dropout=0.4, panel_decoder='GRUDecoderModule',
                                                      pattern_decoder='LSTMDoubleReverseDecoderModule'),
              2, 64, 1310, 'full3d_dropout_gru_2rev', True)
+    # EdgeConv widths outside the fused kernels' menu (EConv_hidden not a multiple of 4 / wider than 256)
+    run_case('GarmentFullPattern3D', lstm_yaml, dict(SMALL_NN, EConv_hidden=30, EConv_feature=22), 2, 64, 1400,
+             'full3d_hidden30', True)
+    run_case('GarmentSegmentPattern3D', att_yaml, dict(SMALL_NN, EConv_hidden=260), 2, 64, 1410, 'segment3d_hidden260', False)
     if not ONLY or 'stitch_pairs_known_answer' in ONLY:
         run_stitch_known_answer()
     if not ONLY or 'pointnetpp_small' in ONLY:

@@ -644,6 +644,54 @@ def test_edgeconv_aggr_and_depth(gpe, aggr, nblocks):
         assert relerr(pn[n].grad, p.grad) < 5e-4, (n, relerr(pn[n].grad, p.grad))
 
 
+@pytest.mark.parametrize('H,Fo,aggr,C', [(30, 22, 'max', 3), (300, 150, 'max', 3), (30, 22, 'mean', 6), (258, 64, 'add', 150),
+                                         (7, 5, 'max', 150)])
+def test_edgeconv_general_widths(gpe, H, Fo, aggr, C):
+    """EConv_hidden outside the fused path's menu (not a multiple of 4, or > 256): the explicit-message formulation
+    (ops.edge_conv_general), same contract as every other width (nn/net_blocks.py:108-135)."""
+    from oracle import ref_path as O
+    B, N, k = 2, 60, 5
+    torch.manual_seed(H)
+    oconv = O.DynamicEdgeConv(O.MLP([2 * C, H, H, Fo]), k=k, aggr=aggr)
+    with torch.no_grad():
+        for blk in oconv.nn:
+            blk[2].weight.uniform_(0.5, 1.5)
+            blk[2].bias.uniform_(-0.3, 0.3)
+        oconv.nn[-1][2].weight[::4] *= -1
+    pconv = gpe.net_blocks.DynamicEdgeConv(gpe.net_blocks.MLP([2 * C, H, H, Fo]), k=k, aggr=aggr)
+    pconv.load_state_dict(oconv.state_dict())
+    pconv = pconv.cuda().train()
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(B * N, C, generator=g)
+    wgt = torch.randn(B * N, Fo, generator=g)
+    batch = torch.arange(B).repeat_interleave(N)
+    xd = x.cuda().requires_grad_()
+    out = pconv(xd, B, N)
+    (out * wgt.cuda()).sum().backward()
+    ref_idx = O.knn_local(x, B, k)
+    assert torch.equal(pconv.last_knn.cpu().view(B * N, k).long(), ref_idx)
+    o64 = copy.deepcopy(oconv).double().train()
+    o64.knn_override = ref_idx
+    xr = x.double().requires_grad_()
+    ref = o64(xr, batch)
+    (ref * wgt.double()).sum().backward()
+    assert relerr(out, ref) < 5e-5
+    assert relerr(xd.grad, xr.grad) < 2e-4
+    pn = dict(pconv.named_parameters())
+    for n, p in o64.named_parameters():
+        assert relerr(pn[n].grad, p.grad) < 5e-4, (n, relerr(pn[n].grad, p.grad))
+    pb = dict(pconv.named_buffers())
+    for n, bbuf in o64.named_buffers():
+        if 'num_batches' in n:
+            assert pb[n].item() == bbuf.item()
+        else:
+            assert relerr(pb[n], bbuf) < 1e-5, n
+    # eval mode (running statistics) through the same path
+    pconv.eval(); o64.eval()
+    with torch.no_grad():
+        assert relerr(pconv(x.cuda(), B, N), o64(x.double(), batch)) < 5e-5
+
+
 @pytest.mark.parametrize('mode', ['max', 'add'])
 def test_segment_pool_max_add(gpe, mode):
     x = torch.randn(3 * 130, 37, generator=torch.Generator().manual_seed(4))

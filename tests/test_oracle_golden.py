@@ -22,7 +22,9 @@ CASES = ['full3d_small', 'segment3d_small', 'full3d_shipped', 'segment3d_shipped
          # round 3: the stitch terms (epoch >= epoch_with_stitches) incl. the re-numbering of stitched edges by the matching
          'full3d_stitch', 'full3d_stitch_match', 'full3d_stitch_hardnet',
          # recurrent dropout between the layers of the LSTM / GRU decoders
-         'full3d_dropout', 'full3d_dropout_gru_2rev']
+         'full3d_dropout', 'full3d_dropout_gru_2rev',
+         # EConv_hidden outside the fused kernels' menu: the explicit-message EdgeConv path
+         'full3d_hidden30', 'segment3d_hidden260']
 
 
 def _build(fx):
