@@ -1073,6 +1073,103 @@ extern "C" int gpe_sparsemax_bwd(const float* out, int ldo, const float* g, int 
     return GPE_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// entmax.SparsemaxLoss() as the reference calls it (nn/metrics/composed_loss.py:4,196,323-332; entmax is third-party and
+// un-vendored: the published Fenchel-Young sparsemax loss, Martins & Astudillo 2016 / Blondel et al. 2019, restated):
+//   p = sparsemax(x);  L_r = (1 - |p|^2)/2 + <p - e_t, x>;  loss = mean_r L_r (reduction 'elementwise_mean', nothing ignored);
+//   dL_r/dx = p - e_t.   One row per lane (same in-register sort as the forward above); gx receives (p - e_t)/rows,
+// part[blockIdx] the block's fp64 sum of L_r; gpe_sparsemax_loss_finish adds the partials in index order.
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gpe_sparsemax_loss_kernel(const float* __restrict__ x, int ldx,
+                                                                 const int32_t* __restrict__ target, long rows, int W,
+                                                                 float* __restrict__ gx, int ldg, double* __restrict__ part,
+                                                                 int* __restrict__ bad)
+{
+    __shared__ double red[256];
+    const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    double L = 0.0;
+    if (r < rows) {
+        float v[SPX_W];
+#pragma unroll
+        for (int i = 0; i < SPX_W; ++i) v[i] = (i < W) ? x[r * ldx + i] : -INFINITY;
+#pragma unroll
+        for (int pass = 0; pass < SPX_W; ++pass) {
+#pragma unroll
+            for (int i = (pass & 1); i + 1 < SPX_W; i += 2) {
+                const float a = v[i], b = v[i + 1];
+                v[i] = fmaxf(a, b); v[i + 1] = fminf(a, b);
+            }
+        }
+        float cs = 0.f, tau = 0.f;
+#pragma unroll
+        for (int i = 0; i < SPX_W; ++i) {
+            if (i < W) {
+                cs += v[i];
+                if (1.f + (float)(i + 1) * v[i] > cs) tau = (cs - 1.f) / (float)(i + 1);
+            }
+        }
+        int t = target[r];
+        if (t < 0 || t >= W) { atomicOr(bad, 1); t = 0; }
+        const float inv = 1.f / (float)rows;
+        float pp = 0.f, dot = 0.f;
+        for (int i = 0; i < W; ++i) {
+            const float xi = x[r * ldx + i];
+            const float p = fmaxf(xi - tau, 0.f);
+            const float d = p - (i == t ? 1.f : 0.f);
+            pp += p * p;
+            dot += d * xi;
+            gx[r * ldg + i] = d * inv;
+        }
+        L = (double)((1.f - pp) * 0.5f + dot);
+    }
+    red[threadIdx.x] = L;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) part[blockIdx.x] = red[0];
+}
+
+__global__ __launch_bounds__(64) void gpe_sparsemax_loss_finish_kernel(const double* __restrict__ part, int nblk, long rows,
+                                                                       float* __restrict__ loss)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double s = 0.0;
+    for (int i = 0; i < nblk; ++i) s += part[i];
+    loss[0] = (float)(s / (double)rows);
+}
+
+// part: >= ceil(rows/256) doubles; bad: one int, set to 1 when a target is outside [0, W) (the caller raises)
+extern "C" int gpe_sparsemax_loss(const float* x, int ldx, const int32_t* target, long rows, int W, float* gx, int ldg,
+                                  double* part, float* loss, int* bad, void* stream)
+{
+    if (!x || !target || !gx || !part || !loss || !bad || rows <= 0 || W <= 0 || W > SPX_W || ldx < W || ldg < W) return GPE_EINVAL;
+    const int nblk = (int)gpe_cdiv(rows, 256);
+    hipLaunchKernelGGL(gpe_sparsemax_loss_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, x, ldx, target, rows, W, gx,
+                       ldg, part, bad);
+    GPE_CHECK_LAUNCH();
+    hipLaunchKernelGGL(gpe_sparsemax_loss_finish_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, part, nblk, rows, loss);
+    GPE_CHECK_LAUNCH();
+    return GPE_OK;
+}
+
+// out = alpha[0] * x with alpha on the device (the upstream gradient of a scalar loss term: no host read-back)
+__global__ void gpe_scale_dev_kernel(const float* __restrict__ x, const float* __restrict__ alpha, float* __restrict__ out, long n)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = alpha[0] * x[i];
+}
+
+extern "C" int gpe_scale_dev(const float* x, const float* alpha, float* out, long n, void* stream)
+{
+    if (!x || !alpha || !out || n < 0) return GPE_EINVAL;
+    if (n == 0) return GPE_OK;
+    hipLaunchKernelGGL(gpe_scale_dev_kernel, dim3((unsigned)gpe_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, x, alpha, out, n);
+    GPE_CHECK_LAUNCH();
+    return GPE_OK;
+}
+
 // y[r][c] = s[c]*a[r][c] + t[c]   (BatchNorm applied to a stored post-ReLU activation; dense-MLP last layer)
 __global__ void gpe_bn_apply_kernel(const float* __restrict__ a, int lda, const float* __restrict__ stats, long rows,
                                     int C, float a_scale, float t_scale, float* __restrict__ y, int ldy)

@@ -16,7 +16,8 @@ On device tensors (the only thing a model of this package can produce) everythin
 There is no CPU or torch-math path in `ComposedPatternLoss`: predictions must be fp32 device tensors (what the models of
 this package produce); anything else raises, like the model path itself.
 
-Not built (raise): the segmentation term (entmax.SparsemaxLoss; no shipped config trains with it).  Quality components are
+The segmentation term (entmax.SparsemaxLoss on the attention weights, composed_loss.py:323-332) runs through
+ops.SparsemaxLossFn (entmax is third-party and un-vendored: its published loss restated).  Quality components are
 evaluation-side bookkeeping: `with_quality_eval` is accepted and ignored, no quality keys are added to the loss dict."""
 import torch
 import torch.nn as nn
@@ -253,18 +254,24 @@ class ComposedPatternLoss:
     def __call__(self, preds, ground_truth, names=None, epoch=1000):
         self.device = preds['outlines'].device
         self.epoch = epoch
-        if 'segmentation' in self.l_components:
-            raise NotImplementedError('segmentation loss (entmax.SparsemaxLoss) is outside the built path')
         self._need_device(preds['outlines'])
         for key in ground_truth:
             ground_truth[key] = ground_truth[key].to(self.device)
         gt = ground_truth
         if self.config['panel_order_inariant_loss']:
+            if 'segmentation' in self.l_components:                            # composed_loss.py:242-243
+                raise NotImplementedError('Order matching not supported for training with segmentation losses')
             gt = self._gt_order_match(preds, gt)
         gt_num_edges = gt['num_edges'].int().view(-1)
         if self.config['panel_origin_invariant_loss']:
             gt = self._rotate_gt(preds, gt, gt_num_edges)
         full_loss, loss_dict = self._main_losses(preds, gt, gt_num_edges)
+        if 'segmentation' in self.l_components:                                # composed_loss.py:323-332
+            from . import ops
+            att = preds['att_weights']
+            segm = ops.SparsemaxLossFn.apply(att.reshape(-1, att.shape[-1]), gt['segmentation'].reshape(-1))
+            full_loss = full_loss + self.config['segm_loss_weight'] * segm
+            loss_dict.update(segm_loss=segm)
         if self._stitch_terms_active(epoch):
             self.last_matched_stitch_gt = {k: gt[k] for k in ('stitches', 'free_edges_mask') if k in gt}   # diagnostics / tests
             extra, extra_dict = self._stitch_losses(preds, gt)

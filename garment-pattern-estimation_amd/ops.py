@@ -999,6 +999,37 @@ def dense_mlp(x, mlp, training):
     return DenseMLPFn.apply(x, training, blocks[0][2].eps, blocks[0][2].momentum, len(blocks), *params, *bufs)
 
 
+class SparsemaxLossFn(torch.autograd.Function):
+    """entmax.SparsemaxLoss()(x, target) as nn/metrics/composed_loss.py:323-332 calls it: mean over rows of the sparsemax
+    Fenchel-Young loss; gradient (sparsemax(x) - onehot(target)) / rows."""
+
+    @staticmethod
+    def forward(ctx, x, target):
+        _dev_check(x)
+        M, W = x.shape
+        if x.stride(1) != 1:
+            x = x.contiguous()
+        tgt = target.to(torch.int32).contiguous()
+        if tgt.numel() != M:
+            raise ValueError('SparsemaxLoss: %d targets for %d rows' % (tgt.numel(), M))
+        gx = torch.empty(M, W, device=x.device, dtype=F32)
+        part = torch.empty((M + 255) // 256, device=x.device, dtype=torch.float64)
+        loss = torch.empty(1, device=x.device, dtype=F32)
+        bad = torch.zeros(1, device=x.device, dtype=torch.int32)
+        L.call('gpe_sparsemax_loss', x, x.stride(0), tgt, M, W, gx, W, part, loss, bad)
+        if bad.item():
+            raise IndexError('SparsemaxLoss: a segmentation label lies outside [0, %d)' % W)
+        ctx.save_for_backward(gx)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        gx, = ctx.saved_tensors
+        out = torch.empty_like(gx)
+        L.call('gpe_scale_dev', gx, g.reshape(1).to(F32).contiguous(), out, gx.numel())
+        return out, None
+
+
 class SparsemaxFn(torch.autograd.Function):
     """sparsemax.Sparsemax(dim=1) (nn/nets.py:225)."""
 

@@ -254,6 +254,12 @@ int gpe_rnn_seq_bwd(int gates, int L, int T, int Bn, int H, const float* dtop, l
 int gpe_sparsemax_fwd(const float* z, int ldz, long rows, int W, float* out, int ldo, void* stream);
 int gpe_sparsemax_bwd(const float* out, int ldo, const float* g, int ldg, long rows, int W, float* gz, int ldgz,
                       void* stream);
+/* entmax.SparsemaxLoss() on the attention weights (nn/metrics/composed_loss.py:196,323-332; third-party, un-vendored: the
+ * published sparsemax Fenchel-Young loss restated): loss[0] = mean_r (1 - |p|^2)/2 + <p - e_t, x>, p = sparsemax(x_r), W <= 32;
+ * gx [rows][ldg] = (p - e_t)/rows (the gradient of loss[0]); part: ceil(rows/256) doubles of scratch; bad[0] |= 1 when a
+ * target lies outside [0, W) (the caller zeroes it before the call and raises after). */
+int gpe_sparsemax_loss(const float* x, int ldx, const int32_t* target, long rows, int W, float* gx, int ldg, double* part,
+                       float* loss, int* bad, void* stream);
 /* y = s*a + t with {s,t} = stats rows 2,3: BatchNorm of a stored post-ReLU activation (last block of a dense MLP) */
 int gpe_bn_apply(const float* a, int lda, const float* stats, long rows, int C, float* y, int ldy, void* stream);
 
@@ -390,6 +396,8 @@ int gpe_w1_split(const float* w1, int ldw1, const float* b1, int H, int C, float
                  void* stream);
 /* out = alpha * x (n floats; out may alias x) */
 int gpe_scale(const float* x, float alpha, float* out, long n, void* stream);
+/* out = alpha[0] * x, alpha a DEVICE scalar (the upstream gradient of a scalar loss term; no host read-back) */
+int gpe_scale_dev(const float* x, const float* alpha, float* out, long n, void* stream);
 /* out = a + b (n floats) */
 int gpe_add(const float* a, const float* b, float* out, long n, void* stream);
 /* inter-layer dropout of nn.LSTM / nn.GRU (nn/net_blocks.py:346,374,418-420,469): out [Bn,T,H] dense = x (strided [Bn,T,H] view:

@@ -209,6 +209,34 @@ class Sparsemax(nn.Module):
         return _SparsemaxFn.apply(z).transpose(self.dim, -1)
 
 
+class _SparsemaxLossFn(torch.autograd.Function):
+    """entmax.SparsemaxLoss's function (deep-spin/entmax, third-party and un-vendored; call site nn/metrics/composed_loss.py:4,
+    196,329): the sparsemax Fenchel-Young loss  L(x, t) = (1 - |p|^2)/2 + <p - e_t, x>,  p = sparsemax(x);  dL/dx = p - e_t
+    (Martins & Astudillo 2016, eq. 19-20; Blondel et al. 2019).  PARITY UNPINNED against entmax itself (absent here)."""
+
+    @staticmethod
+    def forward(ctx, x, target):
+        p = _SparsemaxFn.forward(ctx, x).clone()
+        loss = (1 - (p ** 2).sum(dim=1)) / 2
+        p.scatter_add_(1, target.unsqueeze(1), torch.full_like(p, -1))
+        loss = loss + (p * x).sum(dim=1)
+        ctx.save_for_backward(p)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        p, = ctx.saved_tensors
+        return g.unsqueeze(1) * p, None
+
+
+class SparsemaxLoss(nn.Module):
+    """entmax.SparsemaxLoss() with its defaults (ignore_index=-100: nothing ignored; reduction='elementwise_mean': the sum of
+    the row losses over the number of rows)."""
+
+    def forward(self, x, target):
+        return _SparsemaxLossFn.apply(x, target.long()).sum() / float(target.shape[0])
+
+
 # ---- PointNet++ pieces (torch_geometric.nn.fps / radius / PointConv; call sites nn/net_blocks.py:16-24) ---------------
 def fps(pos, batch, ratio):
     """Farthest point sampling per cloud -> GLOBAL indices, clouds in order, selection order inside a cloud.
@@ -627,7 +655,7 @@ class ComposedPatternLoss:
     also the stitch terms (:336-362 — PatternStitchLoss, supervised stitch tags, free-edge classification), INCLUDING the
     ground-truth pre-processing in front of them: panel-order matching (:428-590) and panel-origin matching (:593-755) with
     the re-numbering of the stitched edges and the per-panel shift of the free-edge mask, restated with the reference's own
-    loops.  The segmentation term raises, so a silent mismatch is impossible."""
+    loops; the segmentation term (:323-332) through the restated entmax.SparsemaxLoss above."""
 
     def __init__(self, data_config, in_config={}):
         self.config = {
@@ -801,10 +829,10 @@ class ComposedPatternLoss:
 
     def __call__(self, preds, ground_truth, names=None, epoch=1000):
         self.epoch = epoch
-        if 'segmentation' in self.l_components:
-            raise NotImplementedError('segmentation loss is outside the restated path')
         gt = ground_truth
         if self.config['panel_order_inariant_loss']:
+            if 'segmentation' in self.l_components:                            # composed_loss.py:242-243
+                raise NotImplementedError('Order matching not supported for training with segmentation losses')
             gt = self._gt_order_match(preds, gt)
         dt = preds['outlines'].dtype
         num_edges = gt['num_edges'].int().view(-1)
@@ -824,6 +852,10 @@ class ComposedPatternLoss:
         if 'translation' in self.l_components:
             d['translation_loss'] = mse(preds['translations'], gt['translations'].to(dt))
             loss = loss + d['translation_loss']
+        if 'segmentation' in self.l_components:                                # composed_loss.py:323-332
+            att = preds['att_weights']
+            d['segm_loss'] = SparsemaxLoss()(att.reshape(-1, att.shape[-1]), gt['segmentation'].reshape(-1))
+            loss = loss + self.config['segm_loss_weight'] * d['segm_loss']
         if self._stitch_terms_active():                                        # :259-266, 336-362
             extra = 0.
             if 'stitch' in self.l_components:

@@ -86,6 +86,9 @@ def run_case(model_name, yaml_rel, nn_override, B, N, seed, tag, keep_state, los
                     free[b, p_, e_] = False
         gt['stitches'], gt['num_stitches'], gt['free_edges_mask'] = st, nst, free
         gt['stitch_tags'] = torch.randn(B, P, L, 3, generator=g)
+    if 'segmentation' in loss_cfg['loss_components']:
+        # per-point panel labels (nn/data/datasets.py: `segmentation` [B, N] class ids in [0, max_pattern_len))
+        gt['segmentation'] = torch.randint(0, P, (B, N), generator=g)
     state0 = copy.deepcopy(model.state_dict())
     torch.manual_seed(seed + 2)            # fixes the random LSTM h0/c0 draw
     preds = model(feats, log_step=0, epoch=epoch)
@@ -265,6 +268,12 @@ if __name__ == '__main__':
     run_case('GarmentFullPattern3D', lstm_yaml, dict(SMALL_NN, EConv_hidden=30, EConv_feature=22), 2, 64, 1400,
              'full3d_hidden30', True)
     run_case('GarmentSegmentPattern3D', att_yaml, dict(SMALL_NN, EConv_hidden=260), 2, 64, 1410, 'segment3d_hidden260', False)
+    # the segmentation term on the attention weights (composed_loss.py:323-332; entmax stub -> PARITY UNPINNED arithmetic)
+    run_case('GarmentSegmentPattern3D', att_yaml, SMALL_NN, 2, 64, 1500, 'segment3d_segmloss', True,
+             loss_override={'loss_components': ['shape', 'loop', 'rotation', 'translation', 'segmentation']})
+    run_case('GarmentSegmentPattern3D', att_yaml, {}, 2, 128, 1510, 'segment3d_segmloss_shipped', False,
+             loss_override={'loss_components': ['shape', 'loop', 'rotation', 'translation', 'segmentation'],
+                            'panel_origin_invariant_loss': True})
     if not ONLY or 'stitch_pairs_known_answer' in ONLY:
         run_stitch_known_answer()
     if not ONLY or 'pointnetpp_small' in ONLY:

@@ -692,6 +692,27 @@ def test_edgeconv_general_widths(gpe, H, Fo, aggr, C):
         assert relerr(pconv(x.cuda(), B, N), o64(x.double(), batch)) < 5e-5
 
 
+@pytest.mark.parametrize('M,W', [(1, 23), (700, 23), (513, 5), (64, 32)])
+def test_sparsemax_loss(gpe, M, W):
+    """entmax.SparsemaxLoss() as composed_loss.py:323-332 calls it, on general scores (not only simplex points) and behind a
+    non-unit upstream gradient."""
+    from oracle import ref_path as O
+    g = torch.Generator().manual_seed(M + W)
+    x = torch.randn(M, W, generator=g) * 1.5
+    x[::3] = torch.softmax(x[::3], -1)                          # rows that already lie on the simplex (the reference's use)
+    t = torch.randint(0, W, (M,), generator=g)
+    xr = x.double().requires_grad_()
+    ref = O.SparsemaxLoss()(xr, t)
+    (0.05 * ref).backward()
+    xd = x.cuda().requires_grad_()
+    out = gpe.ops.SparsemaxLossFn.apply(xd, t.cuda())
+    (0.05 * out).backward()
+    assert abs(out.item() - ref.item()) < 2e-6 * max(1.0, abs(ref.item()))
+    assert relerr(xd.grad, xr.grad) < 2e-6
+    with pytest.raises(IndexError):
+        gpe.ops.SparsemaxLossFn.apply(xd, torch.full((M,), W).cuda())
+
+
 @pytest.mark.parametrize('mode', ['max', 'add'])
 def test_segment_pool_max_add(gpe, mode):
     x = torch.randn(3 * 130, 37, generator=torch.Generator().manual_seed(4))

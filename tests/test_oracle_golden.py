@@ -24,7 +24,9 @@ CASES = ['full3d_small', 'segment3d_small', 'full3d_shipped', 'segment3d_shipped
          # recurrent dropout between the layers of the LSTM / GRU decoders
          'full3d_dropout', 'full3d_dropout_gru_2rev',
          # EConv_hidden outside the fused kernels' menu: the explicit-message EdgeConv path
-         'full3d_hidden30', 'segment3d_hidden260']
+         'full3d_hidden30', 'segment3d_hidden260',
+         # the segmentation term (sparsemax Fenchel-Young loss on the attention weights)
+         'segment3d_segmloss', 'segment3d_segmloss_shipped']
 
 
 def _build(fx):
