@@ -63,7 +63,7 @@ def lib():
     return _lib
 
 
-MATH_MODES = {'f32': 0, 'bf16x3': 1, 'mixed': 2, 'bf16x6': 3}
+MATH_MODES = {'f32': 0, 'bf16x3': 1, 'mixed': 2, 'bf16x6': 3, 'f16x3': 4}
 
 
 def set_math(mode):

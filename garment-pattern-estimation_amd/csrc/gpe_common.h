@@ -75,6 +75,15 @@ int gpe_num_cus();
 // 2: the dummy store image of the straight-line edge kernels);
 // nullptr when the allocation fails.  hipFree synchronises the device, so regrowing is safe.  Defined in gpe_pointwise.hip.
 void* gpe_scratch(int slot, size_t bytes);
+// f16x3 mode (gpe_edgegemm_h3.hip): a kernel that wrote an activation / dz tensor may leave a NOTE with the tensor's largest
+// magnitude for the next edge GEMM.  Every C-ABI entry that writes caller tensors — other than the statistics / weight-packing /
+// reduce-GEMM calls that sit between two edge GEMMs of a layer — opens with GPE_WRITES_TENSORS(), which drops a pending note:
+// a note can only describe a tensor no library call has touched since it was written.
+void gpe_h3_note_drop();
+// drops a pending note; in f16x3 mode returns a cleared device slot to atomicMax the largest magnitude written to `ptr`
+// ([rows][cols], pitch ld) into, and records the note; NULL in every other mode
+unsigned* gpe_h3_note_begin(const void* ptr, long rows, int cols, long ld, hipStream_t s);
+#define GPE_WRITES_TENSORS() gpe_h3_note_drop()
 
 // ---- cloud -> XCD pinning ---------------------------------------------------------------------------------------------
 // Workgroup b is dispatched to XCD b % 8 (observed placement; a wrong guess costs speed, never correctness), and every

@@ -546,7 +546,7 @@ static int eg_dispatch_m(int NT, int KCH, const RgParams& p, int stats_nblk, hip
     return GPE_EINVAL;
 }
 
-static int g_eg_math = 0;            // 0: exact fp32 MFMA, 1: bf16x3, 2: bf16x6 where it fits (gpe_math_set)
+static int g_eg_math = 0;            // 0: exact fp32 MFMA, 1: bf16x3, 2: bf16x6 where it fits, 3: f16x3 (gpe_math_set)
 void gpe_edgegemm_set_math(int m) { g_eg_math = m; }
 
 template <int AMODE, int EMODE>
@@ -560,6 +560,7 @@ static int eg_dispatch(int NT, int KCH, const RgParams& p, int stats_nblk, hipSt
 // LDS-streamed kernel, < 0 on a launch error.
 int gpe_edgegemm_sr_try(const RgParams& p, int amode, int emode, int stats_nblk, hipStream_t s);   // gpe_edgegemm_sr.hip
 int gpe_edgegemm_x6_try(const RgParams& p, int amode, int emode, int stats_nblk, hipStream_t s);   // gpe_edgegemm_x6.hip
+int gpe_edgegemm_h3_try(const RgParams& p, int amode, int emode, int stats_nblk, hipStream_t s);   // gpe_edgegemm_h3.hip
 
 int gpe_edgegemm_try(const RgParams& p, int amode, int emode, int stats_nblk, hipStream_t s)
 {
@@ -571,7 +572,11 @@ int gpe_edgegemm_try(const RgParams& p, int amode, int emode, int stats_nblk, hi
         const int r = gpe_edgegemm_x6_try(p, amode, emode, stats_nblk, s);
         if (r != 0) return r;
     }
-    if ((math == 0 || g_eg_math == 2) && !(p.dbg & 64)) {   // exact fp32: the single-role software-pipelined kernel
+    if (g_eg_math == 3) {                                // f16x3: two-term split-fp16 single-role kernel, every shipped shape
+        const int r = gpe_edgegemm_h3_try(p, amode, emode, stats_nblk, s);
+        if (r != 0) return r;
+    }
+    if ((math == 0 || g_eg_math >= 2) && !(p.dbg & 64)) {   // exact fp32: the single-role software-pipelined kernel
         const int r = gpe_edgegemm_sr_try(p, amode, emode, stats_nblk, s);
         if (r != 0) return r;
     }

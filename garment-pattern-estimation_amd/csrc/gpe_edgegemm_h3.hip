@@ -1,0 +1,204 @@
+// "f16x3": the two-term fp16 policy of the split-precision single-role edge kernel (gpe_edgegemm_split_kernel.h) — three
+// v_mfma_f32_16x16x32_f16 per fp32 product, operands normalised per TENSOR by a power of two so that fp16's 5-bit exponent
+// is never the limit.  Two planes of a 200 x 200 weight take 184 of a wave's 256 accumulation registers, so — unlike the
+// three-plane bf16 policy — every shape of the shipped edge MLPs (10 / 13 output tiles x 10 / 13 K chunks) fits.
+//
+// The largest magnitudes behind the scales are measured ON THE DEVICE, in front of the GEMM, on the same stream:
+//   * packed weight: one-workgroup pass over its 16 KCH x Npad floats (a few microseconds);
+//   * dense A operand: a streaming |x| max over its rows — unless the kernel that produced the tensor left a NOTE: the split
+//     kernels (forward activations, in-place dz) and gpe_edge_dz3 track the largest magnitude they write, and the next edge
+//     GEMM picks the note up when pointer, rows and pitch match.  A note lives from the call that wrote the tensor to the next
+//     gpe_edge_mlp_fwd / gpe_edge_mlp_bwd / gpe_edge_dz3 call on the device, which drops it whatever kernel it runs;
+//   * gathered A operand relu(P_i + Q_j): the bound max(P) + max(Q) from one pass over the per-point [P|Q] table.
+// Slot ring in scratch image 3: [0] A operand, [1] weight, [2..] notes.
+#include "gpe_edgegemm_split_kernel.h"
+
+#define H3_RING 16
+
+// largest |x| over rows x cols (row pitch ld), as the bit pattern of a non-negative float (orders like the float; NaN > inf)
+__global__ __launch_bounds__(256) void gpe_h3_absmax_kernel(const float* __restrict__ x, long rows, int cols4, long ld,
+                                                            unsigned* __restrict__ out)
+{
+    const long total = rows * cols4;
+    unsigned m = 0u;
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+        const long r = t / cols4;
+        const int q = (int)(t - r * cols4);
+        const float4 v = ld4(x + r * ld + 4 * q);
+        const unsigned a = __float_as_uint(v.x) & 0x7fffffffu, b = __float_as_uint(v.y) & 0x7fffffffu;
+        const unsigned c = __float_as_uint(v.z) & 0x7fffffffu, d = __float_as_uint(v.w) & 0x7fffffffu;
+        const unsigned ab = a > b ? a : b, cd = c > d ? c : d;
+        const unsigned e = ab > cd ? ab : cd;
+        m = m > e ? m : e;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned t = (unsigned)__shfl_xor((int)m, o);
+        m = m > t ? m : t;
+    }
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+}
+
+// max(P) + max(Q) over the [rows][>= 2H] table (signed maxima; the bound of relu(P_i + Q_j)), clamped at 0
+__global__ __launch_bounds__(256) void gpe_h3_pqmax_kernel(const float* __restrict__ pq, long rows, int H, long ld,
+                                                           int* __restrict__ smax /* [2] ordered-int maxima of P and Q */)
+{
+    const int h4 = H >> 2;
+    const long total = rows * 2 * h4;
+    float mp = -INFINITY, mq = -INFINITY;
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+        const long r = t / (2 * h4);
+        const int q = (int)(t - r * 2 * h4);
+        const float4 v = ld4(pq + r * ld + 4 * q);
+        const float m = fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w));
+        if (q < h4) mp = fmaxf(mp, m); else mq = fmaxf(mq, m);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { mp = fmaxf(mp, __shfl_xor(mp, o)); mq = fmaxf(mq, __shfl_xor(mq, o)); }
+    if ((threadIdx.x & 63) == 0) {
+        // order-preserving map float -> int: negative floats flipped
+        const int ip = __float_as_int(mp), iq = __float_as_int(mq);
+        atomicMax(smax + 0, ip >= 0 ? ip : ip ^ 0x7fffffff);
+        atomicMax(smax + 1, iq >= 0 ? iq : iq ^ 0x7fffffff);
+    }
+}
+
+// one workgroup: the packed weight's largest magnitude -> slots[1]; clears slots[0] (the A-operand slot the multi-workgroup
+// passes accumulate into), the ordered-int maxima of the gather bound, and the note slot the coming launch will write
+__global__ __launch_bounds__(1024) void gpe_h3_wmax_kernel(const float* __restrict__ w, long n, unsigned* __restrict__ slots,
+                                                           int clear_note)
+{
+    __shared__ unsigned red[16];
+    unsigned m = 0u;
+    for (long t = threadIdx.x; t < n; t += 1024) {
+        const unsigned a = __float_as_uint(w[t]) & 0x7fffffffu;
+        m = m > a ? m : a;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned t = (unsigned)__shfl_xor((int)m, o);
+        m = m > t ? m : t;
+    }
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < 16; ++i) m = m > red[i] ? m : red[i];
+        slots[1] = m;
+        slots[0] = 0u;
+        reinterpret_cast<int*>(slots)[H3_RING + 2] = (int)0x80000000;
+        reinterpret_cast<int*>(slots)[H3_RING + 3] = (int)0x80000000;
+        if (clear_note >= 0) slots[2 + clear_note] = 0u;
+    }
+}
+
+// gather bound: slots[0] = bits of max(0, maxP + maxQ) (rounded up one ulp-ish by a factor 1 + 2^-20: a bound, not a value)
+__global__ void gpe_h3_pqfinish_kernel(unsigned* __restrict__ slots)
+{
+    const int ip = reinterpret_cast<int*>(slots)[H3_RING + 2], iq = reinterpret_cast<int*>(slots)[H3_RING + 3];
+    const float mp = __int_as_float(ip >= 0 ? ip : ip ^ 0x7fffffff), mq = __int_as_float(iq >= 0 ? iq : iq ^ 0x7fffffff);
+    float b = (mp + mq) * 1.000001f;
+    if (!(b > 0.f)) b = (b != b) ? b : 0.f;               // NaN stays NaN (sorts above everything), negative -> all-zero operand
+    slots[0] = __float_as_uint(b) & 0x7fffffffu;
+}
+
+// ---- producer notes ------------------------------------------------------------------------------------------------------
+struct H3Note { const void* ptr; long rows; long ld; int cols; int slot; int dev; };
+static H3Note g_note = {nullptr, 0, 0, 0, -1, -1};
+static int g_ring_next = 0;
+
+void gpe_h3_note_drop() { g_note.ptr = nullptr; }
+static unsigned* h3_slots() { return static_cast<unsigned*>(gpe_scratch(3, (2 + H3_RING + 2) * sizeof(unsigned))); }
+// for producers outside this file (gpe_edge_dz3): a cleared ring slot to atomicMax into + the note that goes with it.
+// Returns NULL when the f16x3 mode is off (the caller then skips the tracking).
+static int g_h3_on = 0;
+void gpe_h3_enable(int on) { g_h3_on = on; if (!on) gpe_h3_note_drop(); }
+unsigned* gpe_h3_note_begin(const void* ptr, long rows, int cols, long ld, hipStream_t s)
+{
+    gpe_h3_note_drop();
+    if (!g_h3_on) return nullptr;
+    unsigned* slots = h3_slots();
+    if (!slots) return nullptr;
+    const int slot = g_ring_next;
+    g_ring_next = (g_ring_next + 1) % H3_RING;
+    if (hipMemsetAsync(slots + 2 + slot, 0, sizeof(unsigned), s) != hipSuccess) return nullptr;
+    int dev = -1;
+    (void)hipGetDevice(&dev);
+    g_note = {ptr, rows, ld, cols, slot, dev};
+    return slots + 2 + slot;
+}
+
+template <int AMODE, int EMODE>
+static int h3_dispatch(int NT, int KCH, const RgParams& p, int stats_nblk, hipStream_t s)
+{
+    if (NT == 13 && KCH == 13) return x6_launch<SplitF16x2, 3, 1, 13, AMODE, EMODE>(p, stats_nblk, s);
+    if (NT == 13 && KCH == 10) return x6_launch<SplitF16x2, 3, 1, 10, AMODE, EMODE>(p, stats_nblk, s);
+    if (NT == 10 && KCH == 13) return x6_launch<SplitF16x2, 2, 2, 13, AMODE, EMODE>(p, stats_nblk, s);
+    if (NT == 10 && KCH == 10) return x6_launch<SplitF16x2, 2, 2, 10, AMODE, EMODE>(p, stats_nblk, s);
+    return GPE_ENOTSUP_SHAPE;
+}
+
+// Returns 1 and launches when the shape is on this kernel's menu, 0 when the caller should try the next kernel,
+// < 0 on a launch error.
+int gpe_edgegemm_h3_try(const RgParams& p_in, int amode, int emode, int stats_nblk, hipStream_t s)
+{
+    // whatever happens next, the tensor a pending note describes may be overwritten by this call
+    const H3Note note = g_note;
+    gpe_h3_note_drop();
+    RgParams p;
+    if (!x6_prepare(p_in, amode, emode, stats_nblk, p)) return 0;
+    const int NT = (p.N <= 160) ? 10 : 13;
+    const int KCH = (p.K <= 160) ? 10 : 13;
+    unsigned* slots = h3_slots();
+    if (!slots) return GPE_EINVAL;
+    int dev = -1;
+    (void)hipGetDevice(&dev);
+
+    // does this launch write a tensor the next edge GEMM reads as its A operand?  forward activations, in-place dz
+    const bool notes = emode == E_EDGE_FWD || emode == E_BWD_INPLACE;
+    int out_slot = -1;
+    if (notes) { out_slot = g_ring_next; g_ring_next = (g_ring_next + 1) % H3_RING; }
+    // a note is usable when it describes exactly this A operand (and its ring slot is not the one being recycled)
+    const bool have_note = amode == A_DENSE && note.ptr == (const void*)p.a.base && note.rows == p.M && note.ld == p.a.stride_outer &&
+                           note.cols == p.K && note.dev == dev && note.slot >= 0 && note.slot != out_slot;
+
+    const long wn = (long)16 * KCH * p.Npad;              // the packed weight: 4 KCH k-quads x Npad columns x 4 (gpe_packed_size)
+    hipLaunchKernelGGL(gpe_h3_wmax_kernel, dim3(1), dim3(1024), 0, s, p.wp, wn, slots, out_slot);
+    GPE_CHECK_LAUNCH();
+    if (have_note) {
+        p.h3_amax_a = slots + 2 + note.slot;
+    } else if (amode == A_DENSE) {
+        const int cols4 = (p.K + 3) >> 2;
+        const long total = p.M * cols4;
+        int gx = (int)((total + 255) / 256);
+        const int cap = gpe_num_cus() * 8;
+        if (gx > cap) gx = cap;
+        hipLaunchKernelGGL(gpe_h3_absmax_kernel, dim3(gx), dim3(256), 0, s, p.a.base, p.M, cols4, (long)p.a.stride_outer, slots);
+        GPE_CHECK_LAUNCH();
+        p.h3_amax_a = slots;
+    } else {
+        if (p.H & 3) return 0;
+        const long rows = p.M / p.k;                      // the per-point table behind the gathered operand
+        const long total = rows * 2 * (p.H >> 2);
+        int gx = (int)((total + 255) / 256);
+        const int cap = gpe_num_cus() * 8;
+        if (gx > cap) gx = cap;
+        hipLaunchKernelGGL(gpe_h3_pqmax_kernel, dim3(gx), dim3(256), 0, s, p.pq, rows, p.H, (long)p.ldpq,
+                           reinterpret_cast<int*>(slots) + H3_RING + 2);
+        GPE_CHECK_LAUNCH();
+        hipLaunchKernelGGL(gpe_h3_pqfinish_kernel, dim3(1), dim3(1), 0, s, slots);
+        GPE_CHECK_LAUNCH();
+        p.h3_amax_a = slots;
+    }
+    p.h3_amax_w = slots + 1;
+    p.amax_out = notes ? slots + 2 + out_slot : nullptr;
+
+    int rc = GPE_EINVAL;
+    if (amode == A_GATHER && emode == E_EDGE_FWD) rc = h3_dispatch<A_GATHER, E_EDGE_FWD>(NT, KCH, p, stats_nblk, s);
+    else if (amode == A_DENSE && emode == E_EDGE_FWD) rc = h3_dispatch<A_DENSE, E_EDGE_FWD>(NT, KCH, p, stats_nblk, s);
+    else if (amode == A_DENSE && emode == E_BWD_INPLACE) rc = h3_dispatch<A_DENSE, E_BWD_INPLACE>(NT, KCH, p, stats_nblk, s);
+    else if (amode == A_DENSE && emode == E_BWD_GATHER) rc = h3_dispatch<A_DENSE, E_BWD_GATHER>(NT, KCH, p, stats_nblk, s);
+    if (rc == GPE_ENOTSUP_SHAPE) return 0;
+    if (rc != GPE_OK) return rc;
+    if (notes) g_note = {p.out, p.M, (long)p.ldo, p.N, out_slot, dev};
+    return 1;
+}

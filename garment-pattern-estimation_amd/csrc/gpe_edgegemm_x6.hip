@@ -1,597 +1,5 @@
-// Split-bf16 ("bf16x6") variant of the single-role fused row GEMM of gpe_edgegemm_sr.hip: the per-edge MLP of
-// DynamicEdgeConv (/root/reference/nn/net_blocks.py:43-47,124-135 forward; its input-gradient half in backward) with
-// fp32-GRADE products on the bf16 matrix pipe.
-//
-// Why: v_mfma_f32_16x16x4_f32 runs at the fp32 VECTOR rate and a wave streaming it owns its SIMD — the epilogue's VALU
-// work adds to the MFMA time (0.54 of the fp32-MFMA roofline is that share).  v_mfma_f32_16x16x32_bf16 is
-// 16x faster per FLOP and co-issues with VALU / LDS / VMEM.  A two-term split (bf16x3, gpe_edgegemm.hip) keeps 16 mantissa
-// bits: good enough for activations, not for gradients (BatchNorm backward amplifies a 2^-17 operand error ~1e3 times).
-// Here every fp32 operand is split in THREE bf16 terms, x = h + m + l (8+8+8 = 24 mantissa bits: exact), and a product
-// keeps the six terms of weight >= 2^-16:  a.b = ah.bh + (ah.bm + am.bh) + (ah.bl + am.bm + al.bh)  [+ O(2^-24)],
-// each an exact bf16 x bf16 product accumulated in fp32: 6 MFMAs at 16x the rate = 0.375 of the fp32-MFMA time, with the
-// fp32 kernel's accuracy class.
-//
-// Structure = the single-role kernel (one persistent 256-thread workgroup per CU, one wave per SIMD, 512 VGPRs):
-//   * the wave's slice of the weight is split once in the prologue and stays resident as bf16 B fragments (AGPRs);
-//   * the A tile stays fp32 in LDS (same 159 KB layout: A[2] + C); a wave splits each A fragment on the fly right after the
-//     ds_read (the split's ~40 VALU ops per fragment co-issue with the MFMAs);
-//   * K runs in slabs of 32 (one MFMA k-extent); slot q = 4*slab + mtile carries the memory pipeline: slot 0 issues every
-//     global load of the iteration, the next slots commit the staged rows to the other A buffer, the last 16 slots run the
-//     epilogue of the previous tile one row each;
-//   * N-tiles: wave w owns tiles [AQ*w, AQ*w+AQ) for all 64 rows; the BQ left-over tiles are split over the waves BY K SLAB
-//     (wave w takes slabs w, w+4): holding a left-over tile's whole K in every wave would not fit the register file.  The
-//     four partial products meet in LDS — in the rows of the just-consumed A buffer that the SAME wave re-stages next, so no
-//     extra barrier — and are summed in a fixed order (bit-reproducible).
-#include "gpe_rowgemm.h"
-#include <math.h>
-
-#define X6_PB 16          // rows a wave stages / finishes per tile
-#define X6_NPW 4          // max points per wave per tile (gather / aggregation paths)
-#define GPE_ENOTSUP_SHAPE 12345
-
-// A wave has 256 architectural VGPRs + 256 accumulation VGPRs; MFMA takes its B operand from either file.  The resident
-// weights (208 registers) are pinned in AGPRs by hand: left to itself the allocator keeps them architectural and, in the
-// gather variants, spills them to scratch memory — reloaded every chunk behind an s_waitcnt vmcnt(0).
-__device__ __forceinline__ float x6_pin_agpr(float x)
-{
-    float a;
-    asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(a) : "v"(x));
-    return a;
-}
-__device__ __forceinline__ float4 x6_UNUSED_pin4(const float4 v)
-{
-    return make_float4(x6_pin_agpr(v.x), x6_pin_agpr(v.y), x6_pin_agpr(v.z), x6_pin_agpr(v.w));
-}
-
-// Wave-uniform choice among the (<= X6_NPW) P rows of a wave's points.  Arguments BY VALUE and selects on values: written
-// as `if (idx == q) dst = arr_q` the compiler turns the phi of loads into a load through a phi of pointers into the lambda
-// closure, which pins the closure AND every captured local (v[], act[], ...) in scratch memory — each access then drags
-// an s_waitcnt vmcnt(0) through the load pipeline.
-__device__ __forceinline__ float4 x6_sel4(const float4 a0, const float4 a1, const float4 a2, const float4 a3, int idx)
-{
-    float4 r = a0;
-    r.x = (idx == 1) ? a1.x : r.x; r.y = (idx == 1) ? a1.y : r.y; r.z = (idx == 1) ? a1.z : r.z; r.w = (idx == 1) ? a1.w : r.w;
-    r.x = (idx == 2) ? a2.x : r.x; r.y = (idx == 2) ? a2.y : r.y; r.z = (idx == 2) ? a2.z : r.z; r.w = (idx == 2) ? a2.w : r.w;
-    r.x = (idx == 3) ? a3.x : r.x; r.y = (idx == 3) ? a3.y : r.y; r.z = (idx == 3) ? a3.z : r.z; r.w = (idx == 3) ? a3.w : r.w;
-    return r;
-}
-
-typedef __bf16 x6_bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 x6_bf16x2 __attribute__((ext_vector_type(2)));
-typedef float x6_f32x2 __attribute__((ext_vector_type(2)));
-typedef unsigned x6_u32x4 __attribute__((ext_vector_type(4)));
-
-// three-term split of 8 consecutive k-values of a lane's MFMA operand: f[0..7] -> h, m, l (8 bf16 each, k order kept)
-struct X6Frag { x6_u32x4 h, m, l; };
-
-__device__ __forceinline__ unsigned x6_cvt2(float a, float b)              // {bf16(a) | bf16(b) << 16}, RNE
-{
-    const x6_f32x2 v = {a, b};
-    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, x6_bf16x2));
-}
-__device__ __forceinline__ void x6_split2(float a, float b, unsigned& h, unsigned& m, unsigned& l)
-{
-    h = x6_cvt2(a, b);
-    const float ra = a - __uint_as_float(h << 16), rb = b - __uint_as_float(h & 0xffff0000u);
-    m = x6_cvt2(ra, rb);
-    const float sa = ra - __uint_as_float(m << 16), sb = rb - __uint_as_float(m & 0xffff0000u);
-    l = x6_cvt2(sa, sb);
-}
-__device__ __forceinline__ X6Frag x6_split8(const float4 lo, const float4 hi)
-{
-    unsigned h0, h1, h2, h3, m0, m1, m2, m3, l0, l1, l2, l3;
-    x6_split2(lo.x, lo.y, h0, m0, l0);
-    x6_split2(lo.z, lo.w, h1, m1, l1);
-    x6_split2(hi.x, hi.y, h2, m2, l2);
-    x6_split2(hi.z, hi.w, h3, m3, l3);
-    X6Frag f;
-    f.h = (x6_u32x4){h0, h1, h2, h3};
-    f.m = (x6_u32x4){m0, m1, m2, m3};
-    f.l = (x6_u32x4){l0, l1, l2, l3};
-    return f;
-}
-__device__ __forceinline__ f32x4 x6_mfma(const x6_u32x4 a, const x6_u32x4 b, const f32x4 c)
-{
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(x6_bf16x8, a), __builtin_bit_cast(x6_bf16x8, b), c, 0, 0, 0);
-}
-// keep a resident B fragment in accumulation registers (MFMA reads B from either file)
-__device__ __forceinline__ void x6_pin(x6_u32x4& v) { asm volatile("" : "+a"(v)); }
-
-// K16: k == 16 (the benchmark configuration): every wave owns exactly ONE point per tile (see gpe_edgegemm_sr.hip).
-// KCH = K extent in 16-wide chunks (the packed-weight granularity); KS = ceil(KCH / 2) slabs of 32.
-template <int AQ, int BQ, int KCH, int AMODE, int EMODE, bool K16>
-__global__ __launch_bounds__(256, 1) void gpe_edgegemm_x6_kernel(RgParams p, int stats_nblk)
-{
-    constexpr int NT = 4 * AQ + BQ;
-    constexpr int KS = (KCH + 1) / 2;
-    constexpr bool KTAIL = (KCH & 1) != 0;               // last slab holds only 16 k: lane groups g >= 2 contribute zeros
-    constexpr int LSL = (KS + 3) / 4;                    // slabs of a left-over tile per wave (K-split over the 4 waves)
-    constexpr int LDA = 16 * KCH + 4, LDC = 16 * NT + 4;
-    constexpr int NSLOT = 4 * KS;                        // memory-pipeline slots per tile: slot q = 4*slab + mtile
-    // slot 0 issues every global load; the staged rows are committed in the CM_SLOTS slots right before the epilogue (late
-    // enough for the loads to have landed, and BEFORE the epilogue's conditional stores: see gpe_edgegemm_sr.hip); the last
-    // slots finish EPR rows of the previous tile each
-    constexpr int EPR = (NSLOT >= 28) ? 1 : 2;
-    constexpr int EP_START = NSLOT - X6_PB / EPR;
-    constexpr int CM_SLOTS = 4, CMR = X6_PB / CM_SLOTS;
-    constexpr int CM_START = EP_START - CM_SLOTS;
-    static_assert(CM_START >= 2, "K too short for the slot schedule");
-    constexpr bool GATHER_ACT = (EMODE == E_BWD_GATHER);
-
-    extern __shared__ __align__(16) float smem[];
-    float* const Abuf0 = smem;
-    float* const Abuf1 = smem + RG_BM * LDA;
-    float* const Cs = smem + 2 * RG_BM * LDA;            // [64][LDC]
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int j = lane & 15, g = lane >> 4;
-    const int rows_w = p.R >> 2;                         // rows of a tile this wave stages / finishes (<= X6_PB)
-    const int rb = wave * rows_w;
-    const int rk16 = (65536 + p.k - 1) / p.k;            // u / k == (u * rk16) >> 16 for u < 64
-    const int PT = p.R / p.k, npw = PT >> 2;             // points per tile / per wave: first point of this wave's
-                                                         // share of tile t is t*PT + wave*npw — no per-tile division
-    const int c = lane << 2;                             // this lane's column quad
-    const bool k_on = c < p.K, n_on = c < p.N;
-    const int ck = k_on ? c : 0, cn = n_on ? c : 0;      // clamped quads for the unconditional loads
-
-    for (int e = tid; e < 2 * RG_BM * LDA; e += 256) smem[e] = 0.f;
-
-    // ---- weights: resident bf16 B fragments, three planes ------------------------------------------------------------------
-    // lane (j, g) of slab sl holds k = 32 sl + 8 g + {0..7} of column 16*tile + j: two float4 of the packed weight
-    // (chunk 2 sl + (g >> 1), k-quads 2 (g & 1) and 2 (g & 1) + 1)
-    x6_u32x4 wH[AQ][KS], wM[AQ][KS], wLo[AQ][KS];
-    x6_u32x4 lH[BQ > 0 ? BQ : 1][LSL], lM[BQ > 0 ? BQ : 1][LSL], lLo[BQ > 0 ? BQ : 1][LSL];
-    {
-        auto load_frag = [&](int col, int sl) -> X6Frag {
-            const int cc = (col < p.Npad) ? col : p.Npad - 1;
-            const int kc = 2 * sl + (g >> 1);
-            const bool on = col < p.Npad && kc < KCH;
-            const int kcc = kc < KCH ? kc : KCH - 1;
-            const float4 f0 = ld4(p.wp + (((long)(kcc * 4 + 2 * (g & 1))) * p.Npad + cc) * 4);
-            const float4 f1 = ld4(p.wp + (((long)(kcc * 4 + 2 * (g & 1) + 1)) * p.Npad + cc) * 4);
-            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-            return x6_split8(on ? f0 : z, on ? f1 : z);
-        };
-#pragma unroll
-        for (int i = 0; i < AQ; ++i)
-#pragma unroll
-            for (int sl = 0; sl < KS; ++sl) {
-                const X6Frag f = load_frag(16 * (AQ * wave + i) + j, sl);
-                wH[i][sl] = f.h; wM[i][sl] = f.m; wLo[i][sl] = f.l;
-                x6_pin(wH[i][sl]); x6_pin(wM[i][sl]); x6_pin(wLo[i][sl]);
-            }
-#pragma unroll
-        for (int b = 0; b < BQ; ++b)
-#pragma unroll
-            for (int q = 0; q < LSL; ++q) {
-                const int sl = wave + 4 * q;               // this wave's K slabs of the left-over tiles
-                const X6Frag f = load_frag(sl < KS ? 16 * (4 * AQ + b) + j : p.Npad, sl < KS ? sl : 0);
-                lH[b][q] = f.h; lM[b][q] = f.m; lLo[b][q] = f.l;
-            }
-    }
-
-    // ---- epilogue constants + running state ---------------------------------------------------------------------------
-    double stS[4] = {0, 0, 0, 0}, stQ[4] = {0, 0, 0, 0};
-    float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    float4 cs4 = bias4, c14 = bias4, k24 = bias4, mu4 = bias4;
-    if (n_on) {
-        if (EMODE == E_EDGE_FWD) {
-            if (p.bias) {
-                bias4.x = p.bias[c];
-                if (c + 1 < p.N) bias4.y = p.bias[c + 1];
-                if (c + 2 < p.N) bias4.z = p.bias[c + 2];
-                if (c + 3 < p.N) bias4.w = p.bias[c + 3];
-            }
-        } else {                                         // N % 4 == 0 guaranteed by the dispatcher
-            cs4 = ld4(p.coef_out + c); c14 = ld4(p.coef_out + p.N + c);
-            k24 = ld4(p.coef_out + 2 * p.N + c); mu4 = ld4(p.coef_out + 3 * p.N + c);
-        }
-    }
-    float s32[4], q32[4], vmx[4], vmn[4];
-    int imx[4], imn[4];
-    float4 dp;
-    int es = 0, ept = 0;                                 // row inside the current point, point inside this wave's share
-    long e_row0 = 0, e_pt0 = 0; int e_rv = 0;            // tile being finished
-
-    float4 v[X6_PB];                                     // rows staged for the next tile
-    float4 pvs0, pvs1, pvs2, pvs3;                       // P rows of the points being staged (gather)
-    pvs0 = pvs1 = pvs2 = pvs3 = make_float4(0.f, 0.f, 0.f, 0.f);
-    float4 act[(EMODE != E_EDGE_FWD) ? X6_PB : 1];       // stored activations of the tile being finished (backward)
-    float4 pve0, pve1, pve2, pve3;                       // P rows of the points being finished (E_BWD_GATHER)
-    pve0 = pve1 = pve2 = pve3 = make_float4(0.f, 0.f, 0.f, 0.f);
-    int s_rv = 0;                                        // valid rows of the tile being staged
-
-    // Row addressing of the gathers stays in VGPRs: 16 rows x 64-bit scalar addresses (plus their clamps) do not fit the
-    // SGPR file next to this kernel's ~60 live scalars, and SGPR spills go to scratch memory (every reload is a
-    // scratch_load + s_waitcnt vmcnt(0) in the middle of the load pipeline).  So a tile's neighbour rows are loaded
-    // lane-distributed ONE ITERATION AHEAD (lane L <-> row rb + min(L, rows_w-1)), a row's value is broadcast with
-    // ds_bpermute, and `vz` (an opaque zero) keeps the point indices per-lane as well.
-    int vz;
-    asm volatile("v_mov_b32 %0, 0" : "=v"(vz));
-    // LICM would hoist ~250 per-row scalars (row numbers, LDS offsets, point indices — all functions of rb, rows_w and
-    // rk16) out of the persistent tile loop and the register allocator would then spill them to scratch; re-deriving them
-    // from an opaque per-iteration zero keeps them transient.
-    int rbl = rb, rwl = rows_w, rkl = rk16;
-#define X6_REFRESH_SCALARS()                                   \
-    {                                                          \
-        int sz_;                                               \
-        asm volatile("s_mov_b32 %0, 0" : "=s"(sz_));           \
-        rbl = rb + sz_; rwl = rows_w + sz_; rkl = rk16 + sz_;  \
-    }
-    auto load_jgv = [&](int tile) -> int {
-        const long row0 = (long)tile * p.R;
-        const int rv = (int)((p.M - row0 < p.R) ? (p.M - row0) : p.R);
-        int r = rbl + ((lane < rwl) ? lane : rwl - 1);
-        r = (r < rv - 1) ? r : rv - 1;
-        return p.jg[row0 + r];
-    };
-    int jgv_s = 0, jgv_e = 0;            // neighbour rows for the NEXT stage (A_GATHER) / the NEXT epilogue (E_BWD_GATHER)
-
-    // ---- VMEM issue: everything this iteration will need --------------------------------------------------------------
-    auto issue_epi_loads = [&](int tile) {
-        e_row0 = (long)tile * p.R;
-        e_pt0 = (long)tile * PT + wave * npw;
-        e_rv = (int)((p.M - e_row0 < p.R) ? (p.M - e_row0) : p.R);
-        es = 0; ept = 0;
-#pragma unroll
-        for (int t = 0; t < 4; ++t) { s32[t] = 0.f; q32[t] = 0.f; vmx[t] = -INFINITY; vmn[t] = INFINITY; imx[t] = 0; imn[t] = 0; }
-        dp = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (EMODE == E_EDGE_FWD) return;
-        // NOTE: every load below is unconditional (clamped rows, clamped column quad): a register that is loaded under a
-        // branch needs a copy at the join, and that copy waits for the load right there — no pipelining left
-        const int last = e_rv - 1;
-#pragma unroll
-        for (int u = 0; u < X6_PB; ++u) {
-            int r = rbl + ((u < rwl) ? u : rwl - 1);
-            r = (r < last) ? r : last;                                  // clamp: unconditional loads
-            if (EMODE == E_BWD_INPLACE) act[u] = ld4(p.out + (e_row0 + r) * p.ldo + cn);
-            else {
-                const int jj = __builtin_amdgcn_ds_bpermute(u << 2, jgv_e);
-                act[u] = ld4(p.pq + (long)jj * p.ldpq + p.H + cn);
-            }
-        }
-        if (GATHER_ACT) {
-            const int pt0 = tile * PT + wave * npw + vz, ptl = tile * PT + ((last * rkl) >> 16);
-            pve0 = ld4(p.pq + (long)((pt0 + 0 < ptl) ? pt0 + 0 : ptl) * p.ldpq + cn);
-            pve1 = ld4(p.pq + (long)((pt0 + 1 < ptl) ? pt0 + 1 : ptl) * p.ldpq + cn);
-            pve2 = ld4(p.pq + (long)((pt0 + 2 < ptl) ? pt0 + 2 : ptl) * p.ldpq + cn);
-            pve3 = ld4(p.pq + (long)((pt0 + 3 < ptl) ? pt0 + 3 : ptl) * p.ldpq + cn);
-        }
-    };
-    auto issue_stage_loads = [&](int tile) {
-        const long row0 = (long)tile * p.R;
-        s_rv = (int)((p.M - row0 < p.R) ? (p.M - row0) : p.R);
-        const int last = s_rv - 1;
-#pragma unroll
-        for (int u = 0; u < X6_PB; ++u) {
-            int r = rbl + ((u < rwl) ? u : rwl - 1);
-            r = (r < last) ? r : last;
-            if (AMODE == A_GATHER) {
-                const int jj = __builtin_amdgcn_ds_bpermute(u << 2, jgv_s);
-                v[u] = ld4(p.pq + (long)jj * p.ldpq + p.H + ck);
-            } else {
-                // rows are 16-B aligned and padded to a multiple of 4 columns (checked by the dispatcher)
-                v[u] = ld4(p.a.base + (row0 + r) * p.a.stride_outer + ck);
-            }
-        }
-        if (AMODE == A_GATHER) {
-            const int pt0 = tile * PT + wave * npw + vz, ptl = tile * PT + ((last * rkl) >> 16);
-            pvs0 = ld4(p.pq + (long)((pt0 + 0 < ptl) ? pt0 + 0 : ptl) * p.ldpq + ck);
-            pvs1 = ld4(p.pq + (long)((pt0 + 1 < ptl) ? pt0 + 1 : ptl) * p.ldpq + ck);
-            pvs2 = ld4(p.pq + (long)((pt0 + 2 < ptl) ? pt0 + 2 : ptl) * p.ldpq + ck);
-            pvs3 = ld4(p.pq + (long)((pt0 + 3 < ptl) ? pt0 + 3 : ptl) * p.ldpq + ck);
-        }
-    };
-    // ---- LDS commit of staged row u (compile-time u) ------------------------------------------------------------------
-    auto commit_row = [&](float* An, int u) {
-        if ((!K16 && u >= rwl) || !k_on) return;
-        const int r = rbl + u;
-        float4 o = v[u];
-        if (AMODE == A_GATHER) {
-            const float4 pv = K16 ? pvs0 : x6_sel4(pvs0, pvs1, pvs2, pvs3, (u * rkl) >> 16);
-            o.x = fmaxf(o.x + pv.x, 0.f); o.y = fmaxf(o.y + pv.y, 0.f);
-            o.z = fmaxf(o.z + pv.z, 0.f); o.w = fmaxf(o.w + pv.w, 0.f);
-        }
-        if (r >= s_rv) o = make_float4(0.f, 0.f, 0.f, 0.f);      // rows past the end of a partial last tile
-        st4(&An[r * LDA + c], o);
-    };
-    // ---- epilogue of row u (compile-time u) of the tile being finished ------------------------------------------------
-    auto epi_row = [&](int u, const float4 z) {
-        if (!K16 && u >= rwl) return;
-        const int r = rbl + u;
-        if (r >= e_rv) return;               // K16: all 16 rows of the wave's point are valid or none is (uniform)
-        const int slot = K16 ? u : es;
-        if (n_on) {
-            if (EMODE == E_EDGE_FWD) {
-                const float vv[4] = {fmaxf(z.x + bias4.x, 0.f), fmaxf(z.y + bias4.y, 0.f), fmaxf(z.z + bias4.z, 0.f),
-                                     fmaxf(z.w + bias4.w, 0.f)};
-                // gather variant: the activation rows stream out past L2 so that they do not evict the cloud's Q table
-                // (counter fetch of this kernel 199 -> <145 MB against 109 MB compulsory, same run time: profiles/r02_b)
-                if (AMODE == A_GATHER) st4_stream(p.out + (e_row0 + r) * p.ldo + c, make_float4(vv[0], vv[1], vv[2], vv[3]));
-                else st4(p.out + (e_row0 + r) * p.ldo + c, make_float4(vv[0], vv[1], vv[2], vv[3]));
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    s32[t] += vv[t];
-                    q32[t] = __builtin_fmaf(vv[t], vv[t], q32[t]);
-                    if (vv[t] > vmx[t]) { vmx[t] = vv[t]; imx[t] = slot; }
-                    if (vv[t] < vmn[t]) { vmn[t] = vv[t]; imn[t] = slot; }
-                }
-            } else {
-                float4 av = act[u];
-                if (GATHER_ACT) {
-                    const float4 pv = K16 ? pve0 : x6_sel4(pve0, pve1, pve2, pve3, (u * rkl) >> 16);
-                    av.x = fmaxf(av.x + pv.x, 0.f); av.y = fmaxf(av.y + pv.y, 0.f);
-                    av.z = fmaxf(av.z + pv.z, 0.f); av.w = fmaxf(av.w + pv.w, 0.f);
-                }
-                float4 o;
-                o.x = (av.x > 0.f) ? z.x * cs4.x - c14.x - (av.x - mu4.x) * k24.x : 0.f;
-                o.y = (av.y > 0.f) ? z.y * cs4.y - c14.y - (av.y - mu4.y) * k24.y : 0.f;
-                o.z = (av.z > 0.f) ? z.z * cs4.z - c14.z - (av.z - mu4.z) * k24.z : 0.f;
-                o.w = (av.w > 0.f) ? z.w * cs4.w - c14.w - (av.w - mu4.w) * k24.w : 0.f;
-                st4(p.out + (e_row0 + r) * p.ldo + c, o);
-                dp.x += o.x; dp.y += o.y; dp.z += o.z; dp.w += o.w;
-            }
-        }
-        if (K16 ? (u == X6_PB - 1) : (++es == p.k)) {        // a point is complete (K16: compile-time)
-            if (n_on) {
-                const long gpt = e_pt0 + (K16 ? 0 : ept);
-                if (EMODE == E_EDGE_FWD && p.agg) {
-                    const long o = gpt * p.oldagg + c;
-                    st4(p.mx + o, make_float4(vmx[0], vmx[1], vmx[2], vmx[3]));
-                    st4(p.mn + o, make_float4(vmn[0], vmn[1], vmn[2], vmn[3]));
-                    *reinterpret_cast<uchar4*>(p.oamx + o) = make_uchar4(imx[0], imx[1], imx[2], imx[3]);
-                    *reinterpret_cast<uchar4*>(p.oamn + o) = make_uchar4(imn[0], imn[1], imn[2], imn[3]);
-                }
-                if (EMODE == E_BWD_GATHER) st4(p.dP + gpt * p.lddp + c, dp);
-            }
-#pragma unroll
-            for (int t = 0; t < 4; ++t) { vmx[t] = -INFINITY; vmn[t] = INFINITY; imx[t] = 0; imn[t] = 0; }
-            dp = make_float4(0.f, 0.f, 0.f, 0.f);
-            es = 0; ++ept;
-        }
-    };
-    auto epi_flush_stats = [&]() {
-        if (EMODE == E_EDGE_FWD) {
-#pragma unroll
-            for (int t = 0; t < 4; ++t) { stS[t] += (double)s32[t]; stQ[t] += (double)q32[t]; }
-        }
-    };
-
-    // ---- tile sequence of this workgroup --------------------------------------------------------------------------------
-    // unpinned: blockIdx.x, +gridDim.x, ...   pinned (p.pin_tpc > 0; gridDim.x % 8 == 0, B % 8 == 0, tiles never straddle
-    // clouds): this workgroup sits on XCD x = blockIdx.x % 8 and takes every (gridDim.x/8)-th tile of clouds x, x+8, ... —
-    // the gathered Q table of a cloud (3.3 MB at the shipped sizes) is then read through ONE 4 MiB L2 instead of eight.
-    // Sequence positions past the end map to tile numbers >= num_tiles in both modes.
-    const int seq_step = p.pin_tpc ? (int)(gridDim.x >> 3) : (int)gridDim.x;
-    int seq_t = p.pin_tpc ? (int)(blockIdx.x >> 3) : (int)blockIdx.x;      // pinned: tile inside the cloud
-    int seq_c = p.pin_tpc ? (int)(blockIdx.x & 7) : 0;                     // pinned: cloud
-    auto seq_tile = [&]() -> int { return p.pin_tpc ? seq_c * p.pin_tpc + seq_t : seq_t; };
-    auto seq_advance = [&]() {
-        seq_t += seq_step;
-        if (p.pin_tpc && seq_t >= p.pin_tpc) { seq_t -= p.pin_tpc; seq_c += GPE_NXCD; }   // host: seq_step <= pin_tpc
-    };
-
-    // ---- prologue: stage tile 0 ---------------------------------------------------------------------------------------
-    __syncthreads();                                     // A buffers zeroed
-    int tile = seq_tile();
-    seq_advance();
-    int next = seq_tile();
-    seq_advance();
-    int next2 = seq_tile();
-    if (tile < p.num_tiles) {
-        if (AMODE == A_GATHER) jgv_s = load_jgv(tile);
-        if (GATHER_ACT) jgv_e = load_jgv(tile);
-    }
-    if (tile < p.num_tiles && !(p.dbg & 1)) {
-        issue_stage_loads(tile);
-#pragma unroll
-        for (int u = 0; u < X6_PB; ++u) commit_row(Abuf0, u);
-    }
-    if (AMODE == A_GATHER && tile < p.num_tiles) jgv_s = load_jgv(next < p.num_tiles ? next : tile);
-    __syncthreads();
-
-    int buf = 0, prev = -1;
-    for (; tile < p.num_tiles; tile = next, next = next2, seq_advance(), next2 = seq_tile()) {
-        X6_REFRESH_SCALARS()
-        const float* As = buf ? Abuf1 : Abuf0;
-        float* An = buf ? Abuf0 : Abuf1;
-        const bool do_epi = prev >= 0 && !(p.dbg & 2);
-        const bool do_stage = next < p.num_tiles && !(p.dbg & 1);
-
-        f32x4 acc[4][AQ], accL[BQ > 0 ? BQ : 1][4];
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-#pragma unroll
-            for (int i = 0; i < AQ; ++i) acc[mt][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int b = 0; b < (BQ > 0 ? BQ : 1); ++b) accL[b][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        }
-
-        // raw fp32 A fragment of slot (sl, mt): 8 consecutive k of row 16 mt + j.  In the 16-wide tail slab the lane groups
-        // g >= 2 lie past the row: they read a valid address and contribute zeros (their weights are zero as well).
-        float4 raw0, raw1;
-        auto read_raw = [&](int sl, int mt) {
-            const bool dead = KTAIL && sl == KS - 1 && g >= 2;
-            const float* src = &As[(16 * mt + j) * LDA + 32 * sl + 8 * (dead ? (g & 1) : g)];
-            raw0 = ld4(src); raw1 = ld4(src + 4);
-            if (dead) { raw0 = make_float4(0.f, 0.f, 0.f, 0.f); raw1 = raw0; }
-        };
-        float4 zq[EPR];
-#pragma unroll
-        for (int q = 0; q < EPR; ++q) zq[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-        read_raw(0, 0);
-
-#pragma unroll
-        for (int sl = 0; sl < KS; ++sl) {
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt) {
-                const int q = 4 * sl + mt;
-                const X6Frag af = x6_split8(raw0, raw1);
-                if (q + 1 < NSLOT) read_raw((q + 1) >> 2, (q + 1) & 3);
-                // ---- this slot's slice of the memory pipeline ----
-                if (q == 0) {
-                    issue_epi_loads(prev >= 0 ? prev : tile);            // clamped: results unused when !do_epi
-                    issue_stage_loads(next < p.num_tiles ? next : tile); // clamped: results unused when !do_stage
-                    if (GATHER_ACT) jgv_e = load_jgv(tile);              // this tile is finished in the next iteration
-                    if (AMODE == A_GATHER) jgv_s = load_jgv(next2 < p.num_tiles ? next2 : tile);
-                }
-                if (q >= CM_START && q < EP_START) {
-                    if (do_stage) {
-#pragma unroll
-                        for (int c4 = 0; c4 < CMR; ++c4) {
-                            const int u = (q - CM_START) * CMR + c4;
-                            if (u < X6_PB) commit_row(An, u);
-                        }
-                    }
-                }
-                if (q >= EP_START) {
-                    if (do_epi) {
-#pragma unroll
-                        for (int e2 = 0; e2 < EPR; ++e2) {
-                            const int u = (q - EP_START) * EPR + e2;
-                            if (u < X6_PB) epi_row(u, zq[e2]);
-                        }
-                    }
-                }
-                if (q + 1 >= EP_START && q + 1 < NSLOT) {                // C rows of the NEXT slot's epilogue (LDS prefetch)
-#pragma unroll
-                    for (int e2 = 0; e2 < EPR; ++e2) {
-                        const int u = (q + 1 - EP_START) * EPR + e2;
-                        const int rr = rbl + ((u < X6_PB) ? u : X6_PB - 1);
-                        zq[e2] = ld4(&Cs[((rr < RG_BM) ? rr : RG_BM - 1) * LDC + cn]);
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);           // memory slice stays in front of this slot's MFMAs
-                // ---- six products per (tile, slab): small terms first; tiles innermost = independent accumulators ----
-#pragma unroll
-                for (int i = 0; i < AQ; ++i) acc[mt][i] = x6_mfma(af.l, wH[i][sl], acc[mt][i]);
-#pragma unroll
-                for (int i = 0; i < AQ; ++i) acc[mt][i] = x6_mfma(af.h, wLo[i][sl], acc[mt][i]);
-#pragma unroll
-                for (int i = 0; i < AQ; ++i) acc[mt][i] = x6_mfma(af.m, wM[i][sl], acc[mt][i]);
-#pragma unroll
-                for (int i = 0; i < AQ; ++i) acc[mt][i] = x6_mfma(af.m, wH[i][sl], acc[mt][i]);
-#pragma unroll
-                for (int i = 0; i < AQ; ++i) acc[mt][i] = x6_mfma(af.h, wM[i][sl], acc[mt][i]);
-#pragma unroll
-                for (int i = 0; i < AQ; ++i) acc[mt][i] = x6_mfma(af.h, wH[i][sl], acc[mt][i]);
-                if (BQ > 0 && (sl & 3) == wave) {            // this wave's K slab of the left-over tiles
-#pragma unroll
-                    for (int b = 0; b < BQ; ++b) accL[b][mt] = x6_mfma(af.l, lH[b][sl >> 2], accL[b][mt]);
-#pragma unroll
-                    for (int b = 0; b < BQ; ++b) accL[b][mt] = x6_mfma(af.h, lLo[b][sl >> 2], accL[b][mt]);
-#pragma unroll
-                    for (int b = 0; b < BQ; ++b) accL[b][mt] = x6_mfma(af.m, lM[b][sl >> 2], accL[b][mt]);
-#pragma unroll
-                    for (int b = 0; b < BQ; ++b) accL[b][mt] = x6_mfma(af.m, lH[b][sl >> 2], accL[b][mt]);
-#pragma unroll
-                    for (int b = 0; b < BQ; ++b) accL[b][mt] = x6_mfma(af.h, lM[b][sl >> 2], accL[b][mt]);
-#pragma unroll
-                    for (int b = 0; b < BQ; ++b) accL[b][mt] = x6_mfma(af.h, lH[b][sl >> 2], accL[b][mt]);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-        if (do_epi) epi_flush_stats();
-        __syncthreads();                                 // (1) every wave is done with C (epilogue of the previous tile) and with As
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-            for (int i = 0; i < AQ; ++i)
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    Cs[(16 * mt + 4 * g + r) * LDC + 16 * (AQ * wave + i) + j] = acc[mt][i][r];
-        if (BQ > 0) {
-            // left-over tiles: this wave's K-partial of row r goes to the scratch slot of that row INSIDE the consumed A buffer
-            // (columns [16 (wave BQ + b), +16)); the row's owner sums the four partials after the barrier
-            float* Sc = const_cast<float*>(As);
-#pragma unroll
-            for (int b = 0; b < BQ; ++b)
-#pragma unroll
-                for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        Sc[(16 * mt + 4 * g + r) * LDA + 16 * (wave * BQ + b) + j] = accL[b][mt][r];
-        }
-        __syncthreads();                                 // (2) C complete, partials complete, next A tile complete
-        if (BQ > 0) {
-            // rows rb .. rb + rows_w - 1 are mine: I finish them, and I am the only wave that re-stages them in this buffer
-            const int ur = lane >> 2, cq = (lane & 3) << 2;
-            if (ur < rwl) {
-                const float* Sr = &As[(rbl + ur) * LDA + cq];
-#pragma unroll
-                for (int b = 0; b < BQ; ++b) {
-                    const float4 p0 = ld4(Sr + 16 * (0 * BQ + b)), p1 = ld4(Sr + 16 * (1 * BQ + b));
-                    const float4 p2 = ld4(Sr + 16 * (2 * BQ + b)), p3 = ld4(Sr + 16 * (3 * BQ + b));
-                    float4 o;
-                    o.x = (p0.x + p1.x) + (p2.x + p3.x); o.y = (p0.y + p1.y) + (p2.y + p3.y);
-                    o.z = (p0.z + p1.z) + (p2.z + p3.z); o.w = (p0.w + p1.w) + (p2.w + p3.w);
-                    st4(&Cs[(rbl + ur) * LDC + 16 * (4 * AQ + b) + cq], o);
-                }
-            }
-        }
-        prev = tile;
-        buf ^= 1;
-    }
-    // ---- tail: epilogue of the last tile -------------------------------------------------------------------------------
-    if (prev >= 0 && !(p.dbg & 2)) {
-        issue_epi_loads(prev);
-#pragma unroll
-        for (int u = 0; u < X6_PB; ++u) {
-            const int rr = rbl + u;
-            epi_row(u, ld4(&Cs[((rr < RG_BM) ? rr : RG_BM - 1) * LDC + cn]));
-        }
-        epi_flush_stats();
-    }
-    __syncthreads();
-    if (EMODE == E_EDGE_FWD && p.stats_part) {
-        double* red = reinterpret_cast<double*>(smem);          // [4 waves][2][16*NT]
-        if (n_on) {
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                red[(wave * 2 + 0) * (16 * NT) + c + t] = stS[t];
-                red[(wave * 2 + 1) * (16 * NT) + c + t] = stQ[t];
-            }
-        }
-        __syncthreads();
-        if (tid < p.N) {
-            constexpr int NC = 16 * NT;
-            const double ss = (red[0 * NC + tid] + red[2 * NC + tid]) + (red[4 * NC + tid] + red[6 * NC + tid]);
-            const double qq = (red[1 * NC + tid] + red[3 * NC + tid]) + (red[5 * NC + tid] + red[7 * NC + tid]);
-            for (int b = blockIdx.x; b < stats_nblk; b += gridDim.x) {
-                double* dst = p.stats_part + (size_t)b * 2 * p.N;
-                dst[tid] = (b == (int)blockIdx.x) ? ss : 0.0;
-                dst[p.N + tid] = (b == (int)blockIdx.x) ? qq : 0.0;
-            }
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------
-static int x6_num_cus() { return gpe_num_cus(); }
-
-template <int AQ, int BQ, int KCH, int AMODE, int EMODE, bool K16>
-static int x6_launch_k(const RgParams& p, int stats_nblk, hipStream_t s)
-{
-    constexpr int NT = 4 * AQ + BQ;
-    constexpr int LDA = 16 * KCH + 4, LDC = 16 * NT + 4;
-    const size_t lds = (size_t)RG_BM * (2 * LDA + LDC) * sizeof(float);
-    GPE_ENSURE_MAX_LDS((gpe_edgegemm_x6_kernel<AQ, BQ, KCH, AMODE, EMODE, K16>));
-    int gx = x6_num_cus();
-    if (gx > p.num_tiles) gx = p.num_tiles;
-    if (stats_nblk > 0 && gx > stats_nblk) gx = stats_nblk;
-    hipLaunchKernelGGL((gpe_edgegemm_x6_kernel<AQ, BQ, KCH, AMODE, EMODE, K16>), dim3(gx), dim3(256), lds, s, p, stats_nblk);
-    GPE_CHECK_LAUNCH();
-    return GPE_OK;
-}
-
-template <int AQ, int BQ, int KCH, int AMODE, int EMODE>
-static int x6_launch(const RgParams& p, int stats_nblk, hipStream_t s)
-{
-    return p.k == 16 ? x6_launch_k<AQ, BQ, KCH, AMODE, EMODE, true>(p, stats_nblk, s)
-                     : x6_launch_k<AQ, BQ, KCH, AMODE, EMODE, false>(p, stats_nblk, s);
-}
+// "bf16x6": the three-term bf16 policy of the split-precision single-role edge kernel (gpe_edgegemm_split_kernel.h).
+#include "gpe_edgegemm_split_kernel.h"
 
 template <int AMODE, int EMODE>
 static int x6_dispatch(int NT, int KCH, const RgParams& p, int stats_nblk, hipStream_t s)
@@ -599,41 +7,18 @@ static int x6_dispatch(int NT, int KCH, const RgParams& p, int stats_nblk, hipSt
     // Only variants that fit the 512-register budget of a lone wave WITHOUT scratch spills are on the menu (checked with
     // scripts/kernel_resources.py): 10 N-tiles always; 13 N-tiles keep 252 + 24 weight registers resident, which leaves too
     // little for the 16-row staging / epilogue state — those shapes stay on the exact-fp32 kernel (caller falls through).
-    if (NT == 10 && KCH == 13) return x6_launch<2, 2, 13, AMODE, EMODE>(p, stats_nblk, s);
-    if (NT == 10 && KCH == 10) return x6_launch<2, 2, 10, AMODE, EMODE>(p, stats_nblk, s);
-    if (NT == 13 && KCH == 10 && EMODE == E_EDGE_FWD) return x6_launch<3, 1, 10, AMODE, EMODE>(p, stats_nblk, s);
+    if (NT == 10 && KCH == 13) return x6_launch<SplitBf16x3, 2, 2, 13, AMODE, EMODE>(p, stats_nblk, s);
+    if (NT == 10 && KCH == 10) return x6_launch<SplitBf16x3, 2, 2, 10, AMODE, EMODE>(p, stats_nblk, s);
+    if (NT == 13 && KCH == 10 && EMODE == E_EDGE_FWD) return x6_launch<SplitBf16x3, 3, 1, 10, AMODE, EMODE>(p, stats_nblk, s);
     return GPE_ENOTSUP_SHAPE;
 }
 
 // Returns 1 and launches when the shape is on this kernel's menu, 0 when the caller should try the next kernel,
-// < 0 on a launch error.  `p` comes with the generic tiling (R = (64/k)*k); this kernel re-tiles so that every wave
-// owns whole points: R = 4 * npw * k with npw * k <= 16.
+// < 0 on a launch error.  `p` comes with the generic tiling (R = (64/k)*k); x6_prepare re-tiles it.
 int gpe_edgegemm_x6_try(const RgParams& p_in, int amode, int emode, int stats_nblk, hipStream_t s)
 {
-    RgParams p = p_in;
-    if (p.N <= 96 || p.N > 208 || p.K <= 96 || p.K > 208) return 0;
-    if (emode != E_EDGE_FWD && (p.N & 3)) return 0;      // the backward epilogues use aligned 16-B coefficient loads
-    if (amode == A_GATHER && (p.K & 3)) return 0;
-    if (amode == A_DENSE && (p.a.inner > 0 || (p.a.stride_outer & 3) || p.a.stride_outer < ((p.K + 3) & ~3) ||
-                             (((uintptr_t)p.a.base) & 15)))
-        return 0;                                        // dense rows must be aligned + padded for plain 16-B loads
-    if (p.k < 1 || p.k > X6_PB) return 0;
-    const int npw = X6_PB / p.k;                         // points per wave per tile
-    const bool per_point = amode == A_GATHER || emode == E_BWD_GATHER || (emode == E_EDGE_FWD && p.agg);
-    if (per_point && npw > X6_NPW) return 0;
-    p.R = 4 * npw * p.k;
-    p.num_tiles = gpe_cdiv(p.M, p.R);
-    p.pin_tpc = 0;
-    if ((amode == A_GATHER || emode == E_BWD_GATHER) && p.pin_clouds > 0 && gpe_pin_clouds(p.pin_clouds) &&
-        p.pin_clouds % GPE_NXCD == 0) {
-        // gather variants only (dense streaming tiles have nothing to keep in L2): tiles must not straddle clouds and
-        // the launcher must keep gridDim.x a multiple of 8 with gridDim.x / 8 <= tiles per cloud
-        const long rows_per_cloud = p.M / p.pin_clouds;
-        const int gx = gpe_num_cus();
-        if (rows_per_cloud % p.R == 0 && gx % GPE_NXCD == 0 && gx <= p.num_tiles &&
-            (stats_nblk <= 0 || gx <= stats_nblk) && rows_per_cloud / p.R >= gx / GPE_NXCD)
-            p.pin_tpc = (int)(rows_per_cloud / p.R);
-    }
+    RgParams p;
+    if (!x6_prepare(p_in, amode, emode, stats_nblk, p)) return 0;
     const int NT = (p.N <= 160) ? 10 : 13;
     const int KCH = (p.K <= 160) ? 10 : 13;
     int rc = GPE_EINVAL;

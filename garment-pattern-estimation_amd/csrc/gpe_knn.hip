@@ -911,6 +911,7 @@ __global__ __launch_bounds__(256) void gpe_knn_rerank_kernel(const float* __rest
 extern "C" int gpe_knn(const float* x, int B, int N, int C, int ldx, int k, int32_t* idx, int32_t* idx_glob,
                        void* stream)
 {
+    GPE_WRITES_TENSORS();
     if (!x || !idx || B < 0 || N <= 0 || C <= 0 || ldx < C || k <= 0 || k > 64 || k > N || (long)B * N * k >= (1L << 31)) return GPE_EINVAL;
     if (B == 0) return GPE_OK;
     static const int force_exact = getenv("GPE_KNN_EXACT") ? atoi(getenv("GPE_KNN_EXACT")) : 0;

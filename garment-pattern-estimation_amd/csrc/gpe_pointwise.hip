@@ -23,7 +23,7 @@ int gpe_num_cus()
 
 void* gpe_scratch(int slot, size_t bytes)
 {
-    constexpr int SLOTS = 3, DEVS = 64;
+    constexpr int SLOTS = 4, DEVS = 64;
     static void* ptr[DEVS][SLOTS] = {};
     static size_t cap[DEVS][SLOTS] = {};
     int dev = 0;
@@ -46,7 +46,14 @@ __device__ __forceinline__ void pw_st4(float* p, float4 v) { *reinterpret_cast<f
 // ---------------------------------------------------------------------------------------------------------
 // weight packing: packed[(kc*4 + plane)*Npad*4 + n*4 + t] = w(n, 16*kc + 4*plane + t) * col_scale
 // ---------------------------------------------------------------------------------------------------------
-extern "C" long gpe_packed_size(int N, int K) { return (long)gpe_round_up(N, 16) * gpe_round_up(K, 16); }
+// K extent of a packed weight: whole 16-k chunks, and a K in (96, 208] is filled up (with zeros) to the 10 or 13 chunks the
+// register-stationary edge kernels keep resident — they load their full chunk count whatever the real K is.
+static int gpe_pack_kpad(int K)
+{
+    const int k16 = gpe_round_up(K, 16);
+    return (k16 > 96 && k16 < 160) ? 160 : (k16 > 160 && k16 < 208) ? 208 : k16;
+}
+extern "C" long gpe_packed_size(int N, int K) { return (long)gpe_round_up(N, 16) * gpe_pack_kpad(K); }
 
 __global__ void gpe_pack_kernel(const float* __restrict__ w, int ldw, int N, int K, int transpose,
                                 const float* __restrict__ col_scale, float* __restrict__ wp, int Npad, long total)
@@ -71,7 +78,7 @@ extern "C" int gpe_pack_weight(const float* w, int ldw, int N, int K, int transp
 {
     if (!w || !wp || N <= 0 || K <= 0 || ldw < (transpose ? N : K)) return GPE_EINVAL;
     const int Npad = gpe_round_up(N, 16);
-    const long total = (long)Npad * gpe_round_up(K, 16);
+    const long total = (long)Npad * gpe_pack_kpad(K);
     hipLaunchKernelGGL(gpe_pack_kernel, dim3(gpe_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, w, ldw, N, K,
                        transpose, col_scale, wp, Npad, total);
     GPE_CHECK_LAUNCH();
@@ -431,6 +438,7 @@ __global__ void gpe_edge_finish_kernel(const float* __restrict__ mx, const float
 extern "C" int gpe_edge_finish(const float* mx, const float* mn, int ldagg, const float* stats, long rows, int C,
                                float* y, int ldy, void* stream)
 {
+    GPE_WRITES_TENSORS();
     if (!mx || !mn || !stats || !y || rows < 0 || C <= 0 || ldagg < C || ldy < C) return GPE_EINVAL;
     if (rows == 0) return GPE_OK;
     hipLaunchKernelGGL(gpe_edge_finish_kernel, dim3(gpe_cdiv(rows * C, 256)), dim3(256), 0, (hipStream_t)stream, mx,
@@ -543,8 +551,13 @@ __global__ __launch_bounds__(256) void gpe_dz3_kernel(float* __restrict__ a3, in
                                                       int ldg, const uint8_t* __restrict__ amx,
                                                       const uint8_t* __restrict__ amn, int ldagg,
                                                       const float* __restrict__ coef, long npts, int k, int F,
-                                                      float gscale)
+                                                      float gscale, unsigned* __restrict__ amax_out)
 {
+    // amax_out (f16x3 mode, else NULL): receives the largest |dz3| written, as the bit pattern of a non-negative float
+    __shared__ unsigned amax_red[4];
+    if (threadIdx.x < 4) amax_red[threadIdx.x] = 0u;
+    __syncthreads();
+    float amax_run = 0.f;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int c = (blockIdx.y * 64 + lane) << 2;
@@ -592,8 +605,18 @@ __global__ __launch_bounds__(256) void gpe_dz3_kernel(float* __restrict__ a3, in
                         o[t] = (c + t < F && av[t] > 0.f) ? hit - c1_[t] - (av[t] - mu_[t]) * k2_[t] : 0.f;
                     }
                     pw_st4(base + (long)(s0 + u) * lda3, make_float4(o[0], o[1], o[2], o[3]));
+                    amax_run = fmaxf(fmaxf(amax_run, fmaxf(fabsf(o[0]), fabsf(o[1]))), fmaxf(fabsf(o[2]), fabsf(o[3])));
                 }
             }
+        }
+    }
+    if (amax_out) {                                    // uniform; lanes past F have left, the barrier counts live waves only
+        atomicMax(&amax_red[wave], __float_as_uint(amax_run));
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const unsigned a = amax_red[0] > amax_red[1] ? amax_red[0] : amax_red[1];
+            const unsigned b = amax_red[2] > amax_red[3] ? amax_red[2] : amax_red[3];
+            atomicMax(amax_out, a > b ? a : b);
         }
     }
 }
@@ -607,8 +630,10 @@ static int dz3_launch(float* a3, int lda3, const float* g, int ldg, const uint8_
     if (E >= (1L << 31)) return GPE_EINVAL;
     const long npts = (long)B * N;
     const int blocks = (int)((npts + 3) / 4 < 4096 ? (npts + 3) / 4 : 4096);
+    // f16x3 mode: leave a note with the largest |dz3| for the edge GEMM that propagates it (NULL in every other mode)
+    unsigned* amax_out = gpe_h3_note_begin(a3, E, F, lda3, stream);
     hipLaunchKernelGGL(gpe_dz3_kernel, dim3(blocks, gpe_cdiv(F, 256)), dim3(256), 0, stream, a3, lda3, g, ldg, amx, amn,
-                       ldagg, coef, npts, k, F, gscale);
+                       ldagg, coef, npts, k, F, gscale, amax_out);
     GPE_CHECK_LAUNCH();
     return GPE_OK;
 }
@@ -755,6 +780,7 @@ __global__ __launch_bounds__(1024) void gpe_knn_reverse_kernel(const int32_t* __
 extern "C" int gpe_knn_reverse(const int32_t* idx, int B, int N, int k, int32_t* rev_off, int32_t* rev_edge,
                                void* stream)
 {
+    GPE_WRITES_TENSORS();
     if (!idx || !rev_off || !rev_edge || B <= 0 || N <= 0 || k <= 0) return GPE_EINVAL;
     const size_t lds = (size_t)(2 * N + 1) * sizeof(int);
     if (lds > 150 * 1024) return GPE_EINVAL;
@@ -809,6 +835,7 @@ __global__ __launch_bounds__(256) void gpe_pull_dq_kernel(const float* __restric
 extern "C" int gpe_edge_pull_dq(const float* dz, int lddz, const int32_t* rev_off, const int32_t* rev_edge, int B,
                                 int N, int k, int H, float* dQ, int lddq, void* stream)
 {
+    GPE_WRITES_TENSORS();
     if (!dz || !rev_off || !rev_edge || !dQ || B <= 0 || N <= 0 || k <= 0 || H <= 0 || H > 256 || (H & 3) ||
         (lddz & 3) || (lddq & 3))
         return GPE_EINVAL;
@@ -858,6 +885,7 @@ __global__ __launch_bounds__(1024) void gpe_segment_mean_fwd_kernel(const float*
 
 extern "C" int gpe_segment_mean_fwd(const float* x, int ldx, int B, int N, int C, float* y, int ldy, void* stream)
 {
+    GPE_WRITES_TENSORS();
     if (!x || !y || B <= 0 || N <= 0 || C <= 0 || ldx < C || ldy < C) return GPE_EINVAL;
     hipLaunchKernelGGL(gpe_segment_mean_fwd_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, x, ldx, N, C, y,
                        ldy);
@@ -880,6 +908,7 @@ __global__ void gpe_segment_mean_bwd_kernel(const float* __restrict__ gy, int ld
 extern "C" int gpe_segment_mean_bwd(const float* gy, int ldgy, int B, int N, int C, float* gx, int ldgx,
                                     int accumulate, void* stream)
 {
+    GPE_WRITES_TENSORS();
     if (!gy || !gx || B <= 0 || N <= 0 || C <= 0) return GPE_EINVAL;
     const long rows = (long)B * N;
     hipLaunchKernelGGL(gpe_segment_mean_bwd_kernel, dim3(gpe_cdiv(rows * C, 256)), dim3(256), 0,
@@ -914,6 +943,7 @@ __global__ void gpe_lstm_cell_fwd_kernel(float* __restrict__ gates, const float*
 extern "C" int gpe_lstm_cell_fwd(float* gates, const float* c_prev, long ldc_prev, float* c, float* h,
                                  long h_stride, int Bn, int H, void* stream)
 {
+    GPE_WRITES_TENSORS();
     if (!gates || !c_prev || !c || !h || Bn <= 0 || H <= 0) return GPE_EINVAL;
     hipLaunchKernelGGL(gpe_lstm_cell_fwd_kernel, dim3(gpe_cdiv((long)Bn * H, 256)), dim3(256), 0,
                        (hipStream_t)stream, gates, c_prev, ldc_prev, c, h, h_stride, Bn, H);
@@ -954,6 +984,7 @@ extern "C" int gpe_lstm_cell_bwd(const float* dh_out, long dho_stride, const flo
                                  const float* gates, const float* c, const float* c_prev, long ldc_prev,
                                  float* dgates, long dg_stride, float* dc_prev, int Bn, int H, void* stream)
 {
+    GPE_WRITES_TENSORS();
     if (!gates || !c || !c_prev || !dgates || !dc_prev || Bn <= 0 || H <= 0) return GPE_EINVAL;
     hipLaunchKernelGGL(gpe_lstm_cell_bwd_kernel, dim3(gpe_cdiv((long)Bn * H, 256)), dim3(256), 0,
                        (hipStream_t)stream, dh_out, dho_stride, dh_rec, n_rec, dc_next, gates, c, c_prev, ldc_prev, dgates,
@@ -998,6 +1029,7 @@ extern "C" int gpe_gru_cell_bwd(const float* dh_out, long dho_stride, const floa
                                 const float* dh_dir_next, const float* saved, const float* h_prev, long hp_stride,
                                 float* dgx, float* dgh, long dg_stride, float* dh_dir_prev, int Bn, int H, void* stream)
 {
+    GPE_WRITES_TENSORS();
     if (!saved || !h_prev || !dgx || !dgh || !dh_dir_prev || Bn <= 0 || H <= 0) return GPE_EINVAL;
     hipLaunchKernelGGL(gpe_gru_cell_bwd_kernel, dim3(gpe_cdiv((long)Bn * H, 256)), dim3(256), 0, (hipStream_t)stream,
                        dh_out, dho_stride, dh_rec, n_rec, dh_dir_next, saved, h_prev, hp_stride, dgx, dgh, dg_stride,
@@ -1054,6 +1086,7 @@ __global__ __launch_bounds__(256) void gpe_sparsemax_bwd_kernel(const float* __r
 
 extern "C" int gpe_sparsemax_fwd(const float* z, int ldz, long rows, int W, float* out, int ldo, void* stream)
 {
+    GPE_WRITES_TENSORS();
     if (!z || !out || rows < 0 || W <= 0 || W > SPX_W || ldz < W || ldo < W) return GPE_EINVAL;
     if (rows == 0) return GPE_OK;
     hipLaunchKernelGGL(gpe_sparsemax_fwd_kernel, dim3(gpe_cdiv(rows, 256)), dim3(256), 0, (hipStream_t)stream, z, ldz,
@@ -1065,6 +1098,7 @@ extern "C" int gpe_sparsemax_fwd(const float* z, int ldz, long rows, int W, floa
 extern "C" int gpe_sparsemax_bwd(const float* out, int ldo, const float* g, int ldg, long rows, int W, float* gz,
                                  int ldgz, void* stream)
 {
+    GPE_WRITES_TENSORS();
     if (!out || !g || !gz || rows < 0 || W <= 0 || ldo < W || ldg < W || ldgz < W) return GPE_EINVAL;
     if (rows == 0) return GPE_OK;
     hipLaunchKernelGGL(gpe_sparsemax_bwd_kernel, dim3(gpe_cdiv(rows, 256)), dim3(256), 0, (hipStream_t)stream, out,
@@ -1144,6 +1178,7 @@ __global__ __launch_bounds__(64) void gpe_sparsemax_loss_finish_kernel(const dou
 extern "C" int gpe_sparsemax_loss(const float* x, int ldx, const int32_t* target, long rows, int W, float* gx, int ldg,
                                   double* part, float* loss, int* bad, void* stream)
 {
+    GPE_WRITES_TENSORS();
     if (!x || !target || !gx || !part || !loss || !bad || rows <= 0 || W <= 0 || W > SPX_W || ldx < W || ldg < W) return GPE_EINVAL;
     const int nblk = (int)gpe_cdiv(rows, 256);
     hipLaunchKernelGGL(gpe_sparsemax_loss_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, x, ldx, target, rows, W, gx,
@@ -1163,6 +1198,7 @@ __global__ void gpe_scale_dev_kernel(const float* __restrict__ x, const float* _
 
 extern "C" int gpe_scale_dev(const float* x, const float* alpha, float* out, long n, void* stream)
 {
+    GPE_WRITES_TENSORS();
     if (!x || !alpha || !out || n < 0) return GPE_EINVAL;
     if (n == 0) return GPE_OK;
     hipLaunchKernelGGL(gpe_scale_dev_kernel, dim3((unsigned)gpe_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, x, alpha, out, n);
@@ -1184,6 +1220,7 @@ __global__ void gpe_bn_apply_kernel(const float* __restrict__ a, int lda, const 
 extern "C" int gpe_bn_apply_scaled(const float* a, int lda, const float* stats, long rows, int C, float a_scale,
                                    float t_scale, float* y, int ldy, void* stream)
 {
+    GPE_WRITES_TENSORS();
     if (!a || !stats || !y || rows < 0 || C <= 0 || lda < C || ldy < C) return GPE_EINVAL;
     if (rows == 0) return GPE_OK;
     hipLaunchKernelGGL(gpe_bn_apply_kernel, dim3(gpe_cdiv(rows * C, 256)), dim3(256), 0, (hipStream_t)stream, a, lda,
@@ -1195,6 +1232,7 @@ extern "C" int gpe_bn_apply_scaled(const float* a, int lda, const float* stats, 
 extern "C" int gpe_bn_apply(const float* a, int lda, const float* stats, long rows, int C, float* y, int ldy,
                             void* stream)
 {
+    GPE_WRITES_TENSORS();
     return gpe_bn_apply_scaled(a, lda, stats, rows, C, 1.f, 1.f, y, ldy, stream);
 }
 
@@ -1217,6 +1255,7 @@ __global__ void gpe_reduce_inner_kernel(const float* __restrict__ x, long x_so, 
 extern "C" int gpe_reduce_inner(const float* x, long x_so, long x_si, int T, int R, int C, float* y, int ldy,
                                 int accumulate, void* stream)
 {
+    GPE_WRITES_TENSORS();
     if (!x || !y || T <= 0 || R <= 0 || C <= 0) return GPE_EINVAL;
     hipLaunchKernelGGL(gpe_reduce_inner_kernel, dim3(gpe_cdiv((long)R * C, 256)), dim3(256), 0, (hipStream_t)stream,
                        x, x_so, x_si, T, R, C, y, ldy, accumulate);
@@ -1240,6 +1279,7 @@ __global__ void gpe_w1_split_kernel(const float* __restrict__ w1, int ldw1, cons
 extern "C" int gpe_w1_split(const float* w1, int ldw1, const float* b1, int H, int C, float* wpq, int ldwpq,
                             float* bias_pq, void* stream)
 {
+    GPE_WRITES_TENSORS();
     if (!w1 || !b1 || !wpq || !bias_pq || H <= 0 || C <= 0 || ldw1 < 2 * C || ldwpq < C) return GPE_EINVAL;
     const int total = (H * C > 2 * H) ? H * C : 2 * H;
     hipLaunchKernelGGL(gpe_w1_split_kernel, dim3(gpe_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, w1, ldw1,
@@ -1261,6 +1301,7 @@ __global__ void gpe_w1_grad_kernel(const float* __restrict__ dwpq, int ld, int H
 
 extern "C" int gpe_w1_grad_from_pq(const float* dwpq, int ld, int H, int C, float* dw1, int lddw1, void* stream)
 {
+    GPE_WRITES_TENSORS();
     if (!dwpq || !dw1 || H <= 0 || C <= 0 || ld < C || lddw1 < 2 * C) return GPE_EINVAL;
     hipLaunchKernelGGL(gpe_w1_grad_kernel, dim3(gpe_cdiv(H * C, 256)), dim3(256), 0, (hipStream_t)stream, dwpq, ld,
                        H, C, dw1, lddw1);
@@ -1282,6 +1323,7 @@ __global__ void gpe_scale_kernel(const float* x, float alpha, float* out, long n
 
 extern "C" int gpe_scale(const float* x, float alpha, float* out, long n, void* stream)
 {
+    GPE_WRITES_TENSORS();
     if (!x || !out || n < 0) return GPE_EINVAL;
     if (n == 0) return GPE_OK;
     hipLaunchKernelGGL(gpe_scale_kernel, dim3(gpe_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, x, alpha, out, n);
@@ -1291,6 +1333,7 @@ extern "C" int gpe_scale(const float* x, float alpha, float* out, long n, void* 
 
 extern "C" int gpe_add(const float* a, const float* b, float* out, long n, void* stream)
 {
+    GPE_WRITES_TENSORS();
     if (!a || !b || !out || n < 0) return GPE_EINVAL;
     if (n == 0) return GPE_OK;
     hipLaunchKernelGGL(gpe_add_kernel, dim3(gpe_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, a, b, out, n);
@@ -1317,6 +1360,7 @@ __global__ void gpe_mul_rows_kernel(const float* __restrict__ x, long x_sb, long
 extern "C" int gpe_mul_rows(const float* x, long x_sb, long x_st, const float* mask, long Bn, int T, int H, float* out,
                             void* stream)
 {
+    GPE_WRITES_TENSORS();
     if (!x || !mask || !out || Bn < 0 || T <= 0 || H <= 0) return GPE_EINVAL;
     const long n = Bn * T * H;
     if (n == 0) return GPE_OK;
@@ -1352,6 +1396,7 @@ __global__ void gpe_edge_inputs_fwd_kernel(const float* __restrict__ x, int ldx,
 extern "C" int gpe_edge_inputs_fwd(const float* x, int ldx, int C, const int32_t* jg, long npts, int k, float* out, int ldo,
                                    void* stream)
 {
+    GPE_WRITES_TENSORS();
     if (!x || !jg || !out || C <= 0 || ldx < C || npts <= 0 || k <= 0 || ldo < 2 * C) return GPE_EINVAL;
     const long total = npts * k * ldo;
     hipLaunchKernelGGL(gpe_edge_inputs_fwd_kernel, dim3((unsigned)gpe_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, x, ldx,
@@ -1386,6 +1431,7 @@ __global__ void gpe_edge_inputs_bwd_kernel(const float* __restrict__ g, int ldg,
 extern "C" int gpe_edge_inputs_bwd(const float* g, int ldg, int C, const int32_t* rev_off, const int32_t* rev_edge, int B,
                                    int N, int k, float* gx, int ldgx, void* stream)
 {
+    GPE_WRITES_TENSORS();
     if (!g || !rev_off || !rev_edge || !gx || C <= 0 || ldg < 2 * C || B <= 0 || N <= 0 || k <= 0 || ldgx < C) return GPE_EINVAL;
     const long total = (long)B * N * C;
     hipLaunchKernelGGL(gpe_edge_inputs_bwd_kernel, dim3((unsigned)gpe_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, g, ldg,

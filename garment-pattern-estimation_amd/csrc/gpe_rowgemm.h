@@ -41,6 +41,11 @@ struct RgParams {
     // 64 KB+ scratch image that absorbs the epilogue stores of a wave with nothing valid to finish (straight-line instances of
     // gpe_edgegemm_sr_kernel); NULL = use the branchy instances
     float* dummy;
+    // f16x3 (SplitF16x2, gpe_edgegemm_split_kernel.h): bit patterns of the largest magnitude of the A operand and of the packed
+    // weight, measured on the device; amax_out (may be NULL) receives (atomicMax) the largest magnitude the kernel writes to `out`
+    const unsigned* h3_amax_a;
+    const unsigned* h3_amax_w;
+    unsigned* amax_out;
 };
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }

@@ -208,6 +208,7 @@ int gpe_edgegemm_try(const RgParams& p, int amode, int emode, int stats_nblk, hi
 
 void gpe_edgegemm_set_math(int m);
 void gpe_redgemm_set_math(int m);
+void gpe_h3_enable(int on);          // gpe_edgegemm_h3.hip
 
 static int g_gpe_dbg = 0;
 extern "C" int gpe_debug_set(int flags) { g_gpe_dbg = flags; return 0; }
@@ -215,11 +216,13 @@ static int g_gpe_math = 0;
 extern "C" int gpe_math_get(void) { return g_gpe_math; }
 extern "C" int gpe_math_set(int mode)
 {
-    if (mode < 0 || mode > 3) return GPE_EINVAL;
+    if (mode < 0 || mode > 4) return GPE_EINVAL;
     const int prev = g_gpe_math;
     g_gpe_math = mode;
-    // row GEMMs (forward, input-gradient half): 0 exact fp32, 1 two-term split-bf16 (modes 1, 2), 2 three-term split (mode 3)
-    gpe_edgegemm_set_math(mode == 3 ? 2 : (mode != 0 ? 1 : 0));
+    // row GEMMs (forward, input-gradient half): 0 exact fp32, 1 two-term split-bf16 (modes 1, 2), 2 three-term split-bf16
+    // (mode 3), 3 two-term split-fp16 on tensor-normalised operands (mode 4)
+    gpe_edgegemm_set_math(mode == 4 ? 3 : mode == 3 ? 2 : (mode != 0 ? 1 : 0));
+    gpe_h3_enable(mode == 4);
     gpe_redgemm_set_math(mode == 1 ? 1 : 0);      // the weight-gradient reduce-GEMM: split-bf16 only in mode 1
     return prev;
 }
@@ -292,6 +295,7 @@ extern "C" int gpe_linear(const float* a, long a_so, long a_si, int a_inner, con
                           const float* addend, long ad_so, long ad_si, int ad_inner, float* y, long y_so,
                           long y_si, int y_inner, int M, int N, int K, int act, void* stream)
 {
+    GPE_WRITES_TENSORS();
     if (!a || !wp || !y || M < 0 || N <= 0 || K <= 0 || (act != 0 && act != 1)) return GPE_EINVAL;
     if (M == 0) return GPE_OK;
     RgParams p = {};

@@ -127,7 +127,7 @@ class PackPlan:
                 total = npad * round_up(K, 16)
             else:
                 npad = round_up(N, 16)
-                total = npad * round_up(K, 16)
+                total = L.query('gpe_packed_size', N, K)      # K filled up to the edge kernels' resident chunk count
             out = torch.empty(total, device=dev, dtype=F32)
             self.outs.append(out)
             tab[i] = (p.data_ptr(), p2.data_ptr() if p2 is not None else 0, out.data_ptr(), total, blk,

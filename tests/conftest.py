@@ -21,7 +21,7 @@ def golden_dir():
     return os.path.join(REPO, 'tests', 'golden')
 
 
-@pytest.fixture(params=['f32', 'bf16x6', 'mixed', 'bf16x3'])
+@pytest.fixture(params=['f32', 'f16x3', 'bf16x6', 'mixed', 'bf16x3'])
 def math_mode(request):
     """Runs a GPU test once per arithmetic of the fused edge GEMMs (include/gpe_hip.h gpe_math_set) and restores the
     library default afterwards."""
