@@ -56,7 +56,7 @@ def parse():
     ap.add_argument('--cpu-steps', type=int, default=3)
     ap.add_argument('--cpu-threads', type=int, default=0, help='0 = all host cores (nproc)')
     ap.add_argument('--no-kernel-timing', action='store_true')
-    ap.add_argument('--math', choices=['f32', 'bf16x6', 'mixed', 'bf16x3'], default='f32',
+    ap.add_argument('--math', choices=['f32', 'f16x3', 'bf16x6', 'mixed', 'bf16x3'], default='f32',
                     help="arithmetic of the fused edge GEMMs for the timed region (gpe_math_set); 'f32' = exact")
     ap.add_argument('--no-fast-math-line', action='store_true', help='skip the extra mixed / bf16x3 measurements')
     ap.add_argument('--call-shapes', default=None, metavar='FILE', help='write per-(entry, int args) launch counts and mean durations')
@@ -385,9 +385,11 @@ def main():
     fast = None
     if world == 1 and args.math == 'f32' and not args.no_fast_math_line:
         fast = {}
-        for mode, note in (('bf16x6', 'three-term split-bf16 products (6 bf16 MFMAs per product) in the 10-tile single-role edge '
-                                      'kernels: each layer meets the exact mode\'s tolerances, end to end the encoder '
-                                      'gradients are within ~1e-2 of max|grad| (tests/test_gpu_model.py); gpe_math_set(3)'),
+        for mode, note in (('f16x3', 'two-term split-fp16 products (3 fp16 MFMAs per product, fp32 accumulate) on tensor-normalised '
+                                     'operands in all four single-role edge kernels; weight-gradient reduce-GEMMs exact fp32.  '
+                                     'PARITY-GRADE: every -m gpu test runs it at the exact mode\'s bars; gpe_math_set(4)'),
+                           ('bf16x6', 'three-term split-bf16 products (6 bf16 MFMAs per product) in the 10-tile single-role edge '
+                                      'kernels; parity-grade (the exact mode\'s bars in every test); gpe_math_set(3)'),
                            ('mixed', 'split-bf16 row GEMMs (forward + input-gradient half) on the bf16 matrix pipe, exact-fp32 '
                                      'weight-gradient / BN-coefficient products: forward within 1e-4, parameter gradients '
                                      '1e-3 .. 1.5e-2 of max|grad| (approximate, tests TOL 3e-2); gpe_math_set(2) / GPE_MATH=mixed'),

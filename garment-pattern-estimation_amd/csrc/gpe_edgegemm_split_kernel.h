@@ -145,6 +145,20 @@ __device__ __forceinline__ float4 x6_scale4(const float4 v, float s) { return ma
 // keep a resident B fragment in accumulation registers (MFMA reads B from either file)
 __device__ __forceinline__ void x6_pin(x6_u32x4& v) { asm volatile("" : "+a"(v)); }
 
+// C-tile pitch in floats
+template <class SP> __host__ __device__ constexpr int x6_ldc(int NT, int KCH) { return 16 * NT + 4; }
+// 16-byte chunks per plane row of the two-plane A tile: 2 KCH of data, padded to a count = 2 (mod 4)
+__host__ __device__ constexpr int x6_pchunks(int KCH) { return ((2 * KCH) & 3) == 2 ? 2 * KCH : 2 * KCH + 2; }
+// float index, inside the consumed A buffer, of the 16 K-partials that wave `w` leaves for left-over tile `b` of row `row`.
+// fp32 tile: columns [16 (w BQ + b), +16) of the row.  Planes: the first 256 bytes of the row in plane b (BQ <= 2 = planes) —
+// either way inside memory that only the row's owner re-stages, which is why no barrier separates the two.
+template <bool PLANES, int BQ, int LDA, int PPITCH, int PLANE>
+__device__ __forceinline__ int x6_scr(int row, int w, int b)
+{
+    if constexpr (PLANES) return (b * PLANE + row * PPITCH) / 4 + 16 * w;
+    else return row * LDA + 16 * (w * BQ + b);
+}
+
 // K16: k == 16 (the benchmark configuration): every wave owns exactly ONE point per tile (see gpe_edgegemm_sr.hip).
 // KCH = K extent in 16-wide chunks (the packed-weight granularity); KS = ceil(KCH / 2) slabs of 32.
 template <class SP, int AQ, int BQ, int KCH, int AMODE, int EMODE, bool K16>
@@ -154,7 +168,16 @@ __global__ __launch_bounds__(256, 1) void gpe_edgegemm_split_kernel(RgParams p, 
     constexpr int KS = (KCH + 1) / 2;
     constexpr bool KTAIL = (KCH & 1) != 0;               // last slab holds only 16 k: lane groups g >= 2 contribute zeros
     constexpr int LSL = (KS + 3) / 4;                    // slabs of a left-over tile per wave (K-split over the 4 waves)
-    constexpr int LDA = 16 * KCH + 4, LDC = 16 * NT + 4;
+    // LDS layout.  fp32 policy: A tile fp32 [64][LDA] x 2 buffers + C [64][LDC].  PLANES (SplitF16x2): the A tile is kept as the
+    // policy's two 16-bit planes, split ONCE when a staged row is committed — h plane [64][PPITCH bytes] then l plane, x 2 buffers;
+    // a plane row is x6_pchunks(KCH) sixteen-byte chunks: a count = 2 (mod 4) keeps every 16-lane group of a ds_read_b128 that
+    // walks down a column (groups {0-3,12-15,20-27}, ... of MI355X_MICROARCH.md "LDS") on 16 distinct bank quads.
+    constexpr bool PLANES = SP::SCALED;
+    constexpr int LDA = 16 * KCH + 4;
+    constexpr int LDC = x6_ldc<SP>(NT, KCH);
+    constexpr int PPITCH = 16 * x6_pchunks(KCH);         // bytes per plane row
+    constexpr int PLANE = RG_BM * PPITCH;                // bytes per plane
+    constexpr int AWORDS = PLANES ? (2 * PLANE) / 4 : RG_BM * LDA;   // one A buffer, in floats
     constexpr int NSLOT = 4 * KS;                        // memory-pipeline slots per tile: slot q = 4*slab + mtile
     // slot 0 issues every global load; the staged rows are committed in the CM_SLOTS slots right before the epilogue (late
     // enough for the loads to have landed, and BEFORE the epilogue's conditional stores: see gpe_edgegemm_sr.hip); the last
@@ -164,17 +187,24 @@ __global__ __launch_bounds__(256, 1) void gpe_edgegemm_split_kernel(RgParams p, 
     constexpr int CM_SLOTS = 4, CMR = X6_PB / CM_SLOTS;
     constexpr int CM_START = EP_START - CM_SLOTS;
     static_assert(CM_START >= 2, "K too short for the slot schedule");
+    // The 13 x 13 backward variants of the two-plane policy stage their 16 rows in TWO batches of 8 through the same registers
+    // (batch 0: issued in slot 0, committed in slots CM_START, CM_START + 1; batch 1: issued in slot CM_START + 2, committed in
+    // the tile's last two slots): 32 staging registers instead of 64, which is what keeps them free of scratch spills.
+    constexpr int NH = (SP::SCALED && NT == 13 && KCH == 13 && EMODE != E_EDGE_FWD) ? 2 : 1;
+    constexpr int RBH = X6_PB / NH;
+    // ... and load the stored activation of epilogue row u in slot u (the row is finished in slot EP_START + u, 12 slots later)
+    // instead of all 16 in slot 0: at most 12 - 13 of them are live at a time.
+    // (gathered activations come from the cloud's L2-resident table: 8 slots of lead instead of 12, 9 rows live)
+    constexpr bool ACT_LATE = NH == 2;
+    constexpr int ACT_SHIFT = (EMODE == E_BWD_GATHER) ? 4 : 0;
+    static_assert(!ACT_LATE || (EPR == 1 && EP_START >= 8), "late activation loads assume one epilogue row per slot");
+    static_assert(NH == 1 || AMODE == A_DENSE, "the second batch would gather through the NEXT tile's neighbour rows");
     constexpr bool GATHER_ACT = (EMODE == E_BWD_GATHER);
-    // SplitF16x2, dense A rows: staged global -> LDS directly (global_load_lds_dwordx4: one 1-KiB piece per row, lane = column
-    // quad, destination = row base + 16 lane), no staging registers and no commit pass — the 64 VGPRs this frees are what lets
-    // the 13 x 13 backward variants run without scratch spills.  (Rows past the end of a partial last tile then hold a copy
-    // of the last valid row instead of zeros: every output row depends on its own A row only, and those rows are never finished.)
-    constexpr bool LDS_DIRECT = SP::SCALED && AMODE == A_DENSE;
 
     extern __shared__ __align__(16) float smem[];
     float* const Abuf0 = smem;
-    float* const Abuf1 = smem + RG_BM * LDA;
-    float* const Cs = smem + 2 * RG_BM * LDA;            // [64][LDC]
+    float* const Abuf1 = smem + AWORDS;
+    float* const Cs = smem + 2 * AWORDS;                 // [64][LDC]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -188,7 +218,7 @@ __global__ __launch_bounds__(256, 1) void gpe_edgegemm_split_kernel(RgParams p, 
     const bool k_on = c < p.K, n_on = c < p.N;
     const int ck = k_on ? c : 0, cn = n_on ? c : 0;      // clamped quads for the unconditional loads
 
-    for (int e = tid; e < 2 * RG_BM * LDA; e += 256) smem[e] = 0.f;
+    for (int e = tid; e < 2 * AWORDS; e += 256) smem[e] = 0.f;
 
     // ---- operand scales (SplitF16x2 only): powers of two from the measured largest magnitudes -------------------------------
     float sA = 1.f, sW = 1.f, invA = 1.f, invW = 1.f;
@@ -258,7 +288,7 @@ __global__ __launch_bounds__(256, 1) void gpe_edgegemm_split_kernel(RgParams p, 
     int es = 0, ept = 0;                                 // row inside the current point, point inside this wave's share
     long e_row0 = 0, e_pt0 = 0; int e_rv = 0;            // tile being finished
 
-    float4 v[LDS_DIRECT ? 1 : X6_PB];                    // rows staged for the next tile
+    float4 v[RBH];                                       // rows staged for the next tile (one batch)
     float4 pvs0, pvs1, pvs2, pvs3;                       // P rows of the points being staged (gather)
     pvs0 = pvs1 = pvs2 = pvs3 = make_float4(0.f, 0.f, 0.f, 0.f);
     float4 act[(EMODE != E_EDGE_FWD) ? X6_PB : 1];       // stored activations of the tile being finished (backward)
@@ -291,8 +321,20 @@ __global__ __launch_bounds__(256, 1) void gpe_edgegemm_split_kernel(RgParams p, 
         return p.jg[row0 + r];
     };
     int jgv_s = 0, jgv_e = 0;            // neighbour rows for the NEXT stage (A_GATHER) / the NEXT epilogue (E_BWD_GATHER)
+    int jgv_cur = 0;                     // ACT_LATE: the neighbour rows of the tile being finished (jgv_e moves on in slot 0)
 
     // ---- VMEM issue: everything this iteration will need --------------------------------------------------------------
+    // stored activation of epilogue row u of the tile being finished (e_row0 / e_rv / jgv_cur set by issue_epi_loads)
+    auto issue_act_load = [&](int u) {
+        const int last = e_rv - 1;
+        int r = rbl + ((u < rwl) ? u : rwl - 1);
+        r = (r < last) ? r : last;                                      // clamp: unconditional loads
+        if (EMODE == E_BWD_INPLACE) act[u] = ld4(p.out + (e_row0 + r) * p.ldo + cn);
+        else {
+            const int jj = __builtin_amdgcn_ds_bpermute(u << 2, jgv_cur);
+            act[u] = ld4(p.pq + (long)jj * p.ldpq + p.H + cn);
+        }
+    };
     auto issue_epi_loads = [&](int tile) {
         e_row0 = (long)tile * p.R;
         e_pt0 = (long)tile * PT + wave * npw;
@@ -305,15 +347,10 @@ __global__ __launch_bounds__(256, 1) void gpe_edgegemm_split_kernel(RgParams p, 
         // NOTE: every load below is unconditional (clamped rows, clamped column quad): a register that is loaded under a
         // branch needs a copy at the join, and that copy waits for the load right there — no pipelining left
         const int last = e_rv - 1;
+        jgv_cur = jgv_e;
+        if (!ACT_LATE) {
 #pragma unroll
-        for (int u = 0; u < X6_PB; ++u) {
-            int r = rbl + ((u < rwl) ? u : rwl - 1);
-            r = (r < last) ? r : last;                                  // clamp: unconditional loads
-            if (EMODE == E_BWD_INPLACE) act[u] = ld4(p.out + (e_row0 + r) * p.ldo + cn);
-            else {
-                const int jj = __builtin_amdgcn_ds_bpermute(u << 2, jgv_e);
-                act[u] = ld4(p.pq + (long)jj * p.ldpq + p.H + cn);
-            }
+            for (int u = 0; u < X6_PB; ++u) issue_act_load(u);
         }
         if (GATHER_ACT) {
             const int pt0 = tile * PT + wave * npw + vz, ptl = tile * PT + ((last * rkl) >> 16);
@@ -323,33 +360,21 @@ __global__ __launch_bounds__(256, 1) void gpe_edgegemm_split_kernel(RgParams p, 
             pve3 = ld4(p.pq + (long)((pt0 + 3 < ptl) ? pt0 + 3 : ptl) * p.ldpq + cn);
         }
     };
-    auto issue_stage_loads = [&](int tile, float* An) {
+    auto issue_stage_loads = [&](int tile, int h) {
         const long row0 = (long)tile * p.R;
         s_rv = (int)((p.M - row0 < p.R) ? (p.M - row0) : p.R);
         const int last = s_rv - 1;
-        if constexpr (LDS_DIRECT) {
 #pragma unroll
-            for (int u = 0; u < X6_PB; ++u) {
-                if (!K16 && u >= rwl) break;
-                int r = rbl + u;
-                r = (r < last) ? r : last;
-                const float* src = p.a.base + (row0 + r) * p.a.stride_outer + c;
-                float* dst = An + (rbl + u) * LDA;                     // wave-uniform; lane L lands at dst + 4 L floats
-                if (k_on)
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                                     (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-            }
-        } else {
-#pragma unroll
-        for (int u = 0; u < X6_PB; ++u) {
+        for (int uu = 0; uu < RBH; ++uu) {
+            const int u = h * RBH + uu;
             int r = rbl + ((u < rwl) ? u : rwl - 1);
             r = (r < last) ? r : last;
             if (AMODE == A_GATHER) {
                 const int jj = __builtin_amdgcn_ds_bpermute(u << 2, jgv_s);
-                v[u] = ld4(p.pq + (long)jj * p.ldpq + p.H + ck);
+                v[uu] = ld4(p.pq + (long)jj * p.ldpq + p.H + ck);
             } else {
                 // rows are 16-B aligned and padded to a multiple of 4 columns (checked by the dispatcher)
-                v[u] = ld4(p.a.base + (row0 + r) * p.a.stride_outer + ck);
+                v[uu] = ld4(p.a.base + (row0 + r) * p.a.stride_outer + ck);
             }
         }
         if (AMODE == A_GATHER) {
@@ -359,21 +384,28 @@ __global__ __launch_bounds__(256, 1) void gpe_edgegemm_split_kernel(RgParams p, 
             pvs2 = ld4(p.pq + (long)((pt0 + 2 < ptl) ? pt0 + 2 : ptl) * p.ldpq + ck);
             pvs3 = ld4(p.pq + (long)((pt0 + 3 < ptl) ? pt0 + 3 : ptl) * p.ldpq + ck);
         }
-        }
     };
     // ---- LDS commit of staged row u (compile-time u) ------------------------------------------------------------------
     auto commit_row = [&](float* An, int u) {
-        if (LDS_DIRECT) return;
         if ((!K16 && u >= rwl) || !k_on) return;
         const int r = rbl + u;
-        float4 o = v[LDS_DIRECT ? 0 : u];
+        float4 o = v[u % RBH];
         if (AMODE == A_GATHER) {
             const float4 pv = K16 ? pvs0 : x6_sel4(pvs0, pvs1, pvs2, pvs3, (u * rkl) >> 16);
             o.x = fmaxf(o.x + pv.x, 0.f); o.y = fmaxf(o.y + pv.y, 0.f);
             o.z = fmaxf(o.z + pv.z, 0.f); o.w = fmaxf(o.w + pv.w, 0.f);
         }
         if (r >= s_rv) o = make_float4(0.f, 0.f, 0.f, 0.f);      // rows past the end of a partial last tile
-        st4(&An[r * LDA + c], o);
+        if constexpr (PLANES) {
+            // the row's quad, normalised and split once: 4 values -> 8 bytes in each plane
+            unsigned q0[SP::P], q1[SP::P];
+            SP::split2(o.x * sA, o.y * sA, q0);
+            SP::split2(o.z * sA, o.w * sA, q1);
+            char* row = reinterpret_cast<char*>(An) + r * PPITCH + 2 * c;
+            *reinterpret_cast<uint2*>(row) = make_uint2(q0[0], q1[0]);
+            *reinterpret_cast<uint2*>(row + PLANE) = make_uint2(q0[1], q1[1]);
+        } else
+            st4(&An[r * LDA + c], o);
     };
     // ---- epilogue of row u (compile-time u) of the tile being finished ------------------------------------------------
     auto epi_row = [&](int u, const float4 zraw) {
@@ -469,9 +501,12 @@ __global__ __launch_bounds__(256, 1) void gpe_edgegemm_split_kernel(RgParams p, 
         if (GATHER_ACT) jgv_e = load_jgv(tile);
     }
     if (tile < p.num_tiles && !(p.dbg & 1)) {
-        issue_stage_loads(tile, Abuf0);
 #pragma unroll
-        for (int u = 0; u < X6_PB; ++u) commit_row(Abuf0, u);
+        for (int h = 0; h < NH; ++h) {
+            issue_stage_loads(tile, h);
+#pragma unroll
+            for (int uu = 0; uu < RBH; ++uu) commit_row(Abuf0, h * RBH + uu);
+        }
     }
     if (AMODE == A_GATHER && tile < p.num_tiles) jgv_s = load_jgv(next < p.num_tiles ? next : tile);
     __syncthreads();
@@ -493,14 +528,25 @@ __global__ __launch_bounds__(256, 1) void gpe_edgegemm_split_kernel(RgParams p, 
             for (int b = 0; b < (BQ > 0 ? BQ : 1); ++b) accL[b][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
 
-        // raw fp32 A fragment of slot (sl, mt): 8 consecutive k of row 16 mt + j.  In the 16-wide tail slab the lane groups
-        // g >= 2 lie past the row: they read a valid address and contribute zeros (their weights are zero as well).
+        // A fragment of slot (sl, mt): 8 consecutive k of row 16 mt + j.  fp32 tile: read raw, split right before use; PLANES: the
+        // fragment's planes are read as they are.  In the 16-wide tail slab the lane groups g >= 2 lie past the row: they read a
+        // valid address and contribute zeros (their weights are zero as well).
         float4 raw0, raw1;
+        X6Frag<SP> nf;
         auto read_raw = [&](int sl, int mt) {
             const bool dead = KTAIL && sl == KS - 1 && g >= 2;
-            const float* src = &As[(16 * mt + j) * LDA + 32 * sl + 8 * (dead ? (g & 1) : g)];
-            raw0 = ld4(src); raw1 = ld4(src + 4);
-            if (dead) { raw0 = make_float4(0.f, 0.f, 0.f, 0.f); raw1 = raw0; }
+            if constexpr (PLANES) {
+                const char* src = reinterpret_cast<const char*>(As) + (16 * mt + j) * PPITCH + 16 * (4 * sl + (dead ? (g & 1) : g));
+#pragma unroll
+                for (int t = 0; t < SP::P; ++t) {
+                    nf.pl[t] = *reinterpret_cast<const x6_u32x4*>(src + t * PLANE);
+                    if (dead) nf.pl[t] = (x6_u32x4){0u, 0u, 0u, 0u};
+                }
+            } else {
+                const float* src = &As[(16 * mt + j) * LDA + 32 * sl + 8 * (dead ? (g & 1) : g)];
+                raw0 = ld4(src); raw1 = ld4(src + 4);
+                if (dead) { raw0 = make_float4(0.f, 0.f, 0.f, 0.f); raw1 = raw0; }
+            }
         };
         float4 zq[EPR];
 #pragma unroll
@@ -512,23 +558,35 @@ __global__ __launch_bounds__(256, 1) void gpe_edgegemm_split_kernel(RgParams p, 
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt) {
                 const int q = 4 * sl + mt;
-                const X6Frag<SP> af = SP::SCALED ? x6_split8<SP>(x6_scale4(raw0, sA), x6_scale4(raw1, sA)) : x6_split8<SP>(raw0, raw1);
+                X6Frag<SP> af;
+                if constexpr (PLANES) af = nf; else af = x6_split8<SP>(raw0, raw1);
                 if (q + 1 < NSLOT) read_raw((q + 1) >> 2, (q + 1) & 3);
                 // ---- this slot's slice of the memory pipeline ----
                 if (q == 0) {
                     issue_epi_loads(prev >= 0 ? prev : tile);            // clamped: results unused when !do_epi
-                    if (!LDS_DIRECT) issue_stage_loads(next < p.num_tiles ? next : tile, An); // clamped: results unused when !do_stage
-                    else if (do_stage) issue_stage_loads(next, An);      // direct-to-LDS pieces are side effects: only when real
+                    issue_stage_loads(next < p.num_tiles ? next : tile, 0);  // clamped: results unused when !do_stage
                     if (GATHER_ACT) jgv_e = load_jgv(tile);              // this tile is finished in the next iteration
                     if (AMODE == A_GATHER) jgv_s = load_jgv(next2 < p.num_tiles ? next2 : tile);
                 }
-                if (q >= CM_START && q < EP_START) {
+                if (ACT_LATE && EMODE != E_EDGE_FWD && q >= ACT_SHIFT && q < X6_PB + ACT_SHIFT) issue_act_load(q - ACT_SHIFT);
+                if (NH == 1 && q >= CM_START && q < EP_START) {
                     if (do_stage) {
 #pragma unroll
                         for (int c4 = 0; c4 < CMR; ++c4) {
                             const int u = (q - CM_START) * CMR + c4;
                             if (u < X6_PB) commit_row(An, u);
                         }
+                    }
+                }
+                if (NH == 2) {
+                    if ((q == CM_START || q == CM_START + 1) && do_stage) {
+#pragma unroll
+                        for (int c4 = 0; c4 < RBH / 2; ++c4) commit_row(An, (q - CM_START) * (RBH / 2) + c4);
+                    }
+                    if (q == CM_START + 2) issue_stage_loads(next < p.num_tiles ? next : tile, 1);
+                    if (q >= NSLOT - 2 && do_stage) {
+#pragma unroll
+                        for (int c4 = 0; c4 < RBH / 2; ++c4) commit_row(An, RBH + (q - (NSLOT - 2)) * (RBH / 2) + c4);
                     }
                 }
                 if (q >= EP_START) {
@@ -582,18 +640,19 @@ __global__ __launch_bounds__(256, 1) void gpe_edgegemm_split_kernel(RgParams p, 
                 for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        Sc[(16 * mt + 4 * g + r) * LDA + 16 * (wave * BQ + b) + j] = accL[b][mt][r];
+                        Sc[x6_scr<PLANES, BQ, LDA, PPITCH, PLANE>(16 * mt + 4 * g + r, wave, b) + j] = accL[b][mt][r];
         }
         __syncthreads();                                 // (2) C complete, partials complete, next A tile complete
         if (BQ > 0) {
             // rows rb .. rb + rows_w - 1 are mine: I finish them, and I am the only wave that re-stages them in this buffer
             const int ur = lane >> 2, cq = (lane & 3) << 2;
             if (ur < rwl) {
-                const float* Sr = &As[(rbl + ur) * LDA + cq];
 #pragma unroll
                 for (int b = 0; b < BQ; ++b) {
-                    const float4 p0 = ld4(Sr + 16 * (0 * BQ + b)), p1 = ld4(Sr + 16 * (1 * BQ + b));
-                    const float4 p2 = ld4(Sr + 16 * (2 * BQ + b)), p3 = ld4(Sr + 16 * (3 * BQ + b));
+                    const float4 p0 = ld4(&As[x6_scr<PLANES, BQ, LDA, PPITCH, PLANE>(rbl + ur, 0, b) + cq]);
+                    const float4 p1 = ld4(&As[x6_scr<PLANES, BQ, LDA, PPITCH, PLANE>(rbl + ur, 1, b) + cq]);
+                    const float4 p2 = ld4(&As[x6_scr<PLANES, BQ, LDA, PPITCH, PLANE>(rbl + ur, 2, b) + cq]);
+                    const float4 p3 = ld4(&As[x6_scr<PLANES, BQ, LDA, PPITCH, PLANE>(rbl + ur, 3, b) + cq]);
                     float4 o;
                     o.x = (p0.x + p1.x) + (p2.x + p3.x); o.y = (p0.y + p1.y) + (p2.y + p3.y);
                     o.z = (p0.z + p1.z) + (p2.z + p3.z); o.w = (p0.w + p1.w) + (p2.w + p3.w);
@@ -607,6 +666,10 @@ __global__ __launch_bounds__(256, 1) void gpe_edgegemm_split_kernel(RgParams p, 
     // ---- tail: epilogue of the last tile -------------------------------------------------------------------------------
     if (prev >= 0 && !(p.dbg & 2)) {
         issue_epi_loads(prev);
+        if (ACT_LATE) {
+#pragma unroll
+            for (int u = 0; u < X6_PB; ++u) issue_act_load(u);
+        }
 #pragma unroll
         for (int u = 0; u < X6_PB; ++u) {
             const int rr = rbl + u;
@@ -650,8 +713,9 @@ template <class SP, int AQ, int BQ, int KCH, int AMODE, int EMODE, bool K16>
 static int x6_launch_k(const RgParams& p, int stats_nblk, hipStream_t s)
 {
     constexpr int NT = 4 * AQ + BQ;
-    constexpr int LDA = 16 * KCH + 4, LDC = 16 * NT + 4;
-    const size_t lds = (size_t)RG_BM * (2 * LDA + LDC) * sizeof(float);
+    constexpr int LDA = 16 * KCH + 4, LDC = x6_ldc<SP>(NT, KCH);
+    constexpr int AWORDS = SP::SCALED ? (2 * RG_BM * 16 * x6_pchunks(KCH)) / 4 : RG_BM * LDA;
+    const size_t lds = (size_t)(2 * AWORDS + RG_BM * LDC) * sizeof(float);
     GPE_ENSURE_MAX_LDS((gpe_edgegemm_split_kernel<SP, AQ, BQ, KCH, AMODE, EMODE, K16>));
     int gx = gpe_num_cus();
     if (gx > p.num_tiles) gx = p.num_tiles;

@@ -45,10 +45,18 @@ def b2a(): L.call('gpe_edge_mlp_bwd', a3, 152, 0, None, 0, None, B, N, k, Fo, H,
 def rg(): L.call('gpe_edge_redgemm', a2, H, 0, None, 0, PQ, 2 * H, jg, shift, B, N, k, H, H, G, H, cs, ws)
 def rd(): L.call('gpe_edge_redgemm', a3, 152, 1, a2, H, None, 0, None, shift, B, N, k, Fo, H, G[:Fo], H, cs, ws)
 
+MODE = sys.argv[1] if len(sys.argv) > 1 else 'f32'
+gpe_amd.set_math(MODE)
+BASE = 128 if MODE == 'f16x3' else 0          # f16x3: measure the GEMM kernel alone (scales of the first launch reused)
+if BASE:
+    for fn in (f2, f3, b2a):
+        fn()
 flops = {'f2': 2.0 * E * H * H, 'f3': 2.0 * E * H * Fo, 'b2a': 2.0 * E * H * Fo, 'rg': 2.0 * E * H * H, 'rd': 2.0 * E * H * Fo}
 for flags, label in [(0, 'production'), (1, 'no staging'), (2, 'no epilogue'), (3, 'no staging, no epilogue'),
                      (7, 'MFMA only + barriers'), (15, 'MFMA only, no barriers'), (32, 'no producer MFMAs'), (16, 'producers only (no consumer MFMA)')]:
-    L.query('gpe_debug_set', flags)
+    if BASE and flags > 3:
+        continue
+    L.query('gpe_debug_set', flags | BASE)
     out = []
     for name, fn in [('f2', f2), ('f3', f3), ('b2a', b2a)]:
         ms = timeit(fn)
