@@ -32,6 +32,13 @@
 #include <math.h>
 
 #define X6_PB 16          // rows a wave stages / finishes per tile
+// scheduling fences around a slot's memory slice: always for the fp32-tile policy.  The two-plane policy runs faster WITHOUT
+// them (its slots hold 6 - 12 short MFMAs: letting the scheduler weave the slice into them, under max-ilp, measured 13.78 ->
+// 13.46 ms per step in one session, scripts/ab_bench.sh); the knob stays for A/B builds.
+#ifndef X6_PLANES_FENCE
+#define X6_PLANES_FENCE 0
+#endif
+#define X6_FENCE(planes) (!(planes) || X6_PLANES_FENCE)
 #define X6_NPW 4          // max points per wave per tile (gather / aggregation paths)
 #define GPE_ENOTSUP_SHAPE 12345
 
@@ -606,7 +613,7 @@ __global__ __launch_bounds__(256, 1) void gpe_edgegemm_split_kernel(RgParams p, 
                         zq[e2] = ld4(&Cs[((rr < RG_BM) ? rr : RG_BM - 1) * LDC + cn]);
                     }
                 }
-                __builtin_amdgcn_sched_barrier(0);           // memory slice stays in front of this slot's MFMAs
+                if (X6_FENCE(PLANES)) __builtin_amdgcn_sched_barrier(0);   // memory slice stays in front of this slot's MFMAs
                 // ---- SP::NPROD plane products per (tile, slab): small terms first; tiles innermost = independent accumulators ----
 #pragma unroll
                 for (int t = 0; t < SP::NPROD; ++t)
@@ -618,7 +625,7 @@ __global__ __launch_bounds__(256, 1) void gpe_edgegemm_split_kernel(RgParams p, 
 #pragma unroll
                         for (int b = 0; b < BQ; ++b) accL[b][mt] = SP::mfma(af.pl[SP::pa(t)], lP[SP::pw(t)][b][sl >> 2], accL[b][mt]);
                 }
-                __builtin_amdgcn_sched_barrier(0);
+                if (X6_FENCE(PLANES)) __builtin_amdgcn_sched_barrier(0);
             }
         }
         if (do_epi) epi_flush_stats();
