@@ -84,6 +84,24 @@ void gpe_h3_note_drop();
 // ([rows][cols], pitch ld) into, and records the note; NULL in every other mode
 unsigned* gpe_h3_note_begin(const void* ptr, long rows, int cols, long ld, hipStream_t s);
 #define GPE_WRITES_TENSORS() gpe_h3_note_drop()
+// the pending note's slot when it describes exactly this tensor, else NULL (the note stays: the edge GEMM after the
+// weight-gradient reduce-GEMM still consumes it)
+const unsigned* gpe_h3_note_peek(const void* ptr, long rows, int cols, long ld);
+// largest magnitude of a FORWARD activation an f16x3 edge kernel wrote (kept until a library call overwrites the tensor or
+// its slot is recycled), else NULL — the dense V operand of the weight-gradient reduce-GEMM
+const unsigned* gpe_h3_fwd_lookup(const void* ptr, long rows, int cols, long ld);
+// bound of relu(P_i + Q_j) over a [rows][>= 2H] table: launches the passes on `s`, returns the device slot (NULL: no scratch)
+const unsigned* gpe_h3_pq_bound(const float* pq, long rows, int H, long ld, hipStream_t s);
+// power of two that brings a tensor whose largest magnitude has the bit pattern `amax` into [2^14, 2^15), and its inverse.
+// The exponent is clamped to +-100 (tensors below 2^-86 lose relative precision gracefully), zero / non-finite -> 1.
+__device__ __forceinline__ void gpe_h3_scale_of(unsigned amax, float& s, float& inv)
+{
+    const int e = (int)((amax >> 23) & 0xff);
+    int sh = (amax == 0u || e == 255) ? 0 : 141 - e;                              // 14 - (e - 127)
+    sh = sh > 100 ? 100 : (sh < -100 ? -100 : sh);
+    s = __uint_as_float((unsigned)(127 + sh) << 23);
+    inv = __uint_as_float((unsigned)(127 - sh) << 23);
+}
 
 // ---- cloud -> XCD pinning ---------------------------------------------------------------------------------------------
 // Workgroup b is dispatched to XCD b % 8 (observed placement; a wrong guess costs speed, never correctness), and every

@@ -13,7 +13,8 @@
 // Slot ring in scratch image 3: [0] A operand, [1] weight, [2..] notes.
 #include "gpe_edgegemm_split_kernel.h"
 
-#define H3_RING 16
+#define H3_RING 64
+#define H3_KEEP 8
 
 // largest |x| over rows x cols (row pitch ld), as the bit pattern of a non-negative float (orders like the float; NaN > inf)
 __global__ __launch_bounds__(256) void gpe_h3_absmax_kernel(const float* __restrict__ x, long rows, int cols4, long ld,
@@ -109,19 +110,45 @@ static H3Note g_note = {nullptr, 0, 0, 0, -1, -1};
 static int g_ring_next = 0;
 
 void gpe_h3_note_drop() { g_note.ptr = nullptr; }
+const unsigned* gpe_h3_note_peek(const void* ptr, long rows, int cols, long ld);
+
+// forward activations written by an f16x3 edge kernel, kept beyond the next edge GEMM for the weight-gradient reduce-GEMM of
+// the backward pass (its dense V operand).  An entry dies when a library call overwrites the tensor (edge GEMM output, dz3 in
+// place), when its ring slot is about to be recycled (seq distance), or with the mode.
+struct H3Keep { const void* ptr; long rows; long ld; int cols; int slot; int dev; unsigned long seq; };
+static H3Keep g_keep[H3_KEEP] = {};
+static unsigned long g_seq = 0;                      // ring slots handed out so far
+static int g_keep_next = 0;
+static void h3_keep_kill(const void* ptr)
+{
+    for (int i = 0; i < H3_KEEP; ++i) if (g_keep[i].ptr == ptr) g_keep[i].ptr = nullptr;
+}
+static void h3_keep_add(const H3Keep& k)
+{
+    h3_keep_kill(k.ptr);
+    g_keep[g_keep_next] = k;
+    g_keep_next = (g_keep_next + 1) % H3_KEEP;
+}
 static unsigned* h3_slots() { return static_cast<unsigned*>(gpe_scratch(3, (2 + H3_RING + 2) * sizeof(unsigned))); }
 // for producers outside this file (gpe_edge_dz3): a cleared ring slot to atomicMax into + the note that goes with it.
 // Returns NULL when the f16x3 mode is off (the caller then skips the tracking).
 static int g_h3_on = 0;
-void gpe_h3_enable(int on) { g_h3_on = on; if (!on) gpe_h3_note_drop(); }
+void gpe_h3_enable(int on)
+{
+    g_h3_on = on;
+    gpe_h3_note_drop();
+    for (int i = 0; i < H3_KEEP; ++i) g_keep[i].ptr = nullptr;
+}
 unsigned* gpe_h3_note_begin(const void* ptr, long rows, int cols, long ld, hipStream_t s)
 {
     gpe_h3_note_drop();
     if (!g_h3_on) return nullptr;
+    h3_keep_kill(ptr);
     unsigned* slots = h3_slots();
     if (!slots) return nullptr;
     const int slot = g_ring_next;
     g_ring_next = (g_ring_next + 1) % H3_RING;
+    ++g_seq;
     if (hipMemsetAsync(slots + 2 + slot, 0, sizeof(unsigned), s) != hipSuccess) return nullptr;
     int dev = -1;
     (void)hipGetDevice(&dev);
@@ -146,6 +173,7 @@ int gpe_edgegemm_h3_try(const RgParams& p_in, int amode, int emode, int stats_nb
     // whatever happens next, the tensor a pending note describes may be overwritten by this call
     const H3Note note = g_note;
     gpe_h3_note_drop();
+    h3_keep_kill(p_in.out);
     RgParams p;
     if (!x6_prepare(p_in, amode, emode, stats_nblk, p)) return 0;
     const int NT = (p.N <= 160) ? 10 : 13;
@@ -158,7 +186,7 @@ int gpe_edgegemm_h3_try(const RgParams& p_in, int amode, int emode, int stats_nb
     // does this launch write a tensor the next edge GEMM reads as its A operand?  forward activations, in-place dz
     const bool notes = emode == E_EDGE_FWD || emode == E_BWD_INPLACE;
     int out_slot = -1;
-    if (notes) { out_slot = g_ring_next; g_ring_next = (g_ring_next + 1) % H3_RING; }
+    if (notes) { out_slot = g_ring_next; g_ring_next = (g_ring_next + 1) % H3_RING; ++g_seq; }
     // a note is usable when it describes exactly this A operand (and its ring slot is not the one being recycled)
     const bool have_note = amode == A_DENSE && note.ptr == (const void*)p.a.base && note.rows == p.M && note.ld == p.a.stride_outer &&
                            note.cols == p.K && note.dev == dev && note.slot >= 0 && note.slot != out_slot;
@@ -206,5 +234,48 @@ int gpe_edgegemm_h3_try(const RgParams& p_in, int amode, int emode, int stats_nb
     if (rc == GPE_ENOTSUP_SHAPE) return 0;
     if (rc != GPE_OK) return rc;
     if (notes) g_note = {p.out, p.M, (long)p.ldo, p.N, out_slot, dev};
+    if (emode == E_EDGE_FWD) h3_keep_add(H3Keep{p.out, p.M, (long)p.ldo, p.N, out_slot, dev, g_seq});
     return 1;
+}
+
+const unsigned* gpe_h3_note_peek(const void* ptr, long rows, int cols, long ld)
+{
+    int dev = -1;
+    (void)hipGetDevice(&dev);
+    if (!g_h3_on || !g_note.ptr || g_note.ptr != ptr || g_note.rows != rows || g_note.cols != cols || g_note.ld != ld ||
+        g_note.dev != dev || g_note.slot < 0)
+        return nullptr;
+    unsigned* slots = h3_slots();
+    return slots ? slots + 2 + g_note.slot : nullptr;
+}
+
+const unsigned* gpe_h3_fwd_lookup(const void* ptr, long rows, int cols, long ld)
+{
+    if (!g_h3_on) return nullptr;
+    int dev = -1;
+    (void)hipGetDevice(&dev);
+    for (int i = 0; i < H3_KEEP; ++i) {
+        const H3Keep& k = g_keep[i];
+        // the slot must not have been handed out again since (H3_RING - 1 newer notes at most)
+        if (k.ptr == ptr && k.rows == rows && k.cols == cols && k.ld == ld && k.dev == dev && g_seq - k.seq < H3_RING - 1) {
+            unsigned* slots = h3_slots();
+            return slots ? slots + 2 + k.slot : nullptr;
+        }
+    }
+    return nullptr;
+}
+
+const unsigned* gpe_h3_pq_bound(const float* pq, long rows, int H, long ld, hipStream_t s)
+{
+    unsigned* slots = h3_slots();
+    if (!slots || (H & 3)) return nullptr;
+    // resets the ordered-int maxima (and slots[0], slots[1]) in stream order, then the two passes
+    hipLaunchKernelGGL(gpe_h3_wmax_kernel, dim3(1), dim3(1024), 0, s, (const float*)nullptr, 0L, slots, -1);
+    int gx = (int)((rows + 3) / 4);
+    const int cap = gpe_num_cus() * 8;
+    if (gx > cap) gx = cap;
+    hipLaunchKernelGGL(gpe_h3_pqmax_kernel, dim3(gx), dim3(256), 0, s, pq, rows, H, ld, reinterpret_cast<int*>(slots) + H3_RING + 2);
+    hipLaunchKernelGGL(gpe_h3_pqfinish_kernel, dim3(1), dim3(1), 0, s, slots);
+    if (hipGetLastError() != hipSuccess) return nullptr;
+    return slots;
 }

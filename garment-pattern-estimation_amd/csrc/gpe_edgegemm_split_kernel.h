@@ -120,16 +120,7 @@ struct SplitF16x2 {
     {
         return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(x6_f16x8, a), __builtin_bit_cast(x6_f16x8, b), c, 0, 0, 0);
     }
-    // power of two that brings a tensor whose largest magnitude has the bit pattern `amax` into [2^14, 2^15), and its inverse.
-    // The exponent is clamped to +-100 (tensors below 2^-86 lose relative precision gracefully), zero / non-finite -> 1.
-    __device__ static __forceinline__ void scale_of(unsigned amax, float& s, float& inv)
-    {
-        int e = (int)((amax >> 23) & 0xff);
-        int sh = (amax == 0u || e == 255) ? 0 : 141 - e;                          // 14 - (e - 127)
-        sh = sh > 100 ? 100 : (sh < -100 ? -100 : sh);
-        s = __uint_as_float((unsigned)(127 + sh) << 23);
-        inv = __uint_as_float((unsigned)(127 - sh) << 23);
-    }
+    __device__ static __forceinline__ void scale_of(unsigned amax, float& s, float& inv) { gpe_h3_scale_of(amax, s, inv); }
 };
 
 // P-plane split of 8 consecutive k-values of a lane's MFMA operand: f[0..7] -> planes (8 16-bit values each, k order kept)

@@ -18,7 +18,7 @@
 #include "gpe_common.h"
 #include <stdlib.h>
 
-static int g_rd_math = 0;            // 0: exact fp32 MFMA, 1: bf16x3 (gpe_math_set)
+static int g_rd_math = 0;            // 0: exact fp32 MFMA, 1: bf16x3, 2: f16x3 where the operand scales are known (gpe_math_set)
 void gpe_redgemm_set_math(int m) { g_rd_math = m; }
 
 #define RD_RT 32
@@ -40,6 +40,9 @@ struct RdParams {
     int pin_tpc;                                 // gather variants of the pc/b3 kernels: tiles per cloud when pinned (gpe_common.h)
     float* part;                                 // [gridDim.x][MgPad][NgPad]
     double* part_cs;                             // [gridDim.x][MgPad]
+    // f16x3 variant of the b3 kernel: bit patterns of the largest magnitudes of U and of V - shift (device memory)
+    const unsigned* amax_u;
+    const unsigned* amax_v;
 };
 
 __device__ __forceinline__ float4 rd_ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
@@ -553,6 +556,30 @@ __device__ __forceinline__ f32x4 rd_mfma32(const uint4 a, const uint4 b, const f
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(rd_bf16x8_t, a), __builtin_bit_cast(rd_bf16x8_t, b),
                                                    c, 0, 0, 0);
 }
+// f16x3 (gpe_math_set(4)): the same kernel with two-term fp16 splits of operands normalised per tensor by a power of two
+// (gpe_edgegemm_split_kernel.h has the arithmetic; the scales come from the notes / bounds of gpe_edgegemm_h3.hip)
+typedef _Float16 rd_f16x2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 rd_f16x8_t __attribute__((ext_vector_type(8)));
+template <bool F16>
+__device__ __forceinline__ void rd_split_pair_p(float x0, float x1, unsigned& hw, unsigned& lw)
+{
+    if constexpr (F16) {
+        const rd_f32x2_t x = {x0, x1};
+        const rd_f16x2_t h = __builtin_convertvector(x, rd_f16x2_t);
+        const rd_f32x2_t r = x - __builtin_convertvector(h, rd_f32x2_t);
+        hw = __builtin_bit_cast(unsigned, h);
+        lw = __builtin_bit_cast(unsigned, __builtin_convertvector(r, rd_f16x2_t));
+    } else
+        rd_split_pair(x0, x1, hw, lw);
+}
+template <bool F16>
+__device__ __forceinline__ f32x4 rd_mfma32_p(const uint4 a, const uint4 b, const f32x4 c)
+{
+    if constexpr (F16)
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(rd_f16x8_t, a), __builtin_bit_cast(rd_f16x8_t, b), c, 0, 0, 0);
+    else
+        return rd_mfma32(a, b, c);
+}
 __device__ __forceinline__ float rd_comp(const float4& v, int t) { return t == 0 ? v.x : t == 1 ? v.y : t == 2 ? v.z : v.w; }
 
 template <int CT> struct RdB3Layout {                 // CT = number of 16-column tiles of the operand
@@ -565,9 +592,21 @@ template <int CT> struct RdB3Layout {                 // CT = number of 16-colum
     }
 };
 
-template <int MT, int NT, int VMODE>
+template <int MT, int NT, int VMODE, bool F16 = false>
 __global__ __launch_bounds__(512, 2) void gpe_redgemm_b3_kernel(RdParams p)
 {
+    float sU = 1.f, sV = 1.f, invU = 1.f, invV = 1.f;
+    if constexpr (F16) {
+        gpe_h3_scale_of(p.amax_u[0], sU, invU);
+        // V enters as V - shift: |V - shift| <= max|V| + max|shift| (uniform loop over <= 208 values, once per workgroup)
+        float bound = __uint_as_float(p.amax_v[0]);
+        if (p.v_shift) {
+            float smx = 0.f;
+            for (int c = 0; c < p.Ng; ++c) smx = fmaxf(smx, fabsf(p.v_shift[c]));
+            bound += smx;
+        }
+        gpe_h3_scale_of(__float_as_uint(bound), sV, invV);
+    }
     static_assert(RD_RT == 32, "one v_mfma_f32_16x16x32_bf16 reduces exactly one row tile");
     constexpr int MB = MT / 2, NB = NT / 2;
     constexpr int LEFT = (MT & 1) * NT + (NT & 1) * (MT - (MT & 1));     // left-over tiles
@@ -611,11 +650,11 @@ __global__ __launch_bounds__(512, 2) void gpe_redgemm_b3_kernel(RdParams p)
                 const uint4 ah = *reinterpret_cast<const uint4*>(ub + LU::slot(0, g, 16 * (mt0 + q) + j));
                 const uint4 al = *reinterpret_cast<const uint4*>(ub + LU::slot(1, g, 16 * (mt0 + q) + j));
 #pragma unroll
-                for (int n = 0; n < NB; ++n) acc[q][n] = rd_mfma32(al, bh[n], acc[q][n]);
+                for (int n = 0; n < NB; ++n) acc[q][n] = rd_mfma32_p<F16>(al, bh[n], acc[q][n]);
 #pragma unroll
-                for (int n = 0; n < NB; ++n) acc[q][n] = rd_mfma32(ah, bl[n], acc[q][n]);
+                for (int n = 0; n < NB; ++n) acc[q][n] = rd_mfma32_p<F16>(ah, bl[n], acc[q][n]);
 #pragma unroll
-                for (int n = 0; n < NB; ++n) acc[q][n] = rd_mfma32(ah, bh[n], acc[q][n]);
+                for (int n = 0; n < NB; ++n) acc[q][n] = rd_mfma32_p<F16>(ah, bh[n], acc[q][n]);
             }
             __syncthreads();
             buf ^= 1;
@@ -626,7 +665,7 @@ __global__ __launch_bounds__(512, 2) void gpe_redgemm_b3_kernel(RdParams p)
             for (int n = 0; n < NB; ++n)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    dst[(size_t)(16 * (mt0 + q) + 4 * g + r) * p.NgPad + 16 * (nt0 + n) + j] = acc[q][n][r];
+                    dst[(size_t)(16 * (mt0 + q) + 4 * g + r) * p.NgPad + 16 * (nt0 + n) + j] = acc[q][n][r] * invU * invV;
         __syncthreads();                           // tail: producers' column sums in LDS
     } else {
         // ================================ producers ================================
@@ -703,7 +742,8 @@ __global__ __launch_bounds__(512, 2) void gpe_redgemm_b3_kernel(RdParams p)
                 for (int t = 0; t < 4; ++t) {
                     unsigned hw[4], lw[4];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) rd_split_pair(rd_comp(ur[2 * e], t), rd_comp(ur[2 * e + 1], t), hw[e], lw[e]);
+                    for (int e = 0; e < 4; ++e)
+                        rd_split_pair_p<F16>(rd_comp(ur[2 * e], t) * sU, rd_comp(ur[2 * e + 1], t) * sU, hw[e], lw[e]);
                     *reinterpret_cast<uint4*>(ub + LU::slot(0, w4, cq + t)) = make_uint4(hw[0], hw[1], hw[2], hw[3]);
                     *reinterpret_cast<uint4*>(ub + LU::slot(1, w4, cq + t)) = make_uint4(lw[0], lw[1], lw[2], lw[3]);
                 }
@@ -729,7 +769,8 @@ __global__ __launch_bounds__(512, 2) void gpe_redgemm_b3_kernel(RdParams p)
                 for (int t = 0; t < 4; ++t) {
                     unsigned hw[4], lw[4];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) rd_split_pair(rd_comp(vr[2 * e], t), rd_comp(vr[2 * e + 1], t), hw[e], lw[e]);
+                    for (int e = 0; e < 4; ++e)
+                        rd_split_pair_p<F16>(rd_comp(vr[2 * e], t) * sV, rd_comp(vr[2 * e + 1], t) * sV, hw[e], lw[e]);
                     *reinterpret_cast<uint4*>(vb + LV::slot(0, w4, cq + t)) = make_uint4(hw[0], hw[1], hw[2], hw[3]);
                     *reinterpret_cast<uint4*>(vb + LV::slot(1, w4, cq + t)) = make_uint4(lw[0], lw[1], lw[2], lw[3]);
                 }
@@ -762,9 +803,9 @@ __global__ __launch_bounds__(512, 2) void gpe_redgemm_b3_kernel(RdParams p)
                         const uint4 al = *reinterpret_cast<const uint4*>(ub + LU::slot(1, g, offU[s_] + j));
                         const uint4 bh = *reinterpret_cast<const uint4*>(vb + LV::slot(0, g, offV[s_] + j));
                         const uint4 bl = *reinterpret_cast<const uint4*>(vb + LV::slot(1, g, offV[s_] + j));
-                        f32x4 a3 = rd_mfma32(al, bh, accP[s_]);   // same shape back to back: accumulator forwarding is fine
-                        a3 = rd_mfma32(ah, bl, a3);
-                        accP[s_] = rd_mfma32(ah, bh, a3);
+                        f32x4 a3 = rd_mfma32_p<F16>(al, bh, accP[s_]);   // same shape back to back: accumulator forwarding is fine
+                        a3 = rd_mfma32_p<F16>(ah, bl, a3);
+                        accP[s_] = rd_mfma32_p<F16>(ah, bh, a3);
                     }
                 }
             }
@@ -777,7 +818,7 @@ __global__ __launch_bounds__(512, 2) void gpe_redgemm_b3_kernel(RdParams p)
             if (s_ < my_count) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    dst[(size_t)(offU[s_] + 4 * g + r) * p.NgPad + offV[s_] + j] = accP[s_][r];
+                    dst[(size_t)(offU[s_] + 4 * g + r) * p.NgPad + offV[s_] + j] = accP[s_][r] * invU * invV;
             }
         }
         double* red = reinterpret_cast<double*>(smem_b3);       // [4][UC]
@@ -1211,12 +1252,12 @@ static int rd_pc_launch(const RdParams& p, int gx, hipStream_t s)
     return GPE_OK;
 }
 
-template <int MT, int NT, int VMODE>
+template <int MT, int NT, int VMODE, bool F16 = false>
 static int rd_b3_launch(const RdParams& p, int gx, hipStream_t s)
 {
     const size_t lds = (size_t)2 * (RdB3Layout<MT>::BYTES + RdB3Layout<NT>::BYTES);
-    GPE_ENSURE_MAX_LDS((gpe_redgemm_b3_kernel<MT, NT, VMODE>));
-    hipLaunchKernelGGL((gpe_redgemm_b3_kernel<MT, NT, VMODE>), dim3(gx), dim3(512), lds, s, p);
+    GPE_ENSURE_MAX_LDS((gpe_redgemm_b3_kernel<MT, NT, VMODE, F16>));
+    hipLaunchKernelGGL((gpe_redgemm_b3_kernel<MT, NT, VMODE, F16>), dim3(gx), dim3(512), lds, s, p);
     GPE_CHECK_LAUNCH();
     return GPE_OK;
 }
@@ -1313,7 +1354,12 @@ static int rd_run(RdParams& p, int vmode, float* G, int ldG, float* colsum, floa
         if (rows_per_cloud % RD_RT == 0 && gx % GPE_NXCD == 0 && rows_per_cloud / RD_RT >= gx / GPE_NXCD)
             p.pin_tpc = (int)(rows_per_cloud / RD_RT);
     }
-    if (pc_ok && g_rd_math == 1) {
+    if (pc_ok && g_rd_math == 2 && p.amax_u && p.amax_v) {
+        if (mt_all == 13 && vmode == V_DENSE) rc = rd_b3_launch<13, 13, V_DENSE, true>(p, gx, s);
+        else if (mt_all == 13) rc = rd_b3_launch<13, 13, V_GATHER, true>(p, gx, s);
+        else if (vmode == V_DENSE) rc = rd_b3_launch<10, 13, V_DENSE, true>(p, gx, s);
+        else rc = rd_b3_launch<10, 13, V_GATHER, true>(p, gx, s);
+    } else if (pc_ok && g_rd_math == 1) {
         if (mt_all == 13 && vmode == V_DENSE) rc = rd_b3_launch<13, 13, V_DENSE>(p, gx, s);
         else if (mt_all == 13) rc = rd_b3_launch<13, 13, V_GATHER>(p, gx, s);
         else if (vmode == V_DENSE) rc = rd_b3_launch<10, 13, V_DENSE>(p, gx, s);
@@ -1362,5 +1408,13 @@ extern "C" int gpe_edge_redgemm(const float* u, int ldu, int v_mode, const float
     p.v = GpeRows{v, ldv, 0, 0};
     p.pq = pq; p.ldpq = ldpq; p.H = Ng; p.jg = jg; p.k = k; p.rcp_k = 1.0 / k; p.kmagic = (unsigned)(((1ull << 32) + k - 1) / k); p.v_shift = v_shift;
     p.pin_clouds = B;
+    if (g_rd_math == 2) {
+        // f16x3: the operand scales must be known without a pass over an E-row tensor — U (a dz tensor) through the note its
+        // producer left, V through the gather bound / the amax kept from the forward kernel that wrote it; else exact fp32
+        p.amax_u = gpe_h3_note_peek(u, p.rows, Mg, ldu);
+        if (p.amax_u)
+            p.amax_v = v_mode == 0 ? gpe_h3_pq_bound(pq, (long)B * N, Ng, ldpq, (hipStream_t)stream)
+                                   : gpe_h3_fwd_lookup(v, p.rows, Ng, ldv);
+    }
     return rd_run(p, v_mode == 0 ? V_GATHER : V_DENSE, G, ldG, colsum, part, 0, (hipStream_t)stream);
 }

@@ -223,7 +223,8 @@ extern "C" int gpe_math_set(int mode)
     // (mode 3), 3 two-term split-fp16 on tensor-normalised operands (mode 4)
     gpe_edgegemm_set_math(mode == 4 ? 3 : mode == 3 ? 2 : (mode != 0 ? 1 : 0));
     gpe_h3_enable(mode == 4);
-    gpe_redgemm_set_math(mode == 1 ? 1 : 0);      // the weight-gradient reduce-GEMM: split-bf16 only in mode 1
+    // the weight-gradient reduce-GEMM: split-bf16 only in mode 1; mode 4: split-fp16 where the operand scales are known
+    gpe_redgemm_set_math(mode == 1 ? 1 : mode == 4 ? 2 : 0);
     return prev;
 }
 
