@@ -2,8 +2,10 @@
 """bench.py — garments/sec of one training step (fwd -> loss -> bwd [-> grad all-reduce] -> Adam) of the
 NeuralTailor LSTM model (GarmentFullPattern3D, reference nn/nets.py:41-184 driven as nn/trainer.py:92-99) on
 synthetic point clouds, BASELINE.json config 2 per GPU:  N=2048 points, batch 32, k=16, EdgeConv encoder + LSTM
-decoders.  fp32 storage, exact-fp32 MFMA (the parity-proven mode; BASELINE's "bf16" is a storage option not built
-yet — see DESIGN.md).
+decoders.  fp32 storage; arithmetic of the timed region = --math, default 'f16x3': every product of the fused edge GEMMs as
+three fp16 MFMAs on tensor-normalised two-term splits (23 mantissa bits), fp32 accumulate — the parity-grade mode (every
+-m gpu test holds it to the exact mode's bars).  The exact-fp32-MFMA step is measured in the same run and reported as
+`exact_f32`; BASELINE's "bf16" is a storage option that is not built.
 
     python bench.py --gpus 1 --steps 20 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
@@ -11,8 +13,10 @@ yet — see DESIGN.md).
 
 Rank 0 prints ONE JSON line.  `value` = garments processed by all ranks / max-over-ranks wall time of exactly K
 steps (barrier + synchronize on both sides).  Extra objects:
-  roofline      — the dominant kernel family of the step (MFMA-bound fp32 edge-MLP GEMMs): algorithmic FLOPs per
-                  launch / average launch duration from HIP events on the launch stream, vs 157.3 TFLOP/s;
+  roofline      — the dominant kernel family of the step (the fused edge-MLP GEMMs): algorithmic FLOPs per launch / average
+                  launch duration from HIP events on the launch stream, vs 157.3 TFLOP/s (the fp32-input MFMA peak: the roof of
+                  the exact formulation); in f16x3 mode also the executed matrix-pipe FLOPs (3 per algorithmic one) vs the
+                  fp16 peak — those kernels are issue-bound, not pipe-bound (DESIGN.md 5.8);
   roofline_gather — the EdgeConv neighbourhood gather: bytes_gather = N*k*(C*s+4) + N*C*s + N*F*s
                   per garment and layer, for (a) the kernel that carries the layer-2 gather (the fused gather->GEMM
                   forward, MFMA-bound: its time is NOT a bandwidth measurement) and (b) the stand-alone gather + BN
@@ -33,6 +37,7 @@ if REPO not in sys.path:
 import torch  # noqa: E402
 
 PEAK_F32_TFLOPS = 157.3     # MI355X fp32 vector = fp32-input MFMA peak (MI355X_MICROARCH.md)
+PEAK_F16_TFLOPS = 2516.6    # dense fp16 / bf16 MFMA peak (256 CUs x 4 SIMDs x 1024 FLOP/clk x 2.4 GHz; no sparsity)
 PEAK_HBM_GBS = 8000.0
 PEAK_L2_GBS = 34500.0        # aggregate of the eight 4 MiB XCD L2s (MI355X_MICROARCH.md, 'L2 (per XCD)')
 
@@ -56,7 +61,7 @@ def parse():
     ap.add_argument('--cpu-steps', type=int, default=3)
     ap.add_argument('--cpu-threads', type=int, default=0, help='0 = all host cores (nproc)')
     ap.add_argument('--no-kernel-timing', action='store_true')
-    ap.add_argument('--math', choices=['f32', 'f16x3', 'bf16x6', 'mixed', 'bf16x3'], default='f32',
+    ap.add_argument('--math', choices=['f32', 'f16x3', 'bf16x6', 'mixed', 'bf16x3'], default='f16x3',
                     help="arithmetic of the fused edge GEMMs for the timed region (gpe_math_set); 'f32' = exact")
     ap.add_argument('--no-fast-math-line', action='store_true', help='skip the extra mixed / bf16x3 measurements')
     ap.add_argument('--call-shapes', default=None, metavar='FILE', help='write per-(entry, int args) launch counts and mean durations')
@@ -117,11 +122,15 @@ def call_work(name, a):
 # from two `rocprofv3 --pmc` runs of this same command); C-ABI entry -> device kernels it launches
 _TRAFFIC_KERNELS = {
     # template tails: rowgemm <NT, AMODE, EMODE>; edgegemm (paired) <.., AMODE, EMODE, MATH>; edgegemm_sr <.., AMODE, EMODE, KC, HALF>
-    'gpe_edge_mlp_fwd': r'gpe_rowgemm_kernel<.*, 1>$|gpe_edgegemm(_sr)?_kernel<\d+, \d+, \d+, \d+, 1(, [-\w]+)+>$',
-    'gpe_edge_mlp_bwd': r'gpe_rowgemm_kernel<.*, [23]>$|gpe_edgegemm(_sr)?_kernel<\d+, \d+, \d+, \d+, [23](, [-\w]+)+>$',
-    'gpe_edge_redgemm': r'gpe_redgemm_pc_kernel<',
+    # split <Policy, AQ, BQ, KCH, AMODE, EMODE, K16>
+    'gpe_edge_mlp_fwd': r'gpe_rowgemm_kernel<.*, 1>$|gpe_edgegemm(_sr)?_kernel<\d+, \d+, \d+, \d+, 1(, [-\w]+)+>$'
+                        r'|gpe_edgegemm_split_kernel<\w+, \d+, \d+, \d+, \d+, 1, \w+>$',
+    'gpe_edge_mlp_bwd': r'gpe_rowgemm_kernel<.*, [23]>$|gpe_edgegemm(_sr)?_kernel<\d+, \d+, \d+, \d+, [23](, [-\w]+)+>$'
+                        r'|gpe_edgegemm_split_kernel<\w+, \d+, \d+, \d+, \d+, [23], \w+>$',
+    'gpe_edge_redgemm': r'gpe_redgemm_pc_kernel<|gpe_redgemm_b3_kernel<',
     'gpe_edge_gather_stats': r'gpe_gather_stats_kernel',
-    'gpe_edge_mlp_fwd:gather': r'gpe_edgegemm(_sr)?_kernel<\d+, \d+, \d+, 1, 1(, [-\w]+)+>$',     # AMODE = A_GATHER, EMODE = fwd
+    # AMODE = A_GATHER, EMODE = fwd
+    'gpe_edge_mlp_fwd:gather': r'gpe_edgegemm(_sr)?_kernel<\d+, \d+, \d+, 1, 1(, [-\w]+)+>$|gpe_edgegemm_split_kernel<\w+, \d+, \d+, \d+, 1, 1, \w+>$',
     'gpe_knn': r'gpe_knn_kernel',
     'gpe_edge_pull_dq': r'gpe_pull_dq_kernel',
 }
@@ -171,9 +180,12 @@ def _workload_name(args):
              else 'GarmentFullPattern3D, EdgeConv encoder + LSTM decoders')
     # BASELINE cfg 2 says "bf16", cfg 5 "fp16 with fp32 accumulate": storage options that are deliberately not built — every
     # edge kernel is >= 1.7x away from its HBM bound (DESIGN.md section 8, row g), so they would not shorten the step
-    return '%s: %s, N=%d, batch %d/GPU, k=%d; fp32 storage and fp32 arithmetic (the half-precision STORAGE the config names ' \
+    arith = {'f32': 'exact fp32 MFMA arithmetic',
+             'f16x3': 'fp32-grade arithmetic: edge-GEMM products as 3 fp16 MFMAs on tensor-normalised two-term splits, fp32 '
+                      'accumulate (parity-grade: the exact mode\'s test bars)'}.get(args.math, 'APPROXIMATE arithmetic (%s)' % args.math)
+    return '%s: %s, N=%d, batch %d/GPU, k=%d; fp32 storage, %s (the half-precision STORAGE the config names ' \
            'is not built: measured not worthwhile, DESIGN.md 8)' % (named.get(shape, 'custom shape'), model, args.points,
-                                                                    args.batch, args.k)
+                                                                    args.batch, args.k, arith)
 
 def _cpu_name():
     try:
@@ -338,7 +350,14 @@ def main():
         roof = {'kernel': dom, 'bound': 'mfma', 'achieved': ach, 'peak': PEAK_F32_TFLOPS, 'unit': 'TFLOP/s',
                 'frac': ach / PEAK_F32_TFLOPS, 'traffic': traffic, 'traffic_unit': 'HBM bytes/launch',
                 'traffic_source': tsrc, 'launches_per_step': n_l / nsteps,
-                'avg_launch_ms': ms / n_l, 'flops_per_launch': fl / n_l}
+                'avg_launch_ms': ms / n_l, 'flops_per_launch': fl / n_l,
+                'peak_note': 'algorithmic FLOPs against the fp32-input MFMA peak, the roof of the exact formulation'}
+        if args.math == 'f16x3':
+            # what the matrix pipe actually executes in this mode: 3 fp16 MFMA FLOPs per algorithmic FLOP
+            roof.update(pipe='v_mfma_f32_16x16x32_f16, 3 per algorithmic product', pipe_achieved=3 * ach,
+                        pipe_peak=PEAK_F16_TFLOPS, pipe_frac=3 * ach / PEAK_F16_TFLOPS,
+                        pipe_note='the two-plane kernels are bound by a lone wave\'s instruction issue (VALU epilogue / staging, '
+                                  'LDS), not by the fp16 pipe: DESIGN.md 5.8')
         # ---- the EdgeConv gather, SURVEY.md §8(d) row 5: bytes_gather(layer) per garment, s = 4 (fp32) -------------
         H, F = nn_cfg['EConv_hidden'], nn_cfg['EConv_feature']
 
@@ -381,13 +400,14 @@ def main():
                           'the matrix pipe', 'bound': 'mfma', 'gather_bytes_per_launch': by, 'avg_launch_ms': ms,
                 'gather_rate_GBs': by / (ms * 1e-3) / 1e9, 'traffic': pmc_traffic('gpe_edge_mlp_fwd:gather')[0]}
 
-    # the opt-in fast mode, measured the same way on the same workload (reported beside `value`, never as `value`)
+    # the other arithmetic modes, measured the same way on the same workload (reported beside `value`, never as `value`)
     fast = None
-    if world == 1 and args.math == 'f32' and not args.no_fast_math_line:
+    if world == 1 and args.math in ('f32', 'f16x3') and not args.no_fast_math_line:
         fast = {}
-        for mode, note in (('f16x3', 'two-term split-fp16 products (3 fp16 MFMAs per product, fp32 accumulate) on tensor-normalised '
-                                     'operands in all four single-role edge kernels; weight-gradient reduce-GEMMs exact fp32.  '
-                                     'PARITY-GRADE: every -m gpu test runs it at the exact mode\'s bars; gpe_math_set(4)'),
+        for mode, note in (('f32', 'exact fp32: every product on v_mfma_f32_16x16x4_f32 (gpe_math_set(0))'),
+                           ('f16x3', 'two-term split-fp16 products (3 fp16 MFMAs per product, fp32 accumulate) on tensor-normalised '
+                                     'operands in all four single-role edge kernels and, where both operand scales are known without a '
+                                     'pass over the tensor, the weight-gradient reduce-GEMMs.  PARITY-GRADE: every -m gpu test runs it at the exact mode\'s bars; gpe_math_set(4)'),
                            ('bf16x6', 'three-term split-bf16 products (6 bf16 MFMAs per product) in the 10-tile single-role edge '
                                       'kernels; parity-grade (the exact mode\'s bars in every test); gpe_math_set(3)'),
                            ('mixed', 'split-bf16 row GEMMs (forward + input-gradient half) on the bf16 matrix pipe, exact-fp32 '
@@ -395,6 +415,8 @@ def main():
                                      '1e-3 .. 1.5e-2 of max|grad| (approximate, tests TOL 3e-2); gpe_math_set(2) / GPE_MATH=mixed'),
                            ('bf16x3', 'every fused edge GEMM split-bf16: forward within 1e-4 of the reference, encoder '
                                       'gradients within ~1e-2 (tests/test_gpu_kernels.py TOL); gpe_math_set(1)')):
+            if mode == args.math:
+                continue
             gpe_amd.set_math(mode)
             n_f = max(3, min(args.steps, 10))
             for i in range(2):
@@ -407,7 +429,7 @@ def main():
             dt = time.perf_counter() - t1
             fast[mode] = {'value': args.batch * n_f / dt, 'unit': 'garments/s', 'steps': n_f,
                           'ms_per_step': dt / n_f * 1e3, 'note': note}
-        gpe_amd.set_math('f32')
+        gpe_amd.set_math(args.math)
 
     # ---- the exchange step, for N > 1: what RCCL saw and what it costs -------------------------------------------------
     exchange = None
@@ -425,14 +447,18 @@ def main():
             'metric': 'garments/sec (fwd+bwd) at N=%d pts, batch %d per GPU' % (args.points, args.batch),
             'value': garments / elapsed, 'unit': 'garments/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True,
-            'scaling': 'weak', 'vs_baseline': None, 'dtype': args.math, 'data': 'synthetic',
+            'scaling': 'weak', 'vs_baseline': None,
+            'dtype': {'f32': 'f32', 'f16x3': 'f32 (f16x3: 3 fp16 MFMAs per product on normalised two-term splits, fp32 accumulate, '
+                                             'fp32 storage)'}.get(args.math, args.math),
+            'math_mode': args.math, 'data': 'synthetic',
             'config': {'workload': _workload_name(args),
                        'global_batch': args.batch * world, 'parallelism': 'dp%d' % world,
                        'loss_epoch': args.epoch,
                        'step': 'fwd + ComposedPatternLoss + bwd' + (' + RCCL grad all-reduce' if world > 1 else '')
                                + (' + Adam (torch)' if args.torch_adam else ' + fused Adam (flat arena)'),
                        'final_loss': final_loss},
-            'roofline': roof, 'roofline_gather': roof_gather, 'cpu_baseline': cpu, 'fast_math': fast,
+            'roofline': roof, 'roofline_gather': roof_gather, 'cpu_baseline': cpu,
+            'exact_f32': (fast or {}).get('f32'), 'fast_math': fast,
             'dist_world': (torch.distributed.get_world_size() if world > 1 else 1),
             'allreduce_ms_per_step': exchange and exchange['ms_per_step'],
             'allreduce_bytes': exchange and exchange['bytes_per_step'], 'exchange': exchange,

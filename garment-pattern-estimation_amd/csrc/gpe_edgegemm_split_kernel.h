@@ -741,9 +741,15 @@ static int x6_prepare(const RgParams& p_in, int amode, int emode, int stats_nblk
     if (amode == A_DENSE && (p.a.inner > 0 || (p.a.stride_outer & 3) || p.a.stride_outer < ((p.K + 3) & ~3) ||
                              (((uintptr_t)p.a.base) & 15)))
         return 0;                                        // dense rows must be aligned + padded for plain 16-B loads
-    if (p.k < 1 || p.k > X6_PB) return 0;
-    const int npw = X6_PB / p.k;                         // points per wave per tile
+    if (p.k < 1) return 0;
     const bool per_point = amode == A_GATHER || emode == E_BWD_GATHER || (emode == E_EDGE_FWD && p.agg);
+    if (p.k > X6_PB) {
+        // k > 16: rows that need nothing per point can be tiled any way (4 rows per "point": 64-row tiles); the per-point
+        // variants stay with the exact-fp32 kernel's pseudo-point split (gpe_edgegemm_sr.hip)
+        if (per_point) return 0;
+        p.k = 4;
+    }
+    const int npw = X6_PB / p.k;                         // points per wave per tile
     if (per_point && npw > X6_NPW) return 0;
     p.R = 4 * npw * p.k;
     p.num_tiles = gpe_cdiv(p.M, p.R);
