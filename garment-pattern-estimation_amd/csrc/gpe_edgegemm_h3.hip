@@ -15,6 +15,7 @@
 
 #define H3_RING 64
 #define H3_KEEP 8
+#define H3_PQ_BLOCKS 1024        // workgroups (= partial maxima) of the gather-bound pass
 
 // largest |x| over rows x cols (row pitch ld), as the bit pattern of a non-negative float (orders like the float; NaN > inf)
 __global__ __launch_bounds__(256) void gpe_h3_absmax_kernel(const float* __restrict__ x, long rows, int cols4, long ld,
@@ -37,37 +38,51 @@ __global__ __launch_bounds__(256) void gpe_h3_absmax_kernel(const float* __restr
         const unsigned t = (unsigned)__shfl_xor((int)m, o);
         m = m > t ? m : t;
     }
-    if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+    // one atomic per workgroup: thousands of same-address atomics issued at once serialise in the L2 (measured: 16 k of them
+    // took longer than the pass itself)
+    __shared__ unsigned red[4];
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned a = red[0] > red[1] ? red[0] : red[1], b = red[2] > red[3] ? red[2] : red[3];
+        const unsigned r = a > b ? a : b;
+        if (r) atomicMax(out, r);
+    }
 }
 
-// max(P) + max(Q) over the [rows][>= 2H] table (signed maxima; the bound of relu(P_i + Q_j)), clamped at 0.
-// One wave per row at a time, lane = column quad (no per-element division).
+// max(P) and max(Q) over the [rows][>= 2H] table (signed maxima; max(P) + max(Q) bounds relu(P_i + Q_j)).  One wave per row
+// at a time, lane = column quad, two rows in flight; every workgroup leaves ONE pair of partial maxima in part[2 b], part[2 b + 1]
+// (no atomics: see gpe_h3_absmax_kernel), gpe_h3_pqfinish_kernel combines them.
 __global__ __launch_bounds__(256) void gpe_h3_pqmax_kernel(const float* __restrict__ pq, long rows, int H, long ld,
-                                                           int* __restrict__ smax /* [2] ordered-int maxima of P and Q */)
+                                                           float* __restrict__ part /* [2 * gridDim.x] */)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int h4 = H >> 2;
     float mp = -INFINITY, mq = -INFINITY;
-    for (long r = (long)blockIdx.x * 4 + wave; r < rows; r += (long)gridDim.x * 4) {
-        const float* row = pq + r * ld;
+    const long stride = (long)gridDim.x * 4;
+    for (long r = (long)blockIdx.x * 4 + wave; r < rows; r += 2 * stride) {
+        const float* row0 = pq + r * ld;
+        const bool two = r + stride < rows;
+        const float* row1 = pq + (two ? r + stride : r) * ld;
         for (int q = lane; q < 2 * h4; q += 64) {
-            const float4 v = ld4(row + 4 * q);
-            const float m = fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w));
+            const float4 v0 = ld4(row0 + 4 * q), v1 = ld4(row1 + 4 * q);
+            const float m = fmaxf(fmaxf(fmaxf(v0.x, v0.y), fmaxf(v0.z, v0.w)), fmaxf(fmaxf(v1.x, v1.y), fmaxf(v1.z, v1.w)));
             if (q < h4) mp = fmaxf(mp, m); else mq = fmaxf(mq, m);
         }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { mp = fmaxf(mp, __shfl_xor(mp, o)); mq = fmaxf(mq, __shfl_xor(mq, o)); }
-    if (lane == 0) {
-        // order-preserving map float -> int: negative floats flipped
-        const int ip = __float_as_int(mp), iq = __float_as_int(mq);
-        atomicMax(smax + 0, ip >= 0 ? ip : ip ^ 0x7fffffff);
-        atomicMax(smax + 1, iq >= 0 ? iq : iq ^ 0x7fffffff);
+    __shared__ float red[8];
+    if (lane == 0) { red[2 * wave] = mp; red[2 * wave + 1] = mq; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        part[2 * blockIdx.x] = fmaxf(fmaxf(red[0], red[2]), fmaxf(red[4], red[6]));
+        part[2 * blockIdx.x + 1] = fmaxf(fmaxf(red[1], red[3]), fmaxf(red[5], red[7]));
     }
 }
 
 // one workgroup: the packed weight's largest magnitude -> slots[1]; clears slots[0] (the A-operand slot the multi-workgroup
-// passes accumulate into), the ordered-int maxima of the gather bound, and the note slot the coming launch will write
+// passes accumulate into) and the note slot the coming launch will write
 __global__ __launch_bounds__(1024) void gpe_h3_wmax_kernel(const float* __restrict__ w, long n, unsigned* __restrict__ slots,
                                                            int clear_note)
 {
@@ -88,20 +103,28 @@ __global__ __launch_bounds__(1024) void gpe_h3_wmax_kernel(const float* __restri
         for (int i = 1; i < 16; ++i) m = m > red[i] ? m : red[i];
         slots[1] = m;
         slots[0] = 0u;
-        reinterpret_cast<int*>(slots)[H3_RING + 2] = (int)0x80000000;
-        reinterpret_cast<int*>(slots)[H3_RING + 3] = (int)0x80000000;
         if (clear_note >= 0) slots[2 + clear_note] = 0u;
     }
 }
 
-// gather bound: slots[0] = bits of max(0, maxP + maxQ) (rounded up one ulp-ish by a factor 1 + 2^-20: a bound, not a value)
-__global__ void gpe_h3_pqfinish_kernel(unsigned* __restrict__ slots)
+// gather bound: slots[0] = bits of max(0, maxP + maxQ) (rounded up by a factor 1 + 1e-6: a bound, not a value) from the
+// nblk partial pairs of gpe_h3_pqmax_kernel
+__global__ __launch_bounds__(256) void gpe_h3_pqfinish_kernel(const float* __restrict__ part, int nblk, unsigned* __restrict__ slots)
 {
-    const int ip = reinterpret_cast<int*>(slots)[H3_RING + 2], iq = reinterpret_cast<int*>(slots)[H3_RING + 3];
-    const float mp = __int_as_float(ip >= 0 ? ip : ip ^ 0x7fffffff), mq = __int_as_float(iq >= 0 ? iq : iq ^ 0x7fffffff);
-    float b = (mp + mq) * 1.000001f;
-    if (!(b > 0.f)) b = (b != b) ? b : 0.f;               // NaN stays NaN (sorts above everything), negative -> all-zero operand
-    slots[0] = __float_as_uint(b) & 0x7fffffffu;
+    float mp = -INFINITY, mq = -INFINITY;
+    for (int b = threadIdx.x; b < nblk; b += 256) { mp = fmaxf(mp, part[2 * b]); mq = fmaxf(mq, part[2 * b + 1]); }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { mp = fmaxf(mp, __shfl_xor(mp, o)); mq = fmaxf(mq, __shfl_xor(mq, o)); }
+    __shared__ float red[8];
+    if ((threadIdx.x & 63) == 0) { red[2 * (threadIdx.x >> 6)] = mp; red[2 * (threadIdx.x >> 6) + 1] = mq; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        mp = fmaxf(fmaxf(red[0], red[2]), fmaxf(red[4], red[6]));
+        mq = fmaxf(fmaxf(red[1], red[3]), fmaxf(red[5], red[7]));
+        float b = (mp + mq) * 1.000001f;
+        if (!(b > 0.f)) b = (b != b) ? b : 0.f;           // NaN stays NaN (sorts above everything), negative -> all-zero operand
+        slots[0] = __float_as_uint(b) & 0x7fffffffu;
+    }
 }
 
 // ---- producer notes ------------------------------------------------------------------------------------------------------
@@ -129,7 +152,19 @@ static void h3_keep_add(const H3Keep& k)
     g_keep[g_keep_next] = k;
     g_keep_next = (g_keep_next + 1) % H3_KEEP;
 }
-static unsigned* h3_slots() { return static_cast<unsigned*>(gpe_scratch(3, (2 + H3_RING + 2) * sizeof(unsigned))); }
+static unsigned* h3_slots() { return static_cast<unsigned*>(gpe_scratch(3, (2 + H3_RING + 2 * H3_PQ_BLOCKS) * sizeof(unsigned))); }
+// the two passes of the gather bound, on stream s -> slots[0]
+static int h3_pq_passes(unsigned* slots, const float* pq, long rows, int H, long ld, hipStream_t s)
+{
+    float* part = reinterpret_cast<float*>(slots + 2 + H3_RING);
+    int gx = (int)((rows + 3) / 4);
+    if (gx > H3_PQ_BLOCKS) gx = H3_PQ_BLOCKS;
+    hipLaunchKernelGGL(gpe_h3_pqmax_kernel, dim3(gx), dim3(256), 0, s, pq, rows, H, ld, part);
+    GPE_CHECK_LAUNCH();
+    hipLaunchKernelGGL(gpe_h3_pqfinish_kernel, dim3(1), dim3(256), 0, s, part, gx, slots);
+    GPE_CHECK_LAUNCH();
+    return GPE_OK;
+}
 // for producers outside this file (gpe_edge_dz3): a cleared ring slot to atomicMax into + the note that goes with it.
 // Returns NULL when the f16x3 mode is off (the caller then skips the tracking).
 static int g_h3_on = 0;
@@ -212,15 +247,8 @@ int gpe_edgegemm_h3_try(const RgParams& p_in, int amode, int emode, int stats_nb
         p.h3_amax_a = slots;
     } else {
         if (p.H & 3) return 0;
-        const long rows = p.M / p.k;                      // the per-point table behind the gathered operand
-        int gx = (int)((rows + 3) / 4);
-        const int cap = gpe_num_cus() * 8;
-        if (gx > cap) gx = cap;
-        hipLaunchKernelGGL(gpe_h3_pqmax_kernel, dim3(gx), dim3(256), 0, s, p.pq, rows, p.H, (long)p.ldpq,
-                           reinterpret_cast<int*>(slots) + H3_RING + 2);
-        GPE_CHECK_LAUNCH();
-        hipLaunchKernelGGL(gpe_h3_pqfinish_kernel, dim3(1), dim3(1), 0, s, slots);
-        GPE_CHECK_LAUNCH();
+        const int rc_pq = h3_pq_passes(slots, p.pq, p.M / p.k, p.H, (long)p.ldpq, s);   // the per-point table behind the gathered operand
+        if (rc_pq != GPE_OK) return rc_pq;
         p.h3_amax_a = slots;
     }
     p.h3_amax_w = slots + 1;
@@ -269,13 +297,6 @@ const unsigned* gpe_h3_pq_bound(const float* pq, long rows, int H, long ld, hipS
 {
     unsigned* slots = h3_slots();
     if (!slots || (H & 3)) return nullptr;
-    // resets the ordered-int maxima (and slots[0], slots[1]) in stream order, then the two passes
-    hipLaunchKernelGGL(gpe_h3_wmax_kernel, dim3(1), dim3(1024), 0, s, (const float*)nullptr, 0L, slots, -1);
-    int gx = (int)((rows + 3) / 4);
-    const int cap = gpe_num_cus() * 8;
-    if (gx > cap) gx = cap;
-    hipLaunchKernelGGL(gpe_h3_pqmax_kernel, dim3(gx), dim3(256), 0, s, pq, rows, H, ld, reinterpret_cast<int*>(slots) + H3_RING + 2);
-    hipLaunchKernelGGL(gpe_h3_pqfinish_kernel, dim3(1), dim3(1), 0, s, slots);
-    if (hipGetLastError() != hipSuccess) return nullptr;
+    if (h3_pq_passes(slots, pq, rows, H, ld, s) != GPE_OK) return nullptr;
     return slots;
 }

@@ -200,6 +200,7 @@ __global__ __launch_bounds__(256, 1) void gpe_edgegemm_split_kernel(RgParams p, 
     constexpr bool GATHER_ACT = (EMODE == E_BWD_GATHER);
 
     extern __shared__ __align__(16) float smem[];
+    __shared__ unsigned amax_sh[4];                      // SplitF16x2: the waves' largest written magnitudes (kernel tail)
     float* const Abuf0 = smem;
     float* const Abuf1 = smem + AWORDS;
     float* const Cs = smem + 2 * AWORDS;                 // [64][LDC]
@@ -680,9 +681,14 @@ __global__ __launch_bounds__(256, 1) void gpe_edgegemm_split_kernel(RgParams p, 
         float m = amax_run;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-        if (lane == 0) atomicMax(p.amax_out, __float_as_uint(m));
+        if (lane == 0) amax_sh[wave] = __float_as_uint(m);
     }
     __syncthreads();
+    if (SP::SCALED && p.amax_out && EMODE != E_BWD_GATHER && tid == 0) {
+        // one atomic per workgroup (same-address atomics issued by every wave at once serialise in the L2)
+        const unsigned a = amax_sh[0] > amax_sh[1] ? amax_sh[0] : amax_sh[1], b = amax_sh[2] > amax_sh[3] ? amax_sh[2] : amax_sh[3];
+        atomicMax(p.amax_out, a > b ? a : b);
+    }
     if (EMODE == E_EDGE_FWD && p.stats_part) {
         double* red = reinterpret_cast<double*>(smem);          // [4 waves][2][16*NT]
         if (n_on) {
@@ -714,7 +720,8 @@ static int x6_launch_k(const RgParams& p, int stats_nblk, hipStream_t s)
     constexpr int LDA = 16 * KCH + 4, LDC = x6_ldc<SP>(NT, KCH);
     constexpr int AWORDS = SP::SCALED ? (2 * RG_BM * 16 * x6_pchunks(KCH)) / 4 : RG_BM * LDA;
     const size_t lds = (size_t)(2 * AWORDS + RG_BM * LDC) * sizeof(float);
-    GPE_ENSURE_MAX_LDS((gpe_edgegemm_split_kernel<SP, AQ, BQ, KCH, AMODE, EMODE, K16>));
+    // 16 bytes of static __shared__ (amax_sh) sit beside the dynamic image
+    GPE_ENSURE_MAX_LDS_N((gpe_edgegemm_split_kernel<SP, AQ, BQ, KCH, AMODE, EMODE, K16>), 160 * 1024 - 64);
     int gx = gpe_num_cus();
     if (gx > p.num_tiles) gx = p.num_tiles;
     if (stats_nblk > 0 && gx > stats_nblk) gx = stats_nblk;
