@@ -694,6 +694,64 @@ def test_edgeconv_general_widths(gpe, H, Fo, aggr, C):
         assert relerr(pconv(x.cuda(), B, N), o64(x.double(), batch)) < 5e-5
 
 
+def _f16x3_dense_block(gpe, a_in, Wm, bias, B, N, k):
+    """One fused dense edge block (gpe_edge_mlp_fwd a_mode 1, no statistics / aggregation) -> a fresh output tensor."""
+    L = gpe._lib
+    E, Cin = a_in.shape
+    Cout = Wm.shape[0]
+    out = torch.empty(E, (Cout + 3) // 4 * 4, device='cuda')
+    L.call('gpe_edge_mlp_fwd', 1, None, 0, None, a_in, a_in.stride(0), B, N, k, Cin, Cout, gpe.ops.pack_weight(Wm), bias, out,
+           out.stride(0), None, 0, None, None, None, None, 0)
+    return out[:, :Cout]
+
+
+@pytest.mark.parametrize('scale', [1e-25, 3e-9, 1.0, 7e6, 1e20])
+def test_f16x3_extreme_magnitudes(gpe, scale):
+    """The f16x3 kernels normalise every operand by a power of two taken from its largest magnitude: activations (and
+    weights) far outside fp16's range give the exact mode's result."""
+    B, N, k, Cin, Cout = 2, 64, 16, 200, 150
+    g = torch.Generator().manual_seed(3)
+    a = (torch.randn(B * N * k, Cin, generator=g).abs() * scale).cuda()
+    a[5, 7] *= 300.0                                            # one outlier sets the scale; the rest keep their precision
+    Wm = (torch.randn(Cout, Cin, generator=g) / 14 / max(scale, 1e-12) ** 0.5).cuda()
+    ref = a.double().cpu() @ Wm.double().cpu().t()
+    outs = {}
+    for mode in ('f32', 'f16x3'):
+        prev = gpe.set_math(mode)
+        try:
+            outs[mode] = _f16x3_dense_block(gpe, a, Wm, None, B, N, k).double().cpu()
+        finally:
+            gpe.set_math(prev)
+    ref = torch.relu(ref)
+    e32, e16 = relerr(outs['f32'], ref), relerr(outs['f16x3'], ref)
+    print('scale %g: f32 %.2e, f16x3 %.2e' % (scale, e32, e16))
+    assert torch.isfinite(outs['f16x3']).all()
+    assert e16 < max(2e-6, 4 * e32)
+
+
+def test_f16x3_note_dropped_by_intervening_write(gpe):
+    """A forward f16x3 kernel leaves a note with the largest magnitude it wrote for the next edge GEMM.  Any library call that
+    writes tensors in between drops it — here the activation is multiplied by 1000 in place, far past the noted maximum — so
+    the consumer measures the operand again instead of overflowing fp16."""
+    L = gpe._lib
+    B, N, k, C = 2, 64, 16, 200
+    g = torch.Generator().manual_seed(4)
+    a0 = torch.randn(B * N * k, C, generator=g).abs().cuda()
+    W1 = (torch.randn(C, C, generator=g) / 14).cuda()
+    W2 = (torch.randn(150, C, generator=g) / 14).cuda()
+    prev = gpe.set_math('f16x3')
+    try:
+        a1 = _f16x3_dense_block(gpe, a0, W1, None, B, N, k)                  # notes max|a1|
+        a1 = a1 if a1.is_contiguous() else a1.contiguous()
+        L.call('gpe_scale', a1, 1000.0, a1, a1.numel())                      # in place, through the library
+        out = _f16x3_dense_block(gpe, a1, W2, None, B, N, k).double().cpu()
+    finally:
+        gpe.set_math(prev)
+    ref = torch.relu(a1.double().cpu() @ W2.double().cpu().t())
+    assert torch.isfinite(out).all()
+    assert relerr(out, ref) < 2e-6
+
+
 @pytest.mark.parametrize('M,W', [(1, 23), (700, 23), (513, 5), (64, 32)])
 def test_sparsemax_loss(gpe, M, W):
     """entmax.SparsemaxLoss() as composed_loss.py:323-332 calls it, on general scores (not only simplex points) and behind a
