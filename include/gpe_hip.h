@@ -41,11 +41,20 @@ int gpe_debug_set(int flags);
  *                sums where a coherent 1e-5 product error would surface as a 1e-2 gradient error.
  *   3 = "bf16x6" THREE-term split x = h + m + l, six bf16 MFMAs per product (every term down to 2^-24 except m*l, l*m,
  *                l*l) for the row GEMMs whose shape fits the register file (10 output tiles; the others stay on the exact
- *                fp32 instruction); reduce-GEMM exact fp32.  Each layer meets the exact mode's tolerances; end to end the
- *                BatchNorm backward amplifies the dropped terms to ~1e-2 of max|grad|: APPROXIMATE, like
- *                modes 1 and 2, and measured only 0.5 % faster than mode 0.
+ *                fp32 instruction); reduce-GEMM exact fp32.  PARITY-GRADE (meets the exact mode's bars in every test once the
+ *                oracle stands on the build's ReLU / argmax decisions), measured 0.5 % faster than mode 0.
+ *   4 = "f16x3"  TWO-term fp16 split of operands normalised per TENSOR by a power of two (largest magnitude -> [2^14, 2^15)),
+ *                three fp16 MFMAs per product, fp32 accumulate: 23 mantissa bits per product, PARITY-GRADE (every test at the
+ *                exact mode's bars; profiles/r03_i_f16x3_grad_errors.md).  All four shapes of the shipped edge MLPs stay
+ *                resident (two weight planes); the weight-gradient reduce-GEMMs join when both operand scales are known without
+ *                a pass over the tensor.  The scales are measured on the device: packed weight and [P|Q] table by small passes,
+ *                activations / dz tensors through a NOTE the producing kernel leaves (largest magnitude written); the note is
+ *                dropped by any call into this library that writes caller tensors other than the statistics / packing /
+ *                reduce-GEMM calls between two edge GEMMs — a caller must not rewrite such a tensor by other means between
+ *                the call that produced it and the next gpe_edge_mlp_fwd / gpe_edge_mlp_bwd / gpe_edge_redgemm.
+ *                The mode bench.py times; 24 % faster than mode 0 at BASELINE cfg 2.
  * Returns the previous mode, or -22 for an unknown one.  kNN, BatchNorm statistics, the LSTM decoder and every
- * elementwise op are fp32 (fp64 for reductions) in both modes. */
+ * elementwise op are fp32 (fp64 for reductions) in every mode. */
 int gpe_math_set(int mode);
 int gpe_math_get(void);
 
@@ -66,7 +75,8 @@ int gpe_knn_reverse(const int32_t* idx, int B, int N, int k, int32_t* rev_off, i
 /* ---- weight packing (+ BatchNorm folding) ------------------------------------------------------------------
  * w [N][ldw] row-major (nn.Linear layout, nn/net_blocks.py:45) or, if transpose != 0, w is [K][ldw] and the packed
  * operand is its transpose.  Optional col_scale[K]: packed(n,k) = w(n,k)*col_scale[k]  (folds the previous
- * BatchNorm's scale s=gamma*rstd into this Linear).  wp holds gpe_packed_size(N,K) floats. */
+ * BatchNorm's scale s=gamma*rstd into this Linear).  wp holds gpe_packed_size(N,K) floats: K in whole 16-k chunks, and a K in
+ * (96, 208] filled up with zeros to the 10 or 13 chunks the register-stationary edge kernels keep resident. */
 long gpe_packed_size(int N, int K);
 int gpe_pack_weight(const float* w, int ldw, int N, int K, int transpose, const float* col_scale,
                     float* wp, void* stream);
