@@ -210,7 +210,9 @@ int gpe_edgegemm_h3_try(const RgParams& p_in, int amode, int emode, int stats_nb
     gpe_h3_note_drop();
     h3_keep_kill(p_in.out);
     RgParams p;
-    if (!x6_prepare(p_in, amode, emode, stats_nblk, p)) return 0;
+    GpeFold fold;
+    if (!x6_prepare(p_in, amode, emode, stats_nblk, p, fold)) return 0;
+    const long npts = p_in.k > 0 ? p_in.M / p_in.k : 0;   // rows of the per-point table (p.k may now count pseudo-point rows)
     const int NT = (p.N <= 160) ? 10 : 13;
     const int KCH = (p.K <= 160) ? 10 : 13;
     unsigned* slots = h3_slots();
@@ -247,7 +249,7 @@ int gpe_edgegemm_h3_try(const RgParams& p_in, int amode, int emode, int stats_nb
         p.h3_amax_a = slots;
     } else {
         if (p.H & 3) return 0;
-        const int rc_pq = h3_pq_passes(slots, p.pq, p.M / p.k, p.H, (long)p.ldpq, s);   // the per-point table behind the gathered operand
+        const int rc_pq = h3_pq_passes(slots, p.pq, npts, p.H, (long)p.ldpq, s);   // the per-point table behind the gathered operand
         if (rc_pq != GPE_OK) return rc_pq;
         p.h3_amax_a = slots;
     }
@@ -260,6 +262,7 @@ int gpe_edgegemm_h3_try(const RgParams& p_in, int amode, int emode, int stats_nb
     else if (amode == A_DENSE && emode == E_BWD_INPLACE) rc = h3_dispatch<A_DENSE, E_BWD_INPLACE>(NT, KCH, p, stats_nblk, s);
     else if (amode == A_DENSE && emode == E_BWD_GATHER) rc = h3_dispatch<A_DENSE, E_BWD_GATHER>(NT, KCH, p, stats_nblk, s);
     if (rc == GPE_ENOTSUP_SHAPE) return 0;
+    if (rc == GPE_OK) rc = gpe_edge_pseudo_fold(p, fold, s);
     if (rc != GPE_OK) return rc;
     if (notes) g_note = {p.out, p.M, (long)p.ldo, p.N, out_slot, dev};
     if (emode == E_EDGE_FWD) h3_keep_add(H3Keep{p.out, p.M, (long)p.ldo, p.N, out_slot, dev, g_seq});

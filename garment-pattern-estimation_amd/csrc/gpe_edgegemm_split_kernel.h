@@ -56,6 +56,10 @@ __device__ __forceinline__ float4 x6_UNUSED_pin4(const float4 v)
     return make_float4(x6_pin_agpr(v.x), x6_pin_agpr(v.y), x6_pin_agpr(v.z), x6_pin_agpr(v.w));
 }
 
+// P row of (pseudo-)point x: x itself, or x / f when a k > 16 point runs as f pseudo-points (RgParams::pmagic, gpe_edgegemm_sr.hip)
+template <bool PSEUDO>
+__device__ __forceinline__ long x6_prow(int x, unsigned pmagic) { return PSEUDO ? (long)__umulhi((unsigned)x, pmagic) : (long)x; }
+
 // Wave-uniform choice among the (<= X6_NPW) P rows of a wave's points.  Arguments BY VALUE and selects on values: written
 // as `if (idx == q) dst = arr_q` the compiler turns the phi of loads into a load through a phi of pointers into the lambda
 // closure, which pins the closure AND every captured local (v[], act[], ...) in scratch memory — each access then drags
@@ -159,7 +163,9 @@ __device__ __forceinline__ int x6_scr(int row, int w, int b)
 
 // K16: k == 16 (the benchmark configuration): every wave owns exactly ONE point per tile (see gpe_edgegemm_sr.hip).
 // KCH = K extent in 16-wide chunks (the packed-weight granularity); KS = ceil(KCH / 2) slabs of 32.
-template <class SP, int AQ, int BQ, int KCH, int AMODE, int EMODE, bool K16>
+// PSEUDO: a k > 16 point runs as pseudo-points (RgParams::pmagic != 0) — its own instances, so that the others do not carry the
+// division (the non-k16 gather-backward variants sit at the register limit)
+template <class SP, int AQ, int BQ, int KCH, int AMODE, int EMODE, bool K16, bool PSEUDO = false>
 __global__ __launch_bounds__(256, 1) void gpe_edgegemm_split_kernel(RgParams p, int stats_nblk)
 {
     constexpr int NT = 4 * AQ + BQ;
@@ -353,10 +359,10 @@ __global__ __launch_bounds__(256, 1) void gpe_edgegemm_split_kernel(RgParams p, 
         }
         if (GATHER_ACT) {
             const int pt0 = tile * PT + wave * npw + vz, ptl = tile * PT + ((last * rkl) >> 16);
-            pve0 = ld4(p.pq + (long)((pt0 + 0 < ptl) ? pt0 + 0 : ptl) * p.ldpq + cn);
-            pve1 = ld4(p.pq + (long)((pt0 + 1 < ptl) ? pt0 + 1 : ptl) * p.ldpq + cn);
-            pve2 = ld4(p.pq + (long)((pt0 + 2 < ptl) ? pt0 + 2 : ptl) * p.ldpq + cn);
-            pve3 = ld4(p.pq + (long)((pt0 + 3 < ptl) ? pt0 + 3 : ptl) * p.ldpq + cn);
+            pve0 = ld4(p.pq + x6_prow<PSEUDO>((pt0 + 0 < ptl) ? pt0 + 0 : ptl, p.pmagic) * p.ldpq + cn);
+            pve1 = ld4(p.pq + x6_prow<PSEUDO>((pt0 + 1 < ptl) ? pt0 + 1 : ptl, p.pmagic) * p.ldpq + cn);
+            pve2 = ld4(p.pq + x6_prow<PSEUDO>((pt0 + 2 < ptl) ? pt0 + 2 : ptl, p.pmagic) * p.ldpq + cn);
+            pve3 = ld4(p.pq + x6_prow<PSEUDO>((pt0 + 3 < ptl) ? pt0 + 3 : ptl, p.pmagic) * p.ldpq + cn);
         }
     };
     auto issue_stage_loads = [&](int tile, int h) {
@@ -378,10 +384,10 @@ __global__ __launch_bounds__(256, 1) void gpe_edgegemm_split_kernel(RgParams p, 
         }
         if (AMODE == A_GATHER) {
             const int pt0 = tile * PT + wave * npw + vz, ptl = tile * PT + ((last * rkl) >> 16);
-            pvs0 = ld4(p.pq + (long)((pt0 + 0 < ptl) ? pt0 + 0 : ptl) * p.ldpq + ck);
-            pvs1 = ld4(p.pq + (long)((pt0 + 1 < ptl) ? pt0 + 1 : ptl) * p.ldpq + ck);
-            pvs2 = ld4(p.pq + (long)((pt0 + 2 < ptl) ? pt0 + 2 : ptl) * p.ldpq + ck);
-            pvs3 = ld4(p.pq + (long)((pt0 + 3 < ptl) ? pt0 + 3 : ptl) * p.ldpq + ck);
+            pvs0 = ld4(p.pq + x6_prow<PSEUDO>((pt0 + 0 < ptl) ? pt0 + 0 : ptl, p.pmagic) * p.ldpq + ck);
+            pvs1 = ld4(p.pq + x6_prow<PSEUDO>((pt0 + 1 < ptl) ? pt0 + 1 : ptl, p.pmagic) * p.ldpq + ck);
+            pvs2 = ld4(p.pq + x6_prow<PSEUDO>((pt0 + 2 < ptl) ? pt0 + 2 : ptl, p.pmagic) * p.ldpq + ck);
+            pvs3 = ld4(p.pq + x6_prow<PSEUDO>((pt0 + 3 < ptl) ? pt0 + 3 : ptl, p.pmagic) * p.ldpq + ck);
         }
     };
     // ---- LDS commit of staged row u (compile-time u) ------------------------------------------------------------------
@@ -713,7 +719,7 @@ __global__ __launch_bounds__(256, 1) void gpe_edgegemm_split_kernel(RgParams p, 
 }
 
 // ---------------------------------------------------------------------------------------------------------
-template <class SP, int AQ, int BQ, int KCH, int AMODE, int EMODE, bool K16>
+template <class SP, int AQ, int BQ, int KCH, int AMODE, int EMODE, bool K16, bool PSEUDO = false>
 static int x6_launch_k(const RgParams& p, int stats_nblk, hipStream_t s)
 {
     constexpr int NT = 4 * AQ + BQ;
@@ -721,11 +727,11 @@ static int x6_launch_k(const RgParams& p, int stats_nblk, hipStream_t s)
     constexpr int AWORDS = SP::SCALED ? (2 * RG_BM * 16 * x6_pchunks(KCH)) / 4 : RG_BM * LDA;
     const size_t lds = (size_t)(2 * AWORDS + RG_BM * LDC) * sizeof(float);
     // 16 bytes of static __shared__ (amax_sh) sit beside the dynamic image
-    GPE_ENSURE_MAX_LDS_N((gpe_edgegemm_split_kernel<SP, AQ, BQ, KCH, AMODE, EMODE, K16>), 160 * 1024 - 64);
+    GPE_ENSURE_MAX_LDS_N((gpe_edgegemm_split_kernel<SP, AQ, BQ, KCH, AMODE, EMODE, K16, PSEUDO>), 160 * 1024 - 64);
     int gx = gpe_num_cus();
     if (gx > p.num_tiles) gx = p.num_tiles;
     if (stats_nblk > 0 && gx > stats_nblk) gx = stats_nblk;
-    hipLaunchKernelGGL((gpe_edgegemm_split_kernel<SP, AQ, BQ, KCH, AMODE, EMODE, K16>), dim3(gx), dim3(256), lds, s, p, stats_nblk);
+    hipLaunchKernelGGL((gpe_edgegemm_split_kernel<SP, AQ, BQ, KCH, AMODE, EMODE, K16, PSEUDO>), dim3(gx), dim3(256), lds, s, p, stats_nblk);
     GPE_CHECK_LAUNCH();
     return GPE_OK;
 }
@@ -733,15 +739,23 @@ static int x6_launch_k(const RgParams& p, int stats_nblk, hipStream_t s)
 template <class SP, int AQ, int BQ, int KCH, int AMODE, int EMODE>
 static int x6_launch(const RgParams& p, int stats_nblk, hipStream_t s)
 {
+    if constexpr (EMODE != E_BWD_INPLACE) {          // the in-place backward needs nothing per point: never pseudo-points
+        if (p.pmagic)
+            return p.k == 16 ? x6_launch_k<SP, AQ, BQ, KCH, AMODE, EMODE, true, true>(p, stats_nblk, s)
+                             : x6_launch_k<SP, AQ, BQ, KCH, AMODE, EMODE, false, true>(p, stats_nblk, s);
+    }
     return p.k == 16 ? x6_launch_k<SP, AQ, BQ, KCH, AMODE, EMODE, true>(p, stats_nblk, s)
                      : x6_launch_k<SP, AQ, BQ, KCH, AMODE, EMODE, false>(p, stats_nblk, s);
 }
 
 // Shape checks + re-tiling shared by both policies.  Returns 1 when the shape is on the single-role split kernels' menu (then
-// `p` is the re-tiled copy: every wave owns whole points, R = 4 * npw * k with npw * k <= 16), 0 when it is not.
-static int x6_prepare(const RgParams& p_in, int amode, int emode, int stats_nblk, RgParams& p)
+// `p` is the re-tiled copy: every wave owns whole points, R = 4 * npw * k with npw * k <= 16; `fold` says what to fold after the
+// launch when a k > 16 point ran as pseudo-points), 0 when it is not.
+static int x6_prepare(const RgParams& p_in, int amode, int emode, int stats_nblk, RgParams& p, GpeFold& fold)
 {
     p = p_in;
+    fold = GpeFold{};
+    fold.f = 1;
     if (p.N <= 96 || p.N > 208 || p.K <= 96 || p.K > 208) return 0;
     if (emode != E_EDGE_FWD && (p.N & 3)) return 0;      // the backward epilogues use aligned 16-B coefficient loads
     if (amode == A_GATHER && (p.K & 3)) return 0;
@@ -750,12 +764,9 @@ static int x6_prepare(const RgParams& p_in, int amode, int emode, int stats_nblk
         return 0;                                        // dense rows must be aligned + padded for plain 16-B loads
     if (p.k < 1) return 0;
     const bool per_point = amode == A_GATHER || emode == E_BWD_GATHER || (emode == E_EDGE_FWD && p.agg);
-    if (p.k > X6_PB) {
-        // k > 16: rows that need nothing per point can be tiled any way (4 rows per "point": 64-row tiles); the per-point
-        // variants stay with the exact-fp32 kernel's pseudo-point split (gpe_edgegemm_sr.hip)
-        if (per_point) return 0;
-        p.k = 4;
-    }
+    // k > 16: rows that need nothing per point are tiled 4 rows per "point"; the per-point variants run a point as f pseudo-points
+    // of <= 16 rows whose results are folded afterwards (gpe_edge_pseudo_setup / _fold, gpe_edgegemm_sr.hip)
+    if (!gpe_edge_pseudo_setup(p, per_point, emode, fold)) return 0;
     const int npw = X6_PB / p.k;                         // points per wave per tile
     if (per_point && npw > X6_NPW) return 0;
     p.R = 4 * npw * p.k;

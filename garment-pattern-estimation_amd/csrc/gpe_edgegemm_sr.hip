@@ -74,6 +74,55 @@ __global__ void gpe_sr_fold_sum_kernel(const float* __restrict__ t, long npts, i
     st4(y + pt * ld + c, s);
 }
 
+// Shared by the single-role kernels (exact fp32 here, the split-precision ones of gpe_edgegemm_split_kernel.h): re-tiles a
+// k > 16 launch.  Returns 0 when the shape cannot run that way (the caller falls through to the producer/consumer kernel).
+int gpe_edge_pseudo_setup(RgParams& p, bool per_point, int emode, GpeFold& fd)
+{
+    fd = GpeFold{};
+    fd.f = 1;
+    if (p.k <= SR_PB) return 1;
+    if (!per_point) { p.k = 4; return 1; }
+    const long npts = p.M / p.k;
+    int best = 0;
+    for (int kq = SR_PB; kq >= SR_PB / SR_NPW; --kq)
+        if (p.k % kq == 0 && (SR_PB / kq) * kq > (best ? (SR_PB / best) * best : 0)) best = kq;
+    if (!best || npts * (p.k / best) >= (1L << 31) || (p.oldagg & 3) || (p.lddp & 3)) return 0;
+    fd.f = p.k / best; fd.kq = best; fd.npts = npts;
+    const long nps = npts * fd.f;                                     // pseudo-points
+    const bool want_agg = emode == E_EDGE_FWD && p.agg, want_dp = emode == E_BWD_GATHER;
+    const size_t agg_f = want_agg ? (size_t)nps * p.oldagg : 0, dp_f = want_dp ? (size_t)nps * p.lddp : 0;
+    const size_t bytes = (2 * agg_f + dp_f) * sizeof(float) + 2 * agg_f + 256;
+    char* ws = (bytes > 256) ? (char*)gpe_scratch(0, bytes) : nullptr;
+    if (bytes > 256 && !ws) return 0;                                 // no scratch: the producer/consumer kernel runs it
+    if (want_agg) {
+        fd.mx = p.mx; fd.mn = p.mn; fd.amx = p.oamx; fd.amn = p.oamn;
+        p.mx = (float*)ws; p.mn = p.mx + agg_f;
+        p.oamx = (uint8_t*)(p.mn + agg_f); p.oamn = p.oamx + agg_f;
+    }
+    if (want_dp) { fd.dp = p.dP; p.dP = (float*)ws; }
+    p.k = best;
+    p.pmagic = (unsigned)(((1ull << 32) + fd.f - 1) / fd.f);          // x / f == umulhi(x, pmagic) for x < 2^31 / f
+    return 1;
+}
+
+// after the launch: folds the per-pseudo-point rows of the scratch image into the caller's per-point outputs
+int gpe_edge_pseudo_fold(const RgParams& p, const GpeFold& fd, hipStream_t s)
+{
+    if (fd.f <= 1) return GPE_OK;
+    const long th = fd.npts * ((p.N + 3) >> 2);
+    if (fd.mx) {
+        hipLaunchKernelGGL(gpe_sr_fold_agg_kernel, dim3((unsigned)gpe_cdiv(th, 256)), dim3(256), 0, s, p.mx, p.mn, p.oamx, p.oamn,
+                           fd.npts, fd.f, fd.kq, p.N, p.oldagg, fd.mx, fd.mn, fd.amx, fd.amn);
+        GPE_CHECK_LAUNCH();
+    }
+    if (fd.dp) {
+        hipLaunchKernelGGL(gpe_sr_fold_sum_kernel, dim3((unsigned)gpe_cdiv(th, 256)), dim3(256), 0, s, p.dP, fd.npts, fd.f, p.N,
+                           p.lddp, fd.dp);
+        GPE_CHECK_LAUNCH();
+    }
+    return GPE_OK;
+}
+
 // Returns 1 and launches when the shape is on this kernel's menu, 0 when the caller should try the next kernel,
 // < 0 on a launch error.  `p` comes with the generic tiling (R = (64/k)*k); this kernel re-tiles so that every wave
 // owns whole points: R = 4 * npw * k with npw * k <= 16.
@@ -90,34 +139,8 @@ int gpe_edgegemm_sr_try(const RgParams& p_in, int amode, int emode, int stats_nb
     const bool per_point = amode == A_GATHER || emode == E_BWD_GATHER || (emode == E_EDGE_FWD && p.agg);
     // k > 16: rows that need nothing per point can be tiled any way (4 rows per "point": 64-row tiles); the per-point
     // variants split a point into f pseudo-points of kq rows and fold the per-pseudo-point results afterwards
-    int fold_f = 1, fold_kq = 0;
-    float *fold_mx = nullptr, *fold_mn = nullptr, *fold_dp = nullptr;
-    uint8_t *fold_amx = nullptr, *fold_amn = nullptr;
-    const long npts = p.M / p.k;
-    if (p.k > SR_PB) {
-        if (!per_point) p.k = 4;
-        else {
-            int best = 0;
-            for (int kq = SR_PB; kq >= SR_PB / SR_NPW; --kq)
-                if (p.k % kq == 0 && (SR_PB / kq) * kq > (best ? (SR_PB / best) * best : 0)) best = kq;
-            if (!best || npts * (p.k / best) >= (1L << 31) || (p.oldagg & 3) || (p.lddp & 3)) return 0;
-            fold_f = p.k / best; fold_kq = best;
-            const long nps = npts * fold_f;                               // pseudo-points
-            const bool want_agg = emode == E_EDGE_FWD && p.agg, want_dp = emode == E_BWD_GATHER;
-            const size_t agg_f = want_agg ? (size_t)nps * p.oldagg : 0, dp_f = want_dp ? (size_t)nps * p.lddp : 0;
-            const size_t bytes = (2 * agg_f + dp_f) * sizeof(float) + 2 * agg_f + 256;
-            char* ws = (bytes > 256) ? (char*)gpe_scratch(0, bytes) : nullptr;
-            if (bytes > 256 && !ws) return 0;                             // no scratch: the producer/consumer kernel runs it
-            if (want_agg) {
-                fold_mx = p.mx; fold_mn = p.mn; fold_amx = p.oamx; fold_amn = p.oamn;
-                p.mx = (float*)ws; p.mn = p.mx + agg_f;
-                p.oamx = (uint8_t*)(p.mn + agg_f); p.oamn = p.oamx + agg_f;
-            }
-            if (want_dp) { fold_dp = p.dP; p.dP = (float*)ws; }
-            p.k = best;
-            p.pmagic = (unsigned)(((1ull << 32) + fold_f - 1) / fold_f);  // x / f == umulhi(x, pmagic) for x < 2^31 / f
-        }
-    }
+    GpeFold fold;
+    if (!gpe_edge_pseudo_setup(p, per_point, emode, fold)) return 0;
     const int npw = SR_PB / p.k;                         // points per wave per tile
     if (per_point && npw > SR_NPW) return 0;
     p.R = 4 * npw * p.k;
@@ -143,19 +166,6 @@ int gpe_edgegemm_sr_try(const RgParams& p_in, int amode, int emode, int stats_nb
         rc = gpe_sr_dispatch_dense(emode, NT, KCH, p, stats_nblk, s);
     else if (amode == A_DENSE && emode == E_BWD_GATHER) rc = sr_dispatch<A_DENSE, E_BWD_GATHER>(NT, KCH, p, stats_nblk, s);
     if (rc == GPE_ENOTSUP_SHAPE) return 0;
-    if (rc == GPE_OK && fold_f > 1) {
-        if (fold_mx) {
-            const long th = npts * ((p.N + 3) >> 2);
-            hipLaunchKernelGGL(gpe_sr_fold_agg_kernel, dim3((unsigned)gpe_cdiv(th, 256)), dim3(256), 0, s, p.mx, p.mn, p.oamx, p.oamn,
-                               npts, fold_f, fold_kq, p.N, p.oldagg, fold_mx, fold_mn, fold_amx, fold_amn);
-            GPE_CHECK_LAUNCH();
-        }
-        if (fold_dp) {
-            const long th = npts * ((p.N + 3) >> 2);
-            hipLaunchKernelGGL(gpe_sr_fold_sum_kernel, dim3((unsigned)gpe_cdiv(th, 256)), dim3(256), 0, s, p.dP, npts, fold_f, p.N,
-                               p.lddp, fold_dp);
-            GPE_CHECK_LAUNCH();
-        }
-    }
+    if (rc == GPE_OK) rc = gpe_edge_pseudo_fold(p, fold, s);
     return rc == GPE_OK ? 1 : rc;
 }

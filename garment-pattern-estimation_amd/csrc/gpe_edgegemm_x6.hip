@@ -18,7 +18,8 @@ static int x6_dispatch(int NT, int KCH, const RgParams& p, int stats_nblk, hipSt
 int gpe_edgegemm_x6_try(const RgParams& p_in, int amode, int emode, int stats_nblk, hipStream_t s)
 {
     RgParams p;
-    if (!x6_prepare(p_in, amode, emode, stats_nblk, p)) return 0;
+    GpeFold fold;
+    if (!x6_prepare(p_in, amode, emode, stats_nblk, p, fold)) return 0;
     const int NT = (p.N <= 160) ? 10 : 13;
     const int KCH = (p.K <= 160) ? 10 : 13;
     int rc = GPE_EINVAL;
@@ -27,5 +28,6 @@ int gpe_edgegemm_x6_try(const RgParams& p_in, int amode, int emode, int stats_nb
     else if (amode == A_DENSE && emode == E_BWD_INPLACE) rc = x6_dispatch<A_DENSE, E_BWD_INPLACE>(NT, KCH, p, stats_nblk, s);
     else if (amode == A_DENSE && emode == E_BWD_GATHER) rc = x6_dispatch<A_DENSE, E_BWD_GATHER>(NT, KCH, p, stats_nblk, s);
     if (rc == GPE_ENOTSUP_SHAPE) return 0;
+    if (rc == GPE_OK) rc = gpe_edge_pseudo_fold(p, fold, s);
     return rc == GPE_OK ? 1 : rc;
 }

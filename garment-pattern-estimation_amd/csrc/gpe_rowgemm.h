@@ -48,6 +48,16 @@ struct RgParams {
     unsigned* amax_out;
 };
 
+// k > 16 on the single-role kernels (gpe_edgegemm_sr.hip): what gpe_edge_pseudo_setup redirected to scratch, for the fold
+struct GpeFold {
+    int f, kq;              // pseudo-points per point (1 = nothing to fold), rows per pseudo-point
+    long npts;
+    float *mx, *mn, *dp;    // the caller's per-point outputs (NULL = not redirected)
+    uint8_t *amx, *amn;
+};
+int gpe_edge_pseudo_setup(RgParams& p, bool per_point, int emode, GpeFold& fd);
+int gpe_edge_pseudo_fold(const RgParams& p, const GpeFold& fd, hipStream_t s);
+
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 // streaming 16-B store that does NOT keep its line in the XCD's L2 (sc1: write-through + drop, MI355X_MICROARCH.md "stores of
