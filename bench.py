@@ -124,13 +124,13 @@ _TRAFFIC_KERNELS = {
     # template tails: rowgemm <NT, AMODE, EMODE>; edgegemm (paired) <.., AMODE, EMODE, MATH>; edgegemm_sr <.., AMODE, EMODE, KC, HALF>
     # split <Policy, AQ, BQ, KCH, AMODE, EMODE, K16>
     'gpe_edge_mlp_fwd': r'gpe_rowgemm_kernel<.*, 1>$|gpe_edgegemm(_sr)?_kernel<\d+, \d+, \d+, \d+, 1(, [-\w]+)+>$'
-                        r'|gpe_edgegemm_split_kernel<\w+, \d+, \d+, \d+, \d+, 1, \w+>$',
+                        r'|gpe_edgegemm_split_kernel<\w+, \d+, \d+, \d+, \d+, 1(, \w+)+>$',
     'gpe_edge_mlp_bwd': r'gpe_rowgemm_kernel<.*, [23]>$|gpe_edgegemm(_sr)?_kernel<\d+, \d+, \d+, \d+, [23](, [-\w]+)+>$'
-                        r'|gpe_edgegemm_split_kernel<\w+, \d+, \d+, \d+, \d+, [23], \w+>$',
+                        r'|gpe_edgegemm_split_kernel<\w+, \d+, \d+, \d+, \d+, [23](, \w+)+>$',
     'gpe_edge_redgemm': r'gpe_redgemm_pc_kernel<|gpe_redgemm_b3_kernel<',
     'gpe_edge_gather_stats': r'gpe_gather_stats_kernel',
     # AMODE = A_GATHER, EMODE = fwd
-    'gpe_edge_mlp_fwd:gather': r'gpe_edgegemm(_sr)?_kernel<\d+, \d+, \d+, 1, 1(, [-\w]+)+>$|gpe_edgegemm_split_kernel<\w+, \d+, \d+, \d+, 1, 1, \w+>$',
+    'gpe_edge_mlp_fwd:gather': r'gpe_edgegemm(_sr)?_kernel<\d+, \d+, \d+, 1, 1(, [-\w]+)+>$|gpe_edgegemm_split_kernel<\w+, \d+, \d+, \d+, 1, 1(, \w+)+>$',
     'gpe_knn': r'gpe_knn_kernel',
     'gpe_edge_pull_dq': r'gpe_pull_dq_kernel',
 }
@@ -182,7 +182,7 @@ def _workload_name(args):
     # edge kernel is >= 1.7x away from its HBM bound (DESIGN.md section 8, row g), so they would not shorten the step
     arith = {'f32': 'exact fp32 MFMA arithmetic',
              'f16x3': 'fp32-grade arithmetic: edge-GEMM products as 3 fp16 MFMAs on tensor-normalised two-term splits, fp32 '
-                      'accumulate (parity-grade: the exact mode\'s test bars)'}.get(args.math, 'APPROXIMATE arithmetic (%s)' % args.math)
+                      'accumulate (parity-grade: the exact mode\'s test bars)'}.get(getattr(args, 'math', 'f16x3'), 'APPROXIMATE arithmetic (%s)' % getattr(args, 'math', '?'))
     return '%s: %s, N=%d, batch %d/GPU, k=%d; fp32 storage, %s (the half-precision STORAGE the config names ' \
            'is not built: measured not worthwhile, DESIGN.md 8)' % (named.get(shape, 'custom shape'), model, args.points,
                                                                     args.batch, args.k, arith)
