@@ -11,10 +11,15 @@
  *     passes; work is enqueued on `stream` of the CURRENT device and the call returns immediately;
  *     process-global state is limited to (a) the arithmetic mode (gpe_math_set) and the profiling switches
  *     (gpe_debug_set), which apply to every stream and device of the process, (b) per-device caches of the
- *     CU count and of the >64 KB LDS opt-in (hipFuncSetAttribute), keyed by device ordinal, and (c) two grow-only
+ *     CU count and of the >64 KB LDS opt-in (hipFuncSetAttribute), keyed by device ordinal, (c) four grow-only
  *     per-device scratch images (hipMalloc on first use / growth, never shared between streams by the library:
  *     use ONE stream per device for these calls): the per-pseudo-point rows of gpe_edge_mlp_fwd / _bwd when
- *     k > 16, and the partial k-lists of gpe_knn when it splits the candidate range (large clouds);
+ *     k > 16, the partial k-lists of gpe_knn when it splits the candidate range (large clouds), the dummy store image
+ *     of the straight-line edge kernels and the operand-scale slots of the f16x3 mode, and (d) in f16x3 mode only
+ *     (gpe_math_set(4)): one pending producer note and a table of <= 8 kept forward maxima — host-side records
+ *     (pointer, shape, slot) of tensors whose largest magnitude a kernel of this library measured while writing them;
+ *     cleared by gpe_math_set, see mode 4 below for the one rule they impose on a caller.  Not thread-safe: one host
+ *     thread per process drives the library;
  *   - return 0 on success, -22 (EINVAL) on bad arguments, -5 (EIO) if the launch failed;
  *   - fp32 storage and arithmetic unless stated; matrix products run on v_mfma_f32_16x16x4_f32 (exact fp32);
  *     BatchNorm statistics are accumulated in fp64;
