@@ -67,15 +67,25 @@ MATH_MODES = {'f32': 0, 'bf16x3': 1, 'mixed': 2, 'bf16x6': 3, 'f16x3': 4}
 
 
 def set_math(mode):
-    """Arithmetic of the fused per-edge GEMMs: 'f32' (exact fp32 MFMA), 'bf16x3' (split-bf16 on the bf16 matrix
-    pipe, fp32 accumulate) or 'mixed' (split-bf16 row GEMMs, exact-fp32 weight-gradient reduce-GEMM) — include/gpe_hip.h gpe_math_set.  Returns the previous mode's name.  The environment
-    variable GPE_MATH selects the mode at library load."""
+    """Arithmetic of the fused per-edge GEMMs (include/gpe_hip.h gpe_math_set): 'f32' exact fp32 MFMA (library default);
+    'f16x3' two-term fp16 split on tensor-normalised operands, three fp16 MFMAs per product, fp32 accumulate — parity-grade, the
+    mode bench.py times; 'bf16x6' three-term bf16 split (parity-grade, superseded); 'bf16x3' / 'mixed' two-term bf16 splits
+    (approximate).  Returns the previous mode's name.  The environment variable GPE_MATH selects the mode at library load."""
     if mode not in MATH_MODES:
         raise ValueError('unknown math mode %r (choose from %s)' % (mode, sorted(MATH_MODES)))
     prev = lib().gpe_math_set(MATH_MODES[mode])
     if prev < 0:
         raise RuntimeError('gpe_math_set failed with code %d' % prev)
     return {v: k for k, v in MATH_MODES.items()}[prev]
+
+
+def set_f16x3_min_rows(rows):
+    """Size gate of the f16x3 mode: edge launches with fewer rows run the exact fp32 kernels (default 65536; 0 = always use the
+    fp16 pipe, which is what the parity tests of small fixtures set).  Returns the previous value."""
+    prev = lib().gpe_f16x3_min_rows_set(int(rows))
+    if prev < 0:
+        raise RuntimeError('gpe_f16x3_min_rows_set failed with code %d' % prev)
+    return prev
 
 
 def get_math():
@@ -95,16 +105,6 @@ def _conv(a):
 TIMING = None
 
 
-# One kernel stream per device.  The library keeps a little per-DEVICE state next to the process-global arithmetic mode — the
-# grow-only scratch images of include/gpe_hip.h (kNN candidate lists, pseudo-point folds, the edge kernels' dummy image) — so
-# two streams of one device running the path concurrently would share them.  The first stream that launches on a device
-# becomes that device's kernel stream; a launch from another stream raises instead of racing.  (Copy-only side streams —
-# staging.BatchStager, the start-state uploader — never come through here.)  GPE_MULTI_STREAM=1 lifts the check for callers
-# that serialise their streams themselves.
-_KERNEL_STREAM = {}
-_MULTI_STREAM_OK = os.environ.get('GPE_MULTI_STREAM') == '1'
-
-
 def call(name, *args):
     """Invoke a C-ABI entry point on torch's current HIP stream (appended as the trailing `stream` argument)."""
     fn = getattr(lib(), name)
@@ -119,10 +119,6 @@ def call(name, *args):
                                    % (name, a.device, cur))
             break
     stream = torch.cuda.current_stream()
-    if _KERNEL_STREAM.setdefault(cur, stream.cuda_stream) != stream.cuda_stream and not _MULTI_STREAM_OK:
-        raise RuntimeError('%s: launched from a second stream of cuda:%d — the library keeps per-device scratch images, so one '
-                           'process drives ONE kernel stream per device (set GPE_MULTI_STREAM=1 if you serialise the streams '
-                           'yourself)' % (name, cur))
     if TIMING is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(stream)

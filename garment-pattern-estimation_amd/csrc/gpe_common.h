@@ -71,27 +71,41 @@ __device__ __forceinline__ unsigned gpe_udiv(unsigned n, unsigned d, double rcp)
 
 // compute units of the CURRENT device (cached per device ordinal); defined in gpe_pointwise.hip
 int gpe_num_cus();
-// grow-only device scratch of the CURRENT device, one image per `slot` (0: edge-kernel fold inputs, 1: kNN lists / norms,
-// 2: the dummy store image of the straight-line edge kernels);
-// nullptr when the allocation fails.  hipFree synchronises the device, so regrowing is safe.  Defined in gpe_pointwise.hip.
-void* gpe_scratch(int slot, size_t bytes);
-// f16x3 mode (gpe_edgegemm_h3.hip): a kernel that wrote an activation / dz tensor may leave a NOTE with the tensor's largest
-// magnitude for the next edge GEMM.  Every C-ABI entry that writes caller tensors — other than the statistics / weight-packing /
-// reduce-GEMM calls that sit between two edge GEMMs of a layer — opens with GPE_WRITES_TENSORS(), which drops a pending note:
-// a note can only describe a tensor no library call has touched since it was written.
-void gpe_h3_note_drop();
-// drops a pending note; in f16x3 mode returns a cleared device slot to atomicMax the largest magnitude written to `ptr`
-// ([rows][cols], pitch ld) into, and records the note; NULL in every other mode
-unsigned* gpe_h3_note_begin(const void* ptr, long rows, int cols, long ld, hipStream_t s);
-#define GPE_WRITES_TENSORS() gpe_h3_note_drop()
-// the pending note's slot when it describes exactly this tensor, else NULL (the note stays: the edge GEMM after the
-// weight-gradient reduce-GEMM still consumes it)
-const unsigned* gpe_h3_note_peek(const void* ptr, long rows, int cols, long ld);
-// largest magnitude of a FORWARD activation an f16x3 edge kernel wrote (kept until a library call overwrites the tensor or
-// its slot is recycled), else NULL — the dense V operand of the weight-gradient reduce-GEMM
-const unsigned* gpe_h3_fwd_lookup(const void* ptr, long rows, int cols, long ld);
-// bound of relu(P_i + Q_j) over a [rows][>= 2H] table: launches the passes on `s`, returns the device slot (NULL: no scratch)
-const unsigned* gpe_h3_pq_bound(const float* pq, long rows, int H, long ld, hipStream_t s);
+// ---- caller-owned workspace of the edge entry points (gpe_edge_mlp_fwd / _bwd / gpe_edge_redgemm / gpe_edge_pq_amax) -----------
+// The library allocates nothing: a caller passes `ws` of gpe_edge_ws_bytes(...) bytes (16-B aligned) and the entry point carves
+//   [0, GPE_WS_DUMMY_BYTES)   the dummy store image of the straight-line edge kernels (64 rows x 512 floats; written, never read)
+//   [.., + GPE_WS_H3_BYTES)   f16x3: word 0 = A-operand amax measured in-call, word 1 = packed-weight amax, then the partial
+//                             maxima of the gather-bound pass
+//   the rest                  per-pseudo-point rows of a k > 16 launch (folded after the kernel)
+// Two calls may run concurrently on different streams as long as they do not share a workspace.  NULL / too small: the entry
+// point runs the variants that need none (slower), never an error.
+#define GPE_WS_DUMMY_BYTES (64 * 512 * 4)
+#define GPE_WS_H3_PARTS 1024                         // workgroups (= partial maxima pairs) of the gather-bound pass
+#define GPE_WS_H3_BYTES (((2 + 2 * GPE_WS_H3_PARTS) * 4 + 255) & ~255)
+struct GpeEdgeWs { float* dummy; unsigned* h3; char* pseudo; size_t pseudo_bytes; };
+static inline GpeEdgeWs gpe_edge_ws(void* ws, long bytes)
+{
+    GpeEdgeWs o = {nullptr, nullptr, nullptr, 0};
+    if (!ws || (((uintptr_t)ws) & 15) || bytes < (long)(GPE_WS_DUMMY_BYTES + GPE_WS_H3_BYTES)) return o;
+    char* b = static_cast<char*>(ws);
+    o.dummy = reinterpret_cast<float*>(b);
+    o.h3 = reinterpret_cast<unsigned*>(b + GPE_WS_DUMMY_BYTES);
+    o.pseudo = b + GPE_WS_DUMMY_BYTES + GPE_WS_H3_BYTES;
+    o.pseudo_bytes = (size_t)bytes - (GPE_WS_DUMMY_BYTES + GPE_WS_H3_BYTES);
+    return o;
+}
+// f16x3 mode (gpe_edgegemm_h3.hip).  Operand scales come from "amax words": device words holding the bit pattern of a
+// non-negative float >= the largest magnitude of a tensor.  They are CALLER-OWNED: an entry point that writes an activation /
+// dz tensor fills the word the caller passes as `amax_out`, the entry point that consumes the tensor takes it as `amax_a` /
+// `amax_u` / `amax_v`.  The library keeps no record of tensors.
+// bound of relu(P_i + Q_j) over a [rows][>= 2H] table -> out[0]; part = 2 * GPE_WS_H3_PARTS floats of workspace
+int gpe_h3_pq_passes(unsigned* out, float* part, const float* pq, long rows, int H, long ld, hipStream_t s);
+// largest |x| over [rows][cols] (pitch ld) -> out[0] (cleared first, on the stream)
+int gpe_h3_absmax(unsigned* out, const float* x, long rows, int cols, long ld, hipStream_t s);
+// rows below which the f16x3 kernels are not used (their scale passes cost more than they save at small E); part of the
+// arithmetic mode: gpe_f16x3_min_rows_set (gpe_rowgemm.hip)
+#define GPE_H3_MIN_ROWS_DEFAULT 65536
+long gpe_h3_min_rows();
 // power of two that brings a tensor whose largest magnitude has the bit pattern `amax` into [2^14, 2^15), and its inverse.
 // The exponent is clamped to +-100 (tensors below 2^-86 lose relative precision gracefully), zero / non-finite -> 1.
 __device__ __forceinline__ void gpe_h3_scale_of(unsigned amax, float& s, float& inv)

@@ -3,19 +3,16 @@
 // is never the limit.  Two planes of a 200 x 200 weight take 184 of a wave's 256 accumulation registers, so — unlike the
 // three-plane bf16 policy — every shape of the shipped edge MLPs (10 / 13 output tiles x 10 / 13 K chunks) fits.
 //
-// The largest magnitudes behind the scales are measured ON THE DEVICE, in front of the GEMM, on the same stream:
-//   * packed weight: one-workgroup pass over its 16 KCH x Npad floats (a few microseconds);
-//   * dense A operand: a streaming |x| max over its rows — unless the kernel that produced the tensor left a NOTE: the split
-//     kernels (forward activations, in-place dz) and gpe_edge_dz3 track the largest magnitude they write, and the next edge
-//     GEMM picks the note up when pointer, rows and pitch match.  A note lives from the call that wrote the tensor to the next
-//     gpe_edge_mlp_fwd / gpe_edge_mlp_bwd / gpe_edge_dz3 call on the device, which drops it whatever kernel it runs;
-//   * gathered A operand relu(P_i + Q_j): the bound max(P) + max(Q) from one pass over the per-point [P|Q] table.
-// Slot ring in scratch image 3: [0] A operand, [1] weight, [2..] notes.
+// The largest magnitudes behind the scales are measured ON THE DEVICE, on the launch stream, and live in CALLER-OWNED words
+// (include/gpe_hip.h "amax words"): the library keeps no record of tensors.
+//   * packed weight: one-workgroup pass over its 16 KCH x Npad floats (a few microseconds) -> workspace word 1;
+//   * dense A operand: the caller's `amax_a` word — filled by the entry point that wrote the tensor (the split kernels track the
+//     largest magnitude they store, gpe_edge_dz3 likewise) — or, when the caller passes none, a streaming |x| max -> word 0;
+//   * gathered A operand relu(P_i + Q_j): the caller's `amax_a` (gpe_edge_pq_amax) or the bound max(P) + max(Q) from one pass
+//     over the per-point [P|Q] table -> word 0.
 #include "gpe_edgegemm_split_kernel.h"
 
-#define H3_RING 64
-#define H3_KEEP 8
-#define H3_PQ_BLOCKS 1024        // workgroups (= partial maxima) of the gather-bound pass
+#define H3_PQ_BLOCKS GPE_WS_H3_PARTS
 
 // largest |x| over rows x cols (row pitch ld), as the bit pattern of a non-negative float (orders like the float; NaN > inf)
 __global__ __launch_bounds__(256) void gpe_h3_absmax_kernel(const float* __restrict__ x, long rows, int cols4, long ld,
@@ -81,10 +78,10 @@ __global__ __launch_bounds__(256) void gpe_h3_pqmax_kernel(const float* __restri
     }
 }
 
-// one workgroup: the packed weight's largest magnitude -> slots[1]; clears slots[0] (the A-operand slot the multi-workgroup
-// passes accumulate into) and the note slot the coming launch will write
+// one workgroup: the packed weight's largest magnitude -> slots[1]; clears slots[0] (the A-operand word the multi-workgroup
+// pass accumulates into) and the caller's output word the coming launch will atomicMax into
 __global__ __launch_bounds__(1024) void gpe_h3_wmax_kernel(const float* __restrict__ w, long n, unsigned* __restrict__ slots,
-                                                           int clear_note)
+                                                           unsigned* __restrict__ clear_word)
 {
     __shared__ unsigned red[16];
     unsigned m = 0u;
@@ -103,7 +100,7 @@ __global__ __launch_bounds__(1024) void gpe_h3_wmax_kernel(const float* __restri
         for (int i = 1; i < 16; ++i) m = m > red[i] ? m : red[i];
         slots[1] = m;
         slots[0] = 0u;
-        if (clear_note >= 0) slots[2 + clear_note] = 0u;
+        if (clear_word) clear_word[0] = 0u;
     }
 }
 
@@ -127,68 +124,31 @@ __global__ __launch_bounds__(256) void gpe_h3_pqfinish_kernel(const float* __res
     }
 }
 
-// ---- producer notes ------------------------------------------------------------------------------------------------------
-struct H3Note { const void* ptr; long rows; long ld; int cols; int slot; int dev; };
-static H3Note g_note = {nullptr, 0, 0, 0, -1, -1};
-static int g_ring_next = 0;
-
-void gpe_h3_note_drop() { g_note.ptr = nullptr; }
-const unsigned* gpe_h3_note_peek(const void* ptr, long rows, int cols, long ld);
-
-// forward activations written by an f16x3 edge kernel, kept beyond the next edge GEMM for the weight-gradient reduce-GEMM of
-// the backward pass (its dense V operand).  An entry dies when a library call overwrites the tensor (edge GEMM output, dz3 in
-// place), when its ring slot is about to be recycled (seq distance), or with the mode.
-struct H3Keep { const void* ptr; long rows; long ld; int cols; int slot; int dev; unsigned long seq; };
-static H3Keep g_keep[H3_KEEP] = {};
-static unsigned long g_seq = 0;                      // ring slots handed out so far
-static int g_keep_next = 0;
-static void h3_keep_kill(const void* ptr)
+// the two passes of the gather bound, on stream s -> out[0]
+int gpe_h3_pq_passes(unsigned* out, float* part, const float* pq, long rows, int H, long ld, hipStream_t s)
 {
-    for (int i = 0; i < H3_KEEP; ++i) if (g_keep[i].ptr == ptr) g_keep[i].ptr = nullptr;
-}
-static void h3_keep_add(const H3Keep& k)
-{
-    h3_keep_kill(k.ptr);
-    g_keep[g_keep_next] = k;
-    g_keep_next = (g_keep_next + 1) % H3_KEEP;
-}
-static unsigned* h3_slots() { return static_cast<unsigned*>(gpe_scratch(3, (2 + H3_RING + 2 * H3_PQ_BLOCKS) * sizeof(unsigned))); }
-// the two passes of the gather bound, on stream s -> slots[0]
-static int h3_pq_passes(unsigned* slots, const float* pq, long rows, int H, long ld, hipStream_t s)
-{
-    float* part = reinterpret_cast<float*>(slots + 2 + H3_RING);
+    if (!out || !part || (H & 3)) return GPE_EINVAL;
     int gx = (int)((rows + 3) / 4);
     if (gx > H3_PQ_BLOCKS) gx = H3_PQ_BLOCKS;
     hipLaunchKernelGGL(gpe_h3_pqmax_kernel, dim3(gx), dim3(256), 0, s, pq, rows, H, ld, part);
     GPE_CHECK_LAUNCH();
-    hipLaunchKernelGGL(gpe_h3_pqfinish_kernel, dim3(1), dim3(256), 0, s, part, gx, slots);
+    hipLaunchKernelGGL(gpe_h3_pqfinish_kernel, dim3(1), dim3(256), 0, s, part, gx, out);
     GPE_CHECK_LAUNCH();
     return GPE_OK;
 }
-// for producers outside this file (gpe_edge_dz3): a cleared ring slot to atomicMax into + the note that goes with it.
-// Returns NULL when the f16x3 mode is off (the caller then skips the tracking).
-static int g_h3_on = 0;
-void gpe_h3_enable(int on)
+int gpe_h3_absmax(unsigned* out, const float* x, long rows, int cols, long ld, hipStream_t s)
 {
-    g_h3_on = on;
-    gpe_h3_note_drop();
-    for (int i = 0; i < H3_KEEP; ++i) g_keep[i].ptr = nullptr;
-}
-unsigned* gpe_h3_note_begin(const void* ptr, long rows, int cols, long ld, hipStream_t s)
-{
-    gpe_h3_note_drop();
-    if (!g_h3_on) return nullptr;
-    h3_keep_kill(ptr);
-    unsigned* slots = h3_slots();
-    if (!slots) return nullptr;
-    const int slot = g_ring_next;
-    g_ring_next = (g_ring_next + 1) % H3_RING;
-    ++g_seq;
-    if (hipMemsetAsync(slots + 2 + slot, 0, sizeof(unsigned), s) != hipSuccess) return nullptr;
-    int dev = -1;
-    (void)hipGetDevice(&dev);
-    g_note = {ptr, rows, ld, cols, slot, dev};
-    return slots + 2 + slot;
+    if (!out || !x) return GPE_EINVAL;
+    if (hipMemsetAsync(out, 0, sizeof(unsigned), s) != hipSuccess) return GPE_ELAUNCH;
+    const int cols4 = (cols + 3) >> 2;
+    const long total = rows * cols4;
+    if (total <= 0) return GPE_OK;
+    int gx = (int)((total + 255) / 256);
+    const int cap = gpe_num_cus() * 8;
+    if (gx > cap) gx = cap;
+    hipLaunchKernelGGL(gpe_h3_absmax_kernel, dim3(gx), dim3(256), 0, s, x, rows, cols4, ld, out);
+    GPE_CHECK_LAUNCH();
+    return GPE_OK;
 }
 
 template <int AMODE, int EMODE>
@@ -202,42 +162,33 @@ static int h3_dispatch(int NT, int KCH, const RgParams& p, int stats_nblk, hipSt
 }
 
 // Returns 1 and launches when the shape is on this kernel's menu, 0 when the caller should try the next kernel,
-// < 0 on a launch error.
+// < 0 on a launch error.  Needs the f16x3 words of the caller's workspace; without them (or below gpe_h3_min_rows() rows, where the
+// scale passes cost more than the kernel saves) the exact kernels run.
 int gpe_edgegemm_h3_try(const RgParams& p_in, int amode, int emode, int stats_nblk, hipStream_t s)
 {
-    // whatever happens next, the tensor a pending note describes may be overwritten by this call
-    const H3Note note = g_note;
-    gpe_h3_note_drop();
-    h3_keep_kill(p_in.out);
+    unsigned* slots = p_in.ws.h3;
+    if (!slots || p_in.M < gpe_h3_min_rows()) return 0;
     RgParams p;
     GpeFold fold;
     if (!x6_prepare(p_in, amode, emode, stats_nblk, p, fold)) return 0;
     const long npts = p_in.k > 0 ? p_in.M / p_in.k : 0;   // rows of the per-point table (p.k may now count pseudo-point rows)
     const int NT = (p.N <= 160) ? 10 : 13;
     const int KCH = (p.K <= 160) ? 10 : 13;
-    unsigned* slots = h3_slots();
-    if (!slots) return GPE_EINVAL;
-    int dev = -1;
-    (void)hipGetDevice(&dev);
+    if (amode == A_GATHER && !p.user_amax_a && (p.H & 3)) return 0;
 
-    // does this launch write a tensor the next edge GEMM reads as its A operand?  forward activations, in-place dz
-    const bool notes = emode == E_EDGE_FWD || emode == E_BWD_INPLACE;
-    int out_slot = -1;
-    if (notes) { out_slot = g_ring_next; g_ring_next = (g_ring_next + 1) % H3_RING; ++g_seq; }
-    // a note is usable when it describes exactly this A operand (and its ring slot is not the one being recycled)
-    const bool have_note = amode == A_DENSE && note.ptr == (const void*)p.a.base && note.rows == p.M && note.ld == p.a.stride_outer &&
-                           note.cols == p.K && note.dev == dev && note.slot >= 0 && note.slot != out_slot;
-
+    // the largest magnitude this launch writes to `out` (forward activations, in-place dz: tensors the next edge GEMM reads as
+    // its A operand) goes to the caller's word; the gathered backward writes dz of block 0, which no GEMM of this library reads
+    const bool tracks = emode == E_EDGE_FWD || emode == E_BWD_INPLACE;
     const bool reuse = (p.dbg & 128) != 0;                // profiling only: keep the scales of the previous launch (no passes)
     const long wn = (long)16 * KCH * p.Npad;              // the packed weight: 4 KCH k-quads x Npad columns x 4 (gpe_packed_size)
     if (!reuse) {
-        hipLaunchKernelGGL(gpe_h3_wmax_kernel, dim3(1), dim3(1024), 0, s, p.wp, wn, slots, out_slot);
+        hipLaunchKernelGGL(gpe_h3_wmax_kernel, dim3(1), dim3(1024), 0, s, p.wp, wn, slots, tracks ? p.user_amax_out : nullptr);
         GPE_CHECK_LAUNCH();
     }
     if (reuse) {
         p.h3_amax_a = slots;
-    } else if (have_note) {
-        p.h3_amax_a = slots + 2 + note.slot;
+    } else if (p.user_amax_a) {
+        p.h3_amax_a = p.user_amax_a;
     } else if (amode == A_DENSE) {
         const int cols4 = (p.K + 3) >> 2;
         const long total = p.M * cols4;
@@ -248,13 +199,13 @@ int gpe_edgegemm_h3_try(const RgParams& p_in, int amode, int emode, int stats_nb
         GPE_CHECK_LAUNCH();
         p.h3_amax_a = slots;
     } else {
-        if (p.H & 3) return 0;
-        const int rc_pq = h3_pq_passes(slots, p.pq, npts, p.H, (long)p.ldpq, s);   // the per-point table behind the gathered operand
+        // the per-point table behind the gathered operand
+        const int rc_pq = gpe_h3_pq_passes(slots, reinterpret_cast<float*>(slots + 2), p.pq, npts, p.H, (long)p.ldpq, s);
         if (rc_pq != GPE_OK) return rc_pq;
         p.h3_amax_a = slots;
     }
     p.h3_amax_w = slots + 1;
-    p.amax_out = notes ? slots + 2 + out_slot : nullptr;
+    p.amax_out = tracks ? p.user_amax_out : nullptr;
 
     int rc = GPE_EINVAL;
     if (amode == A_GATHER && emode == E_EDGE_FWD) rc = h3_dispatch<A_GATHER, E_EDGE_FWD>(NT, KCH, p, stats_nblk, s);
@@ -264,42 +215,6 @@ int gpe_edgegemm_h3_try(const RgParams& p_in, int amode, int emode, int stats_nb
     if (rc == GPE_ENOTSUP_SHAPE) return 0;
     if (rc == GPE_OK) rc = gpe_edge_pseudo_fold(p, fold, s);
     if (rc != GPE_OK) return rc;
-    if (notes) g_note = {p.out, p.M, (long)p.ldo, p.N, out_slot, dev};
-    if (emode == E_EDGE_FWD) h3_keep_add(H3Keep{p.out, p.M, (long)p.ldo, p.N, out_slot, dev, g_seq});
+    if (tracks && p_in.user_amax_out && p_in.tracked) *p_in.tracked = 1;
     return 1;
-}
-
-const unsigned* gpe_h3_note_peek(const void* ptr, long rows, int cols, long ld)
-{
-    int dev = -1;
-    (void)hipGetDevice(&dev);
-    if (!g_h3_on || !g_note.ptr || g_note.ptr != ptr || g_note.rows != rows || g_note.cols != cols || g_note.ld != ld ||
-        g_note.dev != dev || g_note.slot < 0)
-        return nullptr;
-    unsigned* slots = h3_slots();
-    return slots ? slots + 2 + g_note.slot : nullptr;
-}
-
-const unsigned* gpe_h3_fwd_lookup(const void* ptr, long rows, int cols, long ld)
-{
-    if (!g_h3_on) return nullptr;
-    int dev = -1;
-    (void)hipGetDevice(&dev);
-    for (int i = 0; i < H3_KEEP; ++i) {
-        const H3Keep& k = g_keep[i];
-        // the slot must not have been handed out again since (H3_RING - 1 newer notes at most)
-        if (k.ptr == ptr && k.rows == rows && k.cols == cols && k.ld == ld && k.dev == dev && g_seq - k.seq < H3_RING - 1) {
-            unsigned* slots = h3_slots();
-            return slots ? slots + 2 + k.slot : nullptr;
-        }
-    }
-    return nullptr;
-}
-
-const unsigned* gpe_h3_pq_bound(const float* pq, long rows, int H, long ld, hipStream_t s)
-{
-    unsigned* slots = h3_slots();
-    if (!slots || (H & 3)) return nullptr;
-    if (h3_pq_passes(slots, pq, rows, H, ld, s) != GPE_OK) return nullptr;
-    return slots;
 }

@@ -92,8 +92,8 @@ int gpe_edge_pseudo_setup(RgParams& p, bool per_point, int emode, GpeFold& fd)
     const bool want_agg = emode == E_EDGE_FWD && p.agg, want_dp = emode == E_BWD_GATHER;
     const size_t agg_f = want_agg ? (size_t)nps * p.oldagg : 0, dp_f = want_dp ? (size_t)nps * p.lddp : 0;
     const size_t bytes = (2 * agg_f + dp_f) * sizeof(float) + 2 * agg_f + 256;
-    char* ws = (bytes > 256) ? (char*)gpe_scratch(0, bytes) : nullptr;
-    if (bytes > 256 && !ws) return 0;                                 // no scratch: the producer/consumer kernel runs it
+    char* ws = (bytes > 256 && bytes <= p.ws.pseudo_bytes) ? p.ws.pseudo : nullptr;
+    if (bytes > 256 && !ws) return 0;                                 // no workspace: the producer/consumer kernel runs it
     if (want_agg) {
         fd.mx = p.mx; fd.mn = p.mn; fd.amx = p.oamx; fd.amn = p.oamn;
         p.mx = (float*)ws; p.mn = p.mx + agg_f;
@@ -103,6 +103,19 @@ int gpe_edge_pseudo_setup(RgParams& p, bool per_point, int emode, GpeFold& fd)
     p.k = best;
     p.pmagic = (unsigned)(((1ull << 32) + fd.f - 1) / fd.f);          // x / f == umulhi(x, pmagic) for x < 2^31 / f
     return 1;
+}
+
+// bytes of the pseudo-point part of an edge workspace for k neighbours, widths <= Cmax (0 for k <= 16)
+size_t gpe_edge_pseudo_bytes(long npts, int k, int Cmax)
+{
+    if (k <= SR_PB) return 0;
+    int best = 0;
+    for (int kq = SR_PB; kq >= SR_PB / SR_NPW; --kq)
+        if (k % kq == 0 && (SR_PB / kq) * kq > (best ? (SR_PB / best) * best : 0)) best = kq;
+    if (!best) return 0;
+    const size_t nps = (size_t)npts * (k / best), ld = (size_t)((Cmax + 3) & ~3);
+    // forward with aggregation: mx, mn (floats) + amx, amn (bytes); gathered backward: dP (floats) — the larger of the two
+    return nps * ld * (2 * sizeof(float) + 2) + 256;
 }
 
 // after the launch: folds the per-pseudo-point rows of the scratch image into the caller's per-point outputs
@@ -159,7 +172,7 @@ int gpe_edgegemm_sr_try(const RgParams& p_in, int amode, int emode, int stats_nb
     const int NT = (p.N <= 160) ? 10 : 13;
     const int KCH = (p.K <= 160) ? 10 : 13;
     // dummy image of the straight-line instances: 64 rows x 512 floats (row pitches here are <= 256 floats)
-    p.dummy = (p.ldo <= 512 && p.oldagg <= 512 && p.lddp <= 512) ? (float*)gpe_scratch(2, (size_t)64 * 512 * sizeof(float)) : nullptr;
+    p.dummy = (p.ldo <= 512 && p.oldagg <= 512 && p.lddp <= 512) ? p.ws.dummy : nullptr;
     int rc = GPE_EINVAL;
     if (amode == A_GATHER && emode == E_EDGE_FWD) rc = sr_dispatch<A_GATHER, E_EDGE_FWD>(NT, KCH, p, stats_nblk, s);
     else if (amode == A_DENSE && (emode == E_EDGE_FWD || emode == E_BWD_INPLACE))

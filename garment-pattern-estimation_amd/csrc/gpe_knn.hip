@@ -366,7 +366,8 @@ static void knn_launch(long nblocks, size_t lds, hipStream_t s, int probe, const
 }
 
 // all-exact path: every distance by the defined chain (C < 16, k > 48, or GPE_KNN_EXACT=1)
-static int knn_exact(const float* x, int B, int N, int C, int ldx, int k, int32_t* idx, int32_t* idx_glob, void* stream)
+static int knn_exact(const float* x, int B, int N, int C, int ldx, int k, int32_t* idx, int32_t* idx_glob, void* ws,
+                     long ws_bytes, void* stream)
 {
     const size_t lds = ((size_t)2 * KNN_TQ * KNN_LD + 4 * 16 * KNN_LDD) * sizeof(float) + 4 * 64 * sizeof(unsigned long long);
     static const int probe = getenv("GPE_KNN_PROBE") ? atoi(getenv("GPE_KNN_PROBE")) : 0;
@@ -394,8 +395,9 @@ static int knn_exact(const float* x, int B, int N, int C, int ldx, int k, int32_
     if (dbg_split > 0 && dbg_split * k <= 64 && dbg_split <= tiles) nsplit = dbg_split;
     unsigned long long* part = nullptr;
     if (nsplit > 1) {
-        part = (unsigned long long*)gpe_scratch(1, (size_t)B * N * nsplit * k * sizeof(unsigned long long));
-        if (!part) nsplit = 1;                                             // no scratch: one piece, more HBM traffic
+        const size_t need = (size_t)B * N * nsplit * k * sizeof(unsigned long long);
+        part = (ws && !(((uintptr_t)ws) & 15) && (size_t)ws_bytes >= need) ? (unsigned long long*)ws : nullptr;
+        if (!part) nsplit = 1;                                             // no workspace: one piece, more HBM traffic
     }
     const long nblocks = (pin ? (long)GPE_NXCD * gpe_cdiv(B, GPE_NXCD) * tiles : (long)B * tiles) * nsplit;
     if (nblocks >= (1L << 31)) return GPE_EINVAL;
@@ -908,19 +910,36 @@ __global__ __launch_bounds__(256) void gpe_knn_rerank_kernel(const float* __rest
 #endif
 }
 
-extern "C" int gpe_knn(const float* x, int B, int N, int C, int ldx, int k, int32_t* idx, int32_t* idx_glob,
-                       void* stream)
+// what the filter path keeps per query: the K2 best candidates by the matrix-pipe distance
+static int knn_k2(int k, int N)
 {
-    GPE_WRITES_TENSORS();
-    if (!x || !idx || B < 0 || N <= 0 || C <= 0 || ldx < C || k <= 0 || k > 64 || k > N || (long)B * N * k >= (1L << 31)) return GPE_EINVAL;
-    if (B == 0) return GPE_OK;
-    static const int force_exact = getenv("GPE_KNN_EXACT") ? atoi(getenv("GPE_KNN_EXACT")) : 0;
-    if (C < KNN_MF_MINC || k > 48 || force_exact) return knn_exact(x, B, N, C, ldx, k, idx, idx_glob, stream);
-    // ---- matrix-pipe filter + exact recheck ----
     int K2 = (2 * k < 32) ? 2 * k : 32;
     if (K2 < k + 8) K2 = k + 8;
     if (K2 > 64) K2 = 64;
     if (K2 > N) K2 = N;
+    return K2;
+}
+// bytes of the caller's workspace: partial k-lists of up to 4 candidate pieces (all-exact path: k entries each; filter path:
+// K2 entries), the squared norms and the per-cloud maxima
+extern "C" long gpe_knn_ws_bytes(int B, int N, int C, int k)
+{
+    if (B < 0 || N <= 0 || C <= 0 || k <= 0 || k > 64) return GPE_EINVAL;
+    const size_t nq = (size_t)B * N;
+    const size_t lists = nq * 64 * sizeof(unsigned long long);            // nsplit * K2 <= 64 and nsplit * k <= 64 by construction
+    const size_t norm_bytes = (nq * sizeof(float) + 255) & ~(size_t)255;
+    (void)C;
+    return (long)(lists + norm_bytes + (size_t)B * sizeof(int) + 256);
+}
+
+extern "C" int gpe_knn(const float* x, int B, int N, int C, int ldx, int k, int32_t* idx, int32_t* idx_glob, void* ws,
+                       long ws_bytes, void* stream)
+{
+    if (!x || !idx || B < 0 || N <= 0 || C <= 0 || ldx < C || k <= 0 || k > 64 || k > N || (long)B * N * k >= (1L << 31)) return GPE_EINVAL;
+    if (B == 0) return GPE_OK;
+    static const int force_exact = getenv("GPE_KNN_EXACT") ? atoi(getenv("GPE_KNN_EXACT")) : 0;
+    if (C < KNN_MF_MINC || k > 48 || force_exact) return knn_exact(x, B, N, C, ldx, k, idx, idx_glob, ws, ws_bytes, stream);
+    // ---- matrix-pipe filter + exact recheck ----
+    const int K2 = knn_k2(k, N);
     const int tiles = gpe_cdiv(N, KNN_TQ);
     static const int dbg_pin = getenv("GPE_KNN_PIN") ? atoi(getenv("GPE_KNN_PIN")) : -1;
     static const int dbg_vec = getenv("GPE_KNN_VEC") ? atoi(getenv("GPE_KNN_VEC")) : 0;
@@ -937,8 +956,9 @@ extern "C" int gpe_knn(const float* x, int B, int N, int C, int ldx, int k, int3
     const size_t nq = (size_t)B * N;
     const size_t part_bytes = nq * nsplit * K2 * sizeof(unsigned long long);
     const size_t norm_bytes = (nq * sizeof(float) + 255) & ~(size_t)255;
-    char* scratch = (char*)gpe_scratch(1, part_bytes + norm_bytes + (size_t)B * sizeof(int) + 256);
-    if (!scratch) return knn_exact(x, B, N, C, ldx, k, idx, idx_glob, stream);
+    const size_t need = part_bytes + norm_bytes + (size_t)B * sizeof(int) + 256;
+    char* scratch = (ws && !(((uintptr_t)ws) & 15) && (size_t)ws_bytes >= need) ? (char*)ws : nullptr;
+    if (!scratch) return knn_exact(x, B, N, C, ldx, k, idx, idx_glob, nullptr, 0, stream);   // no workspace: the all-exact kernel
     unsigned long long* part = (unsigned long long*)scratch;
     float* norms = (float*)(scratch + part_bytes);
     int* cmax = (int*)(scratch + part_bytes + norm_bytes);

@@ -77,7 +77,6 @@ __global__ __launch_bounds__(FPS_T) void gpe_fps_kernel(const float* __restrict_
 
 extern "C" int gpe_fps(const float* pos, int ldp, int B, int N, int C, int M, int32_t* idx, void* stream)
 {
-    GPE_WRITES_TENSORS();
     if (!pos || !idx || B <= 0 || N <= 0 || C <= 0 || C > 8 || ldp < C || M <= 0 || M > N || N > FPS_T * FPS_PER)
         return GPE_EINVAL;
     hipLaunchKernelGGL(gpe_fps_kernel, dim3(B), dim3(FPS_T), 0, (hipStream_t)stream, pos, ldp, N, C, M, idx);
@@ -119,7 +118,6 @@ __global__ __launch_bounds__(256) void gpe_radius_kernel(const float* __restrict
 extern "C" int gpe_radius(const float* pos, int ldp, const int32_t* cidx, int B, int N, int C, int M, float r, int maxn,
                           int32_t* nbr, int32_t* cnt, void* stream)
 {
-    GPE_WRITES_TENSORS();
     if (!pos || !cidx || !nbr || !cnt || B <= 0 || N <= 0 || M <= 0 || C <= 0 || C > 8 || ldp < C || maxn <= 0 || !(r >= 0))
         return GPE_EINVAL;
     const long total = (long)B * M;
@@ -154,7 +152,6 @@ extern "C" int gpe_ball_messages(const float* pos, int ldp, const float* x, int 
                                  const int32_t* nbr, const int64_t* off, int B, int N, int C, int M, int maxn, float* msg,
                                  int ldm, int32_t* seg_of_row, void* stream)
 {
-    GPE_WRITES_TENSORS();
     if (!pos || !cidx || !nbr || !off || !msg || B <= 0 || N <= 0 || M <= 0 || C <= 0 || maxn <= 0 || Cx < 0 ||
         (Cx > 0 && !x) || ldm < Cx + C)
         return GPE_EINVAL;
@@ -199,7 +196,6 @@ __global__ void gpe_ragged_max_bwd_kernel(const float* __restrict__ gy, int ldgy
 extern "C" int gpe_ragged_max_fwd(const float* x, int ldx, const int64_t* off, long S, int C, float* y, int ldy, int64_t* arg,
                                   void* stream)
 {
-    GPE_WRITES_TENSORS();
     if (!x || !off || !y || !arg || S <= 0 || C <= 0 || ldx < C || ldy < C) return GPE_EINVAL;
     hipLaunchKernelGGL(gpe_ragged_max_fwd_kernel, dim3(gpe_cdiv(S * C, 256)), dim3(256), 0, (hipStream_t)stream, x, ldx, off, S, C,
                        y, ldy, arg);
@@ -210,7 +206,6 @@ extern "C" int gpe_ragged_max_fwd(const float* x, int ldx, const int64_t* off, l
 extern "C" int gpe_ragged_max_bwd(const float* gy, int ldgy, const int64_t* off, const int64_t* arg,
                                   const int32_t* seg_of_row, long E, int C, float* gx, int ldgx, void* stream)
 {
-    GPE_WRITES_TENSORS();
     if (!gy || !off || !arg || !seg_of_row || !gx || E < 0 || C <= 0 || ldgx < C) return GPE_EINVAL;
     if (E == 0) return GPE_OK;
     hipLaunchKernelGGL(gpe_ragged_max_bwd_kernel, dim3(gpe_cdiv(E * C, 256)), dim3(256), 0, (hipStream_t)stream, gy, ldgy, off, arg,

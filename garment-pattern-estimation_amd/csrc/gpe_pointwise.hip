@@ -5,7 +5,7 @@
 #include "gpe_common.h"
 #include <math.h>
 
-extern "C" int gpe_abi_version(void) { return 3; }
+extern "C" int gpe_abi_version(void) { return 4; }
 
 int gpe_num_cus()
 {
@@ -19,25 +19,6 @@ int gpe_num_cus()
         if (c <= 0) c = 256;
     }
     return c;
-}
-
-void* gpe_scratch(int slot, size_t bytes)
-{
-    constexpr int SLOTS = 4, DEVS = 64;
-    static void* ptr[DEVS][SLOTS] = {};
-    static size_t cap[DEVS][SLOTS] = {};
-    int dev = 0;
-    if (slot < 0 || slot >= SLOTS || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= DEVS) return nullptr;
-    if (bytes > cap[dev][slot]) {
-        if (ptr[dev][slot]) {
-            (void)hipDeviceSynchronize();                  // queued kernels may still read the old image
-            (void)hipFree(ptr[dev][slot]);
-        }
-        ptr[dev][slot] = nullptr; cap[dev][slot] = 0;
-        if (hipMalloc(&ptr[dev][slot], bytes) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-        cap[dev][slot] = bytes;
-    }
-    return ptr[dev][slot];
 }
 
 __device__ __forceinline__ float4 pw_ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
@@ -438,7 +419,6 @@ __global__ void gpe_edge_finish_kernel(const float* __restrict__ mx, const float
 extern "C" int gpe_edge_finish(const float* mx, const float* mn, int ldagg, const float* stats, long rows, int C,
                                float* y, int ldy, void* stream)
 {
-    GPE_WRITES_TENSORS();
     if (!mx || !mn || !stats || !y || rows < 0 || C <= 0 || ldagg < C || ldy < C) return GPE_EINVAL;
     if (rows == 0) return GPE_OK;
     hipLaunchKernelGGL(gpe_edge_finish_kernel, dim3(gpe_cdiv(rows * C, 256)), dim3(256), 0, (hipStream_t)stream, mx,
@@ -622,7 +602,7 @@ __global__ __launch_bounds__(256) void gpe_dz3_kernel(float* __restrict__ a3, in
 }
 
 static int dz3_launch(float* a3, int lda3, const float* g, int ldg, const uint8_t* amx, const uint8_t* amn, int ldagg,
-                      const float* coef, int B, int N, int k, int F, float gscale, hipStream_t stream)
+                      const float* coef, int B, int N, int k, int F, float gscale, unsigned* amax_out, hipStream_t stream)
 {
     if (!a3 || !g || !coef || B <= 0 || N <= 0 || k <= 0 || F <= 0 || (lda3 & 3) || lda3 < F) return GPE_EINVAL;
     if (amx && (!amn || (ldagg & 3) || ldagg < F)) return GPE_EINVAL;
@@ -630,8 +610,8 @@ static int dz3_launch(float* a3, int lda3, const float* g, int ldg, const uint8_
     if (E >= (1L << 31)) return GPE_EINVAL;
     const long npts = (long)B * N;
     const int blocks = (int)((npts + 3) / 4 < 4096 ? (npts + 3) / 4 : 4096);
-    // f16x3 mode: leave a note with the largest |dz3| for the edge GEMM that propagates it (NULL in every other mode)
-    unsigned* amax_out = gpe_h3_note_begin(a3, E, F, lda3, stream);
+    // amax_out (may be NULL): the caller's word for the largest |dz3| written — the f16x3 scale of the edge GEMMs that read dz3
+    if (amax_out && hipMemsetAsync(amax_out, 0, sizeof(unsigned), stream) != hipSuccess) return GPE_ELAUNCH;
     hipLaunchKernelGGL(gpe_dz3_kernel, dim3(blocks, gpe_cdiv(F, 256)), dim3(256), 0, stream, a3, lda3, g, ldg, amx, amn,
                        ldagg, coef, npts, k, F, gscale, amax_out);
     GPE_CHECK_LAUNCH();
@@ -639,16 +619,16 @@ static int dz3_launch(float* a3, int lda3, const float* g, int ldg, const uint8_
 }
 
 extern "C" int gpe_edge_dz3(float* a3, int lda3, const float* g, int ldg, const uint8_t* amx, const uint8_t* amn,
-                            int ldagg, const float* coef, int B, int N, int k, int F, void* stream)
+                            int ldagg, const float* coef, int B, int N, int k, int F, uint32_t* amax_out, void* stream)
 {
     if (!amx || !amn) return GPE_EINVAL;
-    return dz3_launch(a3, lda3, g, ldg, amx, amn, ldagg, coef, B, N, k, F, 1.f, (hipStream_t)stream);
+    return dz3_launch(a3, lda3, g, ldg, amx, amn, ldagg, coef, B, N, k, F, 1.f, amax_out, (hipStream_t)stream);
 }
 
 extern "C" int gpe_edge_dz3_all(float* a3, int lda3, const float* g, int ldg, float gscale, const float* coef, int B,
-                                int N, int k, int F, void* stream)
+                                int N, int k, int F, uint32_t* amax_out, void* stream)
 {
-    return dz3_launch(a3, lda3, g, ldg, nullptr, nullptr, 0, coef, B, N, k, F, gscale, (hipStream_t)stream);
+    return dz3_launch(a3, lda3, g, ldg, nullptr, nullptr, 0, coef, B, N, k, F, gscale, amax_out, (hipStream_t)stream);
 }
 
 // sums for an inner BN + true weight gradient of the next Linear, from the CENTRED product
@@ -780,7 +760,6 @@ __global__ __launch_bounds__(1024) void gpe_knn_reverse_kernel(const int32_t* __
 extern "C" int gpe_knn_reverse(const int32_t* idx, int B, int N, int k, int32_t* rev_off, int32_t* rev_edge,
                                void* stream)
 {
-    GPE_WRITES_TENSORS();
     if (!idx || !rev_off || !rev_edge || B <= 0 || N <= 0 || k <= 0) return GPE_EINVAL;
     const size_t lds = (size_t)(2 * N + 1) * sizeof(int);
     if (lds > 150 * 1024) return GPE_EINVAL;
@@ -835,7 +814,6 @@ __global__ __launch_bounds__(256) void gpe_pull_dq_kernel(const float* __restric
 extern "C" int gpe_edge_pull_dq(const float* dz, int lddz, const int32_t* rev_off, const int32_t* rev_edge, int B,
                                 int N, int k, int H, float* dQ, int lddq, void* stream)
 {
-    GPE_WRITES_TENSORS();
     if (!dz || !rev_off || !rev_edge || !dQ || B <= 0 || N <= 0 || k <= 0 || H <= 0 || H > 256 || (H & 3) ||
         (lddz & 3) || (lddq & 3))
         return GPE_EINVAL;
@@ -885,7 +863,6 @@ __global__ __launch_bounds__(1024) void gpe_segment_mean_fwd_kernel(const float*
 
 extern "C" int gpe_segment_mean_fwd(const float* x, int ldx, int B, int N, int C, float* y, int ldy, void* stream)
 {
-    GPE_WRITES_TENSORS();
     if (!x || !y || B <= 0 || N <= 0 || C <= 0 || ldx < C || ldy < C) return GPE_EINVAL;
     hipLaunchKernelGGL(gpe_segment_mean_fwd_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, x, ldx, N, C, y,
                        ldy);
@@ -908,7 +885,6 @@ __global__ void gpe_segment_mean_bwd_kernel(const float* __restrict__ gy, int ld
 extern "C" int gpe_segment_mean_bwd(const float* gy, int ldgy, int B, int N, int C, float* gx, int ldgx,
                                     int accumulate, void* stream)
 {
-    GPE_WRITES_TENSORS();
     if (!gy || !gx || B <= 0 || N <= 0 || C <= 0) return GPE_EINVAL;
     const long rows = (long)B * N;
     hipLaunchKernelGGL(gpe_segment_mean_bwd_kernel, dim3(gpe_cdiv(rows * C, 256)), dim3(256), 0,
@@ -943,7 +919,6 @@ __global__ void gpe_lstm_cell_fwd_kernel(float* __restrict__ gates, const float*
 extern "C" int gpe_lstm_cell_fwd(float* gates, const float* c_prev, long ldc_prev, float* c, float* h,
                                  long h_stride, int Bn, int H, void* stream)
 {
-    GPE_WRITES_TENSORS();
     if (!gates || !c_prev || !c || !h || Bn <= 0 || H <= 0) return GPE_EINVAL;
     hipLaunchKernelGGL(gpe_lstm_cell_fwd_kernel, dim3(gpe_cdiv((long)Bn * H, 256)), dim3(256), 0,
                        (hipStream_t)stream, gates, c_prev, ldc_prev, c, h, h_stride, Bn, H);
@@ -984,7 +959,6 @@ extern "C" int gpe_lstm_cell_bwd(const float* dh_out, long dho_stride, const flo
                                  const float* gates, const float* c, const float* c_prev, long ldc_prev,
                                  float* dgates, long dg_stride, float* dc_prev, int Bn, int H, void* stream)
 {
-    GPE_WRITES_TENSORS();
     if (!gates || !c || !c_prev || !dgates || !dc_prev || Bn <= 0 || H <= 0) return GPE_EINVAL;
     hipLaunchKernelGGL(gpe_lstm_cell_bwd_kernel, dim3(gpe_cdiv((long)Bn * H, 256)), dim3(256), 0,
                        (hipStream_t)stream, dh_out, dho_stride, dh_rec, n_rec, dc_next, gates, c, c_prev, ldc_prev, dgates,
@@ -1029,7 +1003,6 @@ extern "C" int gpe_gru_cell_bwd(const float* dh_out, long dho_stride, const floa
                                 const float* dh_dir_next, const float* saved, const float* h_prev, long hp_stride,
                                 float* dgx, float* dgh, long dg_stride, float* dh_dir_prev, int Bn, int H, void* stream)
 {
-    GPE_WRITES_TENSORS();
     if (!saved || !h_prev || !dgx || !dgh || !dh_dir_prev || Bn <= 0 || H <= 0) return GPE_EINVAL;
     hipLaunchKernelGGL(gpe_gru_cell_bwd_kernel, dim3(gpe_cdiv((long)Bn * H, 256)), dim3(256), 0, (hipStream_t)stream,
                        dh_out, dho_stride, dh_rec, n_rec, dh_dir_next, saved, h_prev, hp_stride, dgx, dgh, dg_stride,
@@ -1086,7 +1059,6 @@ __global__ __launch_bounds__(256) void gpe_sparsemax_bwd_kernel(const float* __r
 
 extern "C" int gpe_sparsemax_fwd(const float* z, int ldz, long rows, int W, float* out, int ldo, void* stream)
 {
-    GPE_WRITES_TENSORS();
     if (!z || !out || rows < 0 || W <= 0 || W > SPX_W || ldz < W || ldo < W) return GPE_EINVAL;
     if (rows == 0) return GPE_OK;
     hipLaunchKernelGGL(gpe_sparsemax_fwd_kernel, dim3(gpe_cdiv(rows, 256)), dim3(256), 0, (hipStream_t)stream, z, ldz,
@@ -1098,7 +1070,6 @@ extern "C" int gpe_sparsemax_fwd(const float* z, int ldz, long rows, int W, floa
 extern "C" int gpe_sparsemax_bwd(const float* out, int ldo, const float* g, int ldg, long rows, int W, float* gz,
                                  int ldgz, void* stream)
 {
-    GPE_WRITES_TENSORS();
     if (!out || !g || !gz || rows < 0 || W <= 0 || ldo < W || ldg < W || ldgz < W) return GPE_EINVAL;
     if (rows == 0) return GPE_OK;
     hipLaunchKernelGGL(gpe_sparsemax_bwd_kernel, dim3(gpe_cdiv(rows, 256)), dim3(256), 0, (hipStream_t)stream, out,
@@ -1178,7 +1149,6 @@ __global__ __launch_bounds__(64) void gpe_sparsemax_loss_finish_kernel(const dou
 extern "C" int gpe_sparsemax_loss(const float* x, int ldx, const int32_t* target, long rows, int W, float* gx, int ldg,
                                   double* part, float* loss, int* bad, void* stream)
 {
-    GPE_WRITES_TENSORS();
     if (!x || !target || !gx || !part || !loss || !bad || rows <= 0 || W <= 0 || W > SPX_W || ldx < W || ldg < W) return GPE_EINVAL;
     const int nblk = (int)gpe_cdiv(rows, 256);
     hipLaunchKernelGGL(gpe_sparsemax_loss_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, x, ldx, target, rows, W, gx,
@@ -1198,7 +1168,6 @@ __global__ void gpe_scale_dev_kernel(const float* __restrict__ x, const float* _
 
 extern "C" int gpe_scale_dev(const float* x, const float* alpha, float* out, long n, void* stream)
 {
-    GPE_WRITES_TENSORS();
     if (!x || !alpha || !out || n < 0) return GPE_EINVAL;
     if (n == 0) return GPE_OK;
     hipLaunchKernelGGL(gpe_scale_dev_kernel, dim3((unsigned)gpe_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, x, alpha, out, n);
@@ -1220,7 +1189,6 @@ __global__ void gpe_bn_apply_kernel(const float* __restrict__ a, int lda, const 
 extern "C" int gpe_bn_apply_scaled(const float* a, int lda, const float* stats, long rows, int C, float a_scale,
                                    float t_scale, float* y, int ldy, void* stream)
 {
-    GPE_WRITES_TENSORS();
     if (!a || !stats || !y || rows < 0 || C <= 0 || lda < C || ldy < C) return GPE_EINVAL;
     if (rows == 0) return GPE_OK;
     hipLaunchKernelGGL(gpe_bn_apply_kernel, dim3(gpe_cdiv(rows * C, 256)), dim3(256), 0, (hipStream_t)stream, a, lda,
@@ -1232,7 +1200,6 @@ extern "C" int gpe_bn_apply_scaled(const float* a, int lda, const float* stats, 
 extern "C" int gpe_bn_apply(const float* a, int lda, const float* stats, long rows, int C, float* y, int ldy,
                             void* stream)
 {
-    GPE_WRITES_TENSORS();
     return gpe_bn_apply_scaled(a, lda, stats, rows, C, 1.f, 1.f, y, ldy, stream);
 }
 
@@ -1255,7 +1222,6 @@ __global__ void gpe_reduce_inner_kernel(const float* __restrict__ x, long x_so, 
 extern "C" int gpe_reduce_inner(const float* x, long x_so, long x_si, int T, int R, int C, float* y, int ldy,
                                 int accumulate, void* stream)
 {
-    GPE_WRITES_TENSORS();
     if (!x || !y || T <= 0 || R <= 0 || C <= 0) return GPE_EINVAL;
     hipLaunchKernelGGL(gpe_reduce_inner_kernel, dim3(gpe_cdiv((long)R * C, 256)), dim3(256), 0, (hipStream_t)stream,
                        x, x_so, x_si, T, R, C, y, ldy, accumulate);
@@ -1279,7 +1245,6 @@ __global__ void gpe_w1_split_kernel(const float* __restrict__ w1, int ldw1, cons
 extern "C" int gpe_w1_split(const float* w1, int ldw1, const float* b1, int H, int C, float* wpq, int ldwpq,
                             float* bias_pq, void* stream)
 {
-    GPE_WRITES_TENSORS();
     if (!w1 || !b1 || !wpq || !bias_pq || H <= 0 || C <= 0 || ldw1 < 2 * C || ldwpq < C) return GPE_EINVAL;
     const int total = (H * C > 2 * H) ? H * C : 2 * H;
     hipLaunchKernelGGL(gpe_w1_split_kernel, dim3(gpe_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, w1, ldw1,
@@ -1301,7 +1266,6 @@ __global__ void gpe_w1_grad_kernel(const float* __restrict__ dwpq, int ld, int H
 
 extern "C" int gpe_w1_grad_from_pq(const float* dwpq, int ld, int H, int C, float* dw1, int lddw1, void* stream)
 {
-    GPE_WRITES_TENSORS();
     if (!dwpq || !dw1 || H <= 0 || C <= 0 || ld < C || lddw1 < 2 * C) return GPE_EINVAL;
     hipLaunchKernelGGL(gpe_w1_grad_kernel, dim3(gpe_cdiv(H * C, 256)), dim3(256), 0, (hipStream_t)stream, dwpq, ld,
                        H, C, dw1, lddw1);
@@ -1323,7 +1287,6 @@ __global__ void gpe_scale_kernel(const float* x, float alpha, float* out, long n
 
 extern "C" int gpe_scale(const float* x, float alpha, float* out, long n, void* stream)
 {
-    GPE_WRITES_TENSORS();
     if (!x || !out || n < 0) return GPE_EINVAL;
     if (n == 0) return GPE_OK;
     hipLaunchKernelGGL(gpe_scale_kernel, dim3(gpe_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, x, alpha, out, n);
@@ -1333,7 +1296,6 @@ extern "C" int gpe_scale(const float* x, float alpha, float* out, long n, void* 
 
 extern "C" int gpe_add(const float* a, const float* b, float* out, long n, void* stream)
 {
-    GPE_WRITES_TENSORS();
     if (!a || !b || !out || n < 0) return GPE_EINVAL;
     if (n == 0) return GPE_OK;
     hipLaunchKernelGGL(gpe_add_kernel, dim3(gpe_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, a, b, out, n);
@@ -1360,7 +1322,6 @@ __global__ void gpe_mul_rows_kernel(const float* __restrict__ x, long x_sb, long
 extern "C" int gpe_mul_rows(const float* x, long x_sb, long x_st, const float* mask, long Bn, int T, int H, float* out,
                             void* stream)
 {
-    GPE_WRITES_TENSORS();
     if (!x || !mask || !out || Bn < 0 || T <= 0 || H <= 0) return GPE_EINVAL;
     const long n = Bn * T * H;
     if (n == 0) return GPE_OK;
@@ -1396,7 +1357,6 @@ __global__ void gpe_edge_inputs_fwd_kernel(const float* __restrict__ x, int ldx,
 extern "C" int gpe_edge_inputs_fwd(const float* x, int ldx, int C, const int32_t* jg, long npts, int k, float* out, int ldo,
                                    void* stream)
 {
-    GPE_WRITES_TENSORS();
     if (!x || !jg || !out || C <= 0 || ldx < C || npts <= 0 || k <= 0 || ldo < 2 * C) return GPE_EINVAL;
     const long total = npts * k * ldo;
     hipLaunchKernelGGL(gpe_edge_inputs_fwd_kernel, dim3((unsigned)gpe_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, x, ldx,
@@ -1431,7 +1391,6 @@ __global__ void gpe_edge_inputs_bwd_kernel(const float* __restrict__ g, int ldg,
 extern "C" int gpe_edge_inputs_bwd(const float* g, int ldg, int C, const int32_t* rev_off, const int32_t* rev_edge, int B,
                                    int N, int k, float* gx, int ldgx, void* stream)
 {
-    GPE_WRITES_TENSORS();
     if (!g || !rev_off || !rev_edge || !gx || C <= 0 || ldg < 2 * C || B <= 0 || N <= 0 || k <= 0 || ldgx < C) return GPE_EINVAL;
     const long total = (long)B * N * C;
     hipLaunchKernelGGL(gpe_edge_inputs_bwd_kernel, dim3((unsigned)gpe_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, g, ldg,

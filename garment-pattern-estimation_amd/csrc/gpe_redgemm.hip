@@ -1395,7 +1395,8 @@ extern "C" int gpe_redgemm(const float* u, long u_so, long u_si, int u_inner, co
 
 extern "C" int gpe_edge_redgemm(const float* u, int ldu, int v_mode, const float* v, int ldv, const float* pq,
                                 int ldpq, const int32_t* jg, const float* v_shift, int B, int N, int k, int Mg,
-                                int Ng, float* G, int ldG, float* colsum, float* part, void* stream)
+                                int Ng, float* G, int ldG, float* colsum, float* part, const uint32_t* amax_u,
+                                const uint32_t* amax_v, void* ws, long ws_bytes, void* stream)
 {
     if (!u || !G || !part || B <= 0 || N <= 0 || k <= 0 || Mg <= 0 || Ng <= 0 || Ng > 256 || ldG < Ng || ldu < Mg)
         return GPE_EINVAL;
@@ -1408,13 +1409,18 @@ extern "C" int gpe_edge_redgemm(const float* u, int ldu, int v_mode, const float
     p.v = GpeRows{v, ldv, 0, 0};
     p.pq = pq; p.ldpq = ldpq; p.H = Ng; p.jg = jg; p.k = k; p.rcp_k = 1.0 / k; p.kmagic = (unsigned)(((1ull << 32) + k - 1) / k); p.v_shift = v_shift;
     p.pin_clouds = B;
-    if (g_rd_math == 2) {
-        // f16x3: the operand scales must be known without a pass over an E-row tensor — U (a dz tensor) through the note its
-        // producer left, V through the gather bound / the amax kept from the forward kernel that wrote it; else exact fp32
-        p.amax_u = gpe_h3_note_peek(u, p.rows, Mg, ldu);
-        if (p.amax_u)
-            p.amax_v = v_mode == 0 ? gpe_h3_pq_bound(pq, (long)B * N, Ng, ldpq, (hipStream_t)stream)
-                                   : gpe_h3_fwd_lookup(v, p.rows, Ng, ldv);
+    if (g_rd_math == 2 && amax_u && p.rows >= gpe_h3_min_rows()) {
+        // f16x3: the operand scales must be known without a pass over an E-row tensor — U (a dz tensor) through the caller's amax
+        // word of it, V through the caller's word (dense: the amax the forward kernel measured; gathered: a bound of
+        // relu(P_i + Q_j), gpe_edge_pq_amax) or, for the gathered operand only, the bound passes run here; else exact fp32
+        p.amax_u = amax_u;
+        p.amax_v = amax_v;
+        if (!p.amax_v && v_mode == 0) {
+            const GpeEdgeWs w = gpe_edge_ws(ws, ws_bytes);
+            if (w.h3 && gpe_h3_pq_passes(w.h3, reinterpret_cast<float*>(w.h3 + 2), pq, (long)B * N, Ng, ldpq, (hipStream_t)stream) == GPE_OK)
+                p.amax_v = w.h3;
+        }
+        if (!p.amax_v) p.amax_u = nullptr;
     }
     return rd_run(p, v_mode == 0 ? V_GATHER : V_DENSE, G, ldG, colsum, part, 0, (hipStream_t)stream);
 }

@@ -376,7 +376,6 @@ extern "C" int gpe_rnn_seq_fwd(int gates, int L, int T, int Bn, int H, const flo
                                const void* const* bhn, float* hs, long hs_sl, long hs_sb, long hs_st, float* cs, long cs_sl, long cs_st,
                                float* saved, long sv_sl, long sv_st, void* stream)
 {
-    GPE_WRITES_TENSORS();
     if ((gates != 3 && gates != 4) || L <= 0 || T <= 0 || Bn <= 0 || H <= 0 || !xproj0 || !whh || !hs || !saved ||
         (L > 1 && (!wih || !bias)) || (gates == 4 && !cs) || (gates == 3 && !bhn) || (hs_sb & 3) || (hs_st & 3))
         return GPE_EINVAL;
@@ -573,7 +572,6 @@ extern "C" int gpe_rnn_seq_bwd(int gates, int L, int T, int Bn, int H, const flo
                                const float* saved, long sv_sl, long sv_st, float* dgx, float* dgh, long dg_sl, long dg_sb,
                                long dg_st, float* part, float* carry, void* stream)
 {
-    GPE_WRITES_TENSORS();
     if ((gates != 3 && gates != 4) || L <= 0 || T <= 0 || Bn <= 0 || H <= 0 || !whh_t || !hs || !saved || !dgx || !dgh ||
         !part || !carry || (L > 1 && !wih_t) || (gates == 4 && !cs) || (dg_sb & 3) || (dg_st & 3))
         return GPE_EINVAL;

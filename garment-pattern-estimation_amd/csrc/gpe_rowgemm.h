@@ -46,6 +46,11 @@ struct RgParams {
     const unsigned* h3_amax_a;
     const unsigned* h3_amax_w;
     unsigned* amax_out;
+    // host side only: what the CALLER passed (include/gpe_hip.h: amax_a / amax_out / ws of the edge entry points)
+    const unsigned* user_amax_a;    // amax word of the A operand (gather: of relu(P_i + Q_j)); NULL = measure in-call
+    unsigned* user_amax_out;        // receives the largest magnitude written to `out`; NULL = not wanted
+    GpeEdgeWs ws;
+    int* tracked;                   // set to 1 by a kernel path that filled user_amax_out itself
 };
 
 // k > 16 on the single-role kernels (gpe_edgegemm_sr.hip): what gpe_edge_pseudo_setup redirected to scratch, for the fold

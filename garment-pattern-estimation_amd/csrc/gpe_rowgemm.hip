@@ -208,7 +208,7 @@ int gpe_edgegemm_try(const RgParams& p, int amode, int emode, int stats_nblk, hi
 
 void gpe_edgegemm_set_math(int m);
 void gpe_redgemm_set_math(int m);
-void gpe_h3_enable(int on);          // gpe_edgegemm_h3.hip
+size_t gpe_edge_pseudo_bytes(long npts, int k, int Cmax);   // gpe_edgegemm_sr.hip
 
 static int g_gpe_dbg = 0;
 extern "C" int gpe_debug_set(int flags) { g_gpe_dbg = flags; return 0; }
@@ -222,7 +222,6 @@ extern "C" int gpe_math_set(int mode)
     // row GEMMs (forward, input-gradient half): 0 exact fp32, 1 two-term split-bf16 (modes 1, 2), 2 three-term split-bf16
     // (mode 3), 3 two-term split-fp16 on tensor-normalised operands (mode 4)
     gpe_edgegemm_set_math(mode == 4 ? 3 : mode == 3 ? 2 : (mode != 0 ? 1 : 0));
-    gpe_h3_enable(mode == 4);
     // the weight-gradient reduce-GEMM: split-bf16 only in mode 1; mode 4: split-fp16 where the operand scales are known
     gpe_redgemm_set_math(mode == 1 ? 1 : mode == 4 ? 2 : 0);
     return prev;
@@ -230,6 +229,36 @@ extern "C" int gpe_math_set(int mode)
 
 #define GPE_STATS_BLOCKS 512
 extern "C" int gpe_stats_blocks(void) { return GPE_STATS_BLOCKS; }
+
+// workspace of the edge entry points: fixed part + the pseudo-point rows of a k > 16 launch (ldmax = the largest row pitch, in
+// floats, of a per-point output the caller will pass: ldagg of gpe_edge_mlp_fwd, lddp of gpe_edge_mlp_bwd)
+extern "C" long gpe_edge_ws_bytes(int B, int N, int k, int ldmax)
+{
+    if (B <= 0 || N <= 0 || k <= 0 || ldmax <= 0) return GPE_EINVAL;
+    return (long)(GPE_WS_DUMMY_BYTES + GPE_WS_H3_BYTES) + (long)gpe_edge_pseudo_bytes((long)B * N, k, ldmax);
+}
+static long g_h3_min_rows = GPE_H3_MIN_ROWS_DEFAULT;
+long gpe_h3_min_rows() { return g_h3_min_rows; }
+extern "C" long gpe_f16x3_min_rows(void) { return g_h3_min_rows; }
+extern "C" long gpe_f16x3_min_rows_set(long rows)
+{
+    if (rows < 0) return GPE_EINVAL;
+    const long prev = g_h3_min_rows;
+    g_h3_min_rows = rows;
+    return prev;
+}
+extern "C" int gpe_edge_pq_amax(const float* pq, int ldpq, int H, long rows, uint32_t* amax, void* ws, long ws_bytes,
+                                void* stream)
+{
+    const GpeEdgeWs w = gpe_edge_ws(ws, ws_bytes);
+    if (!pq || !amax || !w.h3 || rows <= 0 || H <= 0 || (H & 3) || (ldpq & 3) || ldpq < 2 * H) return GPE_EINVAL;
+    return gpe_h3_pq_passes(amax, reinterpret_cast<float*>(w.h3 + 2), pq, rows, H, ldpq, (hipStream_t)stream);
+}
+extern "C" int gpe_absmax(const float* x, int ldx, long rows, int cols, uint32_t* amax, void* stream)
+{
+    if (!x || !amax || rows < 0 || cols <= 0 || ldx < cols || (ldx & 3) || (((uintptr_t)x) & 15)) return GPE_EINVAL;
+    return gpe_h3_absmax(amax, x, rows, cols, ldx, (hipStream_t)stream);
+}
 
 // ---------------------------------------------------------------------------------------------------------
 // K <= 8 Linear (the layer-1 [P|Q] projection of the raw N x 3 positions: 65 536 x 400 outputs from 3 inputs).  Nothing
@@ -296,7 +325,6 @@ extern "C" int gpe_linear(const float* a, long a_so, long a_si, int a_inner, con
                           const float* addend, long ad_so, long ad_si, int ad_inner, float* y, long y_so,
                           long y_si, int y_inner, int M, int N, int K, int act, void* stream)
 {
-    GPE_WRITES_TENSORS();
     if (!a || !wp || !y || M < 0 || N <= 0 || K <= 0 || (act != 0 && act != 1)) return GPE_EINVAL;
     if (M == 0) return GPE_OK;
     RgParams p = {};
@@ -343,7 +371,8 @@ extern "C" int gpe_linear(const float* a, long a_so, long a_si, int a_inner, con
 extern "C" int gpe_edge_mlp_fwd(int a_mode, const float* pq, int ldpq, const int32_t* jg, const float* a_in,
                                 int lda, int B, int N, int k, int Cin, int Cout, const float* wp,
                                 const float* bias, float* out, int ldo, double* stats_part, int agg, float* mx,
-                                float* mn, uint8_t* amx, uint8_t* amn, int ldagg, void* stream)
+                                float* mn, uint8_t* amx, uint8_t* amn, int ldagg, const uint32_t* amax_a,
+                                uint32_t* amax_out, void* ws, long ws_bytes, void* stream)
 {
     if (!wp || !out || B <= 0 || N <= 0 || k <= 0 || k > 64 || Cin <= 0 || Cout <= 0 || (ldo & 3) || ldo < Cout)
         return GPE_EINVAL;
@@ -366,17 +395,26 @@ extern "C" int gpe_edge_mlp_fwd(int a_mode, const float* pq, int ldpq, const int
     p.out = out; p.ldo = ldo; p.stats_part = stats_part;
     p.agg = agg; p.mx = mx; p.mn = mn; p.oamx = amx; p.oamn = amn; p.oldagg = ldagg;
     p.dbg = g_gpe_dbg; p.pin_clouds = B;
-    const int fast = gpe_edgegemm_try(p, a_mode == 0 ? A_GATHER : A_DENSE, E_EDGE_FWD,
-                                      stats_part ? GPE_STATS_BLOCKS : 0, (hipStream_t)stream);
-    if (fast != 0) return fast == 1 ? GPE_OK : fast;
-    dim3 grid(GPE_STATS_BLOCKS, ny);
-    if (a_mode == 0) return rg_dispatch_nt<A_GATHER, E_EDGE_FWD>(NT, p, grid, (hipStream_t)stream);
-    return rg_dispatch_nt<A_DENSE, E_EDGE_FWD>(NT, p, grid, (hipStream_t)stream);
+    p.user_amax_a = amax_a; p.user_amax_out = amax_out; p.ws = gpe_edge_ws(ws, ws_bytes);
+    int tracked = 0;
+    p.tracked = &tracked;
+    int rc = gpe_edgegemm_try(p, a_mode == 0 ? A_GATHER : A_DENSE, E_EDGE_FWD,
+                              stats_part ? GPE_STATS_BLOCKS : 0, (hipStream_t)stream);
+    if (rc == 0) {
+        dim3 grid(GPE_STATS_BLOCKS, ny);
+        rc = (a_mode == 0) ? rg_dispatch_nt<A_GATHER, E_EDGE_FWD>(NT, p, grid, (hipStream_t)stream)
+                           : rg_dispatch_nt<A_DENSE, E_EDGE_FWD>(NT, p, grid, (hipStream_t)stream);
+    } else
+        rc = rc == 1 ? GPE_OK : rc;
+    // the caller asked for the largest magnitude written and the kernel that ran did not track it: one streaming pass
+    if (rc == GPE_OK && amax_out && !tracked) rc = gpe_h3_absmax(amax_out, out, p.M, Cout, ldo, (hipStream_t)stream);
+    return rc;
 }
 
 extern "C" int gpe_edge_mlp_bwd(const float* a, int lda, int act_mode, const float* pq, int ldpq,
                                 const int32_t* jg, int B, int N, int k, int Cin, int Cout, const float* wp,
-                                const float* coef_out, float* dz_out, int ldo, float* dP, int lddp, void* stream)
+                                const float* coef_out, float* dz_out, int ldo, float* dP, int lddp,
+                                const uint32_t* amax_a, uint32_t* amax_out, void* ws, long ws_bytes, void* stream)
 {
     if (!a || !wp || !coef_out || !dz_out || B <= 0 || N <= 0 || k <= 0 || k > 64 || Cin <= 0 || Cout <= 0 ||
         (ldo & 3) || ldo < Cout || lda < Cin)
@@ -394,9 +432,16 @@ extern "C" int gpe_edge_mlp_bwd(const float* a, int lda, int act_mode, const flo
     p.out = dz_out; p.ldo = ldo; p.coef_out = coef_out; p.dP = dP; p.lddp = lddp;
     hipStream_t s = (hipStream_t)stream;
     p.dbg = g_gpe_dbg; p.pin_clouds = B;
-    const int fast = gpe_edgegemm_try(p, A_DENSE, act_mode == 1 ? E_BWD_GATHER : E_BWD_INPLACE, 0, s);
-    if (fast != 0) return fast == 1 ? GPE_OK : fast;
-    dim3 grid(p.num_tiles < 2048 ? p.num_tiles : 2048, ny);
-    if (act_mode == 1) return rg_dispatch_nt<A_DENSE, E_BWD_GATHER>(NT, p, grid, s);
-    return rg_dispatch_nt<A_DENSE, E_BWD_INPLACE>(NT, p, grid, s);
+    p.user_amax_a = amax_a; p.user_amax_out = amax_out; p.ws = gpe_edge_ws(ws, ws_bytes);
+    int tracked = 0;
+    p.tracked = &tracked;
+    int rc = gpe_edgegemm_try(p, A_DENSE, act_mode == 1 ? E_BWD_GATHER : E_BWD_INPLACE, 0, s);
+    if (rc == 0) {
+        dim3 grid(p.num_tiles < 2048 ? p.num_tiles : 2048, ny);
+        rc = (act_mode == 1) ? rg_dispatch_nt<A_DENSE, E_BWD_GATHER>(NT, p, grid, s)
+                             : rg_dispatch_nt<A_DENSE, E_BWD_INPLACE>(NT, p, grid, s);
+    } else
+        rc = rc == 1 ? GPE_OK : rc;
+    if (rc == GPE_OK && amax_out && !tracked) rc = gpe_h3_absmax(amax_out, dz_out, p.M, Cout, ldo, s);
+    return rc;
 }

@@ -298,7 +298,6 @@ extern "C" int gpe_lstm_step_fwd(const float* h_prev, long hp_stride, const floa
                                  float* gates, float* c_out, float* h_out, long h_stride, int Bn, int H,
                                  void* stream)
 {
-    GPE_WRITES_TENSORS();
     if (!h_prev || !whh_gates_packed || !xproj || !c_prev || !gates || !c_out || !h_out || Bn <= 0 || H <= 0)
         return GPE_EINVAL;
     SgParams p = {};
@@ -317,7 +316,6 @@ extern "C" int gpe_lstm_step_fwd(const float* h_prev, long hp_stride, const floa
 extern "C" int gpe_linear_splitk(const float* a, long a_so, const float* wp, float* y, int M, int N, int K,
                                  void* stream)
 {
-    GPE_WRITES_TENSORS();
     if (!a || !wp || !y || M <= 0 || N <= 0 || K <= 0) return GPE_EINVAL;
     SgParams p = {};
     p.M = M; p.N = N; p.K = K;
@@ -336,7 +334,6 @@ extern "C" int gpe_gru_step_fwd(const float* h_prev, long hp_stride, const float
                                 long xp_stride, const float* bhn, float* saved, float* h_out, long h_stride, int Bn,
                                 int H, void* stream)
 {
-    GPE_WRITES_TENSORS();
     if (!h_prev || !whh_gates_packed || !xproj || !bhn || !saved || !h_out || Bn <= 0 || H <= 0) return GPE_EINVAL;
     SgParams p = {};
     p.M = Bn; p.N = 3 * H; p.K = H;

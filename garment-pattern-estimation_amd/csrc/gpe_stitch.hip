@@ -253,7 +253,6 @@ extern "C" int gpe_stitch_loss_fwd(const float* tags, long t_sb, long t_sp, long
                                    const float* gt_mask, const float* gt_tags, int B, int P, int L, int flags, float margin,
                                    float sup_w, double* part, float* out5, void* stream)
 {
-    GPE_WRITES_TENSORS();
     StitchParams p{tags, t_sb, t_sp, t_sl, D, logit, m_sb, m_sp, m_sl, stitches, nums, S, gt_mask, gt_tags, B, P, L, flags,
                    margin, sup_w};
     if (st_check(p, part) != GPE_OK || !out5) return GPE_EINVAL;
@@ -270,7 +269,6 @@ extern "C" int gpe_stitch_loss_bwd(const float* tags, long t_sb, long t_sp, long
                                    float sup_w, const double* part, const float* gscale, float* g_tags, float* g_mask,
                                    void* stream)
 {
-    GPE_WRITES_TENSORS();
     StitchParams p{tags, t_sb, t_sp, t_sl, D, logit, m_sb, m_sp, m_sl, stitches, nums, S, gt_mask, gt_tags, B, P, L, flags,
                    margin, sup_w};
     if (st_check(p, part) != GPE_OK) return GPE_EINVAL;
@@ -323,7 +321,6 @@ extern "C" int gpe_stitch_renumber(const int64_t* stitches, const int64_t* nums,
                                    const int64_t* perm, const int32_t* lead, const int32_t* num_edges, int64_t* out,
                                    void* stream)
 {
-    GPE_WRITES_TENSORS();
     if (!stitches || !nums || !out || B <= 0 || S <= 0 || P <= 0 || L <= 0 || (lead && !num_edges)) return GPE_EINVAL;
     hipLaunchKernelGGL(gpe_stitch_renumber_kernel, dim3(B), dim3(128), 0, (hipStream_t)stream, stitches, nums, S, P, L, perm,
                        lead, num_edges, out);
@@ -354,7 +351,6 @@ __global__ void gpe_panel_shift_kernel(const float* __restrict__ feat, int D, co
 extern "C" int gpe_panel_shift(const float* feat, int D, const int32_t* lead, const int32_t* num_edges, long npanels, int L,
                                float* out, void* stream)
 {
-    GPE_WRITES_TENSORS();
     if (!feat || !lead || !num_edges || !out || D <= 0 || npanels <= 0 || L <= 0) return GPE_EINVAL;
     const long total = npanels * L * D;
     hipLaunchKernelGGL(gpe_panel_shift_kernel, dim3((unsigned)gpe_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, feat, D,

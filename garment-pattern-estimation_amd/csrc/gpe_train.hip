@@ -173,7 +173,6 @@ extern "C" int gpe_pattern_loss_fwd(const float* ol, long ol_sb, long ol_sp, lon
                                     int flags, float pad0, float pad1, float loop_w, double* part, float* loop_sums,
                                     float* out5, void* stream)
 {
-    GPE_WRITES_TENSORS();
     LossParams p;
     const int rc = loss_params(p, ol, ol_sb, ol_sp, ol_sl, rot, rot_s, tr, tr_s, gt_ol, gt_rot, gt_tr, num_edges, B, P, L,
                                R, T, flags, pad0, pad1, loop_w);
@@ -190,7 +189,6 @@ extern "C" int gpe_pattern_loss_bwd(const float* ol, long ol_sb, long ol_sp, lon
                                     int flags, float pad0, float pad1, float loop_w, const float* loop_sums,
                                     const float* gscale, float* g_ol, float* g_rot, float* g_tr, void* stream)
 {
-    GPE_WRITES_TENSORS();
     LossParams p;
     const int rc = loss_params(p, ol, ol_sb, ol_sp, ol_sl, rot, rot_s, tr, tr_s, gt_ol, gt_rot, gt_tr, num_edges, B, P, L,
                                R, T, flags, pad0, pad1, loop_w);
@@ -258,7 +256,6 @@ extern "C" int gpe_origin_match(const float* ol, long ol_sb, long ol_sp, long ol
                                 const int32_t* num_edges, int B, int P, int L, float* gt_out, int32_t* lead,
                                 void* stream)
 {
-    GPE_WRITES_TENSORS();
     if (!ol || !gt_ol || !num_edges || !gt_out || !lead || B <= 0 || P <= 0 || L <= 0 || L > 64 || D <= 0)
         return GPE_EINVAL;
     const int panels = B * P;
@@ -350,7 +347,6 @@ __global__ __launch_bounds__(256) void gpe_order_match_kernel(const float* __res
 extern "C" int gpe_order_match(const float* pred_feat, const float* gt_feat, int B, int P, int D, int64_t* perm,
                                int32_t* fail, void* stream)
 {
-    GPE_WRITES_TENSORS();
     if (!pred_feat || !gt_feat || !perm || !fail || B <= 0 || P <= 0 || P > 64 || D <= 0) return GPE_EINVAL;
     hipLaunchKernelGGL(gpe_order_match_kernel, dim3(B), dim3(256), (size_t)P * P * sizeof(float), (hipStream_t)stream,
                        pred_feat, gt_feat, P, D, perm, fail);
@@ -467,7 +463,6 @@ extern "C" long gpe_attn_pool_ws(int B, int N, int P, int C) { return (long)B * 
 extern "C" int gpe_attn_pool_fwd(const float* w, int ldw, const float* feat, int ldf, int B, int N, int P, int C,
                                  int mode, float* out, int32_t* arg, float* part, int32_t* part_arg, void* stream)
 {
-    GPE_WRITES_TENSORS();
     if (!w || !feat || !out || !part || B <= 0 || N <= 0 || P <= 0 || C <= 0 || ldw < P || ldf < C || mode < 0 ||
         mode > 2 || (long)gpe_cdiv(P, 4) * gpe_cdiv(C, 4) > 256L * AP_TPT)
         return GPE_EINVAL;
@@ -609,7 +604,6 @@ extern "C" int gpe_attn_pool_bwd(const float* w, int ldw, const float* feat, int
                                  const int32_t* arg, int B, int N, int P, int C, int mode, float* gw, int ldgw,
                                  float* gf, int ldgf, void* stream)
 {
-    GPE_WRITES_TENSORS();
     if (!w || !feat || !g || !gw || !gf || B <= 0 || N <= 0 || P <= 0 || C <= 0 || mode < 0 || mode > 2 || ldgw < P ||
         ldgf < C)
         return GPE_EINVAL;
@@ -688,7 +682,6 @@ __global__ void gpe_segment_pool_bwd_kernel(const float* __restrict__ gy, int ld
 extern "C" int gpe_segment_pool_fwd(const float* x, int ldx, int B, int N, int C, int mode, float* y, int ldy,
                                     int32_t* arg, void* stream)
 {
-    GPE_WRITES_TENSORS();
     if (!x || !y || B <= 0 || N <= 0 || C <= 0 || ldx < C || ldy < C || (mode != 1 && mode != 2) || (mode == 1 && !arg))
         return GPE_EINVAL;
     hipLaunchKernelGGL(gpe_segment_pool_fwd_kernel, dim3(B, gpe_cdiv(C, 64)), dim3(1024), 0, (hipStream_t)stream, x, ldx, N,
@@ -700,7 +693,6 @@ extern "C" int gpe_segment_pool_fwd(const float* x, int ldx, int B, int N, int C
 extern "C" int gpe_segment_pool_bwd(const float* gy, int ldgy, const int32_t* arg, int B, int N, int C, int mode,
                                     float* gx, int ldgx, void* stream)
 {
-    GPE_WRITES_TENSORS();
     if (!gy || !gx || B <= 0 || N <= 0 || C <= 0 || (mode != 1 && mode != 2) || (mode == 1 && !arg)) return GPE_EINVAL;
     const long rows = (long)B * N;
     hipLaunchKernelGGL(gpe_segment_pool_bwd_kernel, dim3(gpe_cdiv(rows * C, 256)), dim3(256), 0, (hipStream_t)stream, gy, ldgy,
@@ -726,7 +718,6 @@ __global__ __launch_bounds__(256) void gpe_edge_sum_k_kernel(const float* __rest
 
 extern "C" int gpe_edge_sum_k(const float* a, int lda, long npts, int k, int F, float* out, int ldo, void* stream)
 {
-    GPE_WRITES_TENSORS();
     if (!a || !out || npts <= 0 || k <= 0 || F <= 0 || lda < F || ldo < F) return GPE_EINVAL;
     const int bx = (int)((npts + 3) / 4 < 2048 ? (npts + 3) / 4 : 2048);
     hipLaunchKernelGGL(gpe_edge_sum_k_kernel, dim3(bx, gpe_cdiv(F, 64)), dim3(256), 0, (hipStream_t)stream, a, lda, npts, k,
@@ -777,7 +768,6 @@ __global__ __launch_bounds__(256) void gpe_adam_kernel(float* __restrict__ p, fl
 extern "C" int gpe_adam_step(float* p, float* g, float* m, float* v, long n, float lr, float beta1, float beta2,
                              float eps, float weight_decay, long step, float gscale, int zero_grad, void* stream)
 {
-    GPE_WRITES_TENSORS();
     if (!p || !g || !m || !v || n <= 0 || step <= 0 || (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15))
         return GPE_EINVAL;
     const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
@@ -806,7 +796,6 @@ __global__ void gpe_standardize_kernel(const float* __restrict__ x, long n, int 
 extern "C" int gpe_standardize(const float* x, long rows, int C, const float* shift_host, const float* scale_host,
                                float* out, void* stream)
 {
-    GPE_WRITES_TENSORS();
     if (!x || !out || !shift_host || !scale_host || rows <= 0 || C <= 0 || C > 8) return GPE_EINVAL;
     float s[8] = {0}, d[8] = {1, 1, 1, 1, 1, 1, 1, 1};
     for (int c = 0; c < C; ++c) { s[c] = shift_host[c]; d[c] = scale_host[c]; }

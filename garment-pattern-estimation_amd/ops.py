@@ -47,6 +47,32 @@ def round_up(a, b):
     return (a + b - 1) // b * b
 
 
+def _workspace(nbytes, device):
+    """caller-owned scratch of a C-ABI call (include/gpe_hip.h: `ws`); torch's caching allocator recycles it stream-ordered"""
+    return torch.empty(max(int(nbytes), 16), device=device, dtype=torch.uint8)
+
+
+def edge_workspace(B, N, k, ldmax, device):
+    """-> (ws, bytes) for gpe_edge_mlp_fwd / _bwd / gpe_edge_redgemm / gpe_edge_pq_amax calls on B clouds of N points, k
+    neighbours, per-point output pitches <= ldmax floats."""
+    n = L.query('gpe_edge_ws_bytes', B, N, k, ldmax)
+    if n < 0:
+        raise RuntimeError('gpe_edge_ws_bytes failed with code %d' % n)
+    return _workspace(n, device), n
+
+
+def f16x3_words(n, rows, device):
+    """n caller-owned "amax words" (include/gpe_hip.h) when the f16x3 arithmetic will run on `rows`-row edge launches, else None:
+    one uint32 per tensor whose largest magnitude a kernel measures while storing it and a later kernel scales by."""
+    if L.get_math() != 'f16x3' or rows < L.query('gpe_f16x3_min_rows'):
+        return None
+    return torch.zeros(n, device=device, dtype=torch.int32)
+
+
+def _word(words, i):
+    return None if words is None else words[i:i + 1]
+
+
 # -------------------------------------------------------------------------------------------------
 # PackPlan: weight-derived operands refreshed by one launch
 # -------------------------------------------------------------------------------------------------
@@ -300,7 +326,8 @@ def knn(x, B, N, k, want_global=False):
     _dev_check(x)
     idx = torch.empty(B, N, k, device=x.device, dtype=torch.int32)
     jg = torch.empty(B, N, k, device=x.device, dtype=torch.int32) if want_global else None
-    L.call('gpe_knn', x, B, N, x.shape[1], x.stride(0), k, idx, jg)
+    nws = L.query('gpe_knn_ws_bytes', B, N, x.shape[1], k)
+    L.call('gpe_knn', x, B, N, x.shape[1], x.stride(0), k, idx, jg, _workspace(nws, x.device), nws)
     return (idx, jg) if want_global else idx
 
 
@@ -489,6 +516,12 @@ class EdgeConvFn(torch.autograd.Function):
                 return bn_finalize(part, nblk, widths[l], E, g, be, eps, momentum, rm, rv, nbt)
             return bn_from_running(rm, rv, g, be, eps)
 
+        # caller-owned state of the edge calls: one workspace, and in f16x3 mode the amax words of this layer's tensors —
+        # [0] the bound of relu(P_i + Q_j), [l] activation a_l, [nb + l] dz_l (backward)
+        ews, ews_n = edge_workspace(B, N, k, max(round_up(widths[-1], 4), 2 * H0), dev)
+        words = f16x3_words(2 * nb, E, dev)
+        if words is not None:
+            L.call('gpe_edge_pq_amax', PQ, 2 * H0, H0, BN, _word(words, 0), ews, ews_n)
         part = torch.empty(nblk, 2, H0, device=dev, dtype=torch.float64) if training else None
         if training:
             L.call('gpe_edge_gather_stats', PQ, 2 * H0, H0, jg, B, N, k, part)
@@ -509,13 +542,14 @@ class EdgeConvFn(torch.autograd.Function):
                 amn = torch.empty(BN, ldo, device=dev, dtype=torch.uint8)
             wp = pack_weight(Ws[l], col_scale=stats[l - 1][2])
             bf = fold_bias(Ws[l], params[4 * l + 1], stats[l - 1][3])
+            w_out = None if last else _word(words, l)      # nobody scales by the last activation: dz overwrites it
             if l == 1:
                 L.call('gpe_edge_mlp_fwd', 0, PQ, 2 * H0, jg, None, 0, B, N, k, Cin, Cout, wp, bf, a, ldo, part,
-                       agg, mx, mn, amx, amn, ldo)
+                       agg, mx, mn, amx, amn, ldo, _word(words, 0), w_out, ews, ews_n)
             else:
                 prev = acts[l - 1]
                 L.call('gpe_edge_mlp_fwd', 1, None, 0, None, prev, prev.stride(0), B, N, k, Cin, Cout, wp, bf, a, ldo,
-                       part, agg, mx, mn, amx, amn, ldo)
+                       part, agg, mx, mn, amx, amn, ldo, _word(words, l - 1), w_out, ews, ews_n)
             acts.append(a)
             stats.append(stats_of(part, l))
         Fo = widths[-1]
@@ -533,6 +567,7 @@ class EdgeConvFn(torch.autograd.Function):
         ctx.dims = (B, N, k, C, nb, aggr, training)
         ctx.widths = widths
         ctx.done = False
+        ctx.words = words
         ctx.save_for_backward(x, idx, jg, PQ, *params, *acts[1:], *stats,
                               *([mx, mn, amx, amn] if aggr == 'max' else [abar]))
         ctx.mark_non_differentiable(idx)
@@ -561,6 +596,8 @@ class EdgeConvFn(torch.autograd.Function):
             g_out = g_out.contiguous()
         ldg = g_out.stride(0)
         grads = [None] * (4 * nb)
+        words = ctx.words                  # f16x3 amax words of this layer (None in the other modes): see forward
+        ews, ews_n = edge_workspace(B, N, k, max(ldF, 2 * H0), dev)
 
         # ---- last block: BatchNorm applied after the aggregation -----------------------------------------
         psb = L.query('gpe_point_sums_blocks')
@@ -572,7 +609,7 @@ class EdgeConvFn(torch.autograd.Function):
             L.call('gpe_edge_bwd_point_sums', g_out, ldg, mx, mn, ldF, stats[-1], BN, Fo, part)
             coef, dg, dbe = bn_bwd_coef(part, psb, stats[-1], Fo, E, g_last, be_last, training)
             # dz in place over the stored activation (one coalesced pass)
-            L.call('gpe_edge_dz3', a_last, ldF, g_out, ldg, amx, amn, ldF, coef, B, N, k, Fo)
+            L.call('gpe_edge_dz3', a_last, ldF, g_out, ldg, amx, amn, ldF, coef, B, N, k, Fo, _word(words, 2 * nb - 1))
         else:
             # every message carries dy_e = w * g_i (w = 1/k mean, 1 add): sums over edges = (w*k) * per-point sums at
             # the mean activation of the point
@@ -583,7 +620,8 @@ class EdgeConvFn(torch.autograd.Function):
                 L.call('gpe_scale', g_out.contiguous(), float(k), gs, gs.numel())
             L.call('gpe_edge_bwd_point_sums', gs, gs.stride(0), abar, abar, ldF, stats[-1], BN, Fo, part)
             coef, dg, dbe = bn_bwd_coef(part, psb, stats[-1], Fo, E, g_last, be_last, training)
-            L.call('gpe_edge_dz3_all', a_last, ldF, g_out, ldg, 1.0 / k if aggr == 'mean' else 1.0, coef, B, N, k, Fo)
+            L.call('gpe_edge_dz3_all', a_last, ldF, g_out, ldg, 1.0 / k if aggr == 'mean' else 1.0, coef, B, N, k, Fo,
+                   _word(words, 2 * nb - 1))
         grads[4 * (nb - 1) + 2], grads[4 * (nb - 1) + 3] = _gret(g_last, dg), _gret(be_last, dbe)
 
         # ---- blocks nb-1 .. 1: weight gradient (centred reduce-GEMM) -> previous BN coefficients -> propagate ----
@@ -596,13 +634,14 @@ class EdgeConvFn(torch.autograd.Function):
             W, b = Ws[l], params[4 * l + 1]
             G = torch.empty(Cl, Cp, device=dev, dtype=F32)
             db = _gbuf(b)
+            w_dz = _word(words, nb + l)                    # dz_l: written by dz3 (l = nb - 1) or by the propagation below
             if l == 1:
                 L.call('gpe_edge_redgemm', dz, dz.stride(0), 0, None, 0, PQ, 2 * H0, jg, stats[0][0], B, N, k, Cl, Cp, G,
-                       Cp, db, ws)
+                       Cp, db, ws, w_dz, _word(words, 0), ews, ews_n)
             else:
                 prev = acts[l - 1]
                 L.call('gpe_edge_redgemm', dz, dz.stride(0), 1, prev, prev.stride(0), None, 0, None, stats[l - 1][0],
-                       B, N, k, Cl, Cp, G, Cp, db, ws)
+                       B, N, k, Cl, Cp, G, Cp, db, ws, w_dz, _word(words, l - 1), ews, ews_n)
             sums = torch.empty(1, 2, Cp, device=dev, dtype=torch.float64)
             dW = _gbuf(W)
             L.call('gpe_bn_bwd_from_G', G, Cp, db, W, W.stride(0), Cl, Cp, stats[l - 1], sums, dW, Cp)
@@ -616,12 +655,12 @@ class EdgeConvFn(torch.autograd.Function):
                 # In place over dz_1's buffer when the row pitch fits, else a fresh [E, H0]
                 dst = dz if dz.stride(0) == H0 else torch.empty(E, H0, device=dev, dtype=F32)
                 L.call('gpe_edge_mlp_bwd', dz, dz.stride(0), 1, PQ, 2 * H0, jg, B, N, k, Cl, Cp, wt, coef_p, dst, H0,
-                       dPQ, 2 * H0)
+                       dPQ, 2 * H0, w_dz, None, ews, ews_n)
                 dz = dst
             else:
                 prev = acts[l - 1]
                 L.call('gpe_edge_mlp_bwd', dz, dz.stride(0), 0, None, 0, None, B, N, k, Cl, Cp, wt, coef_p, prev,
-                       prev.stride(0), None, 0)
+                       prev.stride(0), None, 0, w_dz, _word(words, nb + l - 1), ews, ews_n)
                 dz = prev
 
         # ---- block 0: gather backward = deterministic pull through the transposed graph -----------------
@@ -902,6 +941,8 @@ class DenseMLPFn(torch.autograd.Function):
         acts, stats = [], []
         a_in, Cin = x, x.shape[1]
         scale = tvec = None
+        ews, ews_n = edge_workspace(1, M, 1, 4, dev)
+        words = f16x3_words(2 * n_blocks, M, dev)          # [l] activation a_l, [n + l] dz_l (backward)
         for l in range(n_blocks):
             W, b, g, be = params[4 * l: 4 * l + 4]
             rm, rv, nb = bufs[3 * l: 3 * l + 3]
@@ -911,7 +952,8 @@ class DenseMLPFn(torch.autograd.Function):
             part = torch.empty(nblk, 2, Cout, device=dev, dtype=torch.float64) if training else None
             L.call('gpe_edge_mlp_fwd', 1, None, 0, None, a_in, a_in.stride(0), 1, M, 1, Cin, Cout,
                    pack_weight(W, col_scale=scale), b if tvec is None else fold_bias(W, b, tvec), a, ldo, part,
-                   0, None, None, None, None, 0)
+                   0, None, None, None, None, 0, _word(words, l - 1) if l > 0 else None,
+                   _word(words, l) if l < n_blocks - 1 else None, ews, ews_n)
             st = bn_finalize(part, nblk, Cout, M, g, be, eps, momentum, rm, rv, nb) if training \
                 else bn_from_running(rm, rv, g, be, eps)
             acts.append(a)
@@ -923,6 +965,7 @@ class DenseMLPFn(torch.autograd.Function):
         ctx.n_blocks = n_blocks
         ctx.training = training
         ctx.done = False
+        ctx.words = words
         ctx.save_for_backward(x, *params, *acts, *stats)
         return y
 
@@ -947,7 +990,9 @@ class DenseMLPFn(torch.autograd.Function):
         part = torch.empty(psb, 2, C, device=dev, dtype=torch.float64)
         L.call('gpe_edge_bwd_point_sums', gy, C, a, a, a.stride(0), st, M, C, part)
         coef, dgam, dbet = bn_bwd_coef(part, psb, st, C, M, g_l, be_l, training)
-        L.call('gpe_edge_dz3_all', a, a.stride(0), gy, C, 1.0, coef, 1, M, 1, C)
+        words = ctx.words
+        ews, ews_n = edge_workspace(1, M, 1, 4, dev)
+        L.call('gpe_edge_dz3_all', a, a.stride(0), gy, C, 1.0, coef, 1, M, 1, C, _word(words, 2 * n - 1))
         grads[4 * (n - 1) + 2], grads[4 * (n - 1) + 3] = _gret(g_l, dgam), _gret(be_l, dbet)
         for l in reversed(range(n)):
             W, b = params[4 * l], params[4 * l + 1]
@@ -964,14 +1009,15 @@ class DenseMLPFn(torch.autograd.Function):
                 else:
                     ws = torch.empty(L.query('gpe_redgemm_ws', C, Cp), device=dev, dtype=F32)
                     L.call('gpe_edge_redgemm', dz, dz.stride(0), 1, prev, prev.stride(0), None, 0, None, stp[0],
-                           1, M, 1, C, Cp, G, Cp, db, ws)
+                           1, M, 1, C, Cp, G, Cp, db, ws, _word(words, n + l), _word(words, l - 1), ews, ews_n)
                 sums = torch.empty(1, 2, Cp, device=dev, dtype=torch.float64)
                 dW = _gbuf(W)
                 L.call('gpe_bn_bwd_from_G', G, Cp, db, W, W.stride(0), C, Cp, stp, sums, dW, Cp)
                 gp, bp = params[4 * (l - 1) + 2], params[4 * (l - 1) + 3]
                 coef_p, dgam_p, dbet_p = bn_bwd_coef(sums, 1, stp, Cp, M, gp, bp, training)
                 L.call('gpe_edge_mlp_bwd', dz, dz.stride(0), 0, None, 0, None, 1, M, 1, C, Cp,
-                       pack_weight(W, transpose=True), coef_p, prev, prev.stride(0), None, 0)
+                       pack_weight(W, transpose=True), coef_p, prev, prev.stride(0), None, 0,
+                       _word(words, n + l), _word(words, n + l - 1), ews, ews_n)
                 grads[4 * l], grads[4 * l + 1] = _gret(W, dW), _gret(b, db)
                 grads[4 * (l - 1) + 2], grads[4 * (l - 1) + 3] = _gret(gp, dgam_p), _gret(bp, dbet_p)
             else:

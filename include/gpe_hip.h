@@ -7,19 +7,21 @@
  * entry points below.  Each entry point names the reference line(s) whose arithmetic it replaces.
  *
  * Conventions (all functions):
- *   - plain C symbols; raw DEVICE pointers + dims + a hipStream_t passed as void*; the caller owns every buffer it
- *     passes; work is enqueued on `stream` of the CURRENT device and the call returns immediately;
- *     process-global state is limited to (a) the arithmetic mode (gpe_math_set) and the profiling switches
- *     (gpe_debug_set), which apply to every stream and device of the process, (b) per-device caches of the
- *     CU count and of the >64 KB LDS opt-in (hipFuncSetAttribute), keyed by device ordinal, (c) four grow-only
- *     per-device scratch images (hipMalloc on first use / growth, never shared between streams by the library:
- *     use ONE stream per device for these calls): the per-pseudo-point rows of gpe_edge_mlp_fwd / _bwd when
- *     k > 16, the partial k-lists of gpe_knn when it splits the candidate range (large clouds), the dummy store image
- *     of the straight-line edge kernels and the operand-scale slots of the f16x3 mode, and (d) in f16x3 mode only
- *     (gpe_math_set(4)): one pending producer note and a table of <= 8 kept forward maxima — host-side records
- *     (pointer, shape, slot) of tensors whose largest magnitude a kernel of this library measured while writing them;
- *     cleared by gpe_math_set, see mode 4 below for the one rule they impose on a caller.  Not thread-safe: one host
- *     thread per process drives the library;
+ *   - plain C symbols; raw DEVICE pointers + dims + a hipStream_t passed as void*; the caller owns EVERY buffer — outputs,
+ *     workspaces (`part`, `ws`: sizes from the gpe_*_ws* queries) and the f16x3 scale words below; the library never allocates
+ *     device memory and keeps no record of tensors between calls.  Work is enqueued on `stream` of the CURRENT device and the
+ *     call returns immediately.  Calls on different streams may run concurrently as long as they share no output / workspace.
+ *     Process-global state is limited to (a) the arithmetic mode (gpe_math_set, gpe_f16x3_min_rows_set) and the profiling
+ *     switches (gpe_debug_set), which apply to every stream and device of the process, and (b) per-device caches of the CU
+ *     count and of the >64 KB LDS opt-in (hipFuncSetAttribute), keyed by device ordinal.  The mode setters are not
+ *     thread-safe against concurrent launches; everything else is.
+ *   - "amax word" (f16x3 mode): a uint32 in device memory holding the bit pattern of a non-negative float that is >= the
+ *     largest magnitude of a tensor (a bound is as good as the value; tighter = more precise).  An entry point that writes an
+ *     activation / dz tensor fills the word passed as `amax_out` (whatever kernel ran: if it could not track the maximum while
+ *     storing, one extra streaming pass measures it); an entry point that reads the tensor through the fp16 pipe takes the word
+ *     as `amax_a` / `amax_u` / `amax_v`.  All of them may be NULL: nothing is measured / the operand is measured in-call (edge
+ *     GEMMs) or the exact fp32 kernel runs (reduce-GEMM).  The caller vouches for the words it passes: a word that is too small
+ *     for its tensor overflows fp16 silently.  Modes other than f16x3 ignore `amax_a/u/v` and honour `amax_out`.
  *   - return 0 on success, -22 (EINVAL) on bad arguments, -5 (EIO) if the launch failed;
  *   - fp32 storage and arithmetic unless stated; matrix products run on v_mfma_f32_16x16x4_f32 (exact fp32);
  *     BatchNorm statistics are accumulated in fp64;
@@ -51,26 +53,32 @@ int gpe_debug_set(int flags);
  *   4 = "f16x3"  TWO-term fp16 split of operands normalised per TENSOR by a power of two (largest magnitude -> [2^14, 2^15)),
  *                three fp16 MFMAs per product, fp32 accumulate: 23 mantissa bits per product, PARITY-GRADE (every test at the
  *                exact mode's bars; profiles/r03_i_f16x3_grad_errors.md).  All four shapes of the shipped edge MLPs stay
- *                resident (two weight planes); the weight-gradient reduce-GEMMs join when both operand scales are known without
- *                a pass over the tensor.  The scales are measured on the device: packed weight and [P|Q] table by small passes,
- *                activations / dz tensors through a NOTE the producing kernel leaves (largest magnitude written); the note is
- *                dropped by any call into this library that writes caller tensors other than the statistics / packing /
- *                reduce-GEMM calls between two edge GEMMs — a caller must not rewrite such a tensor by other means between
- *                the call that produced it and the next gpe_edge_mlp_fwd / gpe_edge_mlp_bwd / gpe_edge_redgemm.
- *                The mode bench.py times; 24 % faster than mode 0 at BASELINE cfg 2.
+ *                resident (two weight planes); the weight-gradient reduce-GEMMs join when the caller passes both operand words.
+ *                The scales come from caller-owned amax words (see Conventions): the packed weight is measured in-call (one
+ *                workgroup), activations / dz tensors by the kernel that stores them, the gathered operand by a bound over the
+ *                [P|Q] table (gpe_edge_pq_amax, or in-call).  Launches with fewer than gpe_f16x3_min_rows() rows run the exact
+ *                kernels (the scale passes cost more than the fp16 pipe saves there).  The mode bench.py times.
  * Returns the previous mode, or -22 for an unknown one.  kNN, BatchNorm statistics, the LSTM decoder and every
  * elementwise op are fp32 (fp64 for reductions) in every mode. */
 int gpe_math_set(int mode);
 int gpe_math_get(void);
+/* f16x3 size gate (part of the arithmetic mode): edge launches with fewer rows use the exact fp32 kernels.  Default 65536;
+ * the setter returns the previous value (tests set 0 to force the fp16-pipe kernels on small fixtures). */
+long gpe_f16x3_min_rows(void);
+long gpe_f16x3_min_rows_set(long rows);
 
 /* ---- kNN graph: torch_cluster.knn as called by DynamicEdgeConv (nn/net_blocks.py:127-135,174) ------------
  * x [B][N][ldx>=C]; idx [B][N][k] int32, LOCAL to the cloud, ascending (dist, index); self included.
  * dist = fp32 fma chain over channels of (x_c - y_c)^2, ties -> lower index (same rules as oracle/knn_ref.c).
  * Limits: 1 <= k <= min(64, N) (the k-list of a query lives one entry per lane of its wavefront; torch_cluster's own device
  * kernel stops at k = 100, the reference's configurations use k = 5 .. 20), B*N*k < 2^31; anything else returns -22. */
-int gpe_knn(const float* x, int B, int N, int C, int ldx, int k, int32_t* idx, int32_t* idx_glob, void* stream);
+long gpe_knn_ws_bytes(int B, int N, int C, int k);
+int gpe_knn(const float* x, int B, int N, int C, int ldx, int k, int32_t* idx, int32_t* idx_glob, void* ws, long ws_bytes,
+            void* stream);
 /* idx_glob (may be NULL) [B][N][k] = b*N + idx: the GLOBAL row of each neighbour, which is what the gather kernels
- * below take as `jg` (B*N*k must be < 2^31). */
+ * below take as `jg` (B*N*k must be < 2^31).  ws: gpe_knn_ws_bytes(B, N, C, k) bytes, 16-B aligned (squared norms, per-cloud
+ * maxima, candidate lists of the matrix-pipe filter / of a split candidate range); NULL or too small: the all-exact kernel
+ * without candidate split runs (same result, slower). */
 
 /* reverse adjacency of the kNN graph (needed by the gather's backward = scatter-add into x_j rows):
  * rev_off [B][N+1] int32 (local offsets), rev_edge [B][N*k] int32 = local edge ids (i*k+s) sorted ascending
@@ -145,7 +153,17 @@ int gpe_bn_from_running(const float* running_mean, const float* running_var, int
 int gpe_edge_mlp_fwd(int a_mode, const float* pq, int ldpq, const int32_t* jg, const float* a_in, int lda,
                      int B, int N, int k, int Cin, int Cout, const float* wp, const float* bias,
                      float* out, int ldo, double* stats_part,
-                     int agg, float* mx, float* mn, uint8_t* amx, uint8_t* amn, int ldagg, void* stream);
+                     int agg, float* mx, float* mn, uint8_t* amx, uint8_t* amn, int ldagg,
+                     const uint32_t* amax_a, uint32_t* amax_out, void* ws, long ws_bytes, void* stream);
+/* amax_a: amax word of the A operand (a_mode 0: of relu(P_i+Q_j), e.g. from gpe_edge_pq_amax; a_mode 1: of a_in), amax_out: word
+ * that receives the largest |out| — see Conventions.  ws: gpe_edge_ws_bytes(B, N, k, ldagg) bytes, 16-B aligned: the store image
+ * of the straight-line kernels, the in-call f16x3 words, the per-pseudo-point rows of a k > 16 launch.  NULL / too small: the
+ * variants that need none run (slower; f16x3 falls back to exact fp32). */
+long gpe_edge_ws_bytes(int B, int N, int k, int ldmax);   /* ldmax: the largest ldagg / lddp the workspace will be used with */
+/* amax[0] = bits of a bound of relu(P_i + Q_j) over the [rows][ldpq >= 2H] table (max P + max Q, rounded up); ws as above */
+int gpe_edge_pq_amax(const float* pq, int ldpq, int H, long rows, uint32_t* amax, void* ws, long ws_bytes, void* stream);
+/* amax[0] = bits of the largest |x| over [rows][cols] (row pitch ldx, 16-B aligned rows) */
+int gpe_absmax(const float* x, int ldx, long rows, int cols, uint32_t* amax, void* stream);
 
 /* layer output: y[i][c] = s[c]*(s[c]>=0 ? mx : mn)[i][c] + t[c]  (BN applied after the max, sign-aware) */
 int gpe_edge_finish(const float* mx, const float* mn, int ldagg, const float* stats, long rows, int C,
@@ -173,14 +191,17 @@ int gpe_bn_bwd_from_G(const float* G, int ldG, const float* db, const float* w_n
  * (BN-after-max backward + ReLU backward of the last edge-MLP block; g [B*N][ldg] is the layer-output gradient,
  * amx/amn the argmax/argmin slots saved by gpe_edge_mlp_fwd, coef [4][F] from gpe_bn_bwd_coef). */
 int gpe_edge_dz3(float* a3, int lda3, const float* g, int ldg, const uint8_t* amx, const uint8_t* amn, int ldagg,
-                 const float* coef, int B, int N, int k, int F, void* stream);
+                 const float* coef, int B, int N, int k, int F, uint32_t* amax_out, void* stream);
 
 /* reduce-GEMM over the E edges: G[Mg][Ng] = sum_e U[e][:]^T (V[e][:] - v_shift), colsum[Mg] = sum_e U[e][:];
  * U dense [E][ldu]; v_mode 0: V rows = relu(P_i+Q_j) gathered through jg (Ng = H) ; v_mode 1: V rows dense [E][ldv];
  * v_shift [Ng] may be NULL */
 int gpe_edge_redgemm(const float* u, int ldu, int v_mode, const float* v, int ldv, const float* pq, int ldpq,
                      const int32_t* jg, const float* v_shift, int B, int N, int k, int Mg, int Ng, float* G, int ldG,
-                     float* colsum, float* part, void* stream);
+                     float* colsum, float* part, const uint32_t* amax_u, const uint32_t* amax_v, void* ws, long ws_bytes,
+                     void* stream);
+/* amax_u / amax_v: amax words of U and of V (v_mode 0: of relu(P_i+Q_j); NULL there = the bound passes run in `ws`).  f16x3 mode
+ * runs the fp16-pipe kernel only when both are known, else the exact fp32 kernel. */
 
 /* propagate + BN/ReLU backward:  u = A.Wp^T ; dz = (act>0) ? s*u - c1 - (act-mean)*k2 : 0 ; written to dz_out
  * (A dense [E][lda]; coef_out [4][Cout] = {s,c1,k2,mean} of the BatchNorm being crossed; Wp = packed TRANSPOSE of the
@@ -189,7 +210,8 @@ int gpe_edge_redgemm(const float* u, int ldu, int v_mode, const float* v, int ld
  * act_mode 1: act = relu(P_i+Q_j) gathered, and dP[i] = sum_s dz[(i,s)] is also written (ld lddp). */
 int gpe_edge_mlp_bwd(const float* a, int lda, int act_mode, const float* pq, int ldpq, const int32_t* jg,
                      int B, int N, int k, int Cin, int Cout, const float* wp, const float* coef_out,
-                     float* dz_out, int ldo, float* dP, int lddp, void* stream);
+                     float* dz_out, int ldo, float* dP, int lddp, const uint32_t* amax_a, uint32_t* amax_out, void* ws,
+                     long ws_bytes, void* stream);
 
 /* dQ[j] = sum over incoming edges e of dz1[e]  (deterministic pull through the reverse adjacency) */
 int gpe_edge_pull_dq(const float* dz, int lddz, const int32_t* rev_off, const int32_t* rev_edge,
@@ -294,7 +316,7 @@ int gpe_edge_inputs_bwd(const float* g, int ldg, int C, const int32_t* rev_off, 
                         float* gx, int ldgx, void* stream);
 /* gpe_edge_dz3 for aggr 'add' / 'mean': every message of a point receives gscale * g[i] (no arg-slot selection) */
 int gpe_edge_dz3_all(float* a3, int lda3, const float* g, int ldg, float gscale, const float* coef, int B, int N, int k,
-                     int F, void* stream);
+                     int F, uint32_t* amax_out, void* stream);
 
 /* ---- pooling variants (torch_geometric global_max_pool / global_add_pool, nn/net_blocks.py:145-150) -----------------
  * mode 1 = max (arg [B][C] int32 = the winning point, first maximum), 2 = add. */

@@ -17,6 +17,7 @@ W3 = torch.randn(Fo, H, device=dev) / 14
 b3 = torch.randn(Fo, device=dev)
 E = B * N * k
 nblk = L.query('gpe_stats_blocks')
+EWS, NWS = ops.edge_workspace(B, N, k, 2 * H, dev)      # caller-owned workspace of the edge entry points
 w2p, w3p = ops.pack_weight(W2), ops.pack_weight(W3)
 w3t = ops.pack_weight(W3, transpose=True)
 coef = torch.randn(4, H, device=dev)
@@ -31,10 +32,10 @@ def run():
     part3 = torch.zeros(nblk, 2, Fo, device=dev, dtype=torch.float64)
     mx = torch.zeros(B * N, 152, device=dev); mn = torch.zeros_like(mx)
     amx = torch.zeros(B * N, 152, device=dev, dtype=torch.uint8); amn = torch.zeros_like(amx)
-    L.call('gpe_edge_mlp_fwd', 0, PQ, 2 * H, jg, None, 0, B, N, k, H, H, w2p, b2, a2, H, part2, 0, None, None, None, None, 0)
-    L.call('gpe_edge_mlp_fwd', 1, None, 0, None, a2, H, B, N, k, H, Fo, w3p, b3, a3, 152, part3, 1, mx, mn, amx, amn, 152)
+    L.call('gpe_edge_mlp_fwd', 0, PQ, 2 * H, jg, None, 0, B, N, k, H, H, w2p, b2, a2, H, part2, 0, None, None, None, None, 0, None, None, EWS, NWS)
+    L.call('gpe_edge_mlp_fwd', 1, None, 0, None, a2, H, B, N, k, H, Fo, w3p, b3, a3, 152, part3, 1, mx, mn, amx, amn, 152, None, None, EWS, NWS)
     d2 = a2.clone()
-    L.call('gpe_edge_mlp_bwd', dz3, 152, 0, None, 0, None, B, N, k, Fo, H, w3t, coef, d2, H, None, 0)
+    L.call('gpe_edge_mlp_bwd', dz3, 152, 0, None, 0, None, B, N, k, Fo, H, w3t, coef, d2, H, None, 0, None, None, EWS, NWS)
     return a2, a3, mx, part2.sum(0), d2
 
 
@@ -59,9 +60,9 @@ a2 = torch.empty(E, H, device=dev); a3 = torch.empty(E, 152, device=dev)
 part = torch.empty(nblk, 2, H, device=dev, dtype=torch.float64)
 mx = torch.empty(B * N, 152, device=dev); mn = torch.empty_like(mx)
 amx = torch.empty(B * N, 152, device=dev, dtype=torch.uint8); amn = torch.empty_like(amx)
-def f2(): L.call('gpe_edge_mlp_fwd', 0, PQ, 2 * H, jg, None, 0, B, N, k, H, H, w2p, b2, a2, H, part, 0, None, None, None, None, 0)
-def f3(): L.call('gpe_edge_mlp_fwd', 1, None, 0, None, a2, H, B, N, k, H, Fo, w3p, b3, a3, 152, part, 1, mx, mn, amx, amn, 152)
-def b2a(): L.call('gpe_edge_mlp_bwd', a3, 152, 0, None, 0, None, B, N, k, Fo, H, w3t, coef, a2, H, None, 0)
+def f2(): L.call('gpe_edge_mlp_fwd', 0, PQ, 2 * H, jg, None, 0, B, N, k, H, H, w2p, b2, a2, H, part, 0, None, None, None, None, 0, None, None, EWS, NWS)
+def f3(): L.call('gpe_edge_mlp_fwd', 1, None, 0, None, a2, H, B, N, k, H, Fo, w3p, b3, a3, 152, part, 1, mx, mn, amx, amn, 152, None, None, EWS, NWS)
+def b2a(): L.call('gpe_edge_mlp_bwd', a3, 152, 0, None, 0, None, B, N, k, Fo, H, w3t, coef, a2, H, None, 0, None, None, EWS, NWS)
 for mode in ['f32', 'bf16x3']:
     gpe_amd.set_math(mode)
     for flags in [0, 16, 3]:
@@ -81,8 +82,8 @@ G = torch.empty(H, H, device=dev); cs = torch.empty(H, device=dev)
 ws = torch.empty(L.query('gpe_redgemm_ws', H, H), device=dev)
 shift = torch.randn(H, device=dev)
 a2r = torch.randn(E, H, device=dev); a3r = torch.randn(E, 152, device=dev); a3r[:, 150:] = 0
-def rg(): L.call('gpe_edge_redgemm', a2r, H, 0, None, 0, PQ, 2 * H, jg, shift, B, N, k, H, H, G, H, cs, ws)
-def rd(): L.call('gpe_edge_redgemm', a3r, 152, 1, a2r, H, None, 0, None, shift, B, N, k, Fo, H, G[:Fo], H, cs, ws)
+def rg(): L.call('gpe_edge_redgemm', a2r, H, 0, None, 0, PQ, 2 * H, jg, shift, B, N, k, H, H, G, H, cs, ws, None, None, EWS, NWS)
+def rd(): L.call('gpe_edge_redgemm', a3r, 152, 1, a2r, H, None, 0, None, shift, B, N, k, Fo, H, G[:Fo], H, cs, ws, None, None, EWS, NWS)
 res = {}
 for mode in ['f32', 'bf16x3']:
     gpe_amd.set_math(mode)

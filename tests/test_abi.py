@@ -20,7 +20,8 @@ def test_header_declares_expected_surface():
     for name, (res, args) in sigs.items():
         if name in ('gpe_abi_version', 'gpe_packed_size', 'gpe_packed_gates_size', 'gpe_redgemm_ws',
                     'gpe_stats_blocks', 'gpe_point_sums_blocks', 'gpe_debug_set', 'gpe_math_set', 'gpe_math_get',
-                    'gpe_attn_pool_ws', 'gpe_packed_ngates_size', 'gpe_rnn_seq_bwd_ws'):
+                    'gpe_attn_pool_ws', 'gpe_packed_ngates_size', 'gpe_rnn_seq_bwd_ws', 'gpe_f16x3_min_rows',
+                    'gpe_f16x3_min_rows_set', 'gpe_edge_ws_bytes', 'gpe_knn_ws_bytes'):
             continue
         assert res == 'i' and args[-1] == 'p', name
 
@@ -43,7 +44,17 @@ def test_math_mode_switch_is_host_only():
 
 def test_host_only_queries():
     l = _lib.lib()
-    assert l.gpe_abi_version() == 3
+    assert l.gpe_abi_version() == 4
+    # caller-owned workspaces (ABI version 4: the library allocates nothing): sizes are host-only queries
+    fixed = l.gpe_edge_ws_bytes(32, 2048, 16, 400)
+    assert fixed > 64 * 512 * 4 and l.gpe_edge_ws_bytes(1, 10, 5, 4) == fixed              # k <= 16: no pseudo-point rows
+    assert l.gpe_edge_ws_bytes(32, 4096, 20, 400) > fixed + 32 * 4096 * 5 * 400 * 4          # k = 20: 5 pseudo-points per point
+    assert l.gpe_edge_ws_bytes(0, 1, 1, 1) == -22
+    assert l.gpe_knn_ws_bytes(32, 2048, 150, 16) >= 32 * 2048 * (32 * 8 + 4)
+    # the f16x3 size gate is part of the arithmetic mode: settable, restorable
+    gate = l.gpe_f16x3_min_rows()
+    assert gate == 65536 and l.gpe_f16x3_min_rows_set(0) == gate and l.gpe_f16x3_min_rows() == 0
+    assert l.gpe_f16x3_min_rows_set(gate) == 0 and l.gpe_f16x3_min_rows_set(-1) == -22
     assert l.gpe_packed_size(200, 200) == 208 * 208
     assert l.gpe_packed_size(7, 3) == 16 * 16
     assert l.gpe_packed_gates_size(250, 250) == 64 * 16 * 256
@@ -55,9 +66,11 @@ def test_host_only_queries():
 def test_bad_arguments_are_rejected_without_a_gpu():
     l = _lib.lib()
     # NULL pointers / bad dims must come back as -EINVAL before any launch is attempted
-    assert l.gpe_knn(None, 1, 8, 3, 3, 4, None, None, None) == -22
+    assert l.gpe_knn(None, 1, 8, 3, 3, 4, None, None, None, 0, None) == -22
     assert l.gpe_linear(None, 0, 0, 0, None, None, None, 0, 0, 0, None, 0, 0, 0, 4, 4, 4, 0, None) == -22
     assert l.gpe_edge_gather_stats(None, 0, 0, None, 1, 1, 1, None, None) == -22
+    assert l.gpe_edge_pq_amax(None, 0, 0, 0, None, None, 0, None) == -22
+    assert l.gpe_absmax(None, 0, 0, 0, None, None) == -22
 
 
 def test_product_path_has_no_cpu_fallback():

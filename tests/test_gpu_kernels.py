@@ -281,12 +281,12 @@ def test_edge_redgemm_producer_consumer_tiles(gpe, mode, B, N, k, Mg, Ng):
         pv = Ng + 8
         vbuf = torch.full((E, pv), float('nan')).cuda()
         vbuf[:, :Ng] = torch.randn(E, Ng, generator=g).cuda()
-        L.call('gpe_edge_redgemm', ubuf, pu, 1, vbuf, pv, None, 0, None, shift, B, N, k, Mg, Ng, G, Ng, cs, ws)
+        L.call('gpe_edge_redgemm', ubuf, pu, 1, vbuf, pv, None, 0, None, shift, B, N, k, Mg, Ng, G, Ng, cs, ws, None, None, None, 0)
         vref = vbuf[:, :Ng].double() - shift.double()
     else:
         pq = torch.randn(B * N, 2 * Ng, generator=g).cuda()
         jg = (torch.randint(0, N, (B, N, k), generator=g) + torch.arange(B).view(B, 1, 1) * N).int().cuda()
-        L.call('gpe_edge_redgemm', ubuf, pu, 0, None, 0, pq, 2 * Ng, jg, shift, B, N, k, Mg, Ng, G, Ng, cs, ws)
+        L.call('gpe_edge_redgemm', ubuf, pu, 0, None, 0, pq, 2 * Ng, jg, shift, B, N, k, Mg, Ng, G, Ng, cs, ws, None, None, None, 0)
         i = torch.arange(B * N, device='cuda').repeat_interleave(k)
         vref = torch.relu(pq[i, :Ng].double() + pq[jg.view(-1).long(), Ng:].double()) - shift.double()
     uref = ubuf[:, :Mg].double()
@@ -694,15 +694,27 @@ def test_edgeconv_general_widths(gpe, H, Fo, aggr, C):
         assert relerr(pconv(x.cuda(), B, N), o64(x.double(), batch)) < 5e-5
 
 
-def _f16x3_dense_block(gpe, a_in, Wm, bias, B, N, k):
-    """One fused dense edge block (gpe_edge_mlp_fwd a_mode 1, no statistics / aggregation) -> a fresh output tensor."""
+def _f16x3_dense_block(gpe, a_in, Wm, bias, B, N, k, amax_a=None, amax_out=None):
+    """One fused dense edge block (gpe_edge_mlp_fwd a_mode 1, no statistics / aggregation) -> a fresh output tensor.  amax_a /
+    amax_out: the caller-owned f16x3 scale words of include/gpe_hip.h (None: the operand is measured in-call / nothing kept)."""
     L = gpe._lib
     E, Cin = a_in.shape
     Cout = Wm.shape[0]
     out = torch.empty(E, (Cout + 3) // 4 * 4, device='cuda')
+    ws, nws = gpe.ops.edge_workspace(B, N, k, 4, 'cuda')
     L.call('gpe_edge_mlp_fwd', 1, None, 0, None, a_in, a_in.stride(0), B, N, k, Cin, Cout, gpe.ops.pack_weight(Wm), bias, out,
-           out.stride(0), None, 0, None, None, None, None, 0)
+           out.stride(0), None, 0, None, None, None, None, 0, amax_a, amax_out, ws, nws)
     return out[:, :Cout]
+
+
+@pytest.fixture
+def f16x3_ungated(gpe):
+    """f16x3 arithmetic with the size gate lifted (the kernel tests use a few thousand rows)."""
+    prev = gpe.set_math('f16x3')
+    gate = gpe.set_f16x3_min_rows(0)
+    yield
+    gpe.set_f16x3_min_rows(gate)
+    gpe.set_math(prev)
 
 
 @pytest.mark.parametrize('scale', [1e-25, 3e-9, 1.0, 7e6, 1e20])
@@ -716,12 +728,14 @@ def test_f16x3_extreme_magnitudes(gpe, scale):
     Wm = (torch.randn(Cout, Cin, generator=g) / 14 / max(scale, 1e-12) ** 0.5).cuda()
     ref = a.double().cpu() @ Wm.double().cpu().t()
     outs = {}
+    gate = gpe.set_f16x3_min_rows(0)
     for mode in ('f32', 'f16x3'):
         prev = gpe.set_math(mode)
         try:
             outs[mode] = _f16x3_dense_block(gpe, a, Wm, None, B, N, k).double().cpu()
         finally:
             gpe.set_math(prev)
+    gpe.set_f16x3_min_rows(gate)
     ref = torch.relu(ref)
     e32, e16 = relerr(outs['f32'], ref), relerr(outs['f16x3'], ref)
     print('scale %g: f32 %.2e, f16x3 %.2e' % (scale, e32, e16))
@@ -729,27 +743,91 @@ def test_f16x3_extreme_magnitudes(gpe, scale):
     assert e16 < max(2e-6, 4 * e32)
 
 
-def test_f16x3_note_dropped_by_intervening_write(gpe):
-    """A forward f16x3 kernel leaves a note with the largest magnitude it wrote for the next edge GEMM.  Any library call that
-    writes tensors in between drops it — here the activation is multiplied by 1000 in place, far past the noted maximum — so
-    the consumer measures the operand again instead of overflowing fp16."""
+def _word_value(w):
+    return w.view(torch.float32).item()
+
+
+def test_f16x3_amax_words_are_caller_owned(gpe, f16x3_ungated):
+    """The f16x3 scales live in caller-owned words (include/gpe_hip.h "amax word"): the kernel that stores an activation fills
+    `amax_out` with its largest magnitude, the next block takes it as `amax_a`.  The library keeps no record of tensors, so the
+    CALLER re-measures (gpe_absmax) after rewriting a tensor — here the activation is multiplied by 1000 in place — or passes
+    no word and lets the consumer measure the operand itself."""
     L = gpe._lib
     B, N, k, C = 2, 64, 16, 200
     g = torch.Generator().manual_seed(4)
     a0 = torch.randn(B * N * k, C, generator=g).abs().cuda()
     W1 = (torch.randn(C, C, generator=g) / 14).cuda()
     W2 = (torch.randn(150, C, generator=g) / 14).cuda()
-    prev = gpe.set_math('f16x3')
+    words = torch.zeros(2, dtype=torch.int32, device='cuda')
+    a1 = _f16x3_dense_block(gpe, a0, W1, None, B, N, k, None, words[0:1])    # fills word 0 with max|a1|
+    assert _word_value(words[0:1]) == a1.abs().max().item()
+    ref = torch.relu(a1.double().cpu() @ W2.double().cpu().t())
+    out = _f16x3_dense_block(gpe, a1, W2, None, B, N, k, words[0:1], None).double().cpu()
+    assert relerr(out, ref) < 2e-6
+    # a bound instead of the value is as good (tighter = more precise): 4x the maximum costs two mantissa bits of the low plane
+    bound = (a1.abs().max() * 4).view(1).view(torch.int32)
+    assert relerr(_f16x3_dense_block(gpe, a1, W2, None, B, N, k, bound, None).double().cpu(), ref) < 2e-6
+    # the caller rewrites the tensor -> the caller re-measures
+    a1 = a1.contiguous()
+    L.call('gpe_scale', a1, 1000.0, a1, a1.numel())
+    L.call('gpe_absmax', a1, a1.stride(0), a1.shape[0], a1.shape[1], words[1:2])
+    assert _word_value(words[1:2]) == a1.abs().max().item()
+    ref = torch.relu(a1.double().cpu() @ W2.double().cpu().t())
+    for w in (words[1:2], None):
+        out = _f16x3_dense_block(gpe, a1, W2, None, B, N, k, w, None).double().cpu()
+        assert torch.isfinite(out).all()
+        assert relerr(out, ref) < 2e-6
+    # every mode honours amax_out (one extra streaming pass where the kernel that ran does not track it)
+    prev = gpe.set_math('f32')
     try:
-        a1 = _f16x3_dense_block(gpe, a0, W1, None, B, N, k)                  # notes max|a1|
-        a1 = a1 if a1.is_contiguous() else a1.contiguous()
-        L.call('gpe_scale', a1, 1000.0, a1, a1.numel())                      # in place, through the library
-        out = _f16x3_dense_block(gpe, a1, W2, None, B, N, k).double().cpu()
+        words.zero_()
+        a2 = _f16x3_dense_block(gpe, a0, W1, None, B, N, k, None, words[0:1])
+        assert _word_value(words[0:1]) == a2.abs().max().item()
     finally:
         gpe.set_math(prev)
-    ref = torch.relu(a1.double().cpu() @ W2.double().cpu().t())
-    assert torch.isfinite(out).all()
-    assert relerr(out, ref) < 2e-6
+
+
+@pytest.mark.parametrize('v_mode', ['dense', 'gather'])
+def test_f16x3_edge_redgemm_with_words(gpe, f16x3_ungated, v_mode):
+    """The weight-gradient reduce-GEMM on the fp16 pipe: it runs only when the caller passes the amax words of both operands
+    (U: a dz tensor; V: the stored activation, or the bound of the gathered relu(P_i + Q_j) — from gpe_edge_pq_amax, or computed
+    in the call's workspace when the word is NULL); result within the exact kernel's bar of the fp64 product."""
+    ops, L = gpe.ops, gpe._lib
+    B, N, k, Mg, Ng = 8, 512, 16, 150, 200
+    g = torch.Generator().manual_seed(17)
+    E = B * N * k
+    u = (torch.randn(E, 152, generator=g) * 1e-4).cuda()
+    u[:, Mg:] = 0
+    shift = torch.randn(Ng, generator=g).abs().cuda()
+    G, cs = torch.empty(Mg, Ng).cuda(), torch.empty(Mg).cuda()
+    part = torch.empty(L.query('gpe_redgemm_ws', Mg, Ng)).cuda()
+    ws, nws = ops.edge_workspace(B, N, k, 2 * Ng, 'cuda')
+    words = torch.zeros(3, dtype=torch.int32, device='cuda')
+    L.call('gpe_absmax', u, 152, E, Mg, words[0:1])
+    if v_mode == 'dense':
+        v = torch.randn(E, Ng, generator=g).abs().cuda()
+        L.call('gpe_absmax', v, Ng, E, Ng, words[1:2])
+        vref = v.double() - shift.double()
+        variants = [words[1:2]]
+        run = lambda wv: L.call('gpe_edge_redgemm', u, 152, 1, v, Ng, None, 0, None, shift, B, N, k, Mg, Ng, G, Ng, cs, part,
+                                words[0:1], wv, ws, nws)
+    else:
+        pq = torch.randn(B * N, 2 * Ng, generator=g).cuda()
+        jg = (torch.randint(0, N, (B, N, k), generator=g) + torch.arange(B).view(B, 1, 1) * N).int().cuda()
+        L.call('gpe_edge_pq_amax', pq, 2 * Ng, Ng, B * N, words[2:3], ws, nws)
+        i = torch.arange(B * N, device='cuda').repeat_interleave(k)
+        a0 = torch.relu(pq[i, :Ng].double() + pq[jg.view(-1).long(), Ng:].double())
+        assert _word_value(words[2:3]) >= a0.max().item()
+        vref = a0 - shift.double()
+        variants = [words[2:3], None]
+        run = lambda wv: L.call('gpe_edge_redgemm', u, 152, 0, None, 0, pq, 2 * Ng, jg, shift, B, N, k, Mg, Ng, G, Ng, cs, part,
+                                words[0:1], wv, ws, nws)
+    uref = u[:, :Mg].double()
+    for wv in variants:
+        G.zero_(); cs.zero_()
+        run(wv)
+        assert relerr(G, uref.t() @ vref) < 3e-6
+        assert relerr(cs, uref.sum(0)) < 3e-6
 
 
 @pytest.mark.parametrize('M,W', [(1, 23), (700, 23), (513, 5), (64, 32)])
@@ -943,17 +1021,42 @@ def test_stitch_losses_and_renumbering(gpe, hardnet, origin, order, supervised):
     assert set(do0.keys()) == {'pattern_loss', 'loop_loss', 'rotation_loss', 'translation_loss'} and upd0 == bool(order and 0 == 39)
 
 
-def test_second_kernel_stream_is_refused(gpe):
-    """include/gpe_hip.h: per-device scratch images -> one kernel stream per device; a launch from another stream raises
-    instead of racing on them."""
-    x = torch.randn(2 * 64, 3, device='cuda')
-    gpe.ops.knn(x, 2, 64, 4)                                   # the default stream becomes this device's kernel stream
-    side = torch.cuda.Stream()
-    with torch.cuda.stream(side):
-        with pytest.raises(RuntimeError, match='second stream'):
-            gpe.ops.knn(x, 2, 64, 4)
-    gpe.ops.knn(x, 2, 64, 4)                                   # the first stream keeps working
-    torch.cuda.synchronize()
+def test_two_streams_one_device(gpe):
+    """include/gpe_hip.h: every buffer — outputs, workspaces, f16x3 scale words — is the caller's, so two streams of one device
+    can run the path concurrently.  Two EdgeConv layers (kNN, gather, fused edge GEMMs, backward) on two streams give bit-identical
+    results to the same layers run one after the other, in the exact and in the f16x3 arithmetic."""
+    from gpe_amd import net_blocks
+    B, N, C = 8, 512, 3
+    g = torch.Generator().manual_seed(11)
+    xs = [torch.randn(B * N, C, generator=g).cuda() for _ in range(2)]
+    torch.manual_seed(3)
+    conv0 = net_blocks.DynamicEdgeConv(net_blocks.MLP([2 * C, 200, 200, 150]), k=16, aggr='max').cuda().train()
+    convs = [conv0, copy.deepcopy(conv0)]                       # same weights; own BatchNorm buffers and .grad per stream
+
+    def run(i):
+        xr = xs[i].clone().requires_grad_()
+        y = convs[i](xr, B, N)
+        y.square().sum().backward()
+        return y.detach().clone(), xr.grad.clone()
+
+    for mode in ('f32', 'f16x3'):
+        prev = gpe.set_math(mode)
+        gate = gpe.set_f16x3_min_rows(0)
+        try:
+            seq = [run(i) for i in range(2)]
+            torch.cuda.synchronize()
+            streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+            par = [None, None]
+            for rep in range(3):                                   # interleave launches of the two streams
+                for i, st in enumerate(streams):
+                    with torch.cuda.stream(st):
+                        par[i] = run(i)
+            torch.cuda.synchronize()
+            for (y0, g0), (y1, g1) in zip(seq, par):
+                assert torch.equal(y0, y1) and torch.equal(g0, g1), mode
+        finally:
+            gpe.set_f16x3_min_rows(gate)
+            gpe.set_math(prev)
 
 
 def test_panel_loop_loss_standalone(gpe):
