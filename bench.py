@@ -5,7 +5,7 @@ synthetic point clouds, BASELINE.json config 2 per GPU:  N=2048 points, batch 32
 decoders.  fp32 storage; arithmetic of the timed region = --math, default 'f16x3': every product of the fused edge GEMMs as
 three fp16 MFMAs on tensor-normalised two-term splits (23 mantissa bits), fp32 accumulate — the parity-grade mode (every
 -m gpu test holds it to the exact mode's bars).  The exact-fp32-MFMA step is measured in the same run and reported as
-`exact_f32`; BASELINE's "bf16" is a storage option that is not built.
+`exact_f32` (for every world size); tensors stay fp32 in HBM (DESIGN.md 8, row g).
 
     python bench.py --gpus 1 --steps 20 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
@@ -13,16 +13,18 @@ three fp16 MFMAs on tensor-normalised two-term splits (23 mantissa bits), fp32 a
 
 Rank 0 prints ONE JSON line.  `value` = garments processed by all ranks / max-over-ranks wall time of exactly K
 steps (barrier + synchronize on both sides).  Extra objects:
-  roofline      — the dominant kernel family of the step (the fused edge-MLP GEMMs): algorithmic FLOPs per launch / average
-                  launch duration from HIP events on the launch stream, vs 157.3 TFLOP/s (the fp32-input MFMA peak: the roof of
-                  the exact formulation); in f16x3 mode also the executed matrix-pipe FLOPs (3 per algorithmic one) vs the
-                  fp16 peak — those kernels are issue-bound, not pipe-bound (DESIGN.md 5.8);
+  roofline      — the dominant kernel family of the step, priced as SURVEY.md 8(d) prescribes against the roofs it actually sits
+                  under: t_roof = max(HBM bytes / 8 TB/s, EXECUTED matrix-pipe FLOPs / peak of the instruction it runs)
+                  (f16x3: 3 fp16 MFMA FLOPs per algorithmic one vs 2.5 PF; exact: 1 vs 157.3 TF), frac = t_roof / launch
+                  duration (HIP events on the launch stream), `bound` = the larger of the two.  HBM bytes = the counter traffic
+                  of the committed PMC pass of THESE kernel sources, else the algorithmic bytes.
+  roofline_per_kernel — the same for every kernel family of the step, and `roofline_step`: whole-step HBM and pipe fractions;
   roofline_gather — the EdgeConv neighbourhood gather: bytes_gather = N*k*(C*s+4) + N*C*s + N*F*s
                   per garment and layer, for (a) the kernel that carries the layer-2 gather (the fused gather->GEMM
-                  forward, MFMA-bound: its time is NOT a bandwidth measurement) and (b) the stand-alone gather + BN
+                  forward: its time is NOT a bandwidth measurement) and (b) the stand-alone gather + BN
                   statistics pass (bandwidth-bound), each next to the counter-derived HBM bytes of the committed PMC pass;
   cpu_baseline  — the CPU oracle (oracle/ref_path.py, kind "port") timed on this box's host cores on a bounded sample
-                  (cfg-2 shape and the reference's own cfg-1 shape).
+                  (the benchmarked shape at the benchmarked batch, and the reference's own cfg-1 shape).
 """
 import argparse
 import json
@@ -45,7 +47,7 @@ PEAK_L2_GBS = 34500.0        # aggregate of the eight 4 MiB XCD L2s (MI355X_MICR
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--steps', type=int, default=100)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--batch', type=int, default=32, help='garments per GPU')
     ap.add_argument('--points', type=int, default=2048)
@@ -57,8 +59,8 @@ def parse():
                     help='epoch handed to the loss: 0 (default, SURVEY.md 8d) = the four main terms; >= 40 = the shipped YAML\'s '
                          'stitch + free-class terms are active as well (synthetic stitches) — an extra measurement')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-batch', type=int, default=8)
-    ap.add_argument('--cpu-steps', type=int, default=3)
+    ap.add_argument('--cpu-batch', type=int, default=0, help='batch of the CPU baseline sample; 0 = the benchmarked batch (capped at 32)')
+    ap.add_argument('--cpu-steps', type=int, default=2)
     ap.add_argument('--cpu-threads', type=int, default=0, help='0 = all host cores (nproc)')
     ap.add_argument('--no-kernel-timing', action='store_true')
     ap.add_argument('--math', choices=['f32', 'f16x3', 'bf16x6', 'mixed', 'bf16x3'], default='f16x3',
@@ -91,24 +93,36 @@ def synthetic(B, N, data_config, seed, device):
     return feats.to(device), {k: v.to(device) for k, v in gt.items()}
 
 
-# algorithmic work per C-ABI call, from its integer arguments (see include/gpe_hip.h for the argument order)
+# algorithmic work per C-ABI call, from its integer arguments (see include/gpe_hip.h for the argument order; `a` holds the
+# int / float arguments of the call in order — pointers are not recorded)
 def call_work(name, a):
-    """-> (flops, bytes) for one launch"""
+    """-> (flops, bytes) for one launch: algorithmic FLOPs of its matrix product and the bytes it has to move once (fp32)"""
     if name == 'gpe_edge_mlp_fwd':          # a_mode, ldpq, lda, B, N, k, Cin, Cout, ...
         B, N, k, Cin, Cout = a[3], a[4], a[5], a[6], a[7]
-        return 2.0 * B * N * k * Cin * Cout, 0.0
+        E = float(B) * N * k
+        by = E * Cout * 4 + (B * N * 2.0 * Cin * 4 + E * 4 if a[0] == 0 else E * Cin * 4)
+        return 2.0 * E * Cin * Cout, by
     if name == 'gpe_edge_mlp_bwd':          # lda, act_mode, ldpq, B, N, k, Cin, Cout
         B, N, k, Cin, Cout = a[3], a[4], a[5], a[6], a[7]
-        return 2.0 * B * N * k * Cin * Cout, 0.0
+        E = float(B) * N * k
+        by = E * Cin * 4 + E * Cout * 4 + (B * N * 2.0 * Cout * 4 + E * 4 if a[1] == 1 else E * Cout * 4)
+        return 2.0 * E * Cin * Cout, by
     if name == 'gpe_edge_redgemm':          # ldu, v_mode, ldv, ldpq, B, N, k, Mg, Ng
         B, N, k, Mg, Ng = a[4], a[5], a[6], a[7], a[8]
-        return 2.0 * B * N * k * Mg * Ng, 0.0
+        E = float(B) * N * k
+        return 2.0 * E * Mg * Ng, E * Mg * 4 + (B * N * 2.0 * Ng * 4 + E * 4 if a[1] == 0 else E * Ng * 4)
+    if name == 'gpe_edge_dz3':              # lda3, ldg, ldagg, B, N, k, F : the activation read and overwritten
+        B, N, k, F = a[3], a[4], a[5], a[6]
+        return 0.0, 2.0 * B * N * k * F * 4
+    if name == 'gpe_knn':                   # B, N, C, ldx, k : the distance form 2 N^2 C per cloud; the table once + the lists
+        B, N, C, k = a[0], a[1], a[2], a[4]
+        return 2.0 * B * N * N * C, float(B) * N * (C * 4 + 2 * k * 4)
     if name == 'gpe_linear':                # strides..., M, N, K, act  (last four ints)
         M, N, K = a[-4], a[-3], a[-2]
-        return 2.0 * M * N * K, 0.0
+        return 2.0 * M * N * K, 4.0 * M * (N + K)
     if name == 'gpe_redgemm':               # ..., rows, Mg, Ng, ldg, accumulate
         rows, Mg, Ng = a[-5], a[-4], a[-3]
-        return 2.0 * rows * Mg * Ng, 0.0
+        return 2.0 * rows * Mg * Ng, 4.0 * rows * (Mg + Ng)
     if name == 'gpe_edge_gather_stats':     # ldpq, H, B, N, k : SURVEY 8(d) bytes_gather with C = H (P|Q rows), no output row
         H, B, N, k = a[1], a[2], a[3], a[4]
         return 0.0, float(B) * (N * k * (H * 4 + 4) + N * H * 4)
@@ -118,20 +132,35 @@ def call_work(name, a):
     return 0.0, 0.0
 
 
+def call_family(name, a):
+    """kernel family of a launch: the entry point plus the variant its arguments select (they run different kernels)"""
+    if name == 'gpe_edge_mlp_fwd':
+        return name + (':gather' if a[0] == 0 else ':dense')
+    if name == 'gpe_edge_mlp_bwd':
+        return name + (':gather' if a[1] == 1 else ':inplace')
+    if name == 'gpe_edge_redgemm':
+        return name + (':gather' if a[1] == 0 else ':dense')
+    if name == 'gpe_knn':
+        return name + (':filter' if a[2] >= 16 else ':exact')
+    return name
+
+
 # HBM traffic per launch from the committed PMC passes (profiles/*_hbm_traffic.json, made by scripts/collect_profiles.sh
 # from two `rocprofv3 --pmc` runs of this same command); C-ABI entry -> device kernels it launches
 _TRAFFIC_KERNELS = {
     # template tails: rowgemm <NT, AMODE, EMODE>; edgegemm (paired) <.., AMODE, EMODE, MATH>; edgegemm_sr <.., AMODE, EMODE, KC, HALF>
-    # split <Policy, AQ, BQ, KCH, AMODE, EMODE, K16>
-    'gpe_edge_mlp_fwd': r'gpe_rowgemm_kernel<.*, 1>$|gpe_edgegemm(_sr)?_kernel<\d+, \d+, \d+, \d+, 1(, [-\w]+)+>$'
-                        r'|gpe_edgegemm_split_kernel<\w+, \d+, \d+, \d+, \d+, 1(, \w+)+>$',
-    'gpe_edge_mlp_bwd': r'gpe_rowgemm_kernel<.*, [23]>$|gpe_edgegemm(_sr)?_kernel<\d+, \d+, \d+, \d+, [23](, [-\w]+)+>$'
-                        r'|gpe_edgegemm_split_kernel<\w+, \d+, \d+, \d+, \d+, [23](, \w+)+>$',
-    'gpe_edge_redgemm': r'gpe_redgemm_pc_kernel<|gpe_redgemm_b3_kernel<',
-    'gpe_edge_gather_stats': r'gpe_gather_stats_kernel',
-    # AMODE = A_GATHER, EMODE = fwd
+    # split <Policy, AQ, BQ, KCH, AMODE, EMODE, K16, PSEUDO>;  AMODE 1 = gather;  EMODE 1 forward, 2 in-place backward, 3 gathered
+    # backward;  redgemm_pc / _b3 <MT, NT, VMODE(, F16)>: VMODE 0 = gathered V
     'gpe_edge_mlp_fwd:gather': r'gpe_edgegemm(_sr)?_kernel<\d+, \d+, \d+, 1, 1(, [-\w]+)+>$|gpe_edgegemm_split_kernel<\w+, \d+, \d+, \d+, 1, 1(, \w+)+>$',
-    'gpe_knn': r'gpe_knn_kernel',
+    'gpe_edge_mlp_fwd:dense': r'gpe_edgegemm(_sr)?_kernel<\d+, \d+, \d+, 0, 1(, [-\w]+)+>$|gpe_edgegemm_split_kernel<\w+, \d+, \d+, \d+, 0, 1(, \w+)+>$',
+    'gpe_edge_mlp_bwd:inplace': r'gpe_edgegemm(_sr)?_kernel<\d+, \d+, \d+, 0, 2(, [-\w]+)+>$|gpe_edgegemm_split_kernel<\w+, \d+, \d+, \d+, 0, 2(, \w+)+>$',
+    'gpe_edge_mlp_bwd:gather': r'gpe_edgegemm(_sr)?_kernel<\d+, \d+, \d+, 0, 3(, [-\w]+)+>$|gpe_edgegemm_split_kernel<\w+, \d+, \d+, \d+, 0, 3(, \w+)+>$',
+    'gpe_edge_redgemm:gather': r'gpe_redgemm_(pc|b3)_kernel<\d+, \d+, 0(, \w+)?>$',
+    'gpe_edge_redgemm:dense': r'gpe_redgemm_(pc|b3)_kernel<\d+, \d+, 1(, \w+)?>$',
+    'gpe_edge_gather_stats': r'gpe_gather_stats_kernel',
+    'gpe_edge_dz3': r'gpe_dz3_kernel',
+    'gpe_knn:filter': r'gpe_knn_mfma_kernel|gpe_knn_rerank_kernel|gpe_knn_norms_kernel|gpe_knn_cmax_kernel',
+    'gpe_knn:exact': r'gpe_knn_kernel',
     'gpe_edge_pull_dq': r'gpe_pull_dq_kernel',
 }
 
@@ -148,26 +177,49 @@ def csrc_sha():
     return h.hexdigest()[:16]
 
 
-def pmc_traffic(entry):
-    """HBM bytes per launch of the kernels behind a C-ABI entry, from the newest profiles/*_hbm_traffic.json — but only if
-    that file records the csrc hash of THIS tree (profiles/summarize_pmc.py writes it); a summary made from other kernel
-    sources is refused (traffic = null, the reason in traffic_source)."""
+def _pmc_doc():
+    """(doc, source, why-not) of the newest profiles/*_hbm_traffic.json — only if it records the csrc hash of THIS tree
+    (profiles/summarize_pmc.py writes it); a summary made from other kernel sources is refused."""
     import glob
-    import re
     files = sorted(glob.glob(os.path.join(REPO, 'profiles', '*_hbm_traffic.json')))
-    if not files or entry not in _TRAFFIC_KERNELS:
-        return None, None
+    if not files:
+        return None, None, 'no profiles/*_hbm_traffic.json'
     doc = json.load(open(files[-1]))
     if doc.get('csrc_sha') != csrc_sha():
-        return None, 'refused: profiles/%s was measured on csrc %s, this tree is %s' % (
+        return None, None, 'refused: profiles/%s was measured on csrc %s, this tree is %s' % (
             os.path.basename(files[-1]), doc.get('csrc_sha'), csrc_sha())
-    kern = doc['kernels']
-    n = b = 0.0
-    for name, v in kern.items():
-        if re.search(_TRAFFIC_KERNELS[entry], name):
-            n += v['launches']
-            b += v['launches'] * v['hbm_bytes']
-    return (b / n, 'profiles/' + os.path.basename(files[-1])) if n else (None, None)
+    return doc, 'profiles/' + os.path.basename(files[-1]), None
+
+
+def pmc_traffic(family, launches_per_step=None):
+    """HBM bytes per launch of the C-ABI entry `family` (all device kernels it runs, summed), from the committed PMC pass."""
+    import re
+    doc, src, why = _pmc_doc()
+    if doc is None or family not in _TRAFFIC_KERNELS:
+        return None, why
+    steps = float(doc.get('steps_profiled', 3))
+    per_step = 0.0
+    hit = False
+    for name, v in doc['kernels'].items():
+        if re.search(_TRAFFIC_KERNELS[family], name):
+            per_step += v['launches'] * v['hbm_bytes'] / steps
+            hit = True
+    if not hit:
+        return None, None
+    if launches_per_step is None:                       # one device-kernel launch per entry launch: the main kernel's count
+        n = max(v['launches'] for name, v in doc['kernels'].items() if re.search(_TRAFFIC_KERNELS[family], name)) / steps
+    else:
+        n = launches_per_step
+    return per_step / n, src
+
+
+def pmc_step_bytes():
+    """counter HBM bytes of one whole training step (every kernel of the PMC pass), or None"""
+    doc, src, _ = _pmc_doc()
+    if doc is None:
+        return None, None
+    steps = float(doc.get('steps_profiled', 3))
+    return sum(v['launches'] * v['hbm_bytes'] for v in doc['kernels'].values()) / steps, src
 
 
 
@@ -178,14 +230,14 @@ def _workload_name(args):
              ('att', 4096, 32, 20): 'BASELINE cfg 4', ('lstm', 8192, 64, 16): 'BASELINE cfg 5 per-GPU share (fp32)'}
     model = ('GarmentSegmentPattern3D (attention)' if args.model == 'att'
              else 'GarmentFullPattern3D, EdgeConv encoder + LSTM decoders')
-    # BASELINE cfg 2 says "bf16", cfg 5 "fp16 with fp32 accumulate": storage options that are deliberately not built — every
-    # edge kernel is >= 1.7x away from its HBM bound (DESIGN.md section 8, row g), so they would not shorten the step
+    # BASELINE cfg 2 says "bf16", cfg 5 "fp16 with fp32 accumulate": the fp16 matrix pipe with fp32 accumulate is what f16x3 runs;
+    # tensors stay fp32 in HBM (DESIGN.md section 8, row g: which kernels sit near their HBM bound and what was done about it)
     arith = {'f32': 'exact fp32 MFMA arithmetic',
              'f16x3': 'fp32-grade arithmetic: edge-GEMM products as 3 fp16 MFMAs on tensor-normalised two-term splits, fp32 '
                       'accumulate (parity-grade: the exact mode\'s test bars)'}.get(getattr(args, 'math', 'f16x3'), 'APPROXIMATE arithmetic (%s)' % getattr(args, 'math', '?'))
-    return '%s: %s, N=%d, batch %d/GPU, k=%d; fp32 storage, %s (the half-precision STORAGE the config names ' \
-           'is not built: measured not worthwhile, DESIGN.md 8)' % (named.get(shape, 'custom shape'), model, args.points,
-                                                                    args.batch, args.k, arith)
+    return '%s: %s, N=%d, batch %d/GPU, k=%d; fp32 storage, %s' % (named.get(shape, 'custom shape'), model, args.points,
+                                                                  args.batch, args.k, arith)
+
 
 def _cpu_name():
     try:
@@ -234,17 +286,84 @@ def cpu_baseline(args, data_config, nn_cfg):
         ncores = int(min(probe, key=probe.get))
         probe['note'] = 's/step of a B=2 sample at N=%d, k=%d (1 warm-up + 1 timed), measured in this run' % (args.points, args.k)
     torch.set_num_threads(ncores)
-    t2 = timed(args.cpu_batch, args.points, args.k, args.cpu_steps)
+    cpu_batch = args.cpu_batch if args.cpu_batch > 0 else min(args.batch, 32)
+    t2 = timed(cpu_batch, args.points, args.k, args.cpu_steps)
     t1 = timed(8, 1024, 5, max(args.cpu_steps, 5))          # BASELINE cfg 1: the reference's own CPU-runnable case
     O.KNN_IMPL = 'c'
-    return {'value': args.cpu_batch / t2, 'unit': 'garments/s', 'cores': ncores, 'kind': 'port',
+    return {'value': cpu_batch / t2, 'unit': 'garments/s', 'cores': ncores, 'kind': 'port',
             'sample': 'oracle/ref_path.py (kNN by cdist+topk) fwd+loss+bwd, B=%d N=%d k=%d fp32, 1 warm-up + %d timed '
-                      'steps, %.2f s/step' % (args.cpu_batch, args.points, args.k, args.cpu_steps, t2),
+                      'steps, %.2f s/step' % (cpu_batch, args.points, args.k, args.cpu_steps, t2),
             'cfg1': {'value': 8 / t1, 'unit': 'garments/s',
                      'sample': 'BASELINE cfg 1 (N=1024, B=8, k=5), 1 warm-up + %d timed steps, %.3f s/step'
                                % (max(args.cpu_steps, 5), t1)},
             'cpu': _cpu_name(), 'nproc': nproc,
             'thread_probe': probe}
+
+
+def roofline_tables(rec, nsteps, args, step_s, f16_rows):
+    """-> (roofline of the dominant family, per-family table, whole-step table) from the recorded launches `rec` =
+    [(entry, int args, start event, end event)] of `nsteps` training steps; step_s = seconds per step of the timed region."""
+    # ---- roofline per kernel family (SURVEY.md 8d): t_roof = max(HBM bytes / 8 TB/s, executed pipe FLOPs / peak(dtype)) ----
+    fam = {}
+    for name, ints, e0, e1 in rec:
+        fl, by = call_work(name, ints)
+        d = fam.setdefault(call_family(name, ints), [0, 0.0, 0.0, 0.0, name])
+        d[0] += 1
+        d[1] += e0.elapsed_time(e1)
+        d[2] += fl
+        d[3] += by
+    # which matrix instruction a family's product runs on: the fused edge GEMMs follow --math (above the f16x3 size gate),
+    # everything else (Linear, dense reduce-GEMMs, the kNN filter) is the exact fp32 instruction
+    on_f16 = args.math == 'f16x3' and args.batch * args.points * args.k >= f16_rows
+    per_kernel = {}
+    for key, (n_l, ms, fl, by, entry) in fam.items():
+        if not (fl or by):
+            continue
+        t = ms * 1e-3 / n_l
+        edge = entry in ('gpe_edge_mlp_fwd', 'gpe_edge_mlp_bwd', 'gpe_edge_redgemm')
+        f16 = edge and on_f16
+        pipe_peak = PEAK_F16_TFLOPS if f16 else PEAK_F32_TFLOPS
+        exec_fl = (3.0 if f16 else 1.0) * fl / n_l
+        traffic, tsrc = pmc_traffic(key, n_l / nsteps)
+        hbm = traffic if traffic else by / n_l
+        t_hbm, t_pipe = hbm / (PEAK_HBM_GBS * 1e9), exec_fl / (pipe_peak * 1e12)
+        bound = 'hbm' if t_hbm >= t_pipe else 'mfma'
+        per_kernel[key] = {
+            'launches_per_step': n_l / nsteps, 'avg_launch_ms': ms / n_l, 'ms_per_step': ms / nsteps,
+            'bound': bound, 'frac': max(t_hbm, t_pipe) / t,
+            'hbm_bytes_per_launch': hbm, 'hbm_bytes_source': tsrc if traffic else 'algorithmic (no PMC pass of these sources)',
+            'algorithmic_bytes_per_launch': by / n_l, 'hbm_GBs': hbm / t / 1e9, 'hbm_frac': t_hbm / t,
+            'flops_per_launch': fl / n_l, 'pipe': ('v_mfma_f32_16x16x32_f16 x3 per product' if f16 else 'v_mfma_f32_16x16x4_f32') if fl else None,
+            'pipe_TFLOPs': exec_fl / t / 1e12 if fl else None, 'pipe_peak': pipe_peak if fl else None,
+            'pipe_frac': t_pipe / t if fl else None}
+    per_kernel = dict(sorted(per_kernel.items(), key=lambda kv: -kv[1]['ms_per_step']))
+    # dominant entry of the step = the family with the most time per step
+    dom = next(iter(per_kernel))
+    pk = per_kernel[dom]
+    if pk['bound'] == 'hbm':
+        roof = {'kernel': dom, 'bound': 'hbm', 'achieved': pk['hbm_GBs'], 'peak': PEAK_HBM_GBS, 'unit': 'GB/s'}
+    else:
+        roof = {'kernel': dom, 'bound': 'mfma', 'achieved': pk['pipe_TFLOPs'], 'peak': pk['pipe_peak'], 'unit': 'TFLOP/s'}
+    traffic, tsrc = pmc_traffic(dom, pk['launches_per_step'])
+    roof.update(frac=pk['frac'], traffic=traffic, traffic_unit='HBM bytes/launch', traffic_source=tsrc,
+                launches_per_step=pk['launches_per_step'], avg_launch_ms=pk['avg_launch_ms'],
+                flops_per_launch=pk['flops_per_launch'], algorithmic_bytes_per_launch=pk['algorithmic_bytes_per_launch'],
+                hbm_frac=pk['hbm_frac'], pipe=pk['pipe'], pipe_frac=pk['pipe_frac'],
+                rule='frac = max(HBM bytes / 8 TB/s, executed matrix-pipe FLOPs / pipe peak) / launch duration (SURVEY.md 8d); '
+                     'HBM bytes = PMC counter traffic of these kernel sources when committed, else algorithmic bytes')
+    # whole step: counter bytes / step time against HBM, executed pipe FLOPs against the two pipes
+    sb, ssrc = pmc_step_bytes()
+    alg_b = sum(v['algorithmic_bytes_per_launch'] * v['launches_per_step'] for v in per_kernel.values())
+    t_f16 = sum(v['flops_per_launch'] * 3 * v['launches_per_step'] for v in per_kernel.values()
+                if v['pipe'] and 'f16' in v['pipe']) / (PEAK_F16_TFLOPS * 1e12)
+    t_f32 = sum(v['flops_per_launch'] * v['launches_per_step'] for v in per_kernel.values()
+                if v['pipe'] and 'f16' not in v['pipe']) / (PEAK_F32_TFLOPS * 1e12)
+    roof_step = {'ms_per_step': step_s * 1e3, 'hbm_bytes_per_step': sb, 'hbm_bytes_source': ssrc,
+                 'hbm_frac': sb / step_s / (PEAK_HBM_GBS * 1e9) if sb else None,
+                 'algorithmic_bytes_per_step': alg_b, 'algorithmic_hbm_frac': alg_b / step_s / (PEAK_HBM_GBS * 1e9),
+                 'pipe_time_ms': {'fp16 MFMA (x3)': t_f16 * 1e3, 'fp32 MFMA': t_f32 * 1e3},
+                 'pipe_frac': (t_f16 + t_f32) / step_s}
+    return roof, per_kernel, roof_step
 
 
 def main():
@@ -309,7 +428,7 @@ def main():
     final_loss = loss.item()
 
     # ---- per-kernel durations: HIP events on the launch stream, same workload, right after the timed region ----
-    roof, roof_gather, breakdown = None, None, None
+    roof, roof_gather, breakdown, per_kernel, roof_step = None, None, None, None, None
     rec = None
     if not args.no_kernel_timing:
         # every rank runs these extra steps (they contain the gradient all-reduce); only rank 0 records events
@@ -341,23 +460,7 @@ def main():
             with open(args.call_shapes, 'w') as f:
                 for (name, ints), v in sorted(shp.items(), key=lambda kv: -kv[1][1]):
                     f.write('%-24s x%-4d %8.1f us  %s\n' % (name, v[0] // nsteps, 1e3 * v[1] / v[0], ints))
-        # dominant = the fused per-edge GEMM family (forward + backward + weight-gradient kernels)
-        fam = ['gpe_edge_mlp_fwd', 'gpe_edge_mlp_bwd', 'gpe_edge_redgemm']
-        dom = max(fam, key=lambda n: agg.get(n, [0, 0, 0, 0])[1])
-        n_l, ms, fl, _ = agg[dom]
-        ach = fl / (ms * 1e-3) / 1e12
-        traffic, tsrc = pmc_traffic(dom)
-        roof = {'kernel': dom, 'bound': 'mfma', 'achieved': ach, 'peak': PEAK_F32_TFLOPS, 'unit': 'TFLOP/s',
-                'frac': ach / PEAK_F32_TFLOPS, 'traffic': traffic, 'traffic_unit': 'HBM bytes/launch',
-                'traffic_source': tsrc, 'launches_per_step': n_l / nsteps,
-                'avg_launch_ms': ms / n_l, 'flops_per_launch': fl / n_l,
-                'peak_note': 'algorithmic FLOPs against the fp32-input MFMA peak, the roof of the exact formulation'}
-        if args.math == 'f16x3':
-            # what the matrix pipe actually executes in this mode: 3 fp16 MFMA FLOPs per algorithmic FLOP
-            roof.update(pipe='v_mfma_f32_16x16x32_f16, 3 per algorithmic product', pipe_achieved=3 * ach,
-                        pipe_peak=PEAK_F16_TFLOPS, pipe_frac=3 * ach / PEAK_F16_TFLOPS,
-                        pipe_note='the two-plane kernels are bound by a lone wave\'s instruction issue (VALU epilogue / staging, '
-                                  'LDS), not by the fp16 pipe: DESIGN.md 5.8')
+        roof, per_kernel, roof_step = roofline_tables(rec, nsteps, args, elapsed / args.steps, _lib.query('gpe_f16x3_min_rows'))
         # ---- the EdgeConv gather, SURVEY.md §8(d) row 5: bytes_gather(layer) per garment, s = 4 (fp32) -------------
         H, F = nn_cfg['EConv_hidden'], nn_cfg['EConv_feature']
 
@@ -396,14 +499,16 @@ def main():
             ms = sum(t for _, t in gl) / len(gl)
             by = float(args.batch) * (args.points * args.k * (H * 4 + 4) + args.points * H * 4)
             roof_gather['fused_forward'] = {
-                'kernel': 'gpe_edge_mlp_fwd a_mode=0 (gather -> LDS tile -> fp32 MFMA): MFMA-bound, the gather hides under '
-                          'the matrix pipe', 'bound': 'mfma', 'gather_bytes_per_launch': by, 'avg_launch_ms': ms,
-                'gather_rate_GBs': by / (ms * 1e-3) / 1e9, 'traffic': pmc_traffic('gpe_edge_mlp_fwd:gather')[0]}
+                'kernel': 'gpe_edge_mlp_fwd a_mode=0 (gather -> LDS tile -> MFMA): the gather hides under the GEMM; priced in '
+                          'roofline_per_kernel', 'bound': per_kernel['gpe_edge_mlp_fwd:gather']['bound'], 'gather_bytes_per_launch': by, 'avg_launch_ms': ms,
+                'gather_rate_GBs': by / (ms * 1e-3) / 1e9, 'l2_frac': by / (ms * 1e-3) / 1e9 / PEAK_L2_GBS,
+                'traffic': pmc_traffic('gpe_edge_mlp_fwd:gather')[0]}
 
     # the other arithmetic modes, measured the same way on the same workload (reported beside `value`, never as `value`)
     fast = None
-    if world == 1 and args.math in ('f32', 'f16x3') and not args.no_fast_math_line:
+    if args.math in ('f32', 'f16x3') and not args.no_fast_math_line:
         fast = {}
+        only = None if world == 1 else ('f32', 'f16x3')        # N > 1: the two parity-grade modes (both are first-class numbers)
         for mode, note in (('f32', 'exact fp32: every product on v_mfma_f32_16x16x4_f32 (gpe_math_set(0))'),
                            ('f16x3', 'two-term split-fp16 products (3 fp16 MFMAs per product, fp32 accumulate) on tensor-normalised '
                                      'operands in all four single-role edge kernels and, where both operand scales are known without a '
@@ -415,7 +520,7 @@ def main():
                                      '1e-3 .. 1.5e-2 of max|grad| (approximate, tests TOL 3e-2); gpe_math_set(2) / GPE_MATH=mixed'),
                            ('bf16x3', 'every fused edge GEMM split-bf16: forward within 1e-4 of the reference, encoder '
                                       'gradients within ~1e-2 (tests/test_gpu_kernels.py TOL); gpe_math_set(1)')):
-            if mode == args.math:
+            if mode == args.math or (only and mode not in only):
                 continue
             gpe_amd.set_math(mode)
             n_f = max(3, min(args.steps, 10))
@@ -427,7 +532,11 @@ def main():
                 step(10_002 + i)
             barrier()
             dt = time.perf_counter() - t1
-            fast[mode] = {'value': args.batch * n_f / dt, 'unit': 'garments/s', 'steps': n_f,
+            if world > 1:
+                tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+                torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+                dt = tt.item()
+            fast[mode] = {'value': args.batch * world * n_f / dt, 'unit': 'garments/s', 'steps': n_f,
                           'ms_per_step': dt / n_f * 1e3, 'note': note}
         gpe_amd.set_math(args.math)
 
@@ -448,8 +557,7 @@ def main():
             'value': garments / elapsed, 'unit': 'garments/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None,
-            'dtype': {'f32': 'f32', 'f16x3': 'f32 (f16x3: 3 fp16 MFMAs per product on normalised two-term splits, fp32 accumulate, '
-                                             'fp32 storage)'}.get(args.math, args.math),
+            'dtype': 'f32',
             'math_mode': args.math, 'data': 'synthetic',
             'config': {'workload': _workload_name(args),
                        'global_batch': args.batch * world, 'parallelism': 'dp%d' % world,
@@ -457,7 +565,8 @@ def main():
                        'step': 'fwd + ComposedPatternLoss + bwd' + (' + RCCL grad all-reduce' if world > 1 else '')
                                + (' + Adam (torch)' if args.torch_adam else ' + fused Adam (flat arena)'),
                        'final_loss': final_loss},
-            'roofline': roof, 'roofline_gather': roof_gather, 'cpu_baseline': cpu,
+            'roofline': roof, 'roofline_step': roof_step, 'roofline_per_kernel': per_kernel,
+            'roofline_gather': roof_gather, 'cpu_baseline': cpu,
             'exact_f32': (fast or {}).get('f32'), 'fast_math': fast,
             'dist_world': (torch.distributed.get_world_size() if world > 1 else 1),
             'allreduce_ms_per_step': exchange and exchange['ms_per_step'],

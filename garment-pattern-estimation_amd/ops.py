@@ -91,9 +91,15 @@ def bump_weights_epoch():
 
 
 class PackPlan:
-    """Collects the static pack jobs of a model (net_blocks modules call `add_*` from their `register_packs`) and
-    re-runs them all with gpe_pack_multi whenever a parameter changed since the last run (torch version counters +
-    WEIGHTS_EPOCH).  Outputs are persistent buffers, so backward reads what forward used."""
+    """Collects the static pack jobs of a model (net_blocks modules call `add_*` from their `register_packs`) and re-runs them
+    all with ONE gpe_pack_multi launch at the start of every model forward (40 us at the shipped sizes).  Outputs are
+    persistent buffers, so backward reads what forward used.
+
+    Why every forward and not "when a parameter changed": torch's version counters do not see an update made through
+    `p.data` (an EMA of the weights, a hand-written `p.data.copy_()`, a foreign optimizer working on raw storage), and a stale
+    pack gives silently wrong numbers.  In training the weights change every step anyway.  A caller whose weights are truly
+    constant (inference loops) may set `plan.frozen = True` after the first forward: the launch is then skipped while the
+    version counters and WEIGHTS_EPOCH stand still — that caller vouches for not touching `p.data`."""
 
     def __init__(self):
         self.specs = []        # (param, param2, kind, N, K, aux)
@@ -104,8 +110,12 @@ class PackPlan:
         self.epoch = -1
         self.home = None
         self.keys = []
+        self.frozen = False
         self._keys_box = box = []              # shared with the finalizer: the keys this plan currently owns in _PACKS
-        weakref.finalize(self, lambda: [_PACKS.pop(k, None) for k in box])
+        me = weakref.ref(self)
+        # pop only entries that are still THIS plan's: a newer plan over the same parameters may have re-registered the keys
+        weakref.finalize(self, lambda: [_PACKS.pop(k, None) for k in box if (_PACKS.get(k) or (None,))[0] is me])
+        self._me = me
 
     def _add(self, p, kind, N, K, aux=0, p2=None, out_numel=None):
         self.specs.append((p, p2, kind, N, K, aux, out_numel))
@@ -139,7 +149,8 @@ class PackPlan:
 
     def _build(self):
         for k in self.keys:
-            _PACKS.pop(k, None)
+            if (_PACKS.get(k) or (None,))[0] is self._me:
+                _PACKS.pop(k, None)
         self.keys, self.outs = [], []
         del self._keys_box[:]
         dev = self.specs[0][0].device
@@ -160,7 +171,7 @@ class PackPlan:
                       p.stride(0) if p.dim() == 2 else 0, N, K, kind, npad, aux)
             blk += (total + 1023) // 1024            # gpe_pack_multi_kernel: 256 threads x one output quad
             key = (p.data_ptr(), kind)
-            _PACKS[key] = (weakref.ref(self), out, i)
+            _PACKS[key] = (self._me, out, i)
             self.keys.append(key)
             self._keys_box.append(key)
         self.blocks = blk
@@ -173,13 +184,14 @@ class PackPlan:
         return tuple((p.data_ptr(), p2.data_ptr() if p2 is not None else 0, p.device) for p, p2, *_ in self.specs)
 
     def refresh(self):
-        """Called at the start of a model forward: one gpe_pack_multi launch if any parameter changed since the last."""
+        """Called at the start of a model forward: one gpe_pack_multi launch (skipped only by a `frozen` plan whose parameters'
+        version counters and WEIGHTS_EPOCH did not move)."""
         if not self.specs:
             return
         vers = self._versions()
         if self.table is None or self.home != self._home():
             self._build()                      # first use, or a parameter moved (.to(device), arena re-homing)
-        elif self.vers == vers and self.epoch == WEIGHTS_EPOCH:
+        elif self.frozen and self.vers == vers and self.epoch == WEIGHTS_EPOCH:
             return
         L.call('gpe_pack_multi', self.table, len(self.specs), self.blocks)
         self.vers, self.epoch = vers, WEIGHTS_EPOCH

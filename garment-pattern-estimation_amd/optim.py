@@ -123,9 +123,10 @@ class OneCycle:
                 'end1': self.end1, 'end2': self.end2}
 
     def load_state_dict(self, sd):
-        """Accepts this class's own dict, or torch's OneCycleLR.state_dict() (nn/trainer.py:283 saves that one): of the
-        latter `total_steps` and, through `_schedule_phases`, the phase boundaries and rates are taken; `last_epoch`
-        (the step counter) is returned so that the caller can hand it to FusedAdam."""
+        """Accepts this class's own dict, or torch's OneCycleLR.state_dict() (nn/trainer.py:283 saves that one).  torch keeps the
+        schedule's RATES (max_lr / initial_lr / min_lr) in the optimizer's param group, not here: of the scheduler dict
+        `total_steps` and, through `_schedule_phases`, the phase boundaries are taken, and `last_epoch` (the step counter) is
+        returned so that the caller can hand it to FusedAdam; the rates arrive with FusedAdam.load_state_dict (set_rates)."""
         if 'total_steps' in sd and 'max_lr' in sd:
             self.max_lr, self.total = float(sd['max_lr']), int(sd['total_steps'])
             self.initial, self.min_lr = float(sd['initial_lr']), float(sd['min_lr'])
@@ -136,6 +137,15 @@ class OneCycle:
         if ph:
             self.end1, self.end2 = float(ph[0]['end_step']), float(ph[1]['end_step'])
         return sd.get('last_epoch')
+
+    def set_rates(self, group):
+        """takes max_lr / initial_lr / min_lr from an optimizer param group (where torch's OneCycleLR stores them)"""
+        if 'max_lr' in group:
+            self.max_lr = float(group['max_lr'])
+        if 'initial_lr' in group:
+            self.initial = float(group['initial_lr'])
+        if 'min_lr' in group:
+            self.min_lr = float(group['min_lr'])
 
     def lr(self, step):
         """learning rate used BY optimizer step number `step` (0-based: step 0 runs at the initial rate)."""
@@ -162,7 +172,10 @@ class FusedAdam:
         self.schedule = schedule
         self.m = torch.zeros_like(self.arena.flat)
         self.v = torch.zeros_like(self.arena.flat)
-        self.t = 0
+        self.t = 0                                     # optimizer steps taken (drives the schedule)
+        # torch.optim.Adam counts steps PER PARAMETER (state[p]['step']): a parameter that received no gradient in a step keeps
+        # its count, and its bias correction continues from there when a gradient shows up later.  Same here.
+        self.steps = [0] * len(self.arena.params)
         self.last_lr = self.lr if schedule is None else schedule.lr(0)
 
     def step(self, grad_scale=1.0):
@@ -170,26 +183,31 @@ class FusedAdam:
         lr = self.lr if self.schedule is None else self.schedule.lr(self.t)
         self.t += 1
         # torch.optim.Adam leaves a parameter alone in a step in which it received no gradient (grad None): no moment decay,
-        # no weight decay, no move.  Same here: the launch covers the maximal runs of arena segments that were touched
-        # (normally ONE run = the whole arena; the attention model's unused feature_extractor.lin splits it in two).
-        # Nothing recorded at all (gradients written by hand into arena.grad) = everything is live.
-        runs = [(0, a.numel)]
-        if a.touched and len(a.touched) < len(a.params):
-            runs, start = [], None
-            for i in range(len(a.params)):
-                if i in a.touched:
-                    if start is None:
-                        start = a.offsets[i]
-                    end = a.offsets[i] + (a.params[i].numel() + 3) // 4 * 4
-                elif start is not None:
-                    runs.append((start, end))
+        # no weight decay, no move, no step count.  Same here: a launch covers a maximal run of consecutive arena segments that
+        # were touched AND share one step count (normally ONE run = the whole arena; the attention model's unused
+        # feature_extractor.lin splits it in two).  Nothing recorded at all (gradients written by hand into arena.grad) =
+        # everything is live.
+        n = len(a.params)
+        live = a.touched if (a.touched and len(a.touched) < n) else set(range(n))
+        runs, start, cur = [], None, None
+        for i in range(n):
+            if i in live:
+                self.steps[i] += 1
+                if start is not None and self.steps[i] != cur:
+                    runs.append((start, end, cur))
                     start = None
-            if start is not None:
-                runs.append((start, end))
-        for lo, hi in runs:
+                if start is None:
+                    start, cur = a.offsets[i], self.steps[i]
+                end = a.offsets[i] + (a.params[i].numel() + 3) // 4 * 4
+            elif start is not None:
+                runs.append((start, end, cur))
+                start = None
+        if start is not None:
+            runs.append((start, end, cur))
+        for lo, hi, st in runs:
             L.call('gpe_adam_step', a.flat[lo:hi], a.grad[lo:hi], self.m[lo:hi], self.v[lo:hi], hi - lo, float(lr),
-                   float(self.betas[0]), float(self.betas[1]), self.eps, self.weight_decay, self.t, float(grad_scale), 1)
-        if len(runs) != 1 or runs[0] != (0, a.numel):
+                   float(self.betas[0]), float(self.betas[1]), self.eps, self.weight_decay, st, float(grad_scale), 1)
+        if len(runs) != 1 or runs[0][:2] != (0, a.numel):
             a.grad.zero_()             # untouched segments may still hold stale values written by hand
         self.last_lr = lr
         a.begin_step()
@@ -207,35 +225,49 @@ class FusedAdam:
         return [n - 1 - i for i in range(n)]
 
     def state_dict(self):
-        """torch.optim.Adam.state_dict() layout: state[i] = {step, exp_avg, exp_avg_sq} per parameter (index = position in
-        model.parameters()), param_groups[0] with the hyper-parameters.  A checkpoint written here loads into
-        torch.optim.Adam over the same model and vice versa."""
+        """torch.optim.Adam.state_dict() layout: state[i] = {step, exp_avg, exp_avg_sq} per parameter that has taken a step
+        (index = position in model.parameters(); like torch, no entry for a parameter that never received a gradient),
+        param_groups[0] with the hyper-parameters — and, under a OneCycle schedule, the `initial_lr` / `max_lr` / `min_lr` keys
+        torch's OneCycleLR keeps in the group, so that the reference's restore flow (build Adam + OneCycleLR, then
+        optimizer.load_state_dict: nn/trainer.py _restore_run) can step its scheduler on this checkpoint.  A checkpoint written
+        here loads into torch.optim.Adam over the same model and vice versa."""
         a = self.arena
         state = {}
         for i, ai in enumerate(self._module_order()):
+            if self.steps[ai] == 0:
+                continue
             o, n = a.segment(ai)
             shape = a.params[ai].shape
-            state[i] = {'step': torch.tensor(float(self.t)),
+            state[i] = {'step': torch.tensor(float(self.steps[ai])),
                         'exp_avg': self.m[o:o + n].view(shape).clone(),
                         'exp_avg_sq': self.v[o:o + n].view(shape).clone()}
-        group = {'lr': self.last_lr if self.schedule is not None else self.lr, 'betas': tuple(self.betas), 'eps': self.eps,
+        # under a schedule torch's group holds the rate of the NEXT step (scheduler.step() ran after optimizer.step())
+        lr_now = self.lr
+        if self.schedule is not None:
+            lr_now = self.schedule.lr(self.t) if self.t <= self.schedule.end2 else self.last_lr
+        group = {'lr': lr_now, 'betas': tuple(self.betas), 'eps': self.eps,
                  'weight_decay': self.weight_decay, 'amsgrad': False, 'maximize': False, 'foreach': None,
                  'capturable': False, 'differentiable': False, 'fused': None, 'decoupled_weight_decay': False,
                  'params': list(range(len(a.params)))}
         if self.schedule is not None:
             group['initial_lr'] = self.schedule.initial
+            group['max_lr'] = self.schedule.max_lr
+            group['min_lr'] = self.schedule.min_lr
         return {'state': state, 'param_groups': [group]}
 
     def load_state_dict(self, sd):
         """Loads torch.optim.Adam's layout (this class's own output, or a checkpoint of the reference trainer).  Validates the
         parameter count and every shape; parameters without an entry (torch keeps none for a parameter that never received
-        a gradient) start from zero moments.  Hyper-parameters come from param_groups[0]."""
+        a gradient) start from zero moments and step 0.  Hyper-parameters come from param_groups[0]; under a OneCycle schedule
+        its rates (max_lr / initial_lr / min_lr) are taken from there as well.  The schedule position `t` becomes the largest
+        per-parameter step (pass OneCycle.load_state_dict's return value to `self.t` when the scheduler dict is at hand)."""
         a = self.arena
         if 't' in sd and 'm' in sd:                    # round-2 private format: flat buffers in arena order
             if sd['m'].numel() != self.m.numel():
                 raise ValueError('FusedAdam: flat moment buffer of %d elements does not fit this arena (%d)'
                                  % (sd['m'].numel(), self.m.numel()))
             self.t = int(sd['t'])
+            self.steps = [self.t] * len(a.params)
             self.m.copy_(sd['m'])
             self.v.copy_(sd['v'])
             return
@@ -250,7 +282,7 @@ class FusedAdam:
         order = self._module_order()
         self.m.zero_()
         self.v.zero_()
-        t = 0
+        steps = [0] * len(a.params)
         for key, st in sd['state'].items():
             i = g['params'].index(key) if key in g['params'] else int(key)
             ai = order[i]
@@ -261,9 +293,12 @@ class FusedAdam:
                     raise ValueError('FusedAdam: %s of parameter %d has shape %s, the model\'s is %s'
                                      % (name, i, tuple(st[name].shape), tuple(shape)))
                 dst[o:o + n].copy_(st[name].reshape(-1))
-            t = max(t, int(float(st['step'])))
-        self.t = t
+            steps[ai] = int(float(st['step']))
+        self.steps = steps
+        self.t = max(steps) if steps else 0
         self.lr = float(g['lr']) if self.schedule is None else self.lr
         self.betas = tuple(float(b) for b in g['betas'])
         self.eps, self.weight_decay = float(g['eps']), float(g['weight_decay'])
         self.last_lr = float(g['lr'])
+        if self.schedule is not None:
+            self.schedule.set_rates(g)

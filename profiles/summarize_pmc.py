@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-kernel HBM traffic from two rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE are collected in separate runs:
-together they exceed the TCC counter slots).   usage: summarize_pmc.py <fetch-dir> <write-dir> > traffic.json
+together they exceed the TCC counter slots).   usage: summarize_pmc.py <fetch-dir> <write-dir> [training steps profiled] > traffic.json
 
 Units/corrections (MI355X_MICROARCH.md, HBM section): both counters are in KiB; on gfx950 FETCH_SIZE reports half the
 bytes of wide coalesced reads (128-B requests tallied at 64 B), so reads are doubled; WRITE_SIZE is taken as reported
@@ -48,5 +48,5 @@ def csrc_sha():
     return h.hexdigest()[:16]
 
 
-json.dump({'csrc_sha': csrc_sha(), 'source': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), reads x2 (gfx950 correction), per launch',
+json.dump({'csrc_sha': csrc_sha(), 'steps_profiled': int(sys.argv[3]) if len(sys.argv) > 3 else 3, 'source': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), reads x2 (gfx950 correction), per launch',
            'kernels': out}, sys.stdout, indent=1)

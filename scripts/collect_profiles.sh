@@ -21,7 +21,7 @@ for C in FETCH_SIZE WRITE_SIZE; do
   timeout 600 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $D -- python $ROOT/bench.py --steps 2 --warmup 1 \
       --no-cpu-baseline --no-kernel-timing --no-fast-math-line > $OUT/${TAG}_pmc_$C.log 2>&1
 done
-python $ROOT/profiles/summarize_pmc.py $OUT/prof_fetch $OUT/prof_write > $OUT/${TAG}_hbm_traffic.json
+python $ROOT/profiles/summarize_pmc.py $OUT/prof_fetch $OUT/prof_write 3 > $OUT/${TAG}_hbm_traffic.json
 rm -rf $OUT/prof_kt $OUT/prof_fetch $OUT/prof_write          # keep the merge-back small: raw traces stay on the box
 cd $ROOT
 if [ -z "$SKIP_BENCH" ]; then

@@ -1160,6 +1160,81 @@ def test_fused_adam_checkpoint_exchanges_with_torch_adam(gpe):
     assert sched.load_state_dict(rs.state_dict()) == rs.last_epoch
 
 
+def test_fused_adam_onecycle_checkpoint_restores_under_torch(gpe):
+    """The reference's restore flow (nn/trainer.py _restore_run): build Adam + OneCycleLR, then optimizer.load_state_dict()
+    REPLACES the param groups by the checkpoint's — so a FusedAdam checkpoint written under a OneCycle schedule must carry the
+    `initial_lr` / `max_lr` / `min_lr` keys torch's scheduler reads from the group on its next step() — and back: a torch
+    checkpoint's rates are taken by FusedAdam + OneCycle."""
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(11, 13), torch.nn.Tanh(), torch.nn.Linear(13, 2)).cuda()
+    twin = copy.deepcopy(net)
+    g = torch.Generator().manual_seed(5)
+    xs = [torch.randn(8, 11, generator=g).cuda() for _ in range(8)]
+    opt = gpe.optim.FusedAdam(net, lr=1e-3, schedule=gpe.optim.OneCycle(4e-3, 40))
+    for x in xs[:4]:
+        net(x).square().mean().backward()
+        opt.step()
+    sd = opt.state_dict()
+    assert {'initial_lr', 'max_lr', 'min_lr'} <= set(sd['param_groups'][0])
+    twin.load_state_dict(net.state_dict())
+    topt = torch.optim.Adam(twin.parameters(), lr=4e-3)
+    tsch = torch.optim.lr_scheduler.OneCycleLR(topt, max_lr=4e-3, epochs=4, steps_per_epoch=10, cycle_momentum=False)
+    topt.load_state_dict(sd)
+    tsch.last_epoch = opt.t                                     # what scheduler.load_state_dict restores
+    for x in xs[4:]:                                            # both continue: same rates, same parameters
+        assert abs(topt.param_groups[0]['lr'] - opt.schedule.lr(opt.t)) < 1e-12
+        net(x).square().mean().backward()
+        opt.step()
+        topt.zero_grad()
+        twin(x).square().mean().backward()
+        topt.step()
+        tsch.step()                                             # KeyError 'max_lr' here before the group carried the rates
+        assert abs(topt.param_groups[0]['lr'] - opt.schedule.lr(opt.t)) < 1e-12
+    # torch -> FusedAdam: the rates of the checkpoint win over the constructor's
+    other = gpe.optim.FusedAdam(copy.deepcopy(twin), lr=1.0, schedule=gpe.optim.OneCycle(123.0, 40))
+    other.load_state_dict(topt.state_dict())
+    assert other.schedule.max_lr == 4e-3 and abs(other.schedule.initial - 4e-3 / 25) < 1e-15
+    assert abs(other.schedule.min_lr - 4e-3 / 25 / 1e4) < 1e-18
+
+
+def test_fused_adam_intermittent_gradients_follow_torch(gpe):
+    """torch.optim.Adam counts steps per parameter: a parameter that first receives a gradient late (or only now and then)
+    is bias-corrected by ITS step count, and has no state entry before.  FusedAdam keeps the same per-parameter counts."""
+    torch.manual_seed(2)
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.a = torch.nn.Linear(7, 9)
+            self.late = torch.nn.Linear(9, 9)
+            self.b = torch.nn.Linear(9, 2)
+
+        def forward(self, x, use_late):
+            h = torch.relu(self.a(x))
+            if use_late:
+                h = h + self.late(h)
+            return self.b(h)
+
+    net = Net().cuda()
+    twin = copy.deepcopy(net)
+    opt = gpe.optim.FusedAdam(net, lr=1e-2)
+    topt = torch.optim.Adam(twin.parameters(), lr=1e-2)
+    g = torch.Generator().manual_seed(6)
+    for step, use_late in enumerate([False, False, True, False, True, True]):
+        x = torch.randn(5, 7, generator=g).cuda()
+        net(x, use_late).square().mean().backward()
+        opt.step()
+        topt.zero_grad(set_to_none=True)
+        twin(x, use_late).square().mean().backward()
+        topt.step()
+        sd, rsd = opt.state_dict(), topt.state_dict()
+        assert set(sd['state']) == set(rsd['state'])            # no entry for a parameter that never took a step
+        for k, st in sd['state'].items():
+            assert float(st['step']) == float(rsd['state'][k]['step'])
+    for p, q in zip(net.parameters(), twin.parameters()):
+        assert relerr(p, q) < 1e-5
+
+
 def test_fused_adam_skips_parameters_without_gradient(gpe):
     """torch.optim.Adam leaves a parameter whose grad is None alone (no weight decay, no moment decay); FusedAdam does the
     same for arena segments that received no gradient in the step."""
@@ -1259,6 +1334,13 @@ def test_pack_plan_and_grad_sink_are_transparent(gpe, golden_dir):
     plain.zero_grad(set_to_none=True)
     p3, _ = run(plain)
     assert torch.equal(p3['rotations'], p0['rotations'])
+    # an update through `p.data` does not move torch's version counter (EMA weights, hand-written copies): the packs follow anyway
+    v0 = plain.placement_decoder.weight._version
+    plain.placement_decoder.weight.data.mul_(2.0)
+    assert plain.placement_decoder.weight._version == v0
+    plain.zero_grad(set_to_none=True)
+    p4, _ = run(plain)
+    assert torch.equal(p4['rotations'], p2['rotations'])
 
 
 def test_standardize(gpe):
