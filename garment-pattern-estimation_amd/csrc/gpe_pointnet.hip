@@ -1,11 +1,15 @@
 // PointNet++ set abstraction for gfx950 (PointNetPlusPlus, /root/reference/nn/net_blocks.py:10-88: torch_geometric
 // fps + radius + PointConv, then a global PointNet layer).  Third-party arithmetic, absent from /root/reference; restated
-// from the published definitions with the choices upstream leaves open FIXED for oracle and kernels alike
-// (oracle/ref_path.py: fps / radius_neighbors):
-//   farthest point sampling  starts at the cloud's FIRST point (PyG's random_start would make the path non-deterministic),
-//                            distances = fp32 fma chain over x,y,z of (a-b)^2, argmax ties -> lower index;
+// from the published operators WITH PyG's conventions (oracle/ref_path.py: fps / fps_start / radius / pointconv_edges):
+//   farthest point sampling  starts at a caller-given point per cloud (PyG: random_start=True — the host draws it from torch's
+//                            generator, ops.fps); distances = fp32 fma chain over x,y,z of (a-b)^2, argmax ties -> lower index
+//                            (the two choices upstream leaves to the implementation);
 //   ball query               neighbours of a centroid = the first `maxn` points of its cloud in ascending index order with
-//                            squared distance <= r^2.
+//                            squared distance <= r^2;
+//   PointConv edge list      PyG's PointNetConv default add_self_loops=True: remove_self_loops drops the edge whose source index
+//                            (flat point number) EQUALS its target index (flat centroid number) — different index spaces in this
+//                            bipartite call, PyG compares them anyway — and add_self_loops appends i -> i for i < B*M: centroid
+//                            i also hears from flat point i, whichever cloud that point is in.
 // All of it is small integer / latency-bound work next to the two dense MLPs (ops.DenseMLPFn).
 #include "gpe_common.h"
 #include <math.h>
@@ -23,7 +27,7 @@ __device__ __forceinline__ float pn_sqdist(const float* a, const float* b, int C
 #define FPS_T 1024
 #define FPS_PER 16                         // points per thread: N <= 16384
 __global__ __launch_bounds__(FPS_T) void gpe_fps_kernel(const float* __restrict__ pos, int ldp, int N, int C, int M,
-                                                        int32_t* __restrict__ out)
+                                                        const int32_t* __restrict__ start, int32_t* __restrict__ out)
 {
     __shared__ float rv[FPS_T / 64];
     __shared__ int ri[FPS_T / 64];
@@ -34,8 +38,10 @@ __global__ __launch_bounds__(FPS_T) void gpe_fps_kernel(const float* __restrict_
     float mind[FPS_PER];
 #pragma unroll
     for (int q = 0; q < FPS_PER; ++q) mind[q] = INFINITY;
-    if (tid == 0) { cur_i = 0; out[(size_t)b * M] = 0; }
-    if (tid < C) cur[tid] = P[tid];
+    int s0 = start ? start[b] : 0;
+    s0 = s0 < 0 ? 0 : (s0 >= N ? N - 1 : s0);
+    if (tid == 0) { cur_i = s0; out[(size_t)b * M] = s0; }
+    if (tid < C) cur[tid] = P[(size_t)s0 * ldp + tid];
     __syncthreads();
     for (int m = 1; m < M; ++m) {
         float c_[8];
@@ -75,11 +81,11 @@ __global__ __launch_bounds__(FPS_T) void gpe_fps_kernel(const float* __restrict_
     }
 }
 
-extern "C" int gpe_fps(const float* pos, int ldp, int B, int N, int C, int M, int32_t* idx, void* stream)
+extern "C" int gpe_fps(const float* pos, int ldp, int B, int N, int C, int M, const int32_t* start, int32_t* idx, void* stream)
 {
     if (!pos || !idx || B <= 0 || N <= 0 || C <= 0 || C > 8 || ldp < C || M <= 0 || M > N || N > FPS_T * FPS_PER)
         return GPE_EINVAL;
-    hipLaunchKernelGGL(gpe_fps_kernel, dim3(B), dim3(FPS_T), 0, (hipStream_t)stream, pos, ldp, N, C, M, idx);
+    hipLaunchKernelGGL(gpe_fps_kernel, dim3(B), dim3(FPS_T), 0, (hipStream_t)stream, pos, ldp, N, C, M, start, idx);
     GPE_CHECK_LAUNCH();
     return GPE_OK;
 }
@@ -127,21 +133,58 @@ extern "C" int gpe_radius(const float* pos, int ldp, const int32_t* cidx, int B,
     return GPE_OK;
 }
 
-// compact edge list: for centroid s with edges [off[s], off[s+1]):  msg[e][0:Cx] = x[b*N + j][:] (optional), then
-// pos[b*N + j] - pos[b*N + c]  (PointConv message input, nn/net_blocks.py:17,24 -> PyG PointNetConv.message)
+// PyG PointNetConv's add_self_loops=True on the ball-query edge list (see the file header): per centroid s (flat number), the
+// slot of the neighbour whose flat POINT number equals s (drop[s], -1 if none: that edge is removed) and the edge count after
+// removal + the appended loop (cnt_out[s] = cnt[s] - (drop >= 0) + 1).
+__global__ void gpe_pointconv_loops_kernel(const int32_t* __restrict__ nbr, const int32_t* __restrict__ cnt, int N, int M,
+                                           long total, int maxn, int32_t* __restrict__ cnt_out, int32_t* __restrict__ drop)
+{
+    const long s = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= total) return;
+    const long b = s / M;
+    const int n = cnt[s];
+    int d = -1;
+    for (int q = 0; q < n; ++q)
+        if (b * N + nbr[s * maxn + q] == s) d = q;          // ascending, duplicate-free list: at most one hit
+    drop[s] = d;
+    cnt_out[s] = n - (d >= 0 ? 1 : 0) + 1;
+}
+
+extern "C" int gpe_pointconv_self_loops(const int32_t* nbr, const int32_t* cnt, int B, int N, int M, int maxn, int32_t* cnt_out,
+                                        int32_t* drop, void* stream)
+{
+    if (!nbr || !cnt || !cnt_out || !drop || B <= 0 || N <= 0 || M <= 0 || M > N || maxn <= 0) return GPE_EINVAL;
+    const long total = (long)B * M;
+    hipLaunchKernelGGL(gpe_pointconv_loops_kernel, dim3(gpe_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, nbr, cnt, N, M,
+                       total, maxn, cnt_out, drop);
+    GPE_CHECK_LAUNCH();
+    return GPE_OK;
+}
+
+// compact edge list: for centroid s with edges [off[s], off[s+1]):  msg[e][0:Cx] = x[j][:] (optional), then
+// pos[j] - pos[centroid]  (PointConv message input, nn/net_blocks.py:17,24 -> PyG PointNetConv.message), j = the flat source
+// point.  drop == NULL: the edges are the ball-query neighbours.  drop != NULL (PyG's self-loop re-indexing): neighbour slot
+// drop[s] is skipped and the LAST edge of the centroid is the appended loop, source = flat point s.
 __global__ void gpe_ball_messages_kernel(const float* __restrict__ pos, int ldp, const float* __restrict__ x, int ldx, int Cx,
                                          const int32_t* __restrict__ cidx, const int32_t* __restrict__ nbr,
-                                         const int64_t* __restrict__ off, int N, int C, int M, long total, int maxn,
-                                         float* __restrict__ msg, int ldm, int32_t* __restrict__ seg_of_row)
+                                         const int64_t* __restrict__ off, const int32_t* __restrict__ drop, int N, int C, int M,
+                                         long total, int slots, int maxn, float* __restrict__ msg, int ldm,
+                                         int32_t* __restrict__ seg_of_row)
 {
     const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= total * maxn) return;
-    const long s = t / maxn;
-    const int q = (int)(t - s * maxn);
+    if (t >= total * slots) return;
+    const long s = t / slots;
+    const int q = (int)(t - s * slots);
     const long e0 = off[s], e1 = off[s + 1];
     if (q >= e1 - e0) return;
     const long b = s / M;
-    const long j = b * N + nbr[s * maxn + q], c = b * N + cidx[s];
+    long j;
+    if (drop && q == e1 - e0 - 1) j = s;                                   // the appended loop: flat point s -> centroid s
+    else {
+        const int d = drop ? drop[s] : -1;
+        j = b * N + nbr[s * maxn + q + ((d >= 0 && q >= d) ? 1 : 0)];
+    }
+    const long c = b * N + cidx[s];
     float* o = msg + (e0 + q) * ldm;
     for (int k = 0; k < Cx; ++k) o[k] = x[j * ldx + k];
     for (int k = 0; k < C; ++k) o[Cx + k] = pos[j * ldp + k] - pos[c * ldp + k];
@@ -149,15 +192,16 @@ __global__ void gpe_ball_messages_kernel(const float* __restrict__ pos, int ldp,
 }
 
 extern "C" int gpe_ball_messages(const float* pos, int ldp, const float* x, int ldx, int Cx, const int32_t* cidx,
-                                 const int32_t* nbr, const int64_t* off, int B, int N, int C, int M, int maxn, float* msg,
-                                 int ldm, int32_t* seg_of_row, void* stream)
+                                 const int32_t* nbr, const int64_t* off, const int32_t* drop, int B, int N, int C, int M, int maxn,
+                                 float* msg, int ldm, int32_t* seg_of_row, void* stream)
 {
     if (!pos || !cidx || !nbr || !off || !msg || B <= 0 || N <= 0 || M <= 0 || C <= 0 || maxn <= 0 || Cx < 0 ||
         (Cx > 0 && !x) || ldm < Cx + C)
         return GPE_EINVAL;
     const long total = (long)B * M;
-    hipLaunchKernelGGL(gpe_ball_messages_kernel, dim3(gpe_cdiv(total * maxn, 256)), dim3(256), 0, (hipStream_t)stream, pos, ldp,
-                       x, ldx, Cx, cidx, nbr, off, N, C, M, total, maxn, msg, ldm, seg_of_row);
+    const int slots = maxn + (drop ? 1 : 0);
+    hipLaunchKernelGGL(gpe_ball_messages_kernel, dim3(gpe_cdiv(total * slots, 256)), dim3(256), 0, (hipStream_t)stream, pos, ldp,
+                       x, ldx, Cx, cidx, nbr, off, drop, N, C, M, total, slots, maxn, msg, ldm, seg_of_row);
     GPE_CHECK_LAUNCH();
     return GPE_OK;
 }

@@ -131,28 +131,34 @@ class _PointConvHolder(nn.Module):
 
 
 class _SetAbstractionModule(nn.Module):
-    """nn/net_blocks.py:10-27: fps -> ball query (<= 25 neighbours) -> PointConv(MLP) with max aggregation."""
+    """nn/net_blocks.py:10-27: fps -> ball query (<= 25 neighbours) -> PointConv(MLP) with max aggregation, with PyG's defaults:
+    fps(random_start=True) — the start points are drawn from torch's CPU generator (ops.fps_start; `fps_start` overrides) — and
+    PointConv(add_self_loops=True), whose re-indexing of the bipartite edge list is restated in csrc/gpe_pointnet.hip."""
 
     def __init__(self, ratio, conv_radius, per_point_nn):
         super().__init__()
         self.ratio = ratio
         self.radius = conv_radius
         self.conv = _PointConvHolder(per_point_nn)
+        self.fps_start = None              # int32 [B] tensor: fixed start points instead of the random draw
+        self.add_self_loops = True         # PyG PointNetConv's default
         self.last = {}
 
     def forward(self, features, pos_flat, B, N):
         import math
         M = int(math.ceil(self.ratio * N))
-        idx = ops.fps(pos_flat, B, N, M)
+        start = self.fps_start.to(pos_flat.device) if self.fps_start is not None else ops.fps_start(B, N, pos_flat.device)
+        idx = ops.fps(pos_flat, B, N, M, start)
         nbr, cnt = ops.radius_neighbors(pos_flat, idx, B, N, self.radius, 25)
+        ecnt, drop = ops.pointconv_self_loops(nbr, cnt, B, N, M) if self.add_self_loops else (cnt, None)
         off = torch.zeros(B * M + 1, device=pos_flat.device, dtype=torch.int64)
-        torch.cumsum(cnt, 0, out=off[1:])
+        torch.cumsum(ecnt, 0, out=off[1:])
         n_edges = int(off[-1].item())          # ragged edge list: the one host sync of this block (sizes the MLP rows)
-        msg, seg = ops.ball_messages(pos_flat, features, idx, nbr, off, n_edges, B, N)
+        msg, seg = ops.ball_messages(pos_flat, features, idx, nbr, off, n_edges, B, N, drop)
         h = ops.dense_mlp(msg, self.conv.local_nn, self.training)
         out = ops.RaggedMaxFn.apply(h, off, seg, B * M)
         gidx = (idx.long() + (torch.arange(B, device=idx.device) * N)[:, None]).view(-1)
-        self.last = {'idx': idx, 'nbr': nbr, 'cnt': cnt}
+        self.last = {'idx': idx, 'nbr': nbr, 'cnt': cnt, 'edge_cnt': ecnt, 'drop': drop, 'seg': seg}
         return out, pos_flat[gidx], M
 
 
@@ -170,7 +176,9 @@ class _GlobalSetAbstractionModule(nn.Module):
 
 class PointNetPlusPlus(nn.Module):
     """nn/net_blocks.py:50-88 (one set-abstraction level + the global level, as in the reference).  forward(positions [B,N,3])
-    -> [B, out_size].  The upstream fps / radius / PointConv conventions are fixed as described in csrc/gpe_pointnet.hip."""
+    -> [B, out_size].  PyG's conventions (random fps start from torch's generator, PointConv's add_self_loops re-indexing) are
+    restated in csrc/gpe_pointnet.hip; the two implementation-defined choices left (argmax ties, which neighbours survive the
+    cap of 25) are fixed there for oracle and kernels alike."""
 
     def __init__(self, out_size, config={}):
         super().__init__()

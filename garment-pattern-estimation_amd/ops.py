@@ -1302,12 +1302,20 @@ def standardize(x, shift, scale):
 # -------------------------------------------------------------------------------------------------
 # PointNet++ set abstraction (PointNetPlusPlus, nn/net_blocks.py:10-88)
 # -------------------------------------------------------------------------------------------------
-def fps(pos, B, N, M):
-    """torch_geometric.nn.fps over equal-sized clouds: -> int32 [B, M] LOCAL indices in selection order (start = the
-    cloud's first point, ties -> lower index; see csrc/gpe_pointnet.hip for the fixed conventions)."""
+def fps_start(B, N, device):
+    """PyG's fps(random_start=True) (what nn/net_blocks.py:16 calls): the start point of every cloud, drawn as
+    `(torch.rand(B) * N).long()` on torch's default CPU generator — the stream the reference's CPU run consumes, like the
+    random LSTM states — ONE draw per fps call (oracle/ref_path.py fps_start)."""
+    start = (torch.rand(B) * float(N)).long().clamp_(max=N - 1)
+    return start.to(torch.int32).to(device, non_blocking=True)
+
+
+def fps(pos, B, N, M, start=None):
+    """torch_geometric.nn.fps over equal-sized clouds: -> int32 [B, M] LOCAL indices in selection order, starting at
+    start[b] (int32 [B] on the device; None = the cloud's first point, i.e. random_start=False); ties -> lower index."""
     _dev_check(pos)
     idx = torch.empty(B, M, device=pos.device, dtype=torch.int32)
-    L.call('gpe_fps', pos, pos.stride(0), B, N, pos.shape[1], M, idx)
+    L.call('gpe_fps', pos, pos.stride(0), B, N, pos.shape[1], M, start, idx)
     return idx
 
 
@@ -1322,15 +1330,25 @@ def radius_neighbors(pos, cidx, B, N, r, max_num_neighbors):
     return nbr, cnt
 
 
-def ball_messages(pos, x, cidx, nbr, off, n_edges, B, N):
-    """PointConv message inputs [E, Cx + 3] over the compact edge list + the centroid (segment) id of every edge row."""
+def pointconv_self_loops(nbr, cnt, B, N, M):
+    """PyG PointNetConv's default add_self_loops=True on the ball-query edge list: -> (edge count per centroid after the
+    re-indexing, slot of the removed neighbour or -1).  See csrc/gpe_pointnet.hip."""
+    cnt2 = torch.empty_like(cnt)
+    drop = torch.empty_like(cnt)
+    L.call('gpe_pointconv_self_loops', nbr, cnt, B, N, M, nbr.shape[1], cnt2, drop)
+    return cnt2, drop
+
+
+def ball_messages(pos, x, cidx, nbr, off, n_edges, B, N, drop=None):
+    """PointConv message inputs [E, Cx + 3] over the compact edge list + the centroid (segment) id of every edge row.
+    drop: from pointconv_self_loops (then `off` is the scan of ITS counts)."""
     M, maxn = cidx.shape[1], nbr.shape[1]
     C = pos.shape[1]
     Cx = 0 if x is None else x.shape[1]
     msg = torch.empty(n_edges, Cx + C, device=pos.device, dtype=F32)
     seg = torch.empty(n_edges, device=pos.device, dtype=torch.int32)
-    L.call('gpe_ball_messages', pos, pos.stride(0), x, 0 if x is None else x.stride(0), Cx, cidx, nbr, off, B, N, C, M, maxn,
-           msg, Cx + C, seg)
+    L.call('gpe_ball_messages', pos, pos.stride(0), x, 0 if x is None else x.stride(0), Cx, cidx, nbr, off, drop, B, N, C, M,
+           maxn, msg, Cx + C, seg)
     return msg, seg
 
 

@@ -336,17 +336,25 @@ int gpe_attn_pool_bwd(const float* w, int ldw, const float* feat, int ldf, const
                       int N, int P, int C, int mode, float* gw, int ldgw, float* gf, int ldgf, void* stream);
 
 /* ---- PointNet++ set abstraction (PointNetPlusPlus, nn/net_blocks.py:10-88: torch_geometric fps / radius / PointConv) ------
- * pos [B][N][ldp>=C] (C <= 8).  gpe_fps: farthest point sampling of M points per cloud, start = the cloud's first point,
+ * pos [B][N][ldp>=C] (C <= 8).  gpe_fps: farthest point sampling of M points per cloud starting at LOCAL point start[b] (device
+ * array [B]; NULL = point 0.  PyG's fps(random_start=True) draws it at random: the host mirror draws from torch's generator),
  * idx [B][M] LOCAL indices in selection order (ties -> lower index).  gpe_radius: for centroid s = (b, m) the first `maxn`
  * points of cloud b, ascending index, with squared distance <= r^2: nbr [B*M][maxn] local indices, cnt [B*M]. */
-int gpe_fps(const float* pos, int ldp, int B, int N, int C, int M, int32_t* idx, void* stream);
+int gpe_fps(const float* pos, int ldp, int B, int N, int C, int M, const int32_t* start, int32_t* idx, void* stream);
 int gpe_radius(const float* pos, int ldp, const int32_t* cidx, int B, int N, int C, int M, float r, int maxn,
                int32_t* nbr, int32_t* cnt, void* stream);
+/* PyG PointNetConv(add_self_loops=True) on that edge list (nn/net_blocks.py:17,24 use the default): remove_self_loops drops the
+ * edge whose flat source point number equals the flat centroid number s (drop[s] = its slot in nbr[s], -1 if none) and
+ * add_self_loops appends s -> s; cnt_out[s] = cnt[s] - (drop[s] >= 0) + 1. */
+int gpe_pointconv_self_loops(const int32_t* nbr, const int32_t* cnt, int B, int N, int M, int maxn, int32_t* cnt_out,
+                             int32_t* drop, void* stream);
 /* PointConv message inputs over the COMPACT edge list (edges of centroid s at rows off[s]..off[s+1]-1, off = exclusive scan of
- * cnt, int64 [B*M+1]): msg[e] = [x_j (Cx values, optional) | pos_j - pos_centroid]; seg_of_row[e] = s. */
+ * the edge counts, int64 [B*M+1]): msg[e] = [x_j (Cx values, optional) | pos_j - pos_centroid]; seg_of_row[e] = s.  drop == NULL:
+ * the edges are the ball-query neighbours (off from cnt); drop != NULL: PyG's re-indexed list (off from cnt_out; neighbour slot
+ * drop[s] skipped, last edge = the loop from flat point s). */
 int gpe_ball_messages(const float* pos, int ldp, const float* x, int ldx, int Cx, const int32_t* cidx, const int32_t* nbr,
-                      const int64_t* off, int B, int N, int C, int M, int maxn, float* msg, int ldm, int32_t* seg_of_row,
-                      void* stream);
+                      const int64_t* off, const int32_t* drop, int B, int N, int C, int M, int maxn, float* msg, int ldm,
+                      int32_t* seg_of_row, void* stream);
 /* max over each ragged segment of rows (PointConv aggr = 'max'): y [S][ldy], arg [S][C] = winning row or -1 (empty -> 0) */
 int gpe_ragged_max_fwd(const float* x, int ldx, const int64_t* off, long S, int C, float* y, int ldy, int64_t* arg,
                        void* stream);

@@ -238,19 +238,34 @@ class SparsemaxLoss(nn.Module):
 
 
 # ---- PointNet++ pieces (torch_geometric.nn.fps / radius / PointConv; call sites nn/net_blocks.py:16-24) ---------------
-def fps(pos, batch, ratio):
+def fps_start(batch_sizes, random_start=True):
+    """Start point of the farthest-point sampling of every cloud (LOCAL index).  torch_cluster.fps(random_start=True) — PyG's
+    default, and what nn/net_blocks.py:16 calls — draws it at random; the one upstream variant driven by torch's generator is the
+    device kernel's recipe `(torch.rand(batch_size) * deg).long()`, restated here on torch's default CPU generator (the stream the
+    reference's CPU run consumes, like the random LSTM states): ONE torch.rand(B) draw per fps call."""
+    n = torch.as_tensor(batch_sizes, dtype=torch.float32)
+    if not random_start:
+        return torch.zeros(len(batch_sizes), dtype=torch.long)
+    start = (torch.rand(len(batch_sizes)) * n).long()
+    return torch.minimum(start, torch.as_tensor(batch_sizes, dtype=torch.long) - 1)
+
+
+def fps(pos, batch, ratio, random_start=True, start=None):
     """Farthest point sampling per cloud -> GLOBAL indices, clouds in order, selection order inside a cloud.
-    Open upstream (random start point by default): fixed here to START AT THE CLOUD'S FIRST POINT; distances are the
-    fp32 fma chain of (a-b)^2 over the coordinates, argmax ties -> lower index."""
+    `start` (LOCAL index per cloud) defaults to fps_start(...): PyG's random start, drawn from torch's CPU generator.  Still
+    open upstream and fixed here: distances are the fp32 fma chain of (a-b)^2 over the coordinates, argmax ties -> lower index."""
     B = int(batch.max()) + 1
     out = []
     p32 = pos.detach().to(torch.float32)
+    groups = [torch.nonzero(batch == b).view(-1) for b in range(B)]
+    if start is None:
+        start = fps_start([g.numel() for g in groups], random_start)
     for b in range(B):
-        ids = torch.nonzero(batch == b).view(-1)
+        ids = groups[b]
         P = p32[ids].numpy().astype(np.float32)
         n = P.shape[0]
         m = int(np.ceil(ratio * n))
-        sel = [0]
+        sel = [int(start[b])]
         mind = np.full(n, np.inf, dtype=np.float32)
         for _ in range(1, m):
             d = np.zeros(n, dtype=np.float32)
@@ -283,19 +298,36 @@ def radius(x, y, r, batch_x, batch_y, max_num_neighbors=32):
     return torch.tensor(rows, dtype=torch.long), torch.tensor(cols, dtype=torch.long)
 
 
+def pointconv_edges(edge_index, n_src, n_dst):
+    """What PyG's PointNetConv.forward does to a Tensor edge_index under its default add_self_loops=True:
+    `remove_self_loops(edge_index)` — drop every edge whose source INDEX equals its target INDEX, although in the bipartite
+    call of nn/net_blocks.py:24 the two live in different index spaces (all points vs. sampled centroids) — then
+    `add_self_loops(edge_index, num_nodes=min(n_src, n_dst))` (PyG 2.x; 1.6 / 1.7: num_nodes = n_dst — the same number here,
+    centroids are a subset): append i -> i for i < num_nodes at the END of the list, i.e. centroid i also receives a message
+    from the point with flat index i, whichever cloud that point belongs to."""
+    src, dst = edge_index[0], edge_index[1]
+    keep = src != dst
+    n = min(n_src, n_dst)
+    loop = torch.arange(n, dtype=src.dtype)
+    return torch.stack([torch.cat([src[keep], loop]), torch.cat([dst[keep], loop])], dim=0)
+
+
 class PointConv(nn.Module):
     """PointNet set-abstraction convolution (Qi et al. 2017; PyG PointNetConv): out_i = max_j local_nn([x_j, pos_j - pos_i])
-    over the given edges (source j -> target i).  PyG's `add_self_loops` default re-indexes a BIPARTITE edge list as if both
-    sides shared one index space — an upstream quirk, not part of the published operator; not restated (the ball query
-    already contains every centroid itself)."""
+    over the given edges (source j -> target i), with PyG's default `add_self_loops=True` re-indexing of the edge list
+    (pointconv_edges above) — a checkpoint trained under PyG saw exactly those messages."""
 
-    def __init__(self, local_nn=None, global_nn=None):
+    def __init__(self, local_nn=None, global_nn=None, add_self_loops=True):
         super().__init__()
         self.local_nn = local_nn
         self.global_nn = global_nn
+        self.add_self_loops = add_self_loops
 
     def forward(self, x, pos, edge_index):
         pos_src, pos_dst = pos
+        if self.add_self_loops:
+            edge_index = pointconv_edges(edge_index, pos_src.shape[0], pos_dst.shape[0])
+        self.last_edge_index = edge_index
         src, dst = edge_index[0], edge_index[1]
         msg = pos_src[src] - pos_dst[dst]
         if x is not None:

@@ -144,8 +144,9 @@ def run_case(model_name, yaml_rel, nn_override, B, N, seed, tag, keep_state, los
 
 def run_pointnet_case():
     """PointNetPlusPlus (nn/net_blocks.py:50-88) as the reference's own class, with fps / radius / PointConv from the stubs
-    (restated arithmetic, conventions fixed in oracle/ref_path.py).  Block level: the reference's model classes cannot use
-    this extractor (forward_encode indexes its output with [0], nn/nets.py:134-135)."""
+    (restated arithmetic WITH PyG's conventions: fps(random_start=True) drawing its start points from torch's generator,
+    PointConv(add_self_loops=True) re-indexing the bipartite edge list — oracle/ref_path.py).  Block level: the reference's
+    model classes cannot use this extractor (forward_encode indexes its output with [0], nn/nets.py:134-135)."""
     import net_blocks as ref_blocks
     cfg = {'EConv_hidden': 32, 'EConv_feature': 24}
     torch.manual_seed(1100)
@@ -155,9 +156,14 @@ def run_pointnet_case():
     pos = torch.randn(2, 160, 3, generator=g) * 0.45
     wgt = torch.randn(2, 16, generator=g)
     state0 = copy.deepcopy(net.state_dict())
+    torch.manual_seed(1102)                      # the forward draws the random fps start points
     out = net(pos)
     (out * wgt).sum().backward()
-    fx = {'config': cfg, 'out_size': 16, 'seed': 1100, 'positions': pos, 'wgt': wgt, 'out': out.detach().clone(),
+    conv = net.sa1_module.conv
+    fx = {'config': cfg, 'out_size': 16, 'seed': 1100, 'fwd_seed': 1102, 'positions': pos, 'wgt': wgt, 'out': out.detach().clone(),
+          'provenance': 'reference class on restated fps / radius / PointConv with PyG conventions (random fps start from '
+                        'torch.rand, add_self_loops re-indexing)',
+          'edge_index': conv.last_edge_index.clone(),
           'state_dict': state0, 'grads': {n: p.grad.clone() for n, p in net.named_parameters()},
           'state_keys': [(k, tuple(v.shape)) for k, v in state0.items()], 'torch': torch.__version__, 'threads': 1}
     path = os.path.join(REPO, 'tests', 'golden', 'pointnetpp_small.pt')

@@ -1493,39 +1493,59 @@ def test_lstm_encoder_module(gpe):
 
 
 def test_pointnetpp_block(gpe, golden_dir):
-    """PointNetPlusPlus (nn/net_blocks.py:50-88): fps + ball query bit-exact vs the oracle's definitions, outputs within 1e-4
-    of the reference-generated fixture and of the fp64 oracle, parameter gradients vs fp64."""
+    """PointNetPlusPlus (nn/net_blocks.py:50-88) with PyG's conventions — fps(random_start=True) drawing from torch's generator,
+    PointConv(add_self_loops=True) re-indexing the bipartite edge list: fps + ball query + the re-indexed edge list bit-exact vs
+    the oracle's definitions and vs the reference run's edge list, outputs within 1e-4 of the reference-generated fixture and
+    of the fp64 oracle, parameter gradients vs fp64."""
     import os
     from oracle import ref_path as O
     fx = torch.load(os.path.join(golden_dir, 'pointnetpp_small.pt'), weights_only=False)
+    assert 'PyG conventions' in fx['provenance']
     torch.manual_seed(fx['seed'])
     pnet = gpe.net_blocks.PointNetPlusPlus(fx['out_size'], dict(fx['config']))
     assert [(k, tuple(v.shape)) for k, v in pnet.state_dict().items()] == [tuple(x) for x in fx['state_keys']]
     pnet.load_state_dict(fx['state_dict'])
     pnet = pnet.cuda().train()
     pos = fx['positions']
+    torch.manual_seed(fx['fwd_seed'])                    # the forward draws the fps start points (one torch.rand(B))
     out = pnet(pos.cuda())
     (out * fx['wgt'].cuda()).sum().backward()
     o64 = O.PointNetPlusPlus(fx['out_size'], dict(fx['config'])).double().train()
     o64.load_state_dict({k: (v.double() if v.is_floating_point() else v) for k, v in fx['state_dict'].items()})
+    torch.manual_seed(fx['fwd_seed'])
     ref = o64(pos.double())
     (ref * fx['wgt'].double()).sum().backward()
     B, N = pos.shape[:2]
-    # integer work: bit-exact (fps selection order, ball-query neighbour lists)
+    # integer work: bit-exact (fps selection order incl. the random start, ball-query neighbour lists)
     tr = o64.sa1_module.trace
-    M = pnet.sa1_module.last['idx'].shape[1]
-    gidx = (pnet.sa1_module.last['idx'].cpu().long() + (torch.arange(B) * N)[:, None]).view(-1)
+    last = pnet.sa1_module.last
+    M = last['idx'].shape[1]
+    gidx = (last['idx'].cpu().long() + (torch.arange(B) * N)[:, None]).view(-1)
     assert torch.equal(gidx, tr['idx'])
-    cnt = pnet.sa1_module.last['cnt'].cpu().long()
+    assert gidx.view(B, M)[:, 0].tolist() != [0, N]      # the start points are random, not the clouds' first points
+    cnt = last['cnt'].cpu().long()
     assert torch.equal(cnt, torch.bincount(tr['row'], minlength=B * M))
-    nbr = pnet.sa1_module.last['nbr'].cpu().long()
+    nbr = last['nbr'].cpu().long()
     cols = torch.cat([nbr[s, :cnt[s]] + (s // M) * N for s in range(B * M)])
     assert torch.equal(cols, tr['col'])
+    # PyG's re-indexed edge list: per centroid the kept ball neighbours in order, then the loop from flat point s
+    ei = o64.sa1_module.conv.last_edge_index
+    assert torch.equal(ei, fx['edge_index'])             # ... and it is the list the reference's own run used
+    drop, ecnt = last['drop'].cpu().long(), last['edge_cnt'].cpu().long()
+    assert int(ecnt.sum()) == ei.shape[1]
+    for s in range(B * M):
+        srcs = [int(nbr[s, q]) + (s // M) * N for q in range(cnt[s]) if q != drop[s]] + [s]
+        assert srcs == ei[0][ei[1] == s].tolist(), s
+    assert (drop >= 0).any() and (drop < 0).any()        # both cases occur in the fixture
     assert (out.detach().cpu() - fx['out']).abs().max().item() < 1e-4
     assert relerr(out, ref) < 5e-5
     pn = dict(pnet.named_parameters())
     for n, p in o64.named_parameters():
         assert relerr(pn[n].grad, p.grad) < 5e-3 if p.grad.dim() == 1 else relerr(pn[n].grad, p.grad) < 5e-4, n
+    # the start points can be pinned instead (e.g. to replay a run): point 0 of every cloud = random_start=False
+    pnet.sa1_module.fps_start = torch.zeros(B, dtype=torch.int32)
+    pnet(pos.cuda())
+    assert pnet.sa1_module.last['idx'][:, 0].tolist() == [0] * B
 
 
 def test_batch_stager(gpe):

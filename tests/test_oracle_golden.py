@@ -110,8 +110,25 @@ def test_oracle_pointnetpp_matches_reference_fixture(golden_dir):
     assert [(k, tuple(v.shape)) for k, v in sd.items()] == [tuple(x) for x in fx['state_keys']]
     for k, v in fx['state_dict'].items():
         assert torch.equal(sd[k], v), k
+    assert 'PyG conventions' in fx['provenance']
+    torch.manual_seed(fx['fwd_seed'])                   # the forward draws the random fps start points (PyG's default)
     out = net(fx['positions'])
     (out * fx['wgt']).sum().backward()
+    assert torch.equal(net.sa1_module.conv.last_edge_index, fx['edge_index'])     # the self-loop re-indexed edge list
     assert torch.equal(out, fx['out'])
     for n, p in net.named_parameters():
         torch.testing.assert_close(p.grad, fx['grads'][n], rtol=1e-5, atol=1e-8)
+
+
+def test_pointconv_edge_reindexing_definition():
+    """PyG PointNetConv(add_self_loops=True) on a bipartite edge list, as published: remove_self_loops compares source and
+    target INDICES (drops 2 -> 2 although point 2 and centroid 2 are different things), add_self_loops appends i -> i for
+    i < min(n_src, n_dst) at the end."""
+    ei = torch.tensor([[0, 2, 5, 1, 7], [0, 2, 0, 1, 2]])
+    got = O.pointconv_edges(ei, n_src=8, n_dst=3)
+    assert got.tolist() == [[5, 7, 0, 1, 2], [0, 2, 0, 1, 2]]
+    torch.manual_seed(0)
+    a = O.fps_start([10, 10, 7])
+    torch.manual_seed(0)
+    assert a.tolist() == (torch.rand(3) * torch.tensor([10., 10., 7.])).long().tolist()       # one torch.rand(B) draw
+    assert O.fps_start([5, 5], random_start=False).tolist() == [0, 0]
