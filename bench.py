@@ -123,9 +123,15 @@ def call_work(name, a):
     if name == 'gpe_redgemm':               # ..., rows, Mg, Ng, ldg, accumulate
         rows, Mg, Ng = a[-5], a[-4], a[-3]
         return 2.0 * rows * Mg * Ng, 4.0 * rows * (Mg + Ng)
-    if name == 'gpe_edge_gather_stats':     # ldpq, H, B, N, k : SURVEY 8(d) bytes_gather with C = H (P|Q rows), no output row
-        H, B, N, k = a[1], a[2], a[3], a[4]
-        return 0.0, float(B) * (N * k * (H * 4 + 4) + N * H * 4)
+    if name == 'gpe_edge_gather_stats':     # ldpq, H, B, N, k : HBM side = the [P|Q] table once + the neighbour indices (the k-fold
+        H, B, N, k = a[1], a[2], a[3], a[4]  # gather itself is served by the XCD L2s: priced in roofline_gather)
+        return 0.0, float(B) * N * (2 * H * 4 + k * 4)
+    if name == 'gpe_rnn_seq_fwd':           # gates, L, T, Bn, H, ... : cell (l, t) multiplies [Bn, H or 2H] x [., gates*H]
+        G, L_, T, Bn, H = a[0], a[1], a[2], a[3], a[4]
+        return 2.0 * Bn * T * G * H * H * (2 * L_ - 1), 4.0 * Bn * T * L_ * (6 * H + G * H)
+    if name == 'gpe_rnn_seq_bwd':           # the same products transposed (dh = dG W_hh + dG_above W_ih)
+        G, L_, T, Bn, H = a[0], a[1], a[2], a[3], a[4]
+        return 2.0 * Bn * T * G * H * H * (2 * L_ - 1), 4.0 * Bn * T * L_ * (8 * H + 2 * G * H)
     if name == 'gpe_edge_pull_dq':          # lddz, B, N, k, H, lddq : dz rows read once through the reversed graph
         B, N, k, H = a[1], a[2], a[3], a[4]
         return 0.0, float(B) * N * (k * (H * 4 + 4) + H * 4)
@@ -475,7 +481,8 @@ def main():
             # The stand-alone gather + BN-statistics pass is the only kernel whose time IS the gather.  Two honest roofs:
             #   HBM side: counter bytes (FETCH+WRITE of the committed PMC pass of THIS csrc) / time / 8 TB/s
             #   L2 side : algorithmic k-fold bytes (what the gather touches, served by the XCD L2s) / time / 34.5 TB/s
-            n_l, ms, _, by = agg['gpe_edge_gather_stats']
+            n_l, ms, _, _ = agg['gpe_edge_gather_stats']
+            by = n_l * float(args.batch) * (args.points * args.k * (H * 4 + 4) + args.points * H * 4)   # k-fold bytes_gather (C = H)
             t = ms * 1e-3 / n_l
             traffic, tsrc = pmc_traffic('gpe_edge_gather_stats')
             l2_rate = by / n_l / t / 1e9
