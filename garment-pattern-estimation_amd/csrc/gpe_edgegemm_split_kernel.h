@@ -165,9 +165,13 @@ __device__ __forceinline__ int x6_scr(int row, int w, int b)
 // KCH = K extent in 16-wide chunks (the packed-weight granularity); KS = ceil(KCH / 2) slabs of 32.
 // PSEUDO: a k > 16 point runs as pseudo-points (RgParams::pmagic != 0) — its own instances, so that the others do not carry the
 // division (the non-k16 gather-backward variants sit at the register limit)
-template <class SP, int AQ, int BQ, int KCH, int AMODE, int EMODE, bool K16, bool PSEUDO = false>
+// AGGT (forward only): 1 / 0 = the per-point max / min / argmax / argmin tracking of the aggregated last block is compiled in /
+// out; -1 = decided at run time by p.agg (the tracking then always runs: 24 VALU per row, only the stores are skipped).  The
+// k = 16 instances of the benchmark configuration are instantiated with 0 and 1.
+template <class SP, int AQ, int BQ, int KCH, int AMODE, int EMODE, bool K16, bool PSEUDO = false, int AGGT = -1>
 __global__ __launch_bounds__(256, 1) void gpe_edgegemm_split_kernel(RgParams p, int stats_nblk)
 {
+    constexpr bool TRACK = (EMODE == E_EDGE_FWD) && AGGT != 0;
     constexpr int NT = 4 * AQ + BQ;
     constexpr int KS = (KCH + 1) / 2;
     constexpr bool KTAIL = (KCH & 1) != 0;               // last slab holds only 16 k: lane groups g >= 2 contribute zeros
@@ -434,8 +438,10 @@ __global__ __launch_bounds__(256, 1) void gpe_edgegemm_split_kernel(RgParams p, 
                 for (int t = 0; t < 4; ++t) {
                     s32[t] += vv[t];
                     q32[t] = __builtin_fmaf(vv[t], vv[t], q32[t]);
-                    if (vv[t] > vmx[t]) { vmx[t] = vv[t]; imx[t] = slot; }
-                    if (vv[t] < vmn[t]) { vmn[t] = vv[t]; imn[t] = slot; }
+                    if constexpr (TRACK) {
+                        if (vv[t] > vmx[t]) { vmx[t] = vv[t]; imx[t] = slot; }
+                        if (vv[t] < vmn[t]) { vmn[t] = vv[t]; imn[t] = slot; }
+                    }
                 }
             } else {
                 float4 av = act[u];
@@ -458,7 +464,7 @@ __global__ __launch_bounds__(256, 1) void gpe_edgegemm_split_kernel(RgParams p, 
         if (K16 ? (u == X6_PB - 1) : (++es == p.k)) {        // a point is complete (K16: compile-time)
             if (n_on) {
                 const long gpt = e_pt0 + (K16 ? 0 : ept);
-                if (EMODE == E_EDGE_FWD && p.agg) {
+                if (TRACK && (AGGT == 1 || p.agg)) {
                     const long o = gpt * p.oldagg + c;
                     st4(p.mx + o, make_float4(vmx[0], vmx[1], vmx[2], vmx[3]));
                     st4(p.mn + o, make_float4(vmn[0], vmn[1], vmn[2], vmn[3]));
@@ -617,13 +623,42 @@ __global__ __launch_bounds__(256, 1) void gpe_edgegemm_split_kernel(RgParams p, 
                 for (int t = 0; t < SP::NPROD; ++t)
 #pragma unroll
                     for (int i = 0; i < AQ; ++i) acc[mt][i] = SP::mfma(af.pl[SP::pa(t)], wP[SP::pw(t)][i][sl], acc[mt][i]);
-                if (BQ > 0 && (sl & 3) == wave) {            // this wave's K slab of the left-over tiles
+                if constexpr (!PLANES) {
+                    if (BQ > 0 && (sl & 3) == wave) {        // this wave's K slab of the left-over tiles
+#pragma unroll
+                        for (int t = 0; t < SP::NPROD; ++t)
+#pragma unroll
+                            for (int b = 0; b < BQ; ++b) accL[b][mt] = SP::mfma(af.pl[SP::pa(t)], lP[SP::pw(t)][b][sl >> 2], accL[b][mt]);
+                    }
+                }
+                if (X6_FENCE(PLANES)) __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if constexpr (PLANES && BQ > 0) {
+            // The left-over tiles' K slabs of this wave (wave, wave + 4) in a loop of their own, branch-free.  Inside the slot loop
+            // the wave-dependent `(sl & 3) == wave` made every slot a conditional block that modifies accL: the compiler merged the
+            // 16-register aggregate at each join with up to 48 register copies and ran the conditional MFMAs through accumulation
+            // registers with an `s_nop 7` + read-back (static count of the 13 x 13 gather forward: 504 v_mov_b64 + 340
+            // v_accvgpr moves per tile and wave, scripts/isa_mix.py).  Here a slab past the end multiplies the zero weights it was
+            // given in the prologue against a valid (clamped) address, and the A fragments are read a second time (2 LSL x 4
+            // ds_read_b128 per plane pair — the tile is in LDS anyway).
+#pragma unroll
+            for (int q = 0; q < LSL; ++q) {
+                const int slr = wave + 4 * q;                              // wave-uniform
+                const int slc = slr < KS ? slr : KS - 1;
+                const bool dead = KTAIL && slc == KS - 1 && g >= 2;        // 16-wide tail slab: lane groups past the row read a
+                                                                           // valid chunk (finite data) against zero weights
+                const char* base = reinterpret_cast<const char*>(As) + j * PPITCH + 16 * (4 * slc + (dead ? (g & 1) : g));
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) {
+                    X6Frag<SP> lf;
+#pragma unroll
+                    for (int t = 0; t < SP::P; ++t) lf.pl[t] = *reinterpret_cast<const x6_u32x4*>(base + 16 * mt * PPITCH + t * PLANE);
 #pragma unroll
                     for (int t = 0; t < SP::NPROD; ++t)
 #pragma unroll
-                        for (int b = 0; b < BQ; ++b) accL[b][mt] = SP::mfma(af.pl[SP::pa(t)], lP[SP::pw(t)][b][sl >> 2], accL[b][mt]);
+                        for (int b = 0; b < BQ; ++b) accL[b][mt] = SP::mfma(lf.pl[SP::pa(t)], lP[SP::pw(t)][b][q], accL[b][mt]);
                 }
-                if (X6_FENCE(PLANES)) __builtin_amdgcn_sched_barrier(0);
             }
         }
         if (do_epi) epi_flush_stats();
@@ -719,7 +754,7 @@ __global__ __launch_bounds__(256, 1) void gpe_edgegemm_split_kernel(RgParams p, 
 }
 
 // ---------------------------------------------------------------------------------------------------------
-template <class SP, int AQ, int BQ, int KCH, int AMODE, int EMODE, bool K16, bool PSEUDO = false>
+template <class SP, int AQ, int BQ, int KCH, int AMODE, int EMODE, bool K16, bool PSEUDO = false, int AGGT = -1>
 static int x6_launch_k(const RgParams& p, int stats_nblk, hipStream_t s)
 {
     constexpr int NT = 4 * AQ + BQ;
@@ -727,11 +762,11 @@ static int x6_launch_k(const RgParams& p, int stats_nblk, hipStream_t s)
     constexpr int AWORDS = SP::SCALED ? (2 * RG_BM * 16 * x6_pchunks(KCH)) / 4 : RG_BM * LDA;
     const size_t lds = (size_t)(2 * AWORDS + RG_BM * LDC) * sizeof(float);
     // 16 bytes of static __shared__ (amax_sh) sit beside the dynamic image
-    GPE_ENSURE_MAX_LDS_N((gpe_edgegemm_split_kernel<SP, AQ, BQ, KCH, AMODE, EMODE, K16, PSEUDO>), 160 * 1024 - 64);
+    GPE_ENSURE_MAX_LDS_N((gpe_edgegemm_split_kernel<SP, AQ, BQ, KCH, AMODE, EMODE, K16, PSEUDO, AGGT>), 160 * 1024 - 64);
     int gx = gpe_num_cus();
     if (gx > p.num_tiles) gx = p.num_tiles;
     if (stats_nblk > 0 && gx > stats_nblk) gx = stats_nblk;
-    hipLaunchKernelGGL((gpe_edgegemm_split_kernel<SP, AQ, BQ, KCH, AMODE, EMODE, K16, PSEUDO>), dim3(gx), dim3(256), lds, s, p, stats_nblk);
+    hipLaunchKernelGGL((gpe_edgegemm_split_kernel<SP, AQ, BQ, KCH, AMODE, EMODE, K16, PSEUDO, AGGT>), dim3(gx), dim3(256), lds, s, p, stats_nblk);
     GPE_CHECK_LAUNCH();
     return GPE_OK;
 }
@@ -743,6 +778,11 @@ static int x6_launch(const RgParams& p, int stats_nblk, hipStream_t s)
         if (p.pmagic)
             return p.k == 16 ? x6_launch_k<SP, AQ, BQ, KCH, AMODE, EMODE, true, true>(p, stats_nblk, s)
                              : x6_launch_k<SP, AQ, BQ, KCH, AMODE, EMODE, false, true>(p, stats_nblk, s);
+    }
+    if constexpr (EMODE == E_EDGE_FWD && SP::SCALED) {   // the benchmark configuration's forward: tracking compiled in / out
+        if (p.k == 16)
+            return p.agg ? x6_launch_k<SP, AQ, BQ, KCH, AMODE, EMODE, true, false, 1>(p, stats_nblk, s)
+                         : x6_launch_k<SP, AQ, BQ, KCH, AMODE, EMODE, true, false, 0>(p, stats_nblk, s);
     }
     return p.k == 16 ? x6_launch_k<SP, AQ, BQ, KCH, AMODE, EMODE, true>(p, stats_nblk, s)
                      : x6_launch_k<SP, AQ, BQ, KCH, AMODE, EMODE, false>(p, stats_nblk, s);

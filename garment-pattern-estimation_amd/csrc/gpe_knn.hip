@@ -761,6 +761,289 @@ __global__ __launch_bounds__(256, KNN_MF_WGS) void gpe_knn_mfma_kernel(const flo
     }
 }
 
+// =====================================================================================================================
+// The same filter on the fp16 matrix pipe (round 4): d~ from f16x3 products — every operand row x_c * 2^sh = h + l in two fp16
+// terms (its own power of two sh brings the row's largest magnitude into [2^14, 2^15): exact), q.p from three
+// v_mfma_f32_16x16x32_f16 (hq.hp + hq.lp + lq.hp, fp32 accumulate), undone per (candidate, query) pair by the two exact inverse
+// scales.  Why it may replace the exact-product filter: the filter only has to stay inside E.  Per element
+// |x_c 2^sh - h - l| <= 2^-22 |x_c 2^sh| (+ 2^-28 of the row maximum when l underflows), the dropped lq.lp term is another
+// 2^-22, so the product sum is off by < 2^-20 |q||p| <= 2^-21 (|q|^2 + |p|^2), doubled by the factor 2: 16 u (|q|^2 + |p|^2),
+// u = 2^-24 — the host adds 16 to the (6 C + 16) u of the bound above; the MFMA's internal fp32 accumulation is covered by
+// the two-roundings-per-element allowance already in it.  The exact recheck (gpe_knn_rerank_kernel) is unchanged.
+// What it buys (MI355X): 60 short fp16 MFMAs per 64 x 64 x 160 tile and wave instead of 160 fp32 ones that own their SIMD
+// while they run (0.26 of the 0.76 ms); the wave's 16 queries stay RESIDENT in registers as B fragments, so a
+// step stages only the candidate tile (half the loads and LDS writes; pre-split planes: no conversion work in the loop); 64
+// channels per step on two LDS buffers: one barrier per step instead of two per 32 channels; and 60 KB of LDS = two workgroups
+// per CU = two clouds in flight per XCD, whose plane tables (2 x 1.3 MB at the shipped size) stay in the 4 MiB L2 — the
+// fp32 filter streamed four (729 MB fetched for a 39 MB table set, profiles/r03_i_hbm_traffic.json).
+typedef _Float16 knn_f16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned knn_u32x4 __attribute__((ext_vector_type(4)));
+#define KNN_H3_CCH 64                     // channels per staged step: two 32-k MFMA blocks
+#define KNN_H3_PITCH 160                  // bytes per plane row in LDS: 8 data chunks of 16 B + 2 pad (chunk count = 2 mod 4:
+                                          // the ds_read_b128 that walks down a column is conflict-free, gpe_edgegemm_split_kernel.h)
+#define KNN_H3_MAXC 256
+
+// planes of the feature table: pl[row] = [h plane: CP halves | l plane: CP halves] (CP = C rounded up to 32, zero pad),
+// isc[row] = 2^-sh.  Wave = KNN_NORM_ROWS rows; pass 1 the rows' largest magnitudes, pass 2 the split (the rows come from L2).
+__global__ __launch_bounds__(256) void gpe_knn_planes_kernel(const float* __restrict__ x, long rows, int C, int ldx, int CP,
+                                                             _Float16* __restrict__ pl, float* __restrict__ isc)
+{
+    const int lane = threadIdx.x & 63;
+    const long r0 = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * KNN_NORM_ROWS;
+    if (r0 >= rows) return;
+    const long last = rows - 1;
+    float m[KNN_NORM_ROWS];
+#pragma unroll
+    for (int u = 0; u < KNN_NORM_ROWS; ++u) m[u] = 0.f;
+    for (int c0 = 0; c0 < C; c0 += 64) {
+        const int c = c0 + lane;
+        const int cc = (c < C) ? c : 0;
+        float v[KNN_NORM_ROWS];
+#pragma unroll
+        for (int u = 0; u < KNN_NORM_ROWS; ++u) v[u] = x[((r0 + u < last) ? r0 + u : last) * ldx + cc];
+#pragma unroll
+        for (int u = 0; u < KNN_NORM_ROWS; ++u) m[u] = (c < C) ? fmaxf(m[u], fabsf(v[u])) : m[u];
+    }
+    float sc[KNN_NORM_ROWS];
+#pragma unroll
+    for (int u = 0; u < KNN_NORM_ROWS; ++u) {
+        float t = m[u];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) t = fmaxf(t, __int_as_float(__builtin_amdgcn_ds_bpermute((lane ^ o) << 2, __float_as_int(t))));
+        float s_, inv_;
+        gpe_h3_scale_of(__float_as_uint(t), s_, inv_);
+        sc[u] = s_;
+        if (lane == 0 && r0 + u <= last) isc[r0 + u] = inv_;
+    }
+    for (int c0 = 0; c0 < CP; c0 += 64) {
+        const int c = c0 + lane;
+        if (c >= CP) break;
+        const int cc = (c < C) ? c : 0;
+        float v[KNN_NORM_ROWS];
+#pragma unroll
+        for (int u = 0; u < KNN_NORM_ROWS; ++u) v[u] = x[((r0 + u < last) ? r0 + u : last) * ldx + cc];
+#pragma unroll
+        for (int u = 0; u < KNN_NORM_ROWS; ++u) {
+            if (r0 + u <= last) {
+                const float xs = (c < C) ? v[u] * sc[u] : 0.f;
+                const _Float16 h = (_Float16)xs;                      // RNE
+                const _Float16 l = (_Float16)(xs - (float)h);         // the difference is exact in fp32
+                _Float16* row = pl + (r0 + u) * 2 * (long)CP;
+                row[c] = h;
+                row[CP + c] = l;
+            }
+        }
+    }
+}
+
+template <int NBMAX>
+__global__ __launch_bounds__(256, 2) void gpe_knn_h3_kernel(const _Float16* __restrict__ pl, const float* __restrict__ isc, int N,
+                                                            int CP, int kk, int K2, const float* __restrict__ norms,
+                                                            const int* __restrict__ cmax, float ce, int B, int tiles, int pin,
+                                                            int nsplit, unsigned long long* __restrict__ part, int probe)
+{
+    extern __shared__ __align__(16) float smem[];
+    constexpr int PLANE_B = KNN_TC * KNN_H3_PITCH;
+    constexpr int BUF_B = 2 * PLANE_B;
+    char* const cB = reinterpret_cast<char*>(smem);                  // [2 buffers][2 planes][64 rows][KNN_H3_PITCH]
+    float* const dS = reinterpret_cast<float*>(cB + 2 * BUF_B);
+    unsigned long long* const mS = reinterpret_cast<unsigned long long*>(dS + 4 * 16 * KNN_LDD);
+    float* const npS = reinterpret_cast<float*>(mS + 4 * 64);        // [2 tile parities][64] |p|^2 of the candidate tile
+    float* const isS = npS + 2 * KNN_TC;                             // [2][64] inverse row scales of the candidate tile
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int b, item;
+    const int ipc = tiles * nsplit;
+    if (pin) {
+        const int xcd = blockIdx.x & (GPE_NXCD - 1), slot = blockIdx.x >> 3;
+        const int jc = slot / ipc;
+        b = xcd + GPE_NXCD * jc;
+        item = slot - jc * ipc;
+        if (b >= B) return;
+    } else {
+        b = blockIdx.x / ipc;
+        item = blockIdx.x - b * ipc;
+    }
+    const int qt = item / nsplit, piece = item - qt * nsplit;
+    const int q0 = qt * KNN_TQ;
+    const int tps = (tiles + nsplit - 1) / nsplit;
+    const int c_first = piece * tps * KNN_TC;
+    const int c_stop = ((piece + 1) * tps * KNN_TC < N) ? (piece + 1) * tps * KNN_TC : N;
+    const _Float16* cloud = pl + (size_t)b * N * 2 * CP;
+    const float* cnorm = norms + (size_t)b * N;
+    const float* cisc = isc + (size_t)b * N;
+    float* const dW = dS + wave * 16 * KNN_LDD;
+    unsigned long long* const mW = mS + wave * 64;
+
+    float ld_[16];
+    int li_[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { ld_[i] = INFINITY; li_[i] = -1; }
+    float thrq = INFINITY;
+
+    const int j = lane & 15, g = lane >> 4;
+    const int myq = (q0 + 16 * wave + j < N) ? q0 + 16 * wave + j : N - 1;
+    const float nq = cnorm[myq];
+    const float fq = -2.f * cisc[myq];                    // exact (a power of two)
+    const float cm = __int_as_float(cmax[b]);
+    float m2e_of;
+    {
+        const int qi = (q0 + 16 * wave + (lane & 15) < N) ? q0 + 16 * wave + (lane & 15) : N - 1;
+        m2e_of = 2.02f * ce * (cnorm[qi] + cm);
+    }
+    // ---- the wave's 16 queries: resident B fragments (lane (j, g): query j, halves 32 blk + 8 g .. + 7 of both planes) ----
+    const int NB = CP >> 5;
+    knn_u32x4 qh[NBMAX], ql[NBMAX];
+    {
+        const _Float16* qrow = cloud + (size_t)myq * 2 * CP;
+#pragma unroll
+        for (int blk = 0; blk < NBMAX; ++blk) {
+            const int bb = (blk < NB) ? blk : 0;
+            qh[blk] = *reinterpret_cast<const knn_u32x4*>(qrow + 32 * bb + 8 * g);
+            ql[blk] = *reinterpret_cast<const knn_u32x4*>(qrow + CP + 32 * bb + 8 * g);
+        }
+    }
+    // ---- staging: a step = 64 candidates x 64 channels of both planes = 1024 sixteen-byte pieces, four per thread ----------
+    const int nchunk = (CP + KNN_H3_CCH - 1) / KNN_H3_CCH;
+    knn_u32x4 pre[4];
+    float pre_n = 0.f, pre_s = 0.f;
+    int pre_first = 0, pre_tp = 0;
+    int pf_c0 = c_first, pf_ci = 0, pf_tp = 0;
+    auto prefetch = [&]() {
+        const int ch0 = pf_ci * KNN_H3_CCH;
+        const int nv = ((CP - ch0) >> 3) < 8 ? ((CP - ch0) >> 3) : 8;     // valid 16-byte pieces per plane row of this chunk
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int e = tid + 256 * i;
+            const int plane = e >> 9, row = (e >> 3) & 63, c16 = e & 7;
+            const int pr = (pf_c0 + row < N) ? pf_c0 + row : N - 1;
+            const int cc = (c16 < nv) ? c16 : 0;                            // pieces past CP are never read back: any valid address
+            pre[i] = *reinterpret_cast<const knn_u32x4*>(cloud + (size_t)pr * 2 * CP + plane * CP + ch0 + 8 * cc);
+        }
+        pre_first = pf_ci == 0;
+        pre_tp = pf_tp;
+        if (pre_first && tid < KNN_TC) {
+            const int pr = (pf_c0 + tid < N) ? pf_c0 + tid : N - 1;
+            pre_n = cnorm[pr];
+            pre_s = cisc[pr];
+        }
+        if (++pf_ci == nchunk) { pf_ci = 0; pf_c0 += KNN_TC; pf_tp ^= 1; }
+    };
+    auto commit = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int e = tid + 256 * i;
+            const int plane = e >> 9, row = (e >> 3) & 63, c16 = e & 7;
+            *reinterpret_cast<knn_u32x4*>(cB + buf * BUF_B + plane * PLANE_B + row * KNN_H3_PITCH + 16 * c16) = pre[i];
+        }
+        if (pre_first && tid < KNN_TC) { npS[pre_tp * KNN_TC + tid] = pre_n; isS[pre_tp * KNN_TC + tid] = pre_s; }
+    };
+    const int ntile = (c_stop - c_first + KNN_TC - 1) / KNN_TC;
+    const int nsteps = ntile * nchunk;                    // uniform; 0 when a candidate piece lies past the cloud (the empty lists
+    if (nsteps > 0) {                                     // are still written below)
+        prefetch();
+        commit(0);
+        if (nsteps > 1) prefetch();
+    }
+    __syncthreads();
+
+    int step = 0, buf = 0, tp = 0;
+    for (int c0 = c_first; c0 < c_stop; c0 += KNN_TC, tp ^= 1) {
+        f32x4 acc[4];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        // chunk index at compile time (the resident query fragments are register arrays): NBMAX blocks = NCHMAX chunks at most
+        constexpr int NCHMAX = (NBMAX + 1) / 2;
+#pragma unroll
+        for (int ci = 0; ci < NCHMAX; ++ci) {
+            if (ci >= nchunk) break;                      // uniform
+            if (step + 1 < nsteps) {
+                commit(buf ^ 1);                          // every wave left that buffer at the barrier below
+                if (step + 2 < nsteps) prefetch();
+            }
+            int nblk = NB - 2 * ci;
+            nblk = nblk > 2 ? 2 : nblk;
+            if (probe & 4) nblk = 0;
+            const char* tile = cB + buf * BUF_B + j * KNN_H3_PITCH + 16 * g;
+#pragma unroll
+            for (int b2 = 0; b2 < 2; ++b2) {
+                if (2 * ci + b2 < NBMAX && b2 < nblk) {
+                    const knn_u32x4 bh = qh[(2 * ci + b2 < NBMAX) ? 2 * ci + b2 : 0], bl = ql[(2 * ci + b2 < NBMAX) ? 2 * ci + b2 : 0];
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt) {
+                        const char* src = tile + 16 * mt * KNN_H3_PITCH + 64 * b2;
+                        const knn_u32x4 ah = *reinterpret_cast<const knn_u32x4*>(src);
+                        const knn_u32x4 al = *reinterpret_cast<const knn_u32x4*>(src + PLANE_B);
+                        // small terms first
+                        acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(knn_f16x8, al), __builtin_bit_cast(knn_f16x8, bh), acc[mt], 0, 0, 0);
+                        acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(knn_f16x8, ah), __builtin_bit_cast(knn_f16x8, bl), acc[mt], 0, 0, 0);
+                        acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(knn_f16x8, ah), __builtin_bit_cast(knn_f16x8, bh), acc[mt], 0, 0, 0);
+                    }
+                }
+            }
+            if (ci == nchunk - 1) {
+                // d~ = |q|^2 + |p|^2 - 2 q.p with the two row scales undone, clamped at +0 (the bit pattern must order like the value)
+                const bool tail = c0 + KNN_TC > N;
+                float4 dq[4];
+                float dmin = INFINITY;
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) {
+                    const float4 np = *reinterpret_cast<const float4*>(&npS[tp * KNN_TC + 16 * mt + 4 * g]);
+                    const float4 is = *reinterpret_cast<const float4*>(&isS[tp * KNN_TC + 16 * mt + 4 * g]);
+                    float4 d;
+                    d.x = __builtin_fmaf(fq * is.x, acc[mt][0], nq + np.x); d.y = __builtin_fmaf(fq * is.y, acc[mt][1], nq + np.y);
+                    d.z = __builtin_fmaf(fq * is.z, acc[mt][2], nq + np.z); d.w = __builtin_fmaf(fq * is.w, acc[mt][3], nq + np.w);
+                    d.x = d.x > 0.f ? d.x : 0.f; d.y = d.y > 0.f ? d.y : 0.f; d.z = d.z > 0.f ? d.z : 0.f; d.w = d.w > 0.f ? d.w : 0.f;
+                    if (tail) {                                  // candidates past the cloud never qualify
+                        const int cb = c0 + 16 * mt + 4 * g;
+                        d.x = (cb + 0 < N) ? d.x : INFINITY; d.y = (cb + 1 < N) ? d.y : INFINITY;
+                        d.z = (cb + 2 < N) ? d.z : INFINITY; d.w = (cb + 3 < N) ? d.w : INFINITY;
+                    }
+                    dq[mt] = d;
+                    dmin = fminf(fminf(dmin, fminf(d.x, d.y)), fminf(d.z, d.w));
+                }
+                unsigned qm = 0xffffu;
+                if (c0 != c_first) {
+                    const unsigned long long hm = __ballot(dmin < thrq);
+                    qm = (unsigned)((hm | (hm >> 16) | (hm >> 32) | (hm >> 48)) & 0xffffull);
+                }
+                if ((probe & 1) && c0 > c_first) qm = 0;
+                if (qm != 0) {
+                    asm volatile("" ::: "memory");
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt) *reinterpret_cast<float4*>(&dW[j * KNN_LDD + 16 * mt + 4 * g]) = dq[mt];
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    const int cand = c0 + lane;
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        if (!((qm >> i) & 1u)) continue;
+                        const float d = dW[i * KNN_LDD + lane];
+                        float ldv = ld_[i];
+                        int liv = li_[i];
+                        const float t = knn_select_mf(c0 == c_first, d, lane, cand, K2, kk, knn_readlane_f(m2e_of, i),
+                                                      knn_readlane_f(thrq, i), mW, ldv, liv);
+                        ld_[i] = ldv; li_[i] = liv;
+                        thrq = ((lane & 15) == i) ? t : thrq;
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            }
+            __syncthreads();                              // `buf` is free for the commit of step + 2; buf ^ 1 is complete
+            buf ^= 1;
+            ++step;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int q = q0 + 16 * wave + i;
+        if (q < N && lane < K2)
+            part[(((size_t)b * N + q) * nsplit + piece) * K2 + lane] =
+                ((unsigned long long)(unsigned)__float_as_int(ld_[i]) << 32) | (unsigned)li_[i];
+    }
+}
+
 // exact chain distance of one (query row, candidate row) pair per lane — oracle/knn_ref.c's arithmetic
 // (16-byte loads when both rows allow it: a lane walks its own row, so the loads of the next channels must be in flight under
 // the dependent fma chain — one dword load per step was a full L2 round trip per channel, 12 us per re-evaluated candidate)
@@ -925,10 +1208,12 @@ extern "C" long gpe_knn_ws_bytes(int B, int N, int C, int k)
 {
     if (B < 0 || N <= 0 || C <= 0 || k <= 0 || k > 64) return GPE_EINVAL;
     const size_t nq = (size_t)B * N;
-    const size_t lists = nq * 64 * sizeof(unsigned long long);            // nsplit * K2 <= 64 and nsplit * k <= 64 by construction
+    const size_t lists = nq * 64 * sizeof(unsigned long long) + 256;      // nsplit * K2 <= 64 and nsplit * k <= 64 by construction
     const size_t norm_bytes = (nq * sizeof(float) + 255) & ~(size_t)255;
-    (void)C;
-    return (long)(lists + norm_bytes + (size_t)B * sizeof(int) + 256);
+    // fp16-pipe filter (16 <= C <= 256): two fp16 planes of the table (C rounded up to 32) + one inverse scale per row
+    const size_t CP = ((size_t)C + 31) & ~(size_t)31;
+    const size_t plane_bytes = (C >= KNN_MF_MINC && C <= KNN_H3_MAXC) ? ((nq * 2 * CP * sizeof(_Float16) + 255) & ~(size_t)255) + norm_bytes : 0;
+    return (long)(lists + norm_bytes + ((size_t)B * sizeof(int) + 255 & ~(size_t)255) + plane_bytes + 256);
 }
 
 extern "C" int gpe_knn(const float* x, int B, int N, int C, int ldx, int k, int32_t* idx, int32_t* idx_glob, void* ws,
@@ -954,21 +1239,32 @@ extern "C" int gpe_knn(const float* x, int B, int N, int C, int ldx, int k, int3
     int nsplit = 1;
     if (dbg_split > 0 && dbg_split * K2 <= 64 && dbg_split <= tiles) nsplit = dbg_split;
     const size_t nq = (size_t)B * N;
-    const size_t part_bytes = nq * nsplit * K2 * sizeof(unsigned long long);
+    const size_t part_bytes = (nq * nsplit * K2 * sizeof(unsigned long long) + 255) & ~(size_t)255;
     const size_t norm_bytes = (nq * sizeof(float) + 255) & ~(size_t)255;
-    const size_t need = part_bytes + norm_bytes + (size_t)B * sizeof(int) + 256;
+    const size_t cmax_bytes = ((size_t)B * sizeof(int) + 255) & ~(size_t)255;
+    // the fp16-pipe filter (default for C <= 256; GPE_KNN_F32FILTER=1 keeps the exact-product filter for A/B measurements)
+    static const int f32filter = getenv("GPE_KNN_F32FILTER") ? atoi(getenv("GPE_KNN_F32FILTER")) : 0;
+    const int CP = (C + 31) & ~31;
+    const size_t pl_bytes = (nq * 2 * (size_t)CP * sizeof(_Float16) + 255) & ~(size_t)255;
+    bool h3 = !f32filter && C <= KNN_H3_MAXC;
+    size_t need = part_bytes + norm_bytes + cmax_bytes + 256;
+    if (h3 && (!ws || (size_t)ws_bytes < need + pl_bytes + norm_bytes)) h3 = false;      // workspace sized by an older query
+    if (h3) need += pl_bytes + norm_bytes;
     char* scratch = (ws && !(((uintptr_t)ws) & 15) && (size_t)ws_bytes >= need) ? (char*)ws : nullptr;
     if (!scratch) return knn_exact(x, B, N, C, ldx, k, idx, idx_glob, nullptr, 0, stream);   // no workspace: the all-exact kernel
     unsigned long long* part = (unsigned long long*)scratch;
     float* norms = (float*)(scratch + part_bytes);
     int* cmax = (int*)(scratch + part_bytes + norm_bytes);
+    _Float16* planes = (_Float16*)(scratch + part_bytes + norm_bytes + cmax_bytes);
+    float* iscale = (float*)(scratch + part_bytes + norm_bytes + cmax_bytes + pl_bytes);
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(gpe_knn_norms_kernel, dim3((unsigned)gpe_cdiv((long)nq, 4 * KNN_NORM_ROWS)), dim3(256), 0, s, x, (long)nq, N, C, ldx, norms,
                        cmax);
     GPE_CHECK_LAUNCH();
     hipLaunchKernelGGL(gpe_knn_cmax_kernel, dim3(B), dim3(256), 0, s, norms, N, cmax);
     GPE_CHECK_LAUNCH();
-    const float ce = (6.f * C + 16.f) * 5.9604645e-8f;     // (6C + 16) * 2^-24, see the bound above
+    // (6C + 16) * 2^-24, see the bound above; + 16 * 2^-24 for the two-term fp16 products of the fp16-pipe filter
+    const float ce = (6.f * C + (h3 ? 32.f : 16.f)) * 5.9604645e-8f;
     const size_t lds = ((size_t)2 * KNN_TQ * KNN_MF_LD + 4 * 16 * KNN_LDD) * sizeof(float) + 4 * 64 * sizeof(unsigned long long) +
                        KNN_TC * sizeof(float);
     const long nblocks = (pin ? (long)GPE_NXCD * gpe_cdiv(B, GPE_NXCD) * tiles : (long)B * tiles) * nsplit;
@@ -979,7 +1275,23 @@ extern "C" int gpe_knn(const float* x, int B, int N, int C, int ldx, int k, int3
     int vec = (ldx % 4 == 0 && xa % 16 == 0 && ((C + 3) & ~3) <= ldx) ? 4
             : (ldx % 2 == 0 && xa % 8 == 0 && ((C + 1) & ~1) <= ldx) ? 2 : 1;
     if (dbg_vec > 0 && dbg_vec < vec) vec = dbg_vec;
-    if (vec == 4)
+    if (h3) {
+        hipLaunchKernelGGL(gpe_knn_planes_kernel, dim3((unsigned)gpe_cdiv((long)nq, 4 * KNN_NORM_ROWS)), dim3(256), 0, s, x, (long)nq, C,
+                           ldx, CP, planes, iscale);
+        GPE_CHECK_LAUNCH();
+        const size_t lds3 = (size_t)2 * 2 * KNN_TC * KNN_H3_PITCH + (size_t)4 * 16 * KNN_LDD * sizeof(float) +
+                            4 * 64 * sizeof(unsigned long long) + 4 * KNN_TC * sizeof(float);
+        const int NB = CP >> 5;
+        if (NB <= 2)
+            hipLaunchKernelGGL((gpe_knn_h3_kernel<2>), dim3((unsigned)nblocks), dim3(256), lds3, s, planes, iscale, N, CP, k, K2, norms,
+                               cmax, ce, B, tiles, pin, nsplit, part, mprobe);
+        else if (NB <= 5)
+            hipLaunchKernelGGL((gpe_knn_h3_kernel<5>), dim3((unsigned)nblocks), dim3(256), lds3, s, planes, iscale, N, CP, k, K2, norms,
+                               cmax, ce, B, tiles, pin, nsplit, part, mprobe);
+        else
+            hipLaunchKernelGGL((gpe_knn_h3_kernel<8>), dim3((unsigned)nblocks), dim3(256), lds3, s, planes, iscale, N, CP, k, K2, norms,
+                               cmax, ce, B, tiles, pin, nsplit, part, mprobe);
+    } else if (vec == 4)
         hipLaunchKernelGGL((gpe_knn_mfma_kernel<4>), dim3((unsigned)nblocks), dim3(256), lds, s, x, N, C, ldx, k, K2, norms, cmax, ce,
                            B, tiles, pin, nsplit, part, mprobe);
     else if (vec == 2)

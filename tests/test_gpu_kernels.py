@@ -70,7 +70,10 @@ def test_knn_bit_exact(gpe, B, N, C, k):
     assert bad == 0, '%d / %d queries differ' % (bad, B * N)
 
 
+# C -> fp16-pipe filter instance (blocks of 32 channels, NB = ceil(C / 32)): <2> 32, 33, 64; <5> 100 (two full steps), 150;
+# <8> 200 (seven blocks: an odd last step), 256; C = 300 > 256 keeps the exact-product fp32 filter
 MF_CASES = [(2, 300, 150, 152, 16), (1, 1000, 64, 64, 20), (3, 97, 32, 32, 5), (2, 513, 256, 256, 64), (1, 2048, 33, 36, 16),
+            (2, 200, 100, 100, 10), (1, 700, 200, 200, 16), (1, 300, 300, 300, 8),
             (2, 130, 150, 152, 9)]
 
 
@@ -123,11 +126,13 @@ print('alt path ok')
 '''
 
 
-@pytest.mark.parametrize('env', [{'GPE_KNN_EXACT': '1'}, {'GPE_KNN_SPLIT': '2'}, {'GPE_KNN_EXACT': '1', 'GPE_KNN_SPLIT': '2'}])
+@pytest.mark.parametrize('env', [{'GPE_KNN_EXACT': '1'}, {'GPE_KNN_SPLIT': '2'}, {'GPE_KNN_EXACT': '1', 'GPE_KNN_SPLIT': '2'},
+                                 {'GPE_KNN_F32FILTER': '1'}, {'GPE_KNN_F32FILTER': '1', 'GPE_KNN_SPLIT': '2'}])
 def test_knn_alternative_paths(gpe, env, tmp_path):
     """The paths the dispatcher no longer takes by default on wide rows — the all-exact kernel's float4 / float2 staging
-    (C >= 16 now goes through the matrix-pipe filter) and the candidate split with its list merge (forced: B >= 8 pins clouds
-    to XCDs, which is what enables pieces) — stay bit-exact.  The overrides are read once per process, hence the subprocess."""
+    (C >= 16 goes through a matrix-pipe filter), the exact-product fp32 filter (16 <= C <= 256 now runs the fp16-pipe filter)
+    and the candidate split with its list merge (forced: B >= 8 pins clouds to XCDs, which is what enables pieces) — stay
+    bit-exact.  The overrides are read once per process, hence the subprocess."""
     import os, subprocess, sys
     script = tmp_path / 'w.py'
     script.write_text(_KNN_ALT_WORKER % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
