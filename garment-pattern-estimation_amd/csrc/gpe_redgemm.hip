@@ -698,23 +698,29 @@ __global__ __launch_bounds__(512, 2) void gpe_redgemm_b3_kernel(RdParams p)
         float4 ur[RQ], vr[RQ], vr2[VMODE == V_GATHER ? RQ : 1];
 
         int jgv = 0;                                // V_GATHER: lane q <-> neighbour row of this wave's q-th row
-        auto load_jgv = [&](int tile) -> int {
+        // The producers' instruction diet of gpe_redgemm_pc_kernel, applied here in round 4: a partial last tile
+        // is fetched as the LAST 32 rows of the operands (in bounds: the launcher guarantees rows >= 32; row order inside a
+        // tile is irrelevant to the sums; the rows that belong to the previous tile are zeroed by commit's slow path), so every
+        // tile's row addresses are linear, full tiles run without a single mask (pad columns only ever reach pad outputs, which
+        // gpe_redgemm_finish never reads — NaN / inf there are harmless), and the gathered row's point is one s_mul_hi_u32 on the
+        // wave-uniform row instead of the fp64 reciprocal chain.
+        auto tile_row0 = [&](int tile) -> long {
             const long row0 = (long)tile * RD_RT;
-            const int rv = (int)((p.rows - row0 < RD_RT) ? (p.rows - row0) : RD_RT);
-            const int r = RQ * w4 + ((lane < RQ) ? lane : RQ - 1);
-            return p.jg[row0 + ((r < rv) ? r : rv - 1)];
+            return (row0 + RD_RT <= p.rows) ? row0 : p.rows - RD_RT;
+        };
+        auto load_jgv = [&](int tile) -> int {
+            return p.jg[tile_row0(tile) + RQ * w4 + ((lane < RQ) ? lane : RQ - 1)];
         };
         auto fetch = [&](int tile) {
-            const long row0 = (long)tile * RD_RT;
-            const int rv = (int)((p.rows - row0 < RD_RT) ? (p.rows - row0) : RD_RT);
+            const long rb = tile_row0(tile) + RQ * w4;                      // 8 CONSECUTIVE rows per wave
+            const float* up = p.u.base + rb * p.u.stride_outer + cu;
+            const float* vp = p.v.base + rb * p.v.stride_outer + cv;
 #pragma unroll
             for (int q = 0; q < RQ; ++q) {
-                const int r = RQ * w4 + q;                                  // 8 CONSECUTIVE rows per wave
-                const long gr = row0 + ((r < rv) ? r : rv - 1);
-                ur[q] = rd_ld4(p.u.base + gr * p.u.stride_outer + cu);
-                if (VMODE == V_DENSE) vr[q] = rd_ld4(p.v.base + gr * p.v.stride_outer + cv);
+                ur[q] = rd_ld4(up + q * p.u.stride_outer);
+                if (VMODE == V_DENSE) vr[q] = rd_ld4(vp + q * p.v.stride_outer);
                 else {
-                    const long i = (long)gpe_udiv((unsigned)gr, (unsigned)p.k, p.rcp_k);
+                    const long i = (long)__umulhi((unsigned)(rb + q), p.kmagic);
                     const long jj = __builtin_amdgcn_readlane(jgv, q);       // prefetched one tile ahead (load_jgv)
                     vr[q] = rd_ld4(p.pq + i * p.ldpq + cv);
                     vr2[q] = rd_ld4(p.pq + jj * p.ldpq + p.H + cv);
@@ -727,17 +733,23 @@ __global__ __launch_bounds__(512, 2) void gpe_redgemm_b3_kernel(RdParams p)
             const long row0 = (long)tile * RD_RT;
             const int rv = (int)((p.rows - row0 < RD_RT) ? (p.rows - row0) : RD_RT);
             float c32[4] = {0.f, 0.f, 0.f, 0.f};
-            if (cq < UC) {
+            if (rv != RD_RT) {
+                // partial last tile (see fetch: it holds the operands' last 32 rows): rows of the previous tile and pad columns -> 0
 #pragma unroll
                 for (int q = 0; q < RQ; ++q) {
-                    if (!(RQ * w4 + q < rv && u_on)) ur[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    const bool ok = RQ * w4 + q >= RD_RT - rv;
+                    if (!(ok && u_on)) ur[q] = make_float4(0.f, 0.f, 0.f, 0.f);
                     else {
                         if (cq + 1 >= p.Mg) ur[q].y = 0.f;
                         if (cq + 2 >= p.Mg) ur[q].z = 0.f;
                         if (cq + 3 >= p.Mg) ur[q].w = 0.f;
                     }
-                    c32[0] += ur[q].x; c32[1] += ur[q].y; c32[2] += ur[q].z; c32[3] += ur[q].w;
+                    // (V needs no mask: a zero U row contributes 0 * finite to every product and nothing to the column sums)
                 }
+            }
+            if (cq < UC) {
+#pragma unroll
+                for (int q = 0; q < RQ; ++q) { c32[0] += ur[q].x; c32[1] += ur[q].y; c32[2] += ur[q].z; c32[3] += ur[q].w; }
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
                     unsigned hw[4], lw[4];
@@ -757,12 +769,6 @@ __global__ __launch_bounds__(512, 2) void gpe_redgemm_b3_kernel(RdParams p)
                         v.z = fmaxf(v.z + vr2[q].z, 0.f); v.w = fmaxf(v.w + vr2[q].w, 0.f);
                     }
                     v.x -= sh[0]; v.y -= sh[1]; v.z -= sh[2]; v.w -= sh[3];
-                    if (!(RQ * w4 + q < rv && v_on)) v = make_float4(0.f, 0.f, 0.f, 0.f);
-                    else {
-                        if (cq + 1 >= p.Ng) v.y = 0.f;
-                        if (cq + 2 >= p.Ng) v.z = 0.f;
-                        if (cq + 3 >= p.Ng) v.w = 0.f;
-                    }
                     vr[q] = v;
                 }
 #pragma unroll
