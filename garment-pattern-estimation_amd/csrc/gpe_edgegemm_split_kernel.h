@@ -30,6 +30,8 @@
 #pragma once
 #include "gpe_rowgemm.h"
 #include <math.h>
+#include <stdlib.h>
+#include <string.h>
 
 #define X6_PB 16          // rows a wave stages / finishes per tile
 // scheduling fences around a slot's memory slice: always for the fp32-tile policy.  The two-plane policy runs faster WITHOUT
@@ -40,6 +42,13 @@
 #endif
 #define X6_FENCE(planes) (!(planes) || X6_PLANES_FENCE)
 #define X6_NPW 4          // max points per wave per tile (gather / aggregation paths)
+// default left-over scheme per kernel kind (see the LEFT template parameter): measured A/B, profiles/r04_*
+#ifndef X6_LEFT_F2
+#define X6_LEFT_F2 1
+#define X6_LEFT_F3 0
+#define X6_LEFT_B3 0
+#define X6_LEFT_B2 0
+#endif
 #define GPE_ENOTSUP_SHAPE 12345
 
 // A wave has 256 architectural VGPRs + 256 accumulation VGPRs; MFMA takes its B operand from either file.  The resident
@@ -168,7 +177,17 @@ __device__ __forceinline__ int x6_scr(int row, int w, int b)
 // AGGT (forward only): 1 / 0 = the per-point max / min / argmax / argmin tracking of the aggregated last block is compiled in /
 // out; -1 = decided at run time by p.agg (the tracking then always runs: 24 VALU per row, only the stores are skipped).  The
 // k = 16 instances of the benchmark configuration are instantiated with 0 and 1.
-template <class SP, int AQ, int BQ, int KCH, int AMODE, int EMODE, bool K16, bool PSEUDO = false, int AGGT = -1>
+// LEFT (two-plane policy only): where a wave multiplies its K slabs (wave, wave + 4) of the BQ left-over tiles.
+//   0  inside the slot loop under the wave-dependent `(sl & 3) == wave` — every slot becomes a conditional block that modifies accL,
+//      which the compiler merges with up to 48 register copies per join and runs through accumulation registers with `s_nop 7` +
+//      read-back (13 x 13 gather forward: 504 v_mov_b64 + 340 v_accvgpr moves per tile and wave, scripts/isa_mix.py);
+//   1  in a branch-free loop of their own behind the slot loop (the A fragments are read a second time; a slab past the end
+//      multiplies zero weights against a clamped address).  -45 % static instructions, but the loop's LDS reads and MFMAs sit
+//      exposed in front of the tile's barrier: measured (profiles/r04_b) F2 525 -> 464 us, F3 475 -> 521, B3 509 -> 540;
+//   2  ROTATED slabs: wave w walks the K slabs in the order w, w + 1, .. (mod KS), so that ITS left-over slabs are iterations 0
+//      and 4 of every wave — compile-time positions, no branch, no second read.  The resident weights are loaded in that order;
+//      a wave's accumulation order over K differs from its neighbours' (fixed per wave: still bit-reproducible).
+template <class SP, int AQ, int BQ, int KCH, int AMODE, int EMODE, bool K16, bool PSEUDO = false, int AGGT = -1, int LEFT = 0>
 __global__ __launch_bounds__(256, 1) void gpe_edgegemm_split_kernel(RgParams p, int stats_nblk)
 {
     constexpr bool TRACK = (EMODE == E_EDGE_FWD) && AGGT != 0;
@@ -181,6 +200,8 @@ __global__ __launch_bounds__(256, 1) void gpe_edgegemm_split_kernel(RgParams p, 
     // a plane row is x6_pchunks(KCH) sixteen-byte chunks: a count = 2 (mod 4) keeps every 16-lane group of a ds_read_b128 that
     // walks down a column (groups {0-3,12-15,20-27}, ... of MI355X_MICROARCH.md "LDS") on 16 distinct bank quads.
     constexpr bool PLANES = SP::SCALED;
+    constexpr bool ROT = PLANES && BQ > 0 && LEFT == 2;          // rotated slab order (see LEFT above)
+    constexpr bool TAILLOOP = PLANES && BQ > 0 && LEFT == 1;
     constexpr int LDA = 16 * KCH + 4;
     constexpr int LDC = x6_ldc<SP>(NT, KCH);
     constexpr int PPITCH = 16 * x6_pchunks(KCH);         // bytes per plane row
@@ -218,6 +239,7 @@ __global__ __launch_bounds__(256, 1) void gpe_edgegemm_split_kernel(RgParams p, 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 15, g = lane >> 4;
+    const int g_tail = (g >= 2) ? (g & 1) : g;           // ROT: chunk read by a lane of the 16-wide tail slab
     const int rows_w = p.R >> 2;                         // rows of a tile this wave stages / finishes (<= X6_PB)
     const int rb = wave * rows_w;
     const int rk16 = (65536 + p.k - 1) / p.k;            // u / k == (u * rk16) >> 16 for u < 64
@@ -257,7 +279,9 @@ __global__ __launch_bounds__(256, 1) void gpe_edgegemm_split_kernel(RgParams p, 
         for (int i = 0; i < AQ; ++i)
 #pragma unroll
             for (int sl = 0; sl < KS; ++sl) {
-                const X6Frag<SP> f = load_frag(16 * (AQ * wave + i) + j, sl);
+                // ROT: register set `sl` holds the slab this wave multiplies in ITERATION sl
+                const int slw = ROT ? ((sl + wave >= KS) ? sl + wave - KS : sl + wave) : sl;
+                const X6Frag<SP> f = load_frag(16 * (AQ * wave + i) + j, slw);
 #pragma unroll
                 for (int t = 0; t < SP::P; ++t) { wP[t][i][sl] = f.pl[t]; x6_pin(wP[t][i][sl]); }
             }
@@ -545,6 +569,16 @@ __global__ __launch_bounds__(256, 1) void gpe_edgegemm_split_kernel(RgParams p, 
         float4 raw0, raw1;
         X6Frag<SP> nf;
         auto read_raw = [&](int sl, int mt) {
+            if constexpr (ROT) {
+                // iteration sl of this wave = slab (sl + wave) mod KS (wave-uniform).  In the 16-wide tail slab the lane groups
+                // g >= 2 lie past the row: they read a valid chunk (finite data) against the zero weights load_frag gave them
+                const int slr = (sl + wave >= KS) ? sl + wave - KS : sl + wave;
+                const int ge = (KTAIL && slr == KS - 1) ? g_tail : g;
+                const char* src = reinterpret_cast<const char*>(As) + (16 * mt + j) * PPITCH + 16 * (4 * slr + ge);
+#pragma unroll
+                for (int t = 0; t < SP::P; ++t) nf.pl[t] = *reinterpret_cast<const x6_u32x4*>(src + t * PLANE);
+                return;
+            }
             const bool dead = KTAIL && sl == KS - 1 && g >= 2;
             if constexpr (PLANES) {
                 const char* src = reinterpret_cast<const char*>(As) + (16 * mt + j) * PPITCH + 16 * (4 * sl + (dead ? (g & 1) : g));
@@ -623,7 +657,14 @@ __global__ __launch_bounds__(256, 1) void gpe_edgegemm_split_kernel(RgParams p, 
                 for (int t = 0; t < SP::NPROD; ++t)
 #pragma unroll
                     for (int i = 0; i < AQ; ++i) acc[mt][i] = SP::mfma(af.pl[SP::pa(t)], wP[SP::pw(t)][i][sl], acc[mt][i]);
-                if constexpr (!PLANES) {
+                if constexpr (ROT) {
+                    if ((sl & 3) == 0) {                     // compile time: iterations 0 and 4 carry this wave's slabs wave, wave + 4
+#pragma unroll
+                        for (int t = 0; t < SP::NPROD; ++t)
+#pragma unroll
+                            for (int b = 0; b < BQ; ++b) accL[b][mt] = SP::mfma(af.pl[SP::pa(t)], lP[SP::pw(t)][b][sl >> 2], accL[b][mt]);
+                    }
+                } else if constexpr (!TAILLOOP) {
                     if (BQ > 0 && (sl & 3) == wave) {        // this wave's K slab of the left-over tiles
 #pragma unroll
                         for (int t = 0; t < SP::NPROD; ++t)
@@ -634,14 +675,10 @@ __global__ __launch_bounds__(256, 1) void gpe_edgegemm_split_kernel(RgParams p, 
                 if (X6_FENCE(PLANES)) __builtin_amdgcn_sched_barrier(0);
             }
         }
-        if constexpr (PLANES && BQ > 0) {
-            // The left-over tiles' K slabs of this wave (wave, wave + 4) in a loop of their own, branch-free.  Inside the slot loop
-            // the wave-dependent `(sl & 3) == wave` made every slot a conditional block that modifies accL: the compiler merged the
-            // 16-register aggregate at each join with up to 48 register copies and ran the conditional MFMAs through accumulation
-            // registers with an `s_nop 7` + read-back (static count of the 13 x 13 gather forward: 504 v_mov_b64 + 340
-            // v_accvgpr moves per tile and wave, scripts/isa_mix.py).  Here a slab past the end multiplies the zero weights it was
-            // given in the prologue against a valid (clamped) address, and the A fragments are read a second time (2 LSL x 4
-            // ds_read_b128 per plane pair — the tile is in LDS anyway).
+        if constexpr (TAILLOOP) {
+            // LEFT == 1: the left-over tiles' K slabs of this wave (wave, wave + 4) in a loop of their own, branch-free: a slab past
+            // the end multiplies the zero weights it was given in the prologue against a valid (clamped) address, and the A
+            // fragments are read a second time (2 LSL x 4 ds_read_b128 per plane pair — the tile is in LDS anyway).
 #pragma unroll
             for (int q = 0; q < LSL; ++q) {
                 const int slr = wave + 4 * q;                              // wave-uniform
@@ -754,7 +791,25 @@ __global__ __launch_bounds__(256, 1) void gpe_edgegemm_split_kernel(RgParams p, 
 }
 
 // ---------------------------------------------------------------------------------------------------------
-template <class SP, int AQ, int BQ, int KCH, int AMODE, int EMODE, bool K16, bool PSEUDO = false, int AGGT = -1>
+// Left-over scheme (template parameter LEFT) per kernel kind of the k = 16 two-plane instances.  GPE_H3_LEFT = four digits
+// "F2 F3 B3 B2" (gather forward, dense forward, in-place backward, gathered backward), each 0 / 1 / 2, overrides the table.
+static int x6_left_scheme(int amode, int emode)
+{
+    static int tab[4] = {-1, 0, 0, 0};
+    if (tab[0] < 0) {
+        const int def[4] = {X6_LEFT_F2, X6_LEFT_F3, X6_LEFT_B3, X6_LEFT_B2};
+        const char* e = getenv("GPE_H3_LEFT");
+        for (int i = 3; i >= 0; --i) {
+            int v = def[i];
+            if (e && strlen(e) == 4 && e[i] >= '0' && e[i] <= '2') v = e[i] - '0';
+            tab[i] = v;
+        }
+    }
+    const int kind = (emode == E_EDGE_FWD) ? (amode == A_GATHER ? 0 : 1) : (emode == E_BWD_INPLACE ? 2 : 3);
+    return tab[kind];
+}
+
+template <class SP, int AQ, int BQ, int KCH, int AMODE, int EMODE, bool K16, bool PSEUDO = false, int AGGT = -1, int LEFT = 0>
 static int x6_launch_k(const RgParams& p, int stats_nblk, hipStream_t s)
 {
     constexpr int NT = 4 * AQ + BQ;
@@ -762,11 +817,11 @@ static int x6_launch_k(const RgParams& p, int stats_nblk, hipStream_t s)
     constexpr int AWORDS = SP::SCALED ? (2 * RG_BM * 16 * x6_pchunks(KCH)) / 4 : RG_BM * LDA;
     const size_t lds = (size_t)(2 * AWORDS + RG_BM * LDC) * sizeof(float);
     // 16 bytes of static __shared__ (amax_sh) sit beside the dynamic image
-    GPE_ENSURE_MAX_LDS_N((gpe_edgegemm_split_kernel<SP, AQ, BQ, KCH, AMODE, EMODE, K16, PSEUDO, AGGT>), 160 * 1024 - 64);
+    GPE_ENSURE_MAX_LDS_N((gpe_edgegemm_split_kernel<SP, AQ, BQ, KCH, AMODE, EMODE, K16, PSEUDO, AGGT, LEFT>), 160 * 1024 - 64);
     int gx = gpe_num_cus();
     if (gx > p.num_tiles) gx = p.num_tiles;
     if (stats_nblk > 0 && gx > stats_nblk) gx = stats_nblk;
-    hipLaunchKernelGGL((gpe_edgegemm_split_kernel<SP, AQ, BQ, KCH, AMODE, EMODE, K16, PSEUDO, AGGT>), dim3(gx), dim3(256), lds, s, p, stats_nblk);
+    hipLaunchKernelGGL((gpe_edgegemm_split_kernel<SP, AQ, BQ, KCH, AMODE, EMODE, K16, PSEUDO, AGGT, LEFT>), dim3(gx), dim3(256), lds, s, p, stats_nblk);
     GPE_CHECK_LAUNCH();
     return GPE_OK;
 }
@@ -779,10 +834,26 @@ static int x6_launch(const RgParams& p, int stats_nblk, hipStream_t s)
             return p.k == 16 ? x6_launch_k<SP, AQ, BQ, KCH, AMODE, EMODE, true, true>(p, stats_nblk, s)
                              : x6_launch_k<SP, AQ, BQ, KCH, AMODE, EMODE, false, true>(p, stats_nblk, s);
     }
-    if constexpr (EMODE == E_EDGE_FWD && SP::SCALED) {   // the benchmark configuration's forward: tracking compiled in / out
-        if (p.k == 16)
-            return p.agg ? x6_launch_k<SP, AQ, BQ, KCH, AMODE, EMODE, true, false, 1>(p, stats_nblk, s)
-                         : x6_launch_k<SP, AQ, BQ, KCH, AMODE, EMODE, true, false, 0>(p, stats_nblk, s);
+    if constexpr (SP::SCALED) {
+        // the benchmark configuration (k = 16, whole points): forward with the aggregation tracking compiled in / out, and the
+        // left-over scheme of the kernel kind (x6_left_scheme: GPE_H3_LEFT overrides for A/B measurements)
+        if (p.k == 16) {
+            const int left = x6_left_scheme(AMODE, EMODE);
+            if constexpr (EMODE == E_EDGE_FWD) {
+                if (p.agg) {
+                    if (left == 2) return x6_launch_k<SP, AQ, BQ, KCH, AMODE, EMODE, true, false, 1, 2>(p, stats_nblk, s);
+                    if (left == 1) return x6_launch_k<SP, AQ, BQ, KCH, AMODE, EMODE, true, false, 1, 1>(p, stats_nblk, s);
+                    return x6_launch_k<SP, AQ, BQ, KCH, AMODE, EMODE, true, false, 1, 0>(p, stats_nblk, s);
+                }
+                if (left == 2) return x6_launch_k<SP, AQ, BQ, KCH, AMODE, EMODE, true, false, 0, 2>(p, stats_nblk, s);
+                if (left == 1) return x6_launch_k<SP, AQ, BQ, KCH, AMODE, EMODE, true, false, 0, 1>(p, stats_nblk, s);
+                return x6_launch_k<SP, AQ, BQ, KCH, AMODE, EMODE, true, false, 0, 0>(p, stats_nblk, s);
+            } else {
+                if (left == 2) return x6_launch_k<SP, AQ, BQ, KCH, AMODE, EMODE, true, false, -1, 2>(p, stats_nblk, s);
+                if (left == 1) return x6_launch_k<SP, AQ, BQ, KCH, AMODE, EMODE, true, false, -1, 1>(p, stats_nblk, s);
+                return x6_launch_k<SP, AQ, BQ, KCH, AMODE, EMODE, true, false, -1, 0>(p, stats_nblk, s);
+            }
+        }
     }
     return p.k == 16 ? x6_launch_k<SP, AQ, BQ, KCH, AMODE, EMODE, true>(p, stats_nblk, s)
                      : x6_launch_k<SP, AQ, BQ, KCH, AMODE, EMODE, false>(p, stats_nblk, s);
