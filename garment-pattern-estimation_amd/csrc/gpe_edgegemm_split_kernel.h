@@ -42,12 +42,13 @@
 #endif
 #define X6_FENCE(planes) (!(planes) || X6_PLANES_FENCE)
 #define X6_NPW 4          // max points per wave per tile (gather / aggregation paths)
-// default left-over scheme per kernel kind (see the LEFT template parameter): measured A/B, profiles/r04_*
+// default left-over scheme per kernel kind (see the LEFT template parameter), from the A/B of profiles/r04_c_left_schemes.md
+// (us per launch at cfg 2, schemes 0 / 1 / 2): F2 480 / 462 / 448, F3 480 / 516 / 495, B3 518 / 529 / 521, B2 528 / 526 / 517
 #ifndef X6_LEFT_F2
-#define X6_LEFT_F2 1
+#define X6_LEFT_F2 2
 #define X6_LEFT_F3 0
 #define X6_LEFT_B3 0
-#define X6_LEFT_B2 0
+#define X6_LEFT_B2 2
 #endif
 #define GPE_ENOTSUP_SHAPE 12345
 
@@ -183,7 +184,7 @@ __device__ __forceinline__ int x6_scr(int row, int w, int b)
 //      read-back (13 x 13 gather forward: 504 v_mov_b64 + 340 v_accvgpr moves per tile and wave, scripts/isa_mix.py);
 //   1  in a branch-free loop of their own behind the slot loop (the A fragments are read a second time; a slab past the end
 //      multiplies zero weights against a clamped address).  -45 % static instructions, but the loop's LDS reads and MFMAs sit
-//      exposed in front of the tile's barrier: measured (profiles/r04_b) F2 525 -> 464 us, F3 475 -> 521, B3 509 -> 540;
+//      exposed in front of the tile's barrier: F2 480 -> 462 us, but F3 480 -> 516, B3 518 -> 529 (profiles/r04_c_left_schemes.md);
 //   2  ROTATED slabs: wave w walks the K slabs in the order w, w + 1, .. (mod KS), so that ITS left-over slabs are iterations 0
 //      and 4 of every wave — compile-time positions, no branch, no second read.  The resident weights are loaded in that order;
 //      a wave's accumulation order over K differs from its neighbours' (fixed per wave: still bit-reproducible).
