@@ -793,7 +793,8 @@ __global__ __launch_bounds__(256, 1) void gpe_edgegemm_split_kernel(RgParams p, 
 
 // ---------------------------------------------------------------------------------------------------------
 // Left-over scheme (template parameter LEFT) per kernel kind of the k = 16 two-plane instances.  GPE_H3_LEFT = four digits
-// "F2 F3 B3 B2" (gather forward, dense forward, in-place backward, gathered backward), each 0 / 1 / 2, overrides the table.
+// "F2 F3 B3 B2" (gather forward, dense forward, in-place backward, gathered backward), each 0 or 2, overrides the table
+// (scheme 1 was measured — profiles/r04_c_left_schemes.md — never the fastest, and is no longer instantiated).
 static int x6_left_scheme(int amode, int emode)
 {
     static int tab[4] = {-1, 0, 0, 0};
@@ -802,7 +803,7 @@ static int x6_left_scheme(int amode, int emode)
         const char* e = getenv("GPE_H3_LEFT");
         for (int i = 3; i >= 0; --i) {
             int v = def[i];
-            if (e && strlen(e) == 4 && e[i] >= '0' && e[i] <= '2') v = e[i] - '0';
+            if (e && strlen(e) == 4 && (e[i] == '0' || e[i] == '2')) v = e[i] - '0';
             tab[i] = v;
         }
     }
@@ -843,15 +844,12 @@ static int x6_launch(const RgParams& p, int stats_nblk, hipStream_t s)
             if constexpr (EMODE == E_EDGE_FWD) {
                 if (p.agg) {
                     if (left == 2) return x6_launch_k<SP, AQ, BQ, KCH, AMODE, EMODE, true, false, 1, 2>(p, stats_nblk, s);
-                    if (left == 1) return x6_launch_k<SP, AQ, BQ, KCH, AMODE, EMODE, true, false, 1, 1>(p, stats_nblk, s);
                     return x6_launch_k<SP, AQ, BQ, KCH, AMODE, EMODE, true, false, 1, 0>(p, stats_nblk, s);
                 }
                 if (left == 2) return x6_launch_k<SP, AQ, BQ, KCH, AMODE, EMODE, true, false, 0, 2>(p, stats_nblk, s);
-                if (left == 1) return x6_launch_k<SP, AQ, BQ, KCH, AMODE, EMODE, true, false, 0, 1>(p, stats_nblk, s);
                 return x6_launch_k<SP, AQ, BQ, KCH, AMODE, EMODE, true, false, 0, 0>(p, stats_nblk, s);
             } else {
                 if (left == 2) return x6_launch_k<SP, AQ, BQ, KCH, AMODE, EMODE, true, false, -1, 2>(p, stats_nblk, s);
-                if (left == 1) return x6_launch_k<SP, AQ, BQ, KCH, AMODE, EMODE, true, false, -1, 1>(p, stats_nblk, s);
                 return x6_launch_k<SP, AQ, BQ, KCH, AMODE, EMODE, true, false, -1, 0>(p, stats_nblk, s);
             }
         }
