@@ -108,6 +108,8 @@ __device__ __forceinline__ float gpe_pack_elem(const GpePackJob& jb, int n, int 
     return 0.f;
 }
 
+typedef _Float16 pk_f16x8 __attribute__((ext_vector_type(8)));
+
 __global__ __launch_bounds__(256) void gpe_pack_multi_kernel(const GpePackJob* __restrict__ jobs, int njobs)
 {
     // wave-uniform job lookup: jobs are sorted by first_block
@@ -115,7 +117,60 @@ __global__ __launch_bounds__(256) void gpe_pack_multi_kernel(const GpePackJob* _
     for (int q = 1; q < njobs; ++q) ji = ((long)blockIdx.x >= jobs[q].first_block) ? q : ji;
     const GpePackJob jb = jobs[ji];
     const long e = (((long)blockIdx.x - jb.first_block) * 256 + threadIdx.x) * 4;
+    if (jb.kind == 9) {
+        // largest |w| of a [N][K] matrix (row pitch ldw) -> atomicMax into the uint32 word at jb.out (zeroed by the caller):
+        // phase 1 of the fp16-plane packs below, which normalise a weight by a power of two taken from it
+        __shared__ unsigned red[4];
+        unsigned m = 0u;
+        for (int t = 0; t < 4; ++t) {
+            const long i = e + t;
+            if (i < jb.total) {
+                const long n = i / jb.K;
+                const unsigned a = __float_as_uint(jb.w[n * jb.ldw + (i - n * jb.K)]) & 0x7fffffffu;
+                m = m > a ? m : a;
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const unsigned t = (unsigned)__shfl_xor((int)m, o);
+            m = m > t ? m : t;
+        }
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const unsigned a = red[0] > red[1] ? red[0] : red[1], b = red[2] > red[3] ? red[2] : red[3];
+            const unsigned r = a > b ? a : b;
+            if (r) atomicMax(reinterpret_cast<unsigned*>(jb.out), r);
+        }
+        return;
+    }
     if (e >= jb.total) return;
+    if (jb.kind == 8 || jb.kind == 10) {
+        // two-term fp16 planes of a weight in the B-fragment order of v_mfma_f32_16x16x32_f16: out = [plane h | plane l], a plane =
+        // [KP / 8 k-groups][Npad columns][8 halves] (KP = K rounded up to 32, zero fill): lane (j, g) of the MFMA reads ONE 16-byte
+        // piece = k 8 kg .. 8 kg + 7 of column n.  Values: w * 2^sh = h + l with 2^sh from the tensor's largest magnitude (the word at
+        // jb.w2, written by a kind-9 job of an earlier launch).  kind 8: gate-interleaved columns (element map of kind 2);
+        // kind 10: the plain transpose (element map of kind 1).  A thread writes one piece (16 bytes = "4 floats" of `total`).
+        const unsigned u = (unsigned)(e >> 2);
+        const unsigned KP = ((unsigned)jb.K + 31u) & ~31u, KG = KP >> 3;
+        const unsigned per_plane = KG * (unsigned)jb.Npad;
+        const unsigned plane = u / per_plane, r2 = u - plane * per_plane;
+        const unsigned kg = r2 / (unsigned)jb.Npad;
+        const int n = (int)(r2 - kg * (unsigned)jb.Npad);
+        float sc, inv;
+        gpe_h3_scale_of(*reinterpret_cast<const unsigned*>(jb.w2), sc, inv);
+        GpePackJob je = jb;
+        je.kind = (jb.kind == 8) ? 2 : 1;
+        pk_f16x8 o;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const float xs = gpe_pack_elem(je, n, (int)(8 * kg) + t) * sc;
+            const _Float16 h = (_Float16)xs;
+            o[t] = plane ? (_Float16)(xs - (float)h) : h;
+        }
+        *reinterpret_cast<pk_f16x8*>(reinterpret_cast<char*>(jb.out) + (size_t)u * 16) = o;
+        return;
+    }
     if (jb.kind >= 5) {                                              // vector jobs, element-wise
         for (int t = 0; t < 4 && e + t < jb.total; ++t) {
             const long i = e + t;
@@ -136,6 +191,12 @@ __global__ __launch_bounds__(256) void gpe_pack_multi_kernel(const GpePackJob* _
     v.x = gpe_pack_elem(jb, n, k0); v.y = gpe_pack_elem(jb, n, k0 + 1);
     v.z = gpe_pack_elem(jb, n, k0 + 2); v.w = gpe_pack_elem(jb, n, k0 + 3);
     *reinterpret_cast<float4*>(jb.out + e) = v;
+}
+
+extern "C" long gpe_packed_planes_size(int Npad, int K)
+{
+    if (Npad <= 0 || K <= 0) return GPE_EINVAL;
+    return 2L * (((K + 31) & ~31) >> 3) * Npad * 4;
 }
 
 extern "C" int gpe_pack_multi(const void* jobs_dev, int njobs, long total_blocks, void* stream)

@@ -16,11 +16,14 @@
 #include <math.h>
 #include <stdlib.h>
 
+extern "C" int gpe_math_get(void);
+
 #define WV_MAXCELL 4
 
 struct WvFwdCell {
     const float* a0; long a0_stride; const float* w0;       // h_{l,t-1} rows, gate-packed W_hh_l
     const float* a1; long a1_stride; const float* w1;       // h_{l-1,t} rows, gate-packed W_ih_l (NULL for layer 0)
+    const unsigned* s0; const unsigned* s1;                 // H3: amax words of W_hh_l / W_ih_l (w0 / w1 are then plane packs)
     const float* xproj; long xp_stride;                     // addend rows [..][G*H] (stride 0: one bias row)
     const float* c_prev; float* c_out;                      // LSTM
     const float* bhn;                                       // GRU
@@ -128,7 +131,11 @@ struct WvRegs {
     float4 w[(KS * NT + 63) / 64];           // (KS/4 planes) x (16*NT columns) float4 over 256 threads
 };
 
-template <int NT, int KS>
+// H3 (f16x3 arithmetic, round 4): `wp` is the fp16-PLANE pack of the weight (gpe_pack_multi kinds 8 / 10: [plane][K / 8][Npad][8
+// halves]); a slab's share of it has the same number of 16-byte pieces as the fp32 slab, in the order [plane][k-group][column],
+// and lands in LDS in that order — the B fragments of v_mfma_f32_16x16x32_f16 are then single ds_read_b128.  The A slab stays
+// fp32 in LDS (zero-filled to a multiple of 32 columns) and is split at fragment-read time (each element is read by ONE wave).
+template <int NT, int KS, bool H3 = false>
 __device__ __forceinline__ void wv_fetch(WvRegs<NT, KS>& R, const float* __restrict__ a, long stride,
                                          const float* __restrict__ wp, int K, int Npad, int row0, int rv, int n0, int ks)
 {
@@ -143,6 +150,21 @@ __device__ __forceinline__ void wv_fetch(WvRegs<NT, KS>& R, const float* __restr
         R.a[q] = ld4(a + (long)(row0 + (r < rv ? r : rv - 1)) * stride + ks + cc);
     }
     constexpr int per_plane = 16 * NT;
+    if constexpr (H3) {
+        const int kg_slab = ((kslab + 31) & ~31) >> 3;                    // k-groups of 8 in this slab (whole 32-k steps)
+        const int KG = ((K + 31) & ~31) >> 3;                             // ... in the whole K extent of the pack
+        const int half = kg_slab * per_plane, total = 2 * half;
+#pragma unroll
+        for (int u = 0; u < (KS * NT + 63) / 64; ++u) {
+            const int e = tid + 256 * u;
+            const int ec = (e < total) ? e : total - 1;
+            const int plane = ec >= half, r2 = ec - plane * half;
+            const int kg = r2 / per_plane, n = r2 - kg * per_plane;
+            const int nn = (n0 + n < Npad) ? n0 + n : Npad - 1;
+            R.w[u] = ld4(wp + (((long)plane * KG + (ks >> 3) + kg) * Npad + nn) * 4);      // 16-byte pieces = "4 floats"
+        }
+        return;
+    }
     const int total = (kp >> 2) * per_plane;
     const int chunk0 = ks >> 4;
 #pragma unroll
@@ -155,13 +177,13 @@ __device__ __forceinline__ void wv_fetch(WvRegs<NT, KS>& R, const float* __restr
     }
 }
 
-template <int NT, int KS>
+template <int NT, int KS, bool H3 = false>
 __device__ __forceinline__ void wv_commit(const WvRegs<NT, KS>& R, int K, int Npad, int rv, int n0, int ks, float* As,
                                           float* Ws, int lda)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int kslab = (K - ks < KS) ? (K - ks) : KS;
-    const int kp = (kslab + 15) & ~15;
+    const int kp = H3 ? ((kslab + 31) & ~31) : ((kslab + 15) & ~15);
     const int c = lane << 2;
     if (c < kp) {
         const int nvalid = kslab - c;
@@ -179,13 +201,60 @@ __device__ __forceinline__ void wv_commit(const WvRegs<NT, KS>& R, int K, int Np
         }
     }
     constexpr int per_plane = 16 * NT;
-    const int total = (kp >> 2) * per_plane;
+    const int total = H3 ? 2 * (kp >> 3) * per_plane : (kp >> 2) * per_plane;
 #pragma unroll
     for (int u = 0; u < (KS * NT + 63) / 64; ++u) {
         const int e = tid + 256 * u;
         if (e < total) {
             const int n = e % per_plane;
             st4(&Ws[e * 4], (n0 + n < Npad) ? R.w[u] : make_float4(0.f, 0.f, 0.f, 0.f));
+        }
+    }
+}
+
+// f16x3 products of one staged slab: A rows fp32 in LDS, scaled by the power of two `sA` and split into two fp16 terms right
+// after the read; B = the weight's planes in LDS; three MFMAs per 16 x 16 x 32 block, small terms first.  `split` as in wv_mma
+// (a <= 32-row tile: wave w = row tile (w & 1), K half (w >> 1)).
+typedef _Float16 wv_f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 wv_f16x2 __attribute__((ext_vector_type(2)));
+typedef float wv_f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned wv_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void wv_split2(float a, float b, float s, unsigned& h, unsigned& l)
+{
+    const wv_f32x2 v = {a * s, b * s};
+    const wv_f16x2 hh = __builtin_convertvector(v, wv_f16x2);
+    const wv_f32x2 r = v - __builtin_convertvector(hh, wv_f32x2);
+    h = __builtin_bit_cast(unsigned, hh);
+    l = __builtin_bit_cast(unsigned, __builtin_convertvector(r, wv_f16x2));
+}
+template <int NT>
+__device__ __forceinline__ void wv_mma_h3(const float* As, const float* Ws, int lda, int kp, float sA, f32x4 (&acc)[NT],
+                                          bool split = false)
+{
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int j = lane & 15, g = lane >> 4;
+    const int nsteps = kp >> 5;                           // kp is a multiple of 32 here
+    const int rt = split ? (wave & 1) : wave;
+    const int half = (nsteps + 1) >> 1;
+    const int s0 = (split && (wave >> 1)) ? half : 0;
+    const int s1 = (split && !(wave >> 1)) ? half : nsteps;
+    const int plane_f = (kp >> 3) * 16 * NT * 4;          // floats per plane of the staged slab
+    for (int st = s0; st < s1; ++st) {
+        const float* ar = &As[(16 * rt + j) * lda + 32 * st + 8 * g];
+        const float4 a0 = ld4(ar), a1 = ld4(ar + 4);
+        wv_u32x4 ah, al;
+        { unsigned h, l; wv_split2(a0.x, a0.y, sA, h, l); ah[0] = h; al[0] = l; }
+        { unsigned h, l; wv_split2(a0.z, a0.w, sA, h, l); ah[1] = h; al[1] = l; }
+        { unsigned h, l; wv_split2(a1.x, a1.y, sA, h, l); ah[2] = h; al[2] = l; }
+        { unsigned h, l; wv_split2(a1.z, a1.w, sA, h, l); ah[3] = h; al[3] = l; }
+        const float* wb = &Ws[(((4 * st + g) * 16 * NT) + j) * 4];
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            const wv_u32x4 bh = *reinterpret_cast<const wv_u32x4*>(wb + 64 * n);
+            const wv_u32x4 bl = *reinterpret_cast<const wv_u32x4*>(wb + 64 * n + plane_f);
+            acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(wv_f16x8, al), __builtin_bit_cast(wv_f16x8, bh), acc[n], 0, 0, 0);
+            acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(wv_f16x8, ah), __builtin_bit_cast(wv_f16x8, bl), acc[n], 0, 0, 0);
+            acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(wv_f16x8, ah), __builtin_bit_cast(wv_f16x8, bh), acc[n], 0, 0, 0);
         }
     }
 }
@@ -220,12 +289,19 @@ __device__ __forceinline__ void wv_mma(const float* As, const float* Ws, int lda
     }
 }
 
-// G = 4: LSTM (i,f,g,o)   G = 3: GRU (r,z,n)
-template <int G, int KS>
-__global__ __launch_bounds__(256) void gpe_rnn_wave_fwd_kernel(WvFwdParams p)
+// The recurrent state enters the fp16 pipe scaled by 2^12: |h| < 1 for every state an LSTM / GRU cell produces (o * tanh(c);
+// a convex combination of tanh values), start states up to |h0| < 16 stay finite, and a state down to 3e-5 keeps both terms
+// normal (smaller ones keep an absolute error < 1.5e-8).
+#define WV_H3_SA 4096.f
+#define WV_H3_INV_SA (1.f / 4096.f)
+
+// G = 4: LSTM (i,f,g,o)   G = 3: GRU (r,z,n).   H3: f16x3 arithmetic (gpe_math_set(4)) — weights as fp16 plane packs with their
+// amax words, the state rows split on the fly, three fp16 MFMAs per product block, fp32 accumulate (wv_mma_h3).
+template <int G, int KS, bool H3 = false>
+__global__ __launch_bounds__(256, (KS <= 128 ? 2 : 1)) void gpe_rnn_wave_fwd_kernel(WvFwdParams p)
 {
     extern __shared__ __align__(16) float smem[];
-    const int kp_max = ((p.H < KS ? p.H : KS) + 15) & ~15;
+    const int kp_max = H3 ? (((p.H < KS ? p.H : KS) + 31) & ~31) : (((p.H < KS ? p.H : KS) + 15) & ~15);
     const int lda = kp_max + 4;
     constexpr int ldc = 16 * 2 * G + 4;              // GRU keeps the input-side and recurrent-side products apart
     const int a_floats = RG_BM * (lda > ldc ? lda : ldc);
@@ -240,6 +316,14 @@ __global__ __launch_bounds__(256) void gpe_rnn_wave_fwd_kernel(WvFwdParams p)
     const int n0 = blockIdx.y * (16 * G);
 
     const bool split = rv <= 32;                      // wave-pair K split (wv_mma)
+    float h3_inv0 = 1.f, h3_inv1 = 1.f, h3_ratio = 1.f;
+    if constexpr (H3) {
+        float sw0, sw1 = 1.f;
+        gpe_h3_scale_of(c.s0[0], sw0, h3_inv0);
+        if (c.a1) gpe_h3_scale_of(c.s1[0], sw1, h3_inv1);
+        h3_ratio = h3_inv0 * sw1;                     // = inv0 / inv1
+        h3_inv0 *= WV_H3_INV_SA; h3_inv1 *= WV_H3_INV_SA;
+    }
     f32x4 accH[G], accX[G];
 #pragma unroll
     for (int n = 0; n < G; ++n) { accH[n] = (f32x4){0.f, 0.f, 0.f, 0.f}; accX[n] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
@@ -267,21 +351,44 @@ __global__ __launch_bounds__(256) void gpe_rnn_wave_fwd_kernel(WvFwdParams p)
         WvRegs<G, KS> R;
         auto job_fetch = [&](int i) {
             const int seg = (i >= nslab) ? 1 : 0, ks = (i - seg * nslab) * KS;
-            wv_fetch<G, KS>(R, seg ? c.a1 : c.a0, seg ? c.a1_stride : c.a0_stride, seg ? c.w1 : c.w0, p.H, p.Npad, row0, rv,
-                            n0, ks);
+            wv_fetch<G, KS, H3>(R, seg ? c.a1 : c.a0, seg ? c.a1_stride : c.a0_stride, seg ? c.w1 : c.w0, p.H, p.Npad, row0, rv,
+                                n0, ks);
         };
         job_fetch(0);
         for (int i = 0; i < njobs; ++i) {
             const int seg = (i >= nslab) ? 1 : 0, ks = (i - seg * nslab) * KS;
             const int kslab = (p.H - ks < KS) ? (p.H - ks) : KS;
             __syncthreads();                               // the previous slab's MFMAs are done with As / Ws
-            wv_commit<G, KS>(R, p.H, p.Npad, rv, n0, ks, As, Ws, lda);
+            wv_commit<G, KS, H3>(R, p.H, p.Npad, rv, n0, ks, As, Ws, lda);
             __syncthreads();
             job_fetch(i + 1 < njobs ? i + 1 : i);          // unconditional (the last one re-fetches itself): a load under
                                                            // a branch is waited for at the join
-            if (G == 4 || seg == 0) wv_mma<G>(As, Ws, lda, (kslab + 15) & ~15, accH, split);
-            else wv_mma<G>(As, Ws, lda, (kslab + 15) & ~15, accX, split);
+            if constexpr (H3) {
+                if (G == 4 && i == nslab) {
+                    // the LSTM's single accumulator crosses from W_hh's scale into W_ih's: an exact power-of-two rescale
+#pragma unroll
+                    for (int n = 0; n < G; ++n)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) accH[n][r] *= h3_ratio;
+                }
+                if (G == 4 || seg == 0) wv_mma_h3<G>(As, Ws, lda, (kslab + 31) & ~31, WV_H3_SA, accH, split);
+                else wv_mma_h3<G>(As, Ws, lda, (kslab + 31) & ~31, WV_H3_SA, accX, split);
+            } else {
+                if (G == 4 || seg == 0) wv_mma<G>(As, Ws, lda, (kslab + 15) & ~15, accH, split);
+                else wv_mma<G>(As, Ws, lda, (kslab + 15) & ~15, accX, split);
+            }
         }
+    }
+    if constexpr (H3) {
+        // undo the operand scales (exact: powers of two): state 2^-12, weight from its amax word.  LSTM: accH ends in the scale of
+        // its last segment (W_ih for layers > 0, see the rescale above); GRU: one accumulator per segment
+#pragma unroll
+        for (int n = 0; n < G; ++n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (G == 4) accH[n][r] *= (c.a1 ? h3_inv1 : h3_inv0);
+                else { accH[n][r] *= h3_inv0; accX[n][r] *= h3_inv1; }
+            }
     }
     __syncthreads();
 #pragma unroll
@@ -348,38 +455,46 @@ static int wv_ks()
     return ks;
 }
 
-template <int G, int KS>
+template <int G, int KS, bool H3 = false>
 static int wv_fwd_launch_ks(const WvFwdParams& p, hipStream_t s)
 {
-    const int kp_max = gpe_round_up(p.H < KS ? p.H : KS, 16);
+    const int kp_max = gpe_round_up(p.H < KS ? p.H : KS, H3 ? 32 : 16);
     const int lda = kp_max + 4, ldc = 16 * 2 * G + 4;
     const size_t lds = ((size_t)RG_BM * (lda > ldc ? lda : ldc) + (size_t)kp_max * 16 * G) * sizeof(float);
     if (lds > 160 * 1024) return GPE_EINVAL;
-    GPE_ENSURE_MAX_LDS((gpe_rnn_wave_fwd_kernel<G, KS>));
-    hipLaunchKernelGGL((gpe_rnn_wave_fwd_kernel<G, KS>), dim3(gpe_cdiv(p.Bn, RG_BM), gpe_cdiv(p.H, 16), p.ncell), dim3(256),
+    GPE_ENSURE_MAX_LDS((gpe_rnn_wave_fwd_kernel<G, KS, H3>));
+    hipLaunchKernelGGL((gpe_rnn_wave_fwd_kernel<G, KS, H3>), dim3(gpe_cdiv(p.Bn, RG_BM), gpe_cdiv(p.H, 16), p.ncell), dim3(256),
                        lds, s, p);
     GPE_CHECK_LAUNCH();
     return GPE_OK;
 }
 
 template <int G>
-static int wv_fwd_launch(const WvFwdParams& p, hipStream_t s)
+static int wv_fwd_launch(const WvFwdParams& p, bool h3, hipStream_t s)
 {
     // a single row tile (the pattern decoders) is a pure latency chain: the wide slab halves its barrier pairs
     // (a 96-wide slab — 50 KB, three workgroups per CU, the 576-workgroup panel diagonal in one round — measured slower:
     // 686 vs 641 us per panel-decoder forward; three slabs per segment instead of two)
-    return (wv_ks() == 256 || p.Bn <= RG_BM) ? wv_fwd_launch_ks<G, 256>(p, s) : wv_fwd_launch_ks<G, 128>(p, s);
+    const bool wide = wv_ks() == 256 || p.Bn <= RG_BM;
+    if (h3) return wide ? wv_fwd_launch_ks<G, 256, true>(p, s) : wv_fwd_launch_ks<G, 128, true>(p, s);
+    return wide ? wv_fwd_launch_ks<G, 256>(p, s) : wv_fwd_launch_ks<G, 128>(p, s);
 }
 
 extern "C" int gpe_rnn_seq_fwd(int gates, int L, int T, int Bn, int H, const float* xproj0, long xp0_sb, long xp0_st,
                                const void* const* whh, const void* const* wih, const void* const* bias,
                                const void* const* bhn, float* hs, long hs_sl, long hs_sb, long hs_st, float* cs, long cs_sl, long cs_st,
-                               float* saved, long sv_sl, long sv_st, void* stream)
+                               float* saved, long sv_sl, long sv_st, const void* const* whh_pl, const void* const* wih_pl,
+                               const void* const* whh_amax, const void* const* wih_amax, void* stream)
 {
     if ((gates != 3 && gates != 4) || L <= 0 || T <= 0 || Bn <= 0 || H <= 0 || !xproj0 || !whh || !hs || !saved ||
         (L > 1 && (!wih || !bias)) || (gates == 4 && !cs) || (gates == 3 && !bhn) || (hs_sb & 3) || (hs_st & 3))
         return GPE_EINVAL;
     const int G = gates;
+    // f16x3: the gate products on the fp16 pipe when the arithmetic mode asks for it and the caller supplies the plane packs and
+    // amax words of every weight (gpe_pack_multi kinds 9 + 8); else the exact fp32 instruction
+    bool h3 = gpe_math_get() == 4 && whh_pl && whh_amax && (L == 1 || (wih_pl && wih_amax));
+    for (int l = 0; h3 && l < L; ++l)
+        if (!whh_pl[l] || !whh_amax[l] || (l > 0 && (!wih_pl[l] || !wih_amax[l]))) h3 = false;
     for (int d = 0; d <= T + L - 2; ++d) {
         const int l_lo = (d - (T - 1) > 0) ? d - (T - 1) : 0;
         const int l_hi = (d < L - 1) ? d : L - 1;
@@ -395,11 +510,13 @@ extern "C" int gpe_rnn_seq_fwd(int gates, int L, int T, int Bn, int H, const flo
                 WvFwdCell& c = p.cell[n];
                 c.a0 = hs + l * hs_sl + (long)t * hs_st;             // h_{l,t-1} lives at time slot t
                 c.a0_stride = hs_sb;
-                c.w0 = (const float*)whh[l];
+                c.w0 = (const float*)(h3 ? whh_pl[l] : whh[l]);
+                c.s0 = h3 ? (const unsigned*)whh_amax[l] : nullptr;
                 if (l > 0) {
                     c.a1 = hs + (l - 1) * hs_sl + (long)(t + 1) * hs_st;   // h_{l-1,t} at slot t+1
                     c.a1_stride = hs_sb;
-                    c.w1 = (const float*)wih[l];
+                    c.w1 = (const float*)(h3 ? wih_pl[l] : wih[l]);
+                    c.s1 = h3 ? (const unsigned*)wih_amax[l] : nullptr;
                     c.xproj = (const float*)bias[l];
                     c.xp_stride = 0;
                 } else {
@@ -416,7 +533,7 @@ extern "C" int gpe_rnn_seq_fwd(int gates, int L, int T, int Bn, int H, const flo
                 c.h_stride = hs_sb;
             }
             p.ncell = n;
-            const int rc = (G == 4) ? wv_fwd_launch<4>(p, (hipStream_t)stream) : wv_fwd_launch<3>(p, (hipStream_t)stream);
+            const int rc = (G == 4) ? wv_fwd_launch<4>(p, h3, (hipStream_t)stream) : wv_fwd_launch<3>(p, h3, (hipStream_t)stream);
             if (rc != GPE_OK) return rc;
         }
     }

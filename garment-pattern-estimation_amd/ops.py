@@ -80,6 +80,7 @@ WEIGHTS_EPOCH = 0          # bumped by optimizers that update parameters through
 _PACKS = {}                # (param data_ptr, kind) -> (plan, output tensor); a plan's entries die with the plan (weakref.finalize)
 
 K_PLAIN, K_TRANS, K_GATES, K_PQ, K_PQT, K_VADD, K_BPQ, K_GRUB = 0, 1, 2, 3, 4, 5, 6, 7
+K_GATES_H3, K_AMAX, K_TRANS_H3 = 8, 9, 10      # f16x3 operands of the recurrences: fp16 plane packs + the amax job they depend on
 _JOB = np.dtype([('w', '<u8'), ('w2', '<u8'), ('out', '<u8'), ('total', '<i8'), ('first_block', '<i8'),
                  ('ldw', '<i4'), ('N', '<i4'), ('K', '<i4'), ('kind', '<i4'), ('Npad', '<i4'), ('aux', '<i4')])
 assert _JOB.itemsize == 64
@@ -127,8 +128,10 @@ class PackPlan:
             self._add(w, K_TRANS, w.shape[1], w.shape[0])
 
     def add_gates(self, w, H, G=4):
-        """gate-interleaved pack of a recurrent weight [G*H, K] (LSTM G = 4, GRU G = 3)."""
+        """gate-interleaved pack of a recurrent weight [G*H, K] (LSTM G = 4, GRU G = 3) — and, for the f16x3 arithmetic, its two
+        fp16 planes + the amax word they are normalised by (a kind-9 job of the plan's FIRST launch)."""
         self._add(w, K_GATES, G * H, w.shape[1], aux=H)
+        self._add(w, K_GATES_H3, G * H, w.shape[1], aux=H)
 
     def add_edge_first(self, w1, b1):
         H, C2 = w1.shape
@@ -156,18 +159,39 @@ class PackPlan:
         dev = self.specs[0][0].device
         tab = np.zeros(len(self.specs), dtype=_JOB)
         blk = 0
+        # f16x3 plane packs are normalised by their tensor's largest magnitude: one amax word per planes job, filled by a kind-9
+        # job of an EARLIER launch (self.pre_table) into self.words (zeroed before every refresh)
+        h3 = [i for i, sp in enumerate(self.specs) if sp[2] in (K_GATES_H3, K_TRANS_H3)]
+        self.words = torch.zeros(max(len(h3), 1), device=dev, dtype=torch.int32)
+        pre = np.zeros(len(h3), dtype=_JOB)
+        pblk = 0
+        for wi, i in enumerate(h3):
+            p = self.specs[i][0]
+            n_el = p.numel()
+            pre[wi] = (p.data_ptr(), 0, self.words[wi:wi + 1].data_ptr(), n_el, pblk, p.stride(0), p.shape[0], p.shape[1], K_AMAX, 0, 0)
+            pblk += (n_el + 1023) // 1024
+        self.pre_blocks = pblk
+        self.pre_table = torch.from_numpy(pre.view(np.uint8).copy()).to(dev) if h3 else None
+        self.word_of = {}
         for i, (p, p2, kind, N, K, aux, out_numel) in enumerate(self.specs):
+            w2 = p2.data_ptr() if p2 is not None else 0
             if kind in (K_VADD, K_BPQ, K_GRUB):
                 total, npad = out_numel, 0
             elif kind == K_GATES:
                 npad = 16 * (N // aux) * ((aux + 15) // 16)
                 total = npad * round_up(K, 16)
+            elif kind in (K_GATES_H3, K_TRANS_H3):
+                npad = 16 * (N // aux) * ((aux + 15) // 16) if kind == K_GATES_H3 else round_up(N, 16)
+                total = L.query('gpe_packed_planes_size', npad, K)
+                word = self.words[h3.index(i):h3.index(i) + 1]
+                w2 = word.data_ptr()
+                self.word_of[(p.data_ptr(), kind)] = word
             else:
                 npad = round_up(N, 16)
                 total = L.query('gpe_packed_size', N, K)      # K filled up to the edge kernels' resident chunk count
             out = torch.empty(total, device=dev, dtype=F32)
             self.outs.append(out)
-            tab[i] = (p.data_ptr(), p2.data_ptr() if p2 is not None else 0, out.data_ptr(), total, blk,
+            tab[i] = (p.data_ptr(), w2, out.data_ptr(), total, blk,
                       p.stride(0) if p.dim() == 2 else 0, N, K, kind, npad, aux)
             blk += (total + 1023) // 1024            # gpe_pack_multi_kernel: 256 threads x one output quad
             key = (p.data_ptr(), kind)
@@ -193,6 +217,9 @@ class PackPlan:
             self._build()                      # first use, or a parameter moved (.to(device), arena re-homing)
         elif self.frozen and self.vers == vers and self.epoch == WEIGHTS_EPOCH:
             return
+        if self.pre_table is not None:
+            self.words.zero_()
+            L.call('gpe_pack_multi', self.pre_table, self.pre_table.numel() // 64, self.pre_blocks)
         L.call('gpe_pack_multi', self.table, len(self.specs), self.blocks)
         self.vers, self.epoch = vers, WEIGHTS_EPOCH
 
@@ -261,6 +288,19 @@ def pack_gates(w, H, G=4):
     wp = torch.empty(L.query('gpe_packed_ngates_size', H, G, w.shape[1]), device=w.device, dtype=F32)
     L.call('gpe_pack_weight_ngates', w, w.stride(0), H, G, w.shape[1], wp)
     return wp
+
+
+def planned_planes(w, kind):
+    """(fp16 plane pack, amax word) of a recurrent weight when a PackPlan owns them (f16x3 arithmetic of the recurrences), else
+    (None, None): the wavefront kernels then run the exact fp32 instruction."""
+    hit = _PACKS.get((w.data_ptr(), kind))
+    if hit is None:
+        return None, None
+    plan = hit[0]()
+    out = _planned(w, kind)
+    if plan is None or out is None:
+        return None, None
+    return out, plan.word_of.get((w.data_ptr(), kind))
 
 
 def bias_sum(b_ih, b_hh):
@@ -793,10 +833,22 @@ class RNNStackFn(torch.autograd.Function):
                 wih.append(pack_gates(w_ih, Hh, G))
                 biases.append(bias_sum(b_ih, b_hh) if lstm else gru_bias(b_ih, b_hh, Hh))
             bhns.append(None if lstm else b_hh[2 * Hh:])
-        keep = (whh, wih, biases)                  # operands stay referenced until the launches are queued
+        # f16x3 arithmetic: the plan's fp16 plane packs + amax words of every recurrent weight (absent -> exact fp32 kernels)
+        pl_hh, am_hh, pl_ih, am_ih = [], [], [None], [None]
+        for l in range(Lr):
+            w_ih, w_hh = params[4 * l], params[4 * l + 1]
+            a, b = planned_planes(w_hh, K_GATES_H3)
+            pl_hh.append(a); am_hh.append(b)
+            if l > 0:
+                a, b = planned_planes(w_ih, K_GATES_H3)
+                pl_ih.append(a); am_ih.append(b)
+        h3 = all(t is not None for t in pl_hh + am_hh + pl_ih[1:] + am_ih[1:])
+        keep = (whh, wih, biases, pl_hh, am_hh, pl_ih, am_ih)   # operands stay referenced until the launches are queued
         L.call('gpe_rnn_seq_fwd', G, Lr, T, Bn, Hh, xproj, xp_sb, xp_st, _ptr_array(whh), _ptr_array(wih),
                _ptr_array(biases), None if lstm else _ptr_array(bhns), hs, hs.stride(0), hs.stride(1), hs.stride(2),
-               cs, cs.stride(0) if lstm else 0, cs.stride(1) if lstm else 0, saved, saved.stride(0), saved.stride(1))
+               cs, cs.stride(0) if lstm else 0, cs.stride(1) if lstm else 0, saved, saved.stride(0), saved.stride(1),
+               _ptr_array(pl_hh) if h3 else None, _ptr_array(pl_ih) if h3 else None,
+               _ptr_array(am_hh) if h3 else None, _ptr_array(am_ih) if h3 else None)
         del keep
         hN = cN = None
         if want_state:

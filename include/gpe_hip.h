@@ -97,7 +97,14 @@ int gpe_pack_weight(const float* w, int ldw, int N, int K, int transpose, const 
  * of njobs 64-byte records {const float* w, w2; float* out; long total, first_block; int ldw, N, K, kind, Npad, aux}
  * sorted by first_block (1024 outputs per 256-thread block: one float4 per thread; ABI version 3 — version 2 had 256).  kind 0 plain pack, 1 transposed pack, 2 gate-interleaved pack (aux = H),
  * 3 pack of [W1a-W1b ; W1b] from W1 [H][2C] (gpe_w1_split + pack; aux = H), 4 its transpose, 5 out = w + w2 (N floats),
- * 6 out = [w[0:aux] | 0] (N floats), 7 out = w + [w2[0:aux] | 0] (N floats; GRU input-side bias b_ih + [b_hr | b_hz | 0]). */
+ * 6 out = [w[0:aux] | 0] (N floats), 7 out = w + [w2[0:aux] | 0] (N floats; GRU input-side bias b_ih + [b_hr | b_hz | 0]).
+ * f16x3 operands of the recurrences (ABI version 4): kind 9 = largest |w| of the [N][K] matrix, atomicMax into the uint32 word at
+ * `out` (zeroed by the caller; total = N*K); kind 8 / 10 = two-term fp16 PLANES of the gate-interleaved pack (element map of
+ * kind 2) / of the plain transpose (kind 1) in the B-fragment order of v_mfma_f32_16x16x32_f16 — out = [plane h | plane l], a
+ * plane = [KP/8][Npad][8 halves], KP = K rounded up to 32; w * 2^sh = h + l with 2^sh from the amax word at `w2`
+ * (total = 2 * (KP/8) * Npad * 4; gpe_packed_planes_size).  A kind-9 job must run in an EARLIER launch than the planes that
+ * read its word. */
+long gpe_packed_planes_size(int Npad, int K);        /* floats (4-byte units) of a kind-8 / kind-10 output */
 int gpe_pack_multi(const void* jobs_dev, int njobs, long total_blocks, void* stream);
 /* folded bias: out[n] = bias[n] + sum_k w[n][k]*t[k]   (t = beta - mean*s of the previous BatchNorm) */
 int gpe_fold_bias(const float* w, int ldw, int N, int K, const float* bias, const float* t, float* out,
@@ -272,7 +279,13 @@ int gpe_gru_cell_bwd(const float* dh_out, long dho_stride, const float* dh_rec, 
 int gpe_rnn_seq_fwd(int gates, int L, int T, int Bn, int H, const float* xproj0, long xp0_sb, long xp0_st,
                     const void* const* whh, const void* const* wih, const void* const* bias, const void* const* bhn,
                     float* hs, long hs_sl, long hs_sb, long hs_st, float* cs, long cs_sl, long cs_st, float* saved,
-                    long sv_sl, long sv_st, void* stream);
+                    long sv_sl, long sv_st, const void* const* whh_pl, const void* const* wih_pl,
+                    const void* const* whh_amax, const void* const* wih_amax, void* stream);
+/* whh_pl / wih_pl / whh_amax / wih_amax (host arrays of L device pointers, or NULL; entry 0 of the wih arrays unused): the fp16
+ * plane packs (gpe_pack_multi kind 8) of W_hh_l / W_ih_l and their amax words (kind 9).  With all of them present and the f16x3
+ * arithmetic selected (gpe_math_set(4)) the gate products run on the fp16 pipe: the state rows enter scaled by 2^12 and split in
+ * two fp16 terms (|h| < 1 for every state a cell produces; start states must satisfy |h0| < 16), three MFMAs per product, fp32
+ * accumulate — same bars as the exact kernel in every test.  Otherwise: exact fp32. */
 /* backward through the same recurrence.  dtop: gradient of the top layer's outputs, row (b, t) at dtop + b*dt_sb + t*dt_st
  * (may be NULL); d_hN / d_cN [L][Bn][H]: gradients of the final states (may be NULL).  whh_t / wih_t: host arrays of the
  * plain TRANSPOSED packs (gpe_pack_weight(.., transpose = 1)).  Outputs: dgx / dgh [L][Bn][T][ld], element (l, b, t) at

@@ -470,6 +470,60 @@ def test_lstm_decoder_fwd_bwd(gpe, Bn, In, Hh, T, L, Out):
         assert e < 1e-4, (n, e)
 
 
+@pytest.mark.parametrize('kind,Bn,In,Hh,T,L', [('lstm', 32, 250, 250, 23, 2), ('lstm', 200, 250, 250, 14, 3), ('lstm', 46, 40, 40, 6, 2),
+                                               ('gru', 70, 250, 250, 9, 2), ('lstm', 64, 100, 100, 5, 1)])
+def test_recurrences_on_the_fp16_pipe(gpe, kind, Bn, In, Hh, T, L):
+    """f16x3 arithmetic of the wavefront recurrences (round 4): with a PackPlan that holds the fp16 plane packs + amax words of
+    the recurrent weights, the gate products of the forward run as three fp16 MFMAs per product block (state rows scaled by 2^12
+    and split on the fly).  Same bars as the exact kernels against the fp64 oracle — forward, input gradient, every parameter
+    gradient — and the exact path must give (nearly) the same numbers: a plan-less call in the same mode runs it."""
+    from oracle import ref_path as O
+    from gpe_amd import ops, net_blocks
+    torch.manual_seed(Bn + T)
+    rnn = (torch.nn.LSTM if kind == 'lstm' else torch.nn.GRU)(In, Hh, L, batch_first=True)
+    with torch.no_grad():
+        rnn.weight_hh_l0.mul_(37.0)                              # weights far from unit scale: the amax word must carry it
+    ref = copy.deepcopy(rnn).double()
+    rnn = rnn.cuda()
+    G = 4 if kind == 'lstm' else 3
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(Bn, In, generator=g)
+    h0 = torch.randn(L, Bn, Hh, generator=g) * 0.3
+    c0 = torch.randn(L, Bn, Hh, generator=g) * 0.3
+    wgt = torch.randn(Bn, T, Hh, generator=g)
+    xr = x.double().requires_grad_()
+    seq = xr[:, None, :].expand(Bn, T, In)
+    out_r, _ = ref(seq, (h0.double(), c0.double())) if kind == 'lstm' else ref(seq, h0.double())
+    (out_r * wgt.double()).sum().backward()
+    params = net_blocks._rnn_params(rnn, L)
+    plan = ops.PackPlan()
+    net_blocks._register_rnn_packs(plan, rnn, L, Hh, G)
+    prev = gpe.set_math('f16x3')
+    try:
+        outs = {}
+        for with_plan in (True, False):
+            for p in rnn.parameters():
+                p.grad = None
+            if with_plan:
+                plan.refresh()
+                assert ops.planned_planes(rnn.weight_hh_l0, ops.K_GATES_H3)[0] is not None
+            else:
+                ops.bump_weights_epoch()                          # the plan's packs are stale now: the exact kernels run
+                assert ops.planned_planes(rnn.weight_hh_l0, ops.K_GATES_H3)[0] is None
+            xd = x.cuda().requires_grad_()
+            top, _, _ = ops.rnn_stack(xd, h0.cuda(), c0.cuda() if kind == 'lstm' else None, T, L, kind, params)
+            (top * wgt.cuda()).sum().backward()
+            outs[with_plan] = top.detach().clone()
+            assert relerr(top, out_r) < 2e-5, with_plan
+            assert relerr(xd.grad, xr.grad) < 1e-4, with_plan
+            for (n, p), q in zip(rnn.named_parameters(), ref.parameters()):
+                assert relerr(p.grad, q.grad) < 1e-4, (with_plan, n)
+        assert relerr(outs[True], outs[False]) < 2e-5
+        assert not torch.equal(outs[True], outs[False])          # ... and it really was another arithmetic
+    finally:
+        gpe.set_math(prev)
+
+
 # --------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize('M,chans', [(300, [27, 27, 27, 23]), (1000, [153, 153, 153, 23]), (130, [16, 200, 200, 200, 1])])
 def test_dense_mlp_fwd_bwd(gpe, math_mode, M, chans):
