@@ -157,15 +157,15 @@ _TRAFFIC_KERNELS = {
     # template tails: rowgemm <NT, AMODE, EMODE>; edgegemm (paired) <.., AMODE, EMODE, MATH>; edgegemm_sr <.., AMODE, EMODE, KC, HALF>
     # split <Policy, AQ, BQ, KCH, AMODE, EMODE, K16, PSEUDO>;  AMODE 1 = gather;  EMODE 1 forward, 2 in-place backward, 3 gathered
     # backward;  redgemm_pc / _b3 <MT, NT, VMODE(, F16)>: VMODE 0 = gathered V
-    'gpe_edge_mlp_fwd:gather': r'gpe_edgegemm(_sr)?_kernel<\d+, \d+, \d+, 1, 1(, [-\w]+)+>$|gpe_edgegemm_split_kernel<\w+, \d+, \d+, \d+, 1, 1(, \w+)+>$',
-    'gpe_edge_mlp_fwd:dense': r'gpe_edgegemm(_sr)?_kernel<\d+, \d+, \d+, 0, 1(, [-\w]+)+>$|gpe_edgegemm_split_kernel<\w+, \d+, \d+, \d+, 0, 1(, \w+)+>$',
-    'gpe_edge_mlp_bwd:inplace': r'gpe_edgegemm(_sr)?_kernel<\d+, \d+, \d+, 0, 2(, [-\w]+)+>$|gpe_edgegemm_split_kernel<\w+, \d+, \d+, \d+, 0, 2(, \w+)+>$',
-    'gpe_edge_mlp_bwd:gather': r'gpe_edgegemm(_sr)?_kernel<\d+, \d+, \d+, 0, 3(, [-\w]+)+>$|gpe_edgegemm_split_kernel<\w+, \d+, \d+, \d+, 0, 3(, \w+)+>$',
+    'gpe_edge_mlp_fwd:gather': r'gpe_edgegemm(_sr)?_kernel<\d+, \d+, \d+, 1, 1(, [-\w]+)+>$|gpe_edgegemm_split_kernel<\w+, \d+, \d+, \d+, 1, 1(, [-\w]+)+>$',
+    'gpe_edge_mlp_fwd:dense': r'gpe_edgegemm(_sr)?_kernel<\d+, \d+, \d+, 0, 1(, [-\w]+)+>$|gpe_edgegemm_split_kernel<\w+, \d+, \d+, \d+, 0, 1(, [-\w]+)+>$',
+    'gpe_edge_mlp_bwd:inplace': r'gpe_edgegemm(_sr)?_kernel<\d+, \d+, \d+, 0, 2(, [-\w]+)+>$|gpe_edgegemm_split_kernel<\w+, \d+, \d+, \d+, 0, 2(, [-\w]+)+>$',
+    'gpe_edge_mlp_bwd:gather': r'gpe_edgegemm(_sr)?_kernel<\d+, \d+, \d+, 0, 3(, [-\w]+)+>$|gpe_edgegemm_split_kernel<\w+, \d+, \d+, \d+, 0, 3(, [-\w]+)+>$',
     'gpe_edge_redgemm:gather': r'gpe_redgemm_(pc|b3)_kernel<\d+, \d+, 0(, \w+)?>$',
     'gpe_edge_redgemm:dense': r'gpe_redgemm_(pc|b3)_kernel<\d+, \d+, 1(, \w+)?>$',
     'gpe_edge_gather_stats': r'gpe_gather_stats_kernel',
     'gpe_edge_dz3': r'gpe_dz3_kernel',
-    'gpe_knn:filter': r'gpe_knn_mfma_kernel|gpe_knn_rerank_kernel|gpe_knn_norms_kernel|gpe_knn_cmax_kernel',
+    'gpe_knn:filter': r'gpe_knn_mfma_kernel|gpe_knn_h3_kernel|gpe_knn_planes_kernel|gpe_knn_rerank_kernel|gpe_knn_norms_kernel|gpe_knn_cmax_kernel',
     'gpe_knn:exact': r'gpe_knn_kernel',
     'gpe_edge_pull_dq': r'gpe_pull_dq_kernel',
 }
@@ -327,7 +327,10 @@ def roofline_tables(rec, nsteps, args, step_s, f16_rows):
             continue
         t = ms * 1e-3 / n_l
         edge = entry in ('gpe_edge_mlp_fwd', 'gpe_edge_mlp_bwd', 'gpe_edge_redgemm')
-        f16 = edge and on_f16
+        # the kNN filter (16 <= C <= 256) runs on the fp16 pipe in EVERY arithmetic mode: it only has to stay inside a proven bound,
+        # the exact recheck behind it makes the result bit-exact (csrc/gpe_knn.hip); the forward recurrences follow --math (plane
+        # packs from the model's PackPlan)
+        f16 = (edge and on_f16) or key == 'gpe_knn:filter' or (entry == 'gpe_rnn_seq_fwd' and args.math == 'f16x3')
         pipe_peak = PEAK_F16_TFLOPS if f16 else PEAK_F32_TFLOPS
         exec_fl = (3.0 if f16 else 1.0) * fl / n_l
         traffic, tsrc = pmc_traffic(key, n_l / nsteps)
