@@ -492,7 +492,8 @@ extern "C" int gpe_rnn_seq_fwd(int gates, int L, int T, int Bn, int H, const flo
     const int G = gates;
     // f16x3: the gate products on the fp16 pipe when the arithmetic mode asks for it and the caller supplies the plane packs and
     // amax words of every weight (gpe_pack_multi kinds 9 + 8); else the exact fp32 instruction
-    bool h3 = gpe_math_get() == 4 && whh_pl && whh_amax && (L == 1 || (wih_pl && wih_amax));
+    static const int dbg_f32 = getenv("GPE_RNN_F32") ? atoi(getenv("GPE_RNN_F32")) : 0;        // A/B measurements: keep the exact kernels
+    bool h3 = !dbg_f32 && gpe_math_get() == 4 && whh_pl && whh_amax && (L == 1 || (wih_pl && wih_amax));
     for (int l = 0; h3 && l < L; ++l)
         if (!whh_pl[l] || !whh_amax[l] || (l > 0 && (!wih_pl[l] || !wih_amax[l]))) h3 = false;
     for (int d = 0; d <= T + L - 2; ++d) {
