@@ -481,8 +481,10 @@ def test_recurrences_on_the_fp16_pipe(gpe, kind, Bn, In, Hh, T, L):
     from gpe_amd import ops, net_blocks
     torch.manual_seed(Bn + T)
     rnn = (torch.nn.LSTM if kind == 'lstm' else torch.nn.GRU)(In, Hh, L, batch_first=True)
-    with torch.no_grad():
-        rnn.weight_hh_l0.mul_(37.0)                              # weights far from unit scale: the amax word must carry it
+    with torch.no_grad():                                        # weights away from unit scale: the amax words must carry it
+        rnn.weight_hh_l0.mul_(2.5)                               # (mild factors: a recurrence with large weights is chaotic —
+        if L > 1:                                                # ANY rounding difference then grows to O(1) within a few steps)
+            rnn.weight_ih_l1.mul_(1.0 / 64)
     ref = copy.deepcopy(rnn).double()
     rnn = rnn.cuda()
     G = 4 if kind == 'lstm' else 3
