@@ -492,8 +492,8 @@ extern "C" int gpe_rnn_seq_fwd(int gates, int L, int T, int Bn, int H, const flo
     const int G = gates;
     // f16x3: the gate products on the fp16 pipe when the arithmetic mode asks for it and the caller supplies the plane packs and
     // amax words of every weight (gpe_pack_multi kinds 9 + 8); else the exact fp32 instruction
-    static const int dbg_f32 = getenv("GPE_RNN_F32") ? atoi(getenv("GPE_RNN_F32")) : 0;        // A/B: bit 0 forward, bit 1 backward stay exact
-    bool h3 = !(dbg_f32 & 1) && gpe_math_get() == 4 && whh_pl && whh_amax && (L == 1 || (wih_pl && wih_amax));
+    static const int dbg_f32 = getenv("GPE_RNN_F32") ? atoi(getenv("GPE_RNN_F32")) : 0;        // A/B measurements: keep the exact kernels
+    bool h3 = !dbg_f32 && gpe_math_get() == 4 && whh_pl && whh_amax && (L == 1 || (wih_pl && wih_amax));
     for (int l = 0; h3 && l < L; ++l)
         if (!whh_pl[l] || !whh_amax[l] || (l > 0 && (!wih_pl[l] || !wih_amax[l]))) h3 = false;
     for (int d = 0; d <= T + L - 2; ++d) {
@@ -713,18 +713,11 @@ __global__ __launch_bounds__(256) void gpe_rnn_wave_cell_bwd_kernel(WvBwdParams 
     }
 }
 
-// floats of the partial-product image (sized for the narrow slab; the wide one needs half)
-static long wv_bwd_part_floats(int gates, int L, int Bn, int H)
+extern "C" long gpe_rnn_seq_bwd_ws(int gates, int L, int Bn, int H)
 {
-    const int nz = gpe_cdiv(gates * H, 128);
+    const int nz = gpe_cdiv(gates * H, 128);              // sized for the narrow slab (the wide one needs half)
     const int ncell = L < WV_MAXCELL ? L : WV_MAXCELL;
-    return (((long)ncell * 2 * nz * Bn * H) + 3) & ~3L;
-}
-// workspace of gpe_rnn_seq_bwd in floats: the partial-product image + one amax word per cell (l, t) for the f16x3 arithmetic
-extern "C" long gpe_rnn_seq_bwd_ws(int gates, int L, int T, int Bn, int H)
-{
-    if (L <= 0 || T <= 0) return GPE_EINVAL;
-    return wv_bwd_part_floats(gates, L, Bn, H) + (((long)L * T + 3) & ~3L);
+    return (long)ncell * 2 * nz * Bn * H;
 }
 
 // dgx / dgh: [L][Bn][T][G*H] (for LSTM pass the same buffer twice); carry: [2][L][Bn][H] scratch;
@@ -735,22 +728,12 @@ extern "C" int gpe_rnn_seq_bwd(int gates, int L, int T, int Bn, int H, const flo
                                const float* d_hN, const float* d_cN, const void* const* whh_t, const void* const* wih_t,
                                const float* hs, long hs_sl, long hs_sb, long hs_st, const float* cs, long cs_sl, long cs_st,
                                const float* saved, long sv_sl, long sv_st, float* dgx, float* dgh, long dg_sl, long dg_sb,
-                               long dg_st, float* part, float* carry, const void* const* whh_t_pl, const void* const* wih_t_pl,
-                               const void* const* whh_t_amax, const void* const* wih_t_amax, void* stream)
+                               long dg_st, float* part, float* carry, void* stream)
 {
     if ((gates != 3 && gates != 4) || L <= 0 || T <= 0 || Bn <= 0 || H <= 0 || !whh_t || !hs || !saved || !dgx || !dgh ||
         !part || !carry || (L > 1 && !wih_t) || (gates == 4 && !cs) || (dg_sb & 3) || (dg_st & 3))
         return GPE_EINVAL;
     const int G = gates, K = G * H;
-    // f16x3: the dh products on the fp16 pipe when the mode asks for it and the caller supplies the transposed plane packs + amax
-    // words of every weight; the dG operands are scaled by the amax word their cell's pointwise kernel fills (one per cell, at the
-    // tail of `part`)
-    static const int dbg_f32 = getenv("GPE_RNN_F32") ? atoi(getenv("GPE_RNN_F32")) : 0;
-    bool h3 = !(dbg_f32 & 2) && gpe_math_get() == 4 && whh_t_pl && whh_t_amax && (L == 1 || (wih_t_pl && wih_t_amax));
-    for (int l = 0; h3 && l < L; ++l)
-        if (!whh_t_pl[l] || !whh_t_amax[l] || (l > 0 && (!wih_t_pl[l] || !wih_t_amax[l]))) h3 = false;
-    unsigned* words = reinterpret_cast<unsigned*>(part + wv_bwd_part_floats(G, L, Bn, H));
-    if (h3 && hipMemsetAsync(words, 0, (size_t)L * T * sizeof(unsigned), (hipStream_t)stream) != hipSuccess) return GPE_ELAUNCH;
     const int KS = wv_ks();
     // big batches: four slabs per workgroup (a 3-cell panel diagonal: 2304 single-slab workgroups in 4.5 rounds -> 480 in one,
     // a quarter of the partial images; measured 804 / 717 / 621 / 689 us per backward at 1 / 2 / 4 / 8 slabs); a single row
@@ -762,8 +745,8 @@ extern "C" int gpe_rnn_seq_bwd(int gates, int L, int T, int Bn, int H, const flo
     const long BH = (long)Bn * H;
     hipStream_t s = (hipStream_t)stream;
     const size_t lds = ((size_t)RG_BM * (KS + 4) + (size_t)KS * 64) * sizeof(float);
-    if (KS == 256) { GPE_ENSURE_MAX_LDS((gpe_rnn_wave_splitk_kernel<256>)); GPE_ENSURE_MAX_LDS((gpe_rnn_wave_splitk_kernel<256, true>)); }
-    else { GPE_ENSURE_MAX_LDS((gpe_rnn_wave_splitk_kernel<128>)); GPE_ENSURE_MAX_LDS((gpe_rnn_wave_splitk_kernel<128, true>)); }
+    if (KS == 256) GPE_ENSURE_MAX_LDS((gpe_rnn_wave_splitk_kernel<256>));
+    else GPE_ENSURE_MAX_LDS((gpe_rnn_wave_splitk_kernel<128>));
     for (int d = T + L - 2; d >= 0; --d) {
         const int l_lo = (d - (T - 1) > 0) ? d - (T - 1) : 0;
         const int l_hi = (d < L - 1) ? d : L - 1;
@@ -776,18 +759,13 @@ extern "C" int gpe_rnn_seq_bwd(int gates, int L, int T, int Bn, int H, const flo
                 WvBwdCell& c = p.cell[n];
                 c.part = part + (long)n * 2 * nz * BH;
                 if (t < T - 1) {                 // recurrent path: dGh_{l,t+1} . W_hh_l
-                    c.a[0] = dgh + l * dg_sl + (long)(t + 1) * dg_st; c.as[0] = dg_sb;
-                    c.w[0] = (const float*)(h3 ? whh_t_pl[l] : whh_t[l]);
+                    c.a[0] = dgh + l * dg_sl + (long)(t + 1) * dg_st; c.as[0] = dg_sb; c.w[0] = (const float*)whh_t[l];
                     c.nseg_mask |= 1;
-                    if (h3) { c.sa[0] = words + (long)l * T + (t + 1); c.sw[0] = (const unsigned*)whh_t_amax[l]; }
                 }
                 if (l < L - 1) {                 // from the layer above: dGx_{l+1,t} . W_ih_{l+1}
-                    c.a[1] = dgx + (l + 1) * dg_sl + (long)t * dg_st; c.as[1] = dg_sb;
-                    c.w[1] = (const float*)(h3 ? wih_t_pl[l + 1] : wih_t[l + 1]);
+                    c.a[1] = dgx + (l + 1) * dg_sl + (long)t * dg_st; c.as[1] = dg_sb; c.w[1] = (const float*)wih_t[l + 1];
                     c.nseg_mask |= 2;
-                    if (h3) { c.sa[1] = words + (long)(l + 1) * T + t; c.sw[1] = (const unsigned*)wih_t_amax[l + 1]; }
                 }
-                if (h3) c.amax_out = words + (long)l * T + t;
                 any_seg |= c.nseg_mask;
                 if (l == L - 1 && dtop) { c.dh_out = dtop + (long)t * dt_st; c.dho_stride = dt_sb; }
                 if (t == T - 1) {
@@ -810,10 +788,7 @@ extern "C" int gpe_rnn_seq_bwd(int gates, int L, int T, int Bn, int H, const flo
             p.ncell = n;
             if (any_seg) {
                 const dim3 grid(gpe_cdiv(Bn, RG_BM), gpe_cdiv(H, 64), n * 2 * nz);
-                if (h3) {
-                    if (KS == 256) hipLaunchKernelGGL((gpe_rnn_wave_splitk_kernel<256, true>), grid, dim3(256), lds, s, p);
-                    else hipLaunchKernelGGL((gpe_rnn_wave_splitk_kernel<128, true>), grid, dim3(256), lds, s, p);
-                } else if (KS == 256) hipLaunchKernelGGL(gpe_rnn_wave_splitk_kernel<256>, grid, dim3(256), lds, s, p);
+                if (KS == 256) hipLaunchKernelGGL(gpe_rnn_wave_splitk_kernel<256>, grid, dim3(256), lds, s, p);
                 else hipLaunchKernelGGL(gpe_rnn_wave_splitk_kernel<128>, grid, dim3(256), lds, s, p);
                 GPE_CHECK_LAUNCH();
             }

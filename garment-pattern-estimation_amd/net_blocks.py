@@ -281,11 +281,9 @@ def _register_rnn_packs(plan, rnn, n_layers, hidden, gates):
         plan.add_linear(w_ih)
         plan.add_gates(w_hh, hidden, gates)
         plan.add_linear(w_hh, fwd=False, bwd=True)
-        plan.add_trans_h3(w_hh)                        # f16x3 backward: dh = dG . W_hh on the fp16 pipe
         b_ih, b_hh = getattr(rnn, 'bias_ih_l%d' % l), getattr(rnn, 'bias_hh_l%d' % l)
         if l > 0:
             plan.add_gates(w_ih, hidden, gates)        # layers > 0 project h_{l-1,t} inside the fused cell launch
-            plan.add_trans_h3(w_ih)
         if gates == 4:
             plan.add_bias_sum(b_ih, b_hh)
         else:

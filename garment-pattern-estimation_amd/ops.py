@@ -133,11 +133,6 @@ class PackPlan:
         self._add(w, K_GATES, G * H, w.shape[1], aux=H)
         self._add(w, K_GATES_H3, G * H, w.shape[1], aux=H)
 
-    def add_trans_h3(self, w):
-        """fp16 planes of the transpose of a recurrent weight [G*H, K] (+ its amax word): the B operand of the backward's dh
-        products in the f16x3 arithmetic."""
-        self._add(w, K_TRANS_H3, w.shape[1], w.shape[0])
-
     def add_edge_first(self, w1, b1):
         H, C2 = w1.shape
         C = C2 // 2
@@ -881,7 +876,7 @@ class RNNStackFn(torch.autograd.Function):
         GHp = round_up(GH, 4)
         dgx = torch.empty(Lr, Bn, T, GHp, device=dev, dtype=F32)
         dgh = dgx if lstm else torch.empty(Lr, Bn, T, GHp, device=dev, dtype=F32)
-        part = torch.empty(L.query('gpe_rnn_seq_bwd_ws', G, Lr, T, Bn, Hh), device=dev, dtype=F32)
+        part = torch.empty(L.query('gpe_rnn_seq_bwd_ws', G, Lr, Bn, Hh), device=dev, dtype=F32)
         carry = torch.empty(2, Lr, Bn, Hh, device=dev, dtype=F32)
         whh_t = [pack_weight(params[4 * l + 1], transpose=True) for l in range(Lr)]
         wih_t = [None] + [pack_weight(params[4 * l], transpose=True) for l in range(1, Lr)]
@@ -889,20 +884,10 @@ class RNNStackFn(torch.autograd.Function):
             g_top = g_top.contiguous()
         ghN = g_hN.contiguous() if g_hN is not None else None
         gcN = g_cN.contiguous() if (lstm and g_cN is not None) else None
-        pl_hh, am_hh, pl_ih, am_ih = [], [], [None], [None]
-        for l in range(Lr):
-            a, b = planned_planes(params[4 * l + 1], K_TRANS_H3)
-            pl_hh.append(a); am_hh.append(b)
-            if l > 0:
-                a, b = planned_planes(params[4 * l], K_TRANS_H3)
-                pl_ih.append(a); am_ih.append(b)
-        h3 = all(t is not None for t in pl_hh + am_hh + pl_ih[1:] + am_ih[1:])
         L.call('gpe_rnn_seq_bwd', G, Lr, T, Bn, Hh, g_top, g_top.stride(0) if g_top is not None else 0,
                g_top.stride(1) if g_top is not None else 0, ghN, gcN, _ptr_array(whh_t), _ptr_array(wih_t),
                hs, hs.stride(0), hs.stride(1), hs.stride(2), cs, cs.stride(0) if lstm else 0, cs.stride(1) if lstm else 0,
-               saved, saved.stride(0), saved.stride(1), dgx, dgh, dgx.stride(0), dgx.stride(1), dgx.stride(2), part, carry,
-               _ptr_array(pl_hh) if h3 else None, _ptr_array(pl_ih) if h3 else None,
-               _ptr_array(am_hh) if h3 else None, _ptr_array(am_ih) if h3 else None)
+               saved, saved.stride(0), saved.stride(1), dgx, dgh, dgx.stride(0), dgx.stride(1), dgx.stride(2), part, carry)
         grads = [None] * (4 * Lr)
         d_x = None
         d_h0 = torch.empty(Lr, Bn, Hh, device=dev, dtype=F32) if want_h0 else None

@@ -290,18 +290,14 @@ int gpe_rnn_seq_fwd(int gates, int L, int T, int Bn, int H, const float* xproj0,
  * (may be NULL); d_hN / d_cN [L][Bn][H]: gradients of the final states (may be NULL).  whh_t / wih_t: host arrays of the
  * plain TRANSPOSED packs (gpe_pack_weight(.., transpose = 1)).  Outputs: dgx / dgh [L][Bn][T][ld], element (l, b, t) at
  * + l*dg_sl + b*dg_sb + t*dg_st (pitches % 4 == 0): pre-activation gradients on the input side / recurrent side (LSTM: pass
- * the same buffer twice).  part: workspace of gpe_rnn_seq_bwd_ws(gates, L, T, Bn, H) floats; carry: [2][L][Bn][H] scratch — on return
+ * the same buffer twice).  part: workspace of gpe_rnn_seq_bwd_ws floats; carry: [2][L][Bn][H] scratch — on return
  * carry[0][l] holds dc_0 (LSTM) / the z-gated part of dh_0 (GRU) of layer l. */
-long gpe_rnn_seq_bwd_ws(int gates, int L, int T, int Bn, int H);
+long gpe_rnn_seq_bwd_ws(int gates, int L, int Bn, int H);
 int gpe_rnn_seq_bwd(int gates, int L, int T, int Bn, int H, const float* dtop, long dt_sb, long dt_st, const float* d_hN,
                     const float* d_cN, const void* const* whh_t, const void* const* wih_t, const float* hs, long hs_sl,
                     long hs_sb, long hs_st, const float* cs, long cs_sl, long cs_st, const float* saved, long sv_sl,
                     long sv_st, float* dgx, float* dgh, long dg_sl, long dg_sb, long dg_st, float* part, float* carry,
-                    const void* const* whh_t_pl, const void* const* wih_t_pl, const void* const* whh_t_amax,
-                    const void* const* wih_t_amax, void* stream);
-/* whh_t_pl / wih_t_pl / *_amax (host arrays of L device pointers, or NULL): transposed fp16 plane packs (gpe_pack_multi kind 10)
- * and amax words of the weights.  With all of them and gpe_math_set(4) the split-K dh products run on the fp16 pipe: a cell's dG rows
- * are scaled by the amax word its pointwise kernel filled one diagonal earlier (L*T words at the tail of `part`). */
+                    void* stream);
 
 /* ---- attention variant (GarmentSegmentPattern3D, nn/nets.py:187-299) ------------------------------------------ */
 /* sparsemax.Sparsemax(dim=1) over rows of width W <= 32 (nn/nets.py:225): forward and backward */
