@@ -557,18 +557,16 @@ struct WvBwdCell {
     const float* h_prev; long hp_stride;           // GRU
     float* dgx; float* dgh; long dg_stride;        // pre-activation gradients of the cell, rows [Bn] pitch dg_stride
     int nseg_mask;                                 // bit s: segment s present
-    // H3 (f16x3): amax words of the two A operands (written by the cell backward of the diagonal before) and of the two weights
-    // (w[] are then transposed plane packs); amax_out = this cell's word, filled by the pointwise kernel
-    const unsigned* sa[2]; const unsigned* sw[2];
-    unsigned* amax_out;
 };
 // nz = K-slab GROUPS of the launch (partials per segment); a workgroup multiplies `jslabs` consecutive slabs of its group
 struct WvBwdParams { int Bn, H, K, Kpad_n, nz, jslabs, ncell; WvBwdCell cell[WV_MAXCELL]; };
 
 // grid (row tiles, cdiv(H, 64), ncell * 2 * nz): block z -> (cell, segment, K slab)
-// H3: f16x3 products — dG rows scaled by the power of two of their cell's amax word and split on the fly, weights as transposed
-// fp16 plane packs (gpe_pack_multi kind 10)
-template <int KS, bool H3 = false>
+// (The same products on the fp16 pipe were built and measured in round 4 — dG rows scaled by a per-cell amax word that the
+// pointwise kernel filled by atomicMax, transposed plane packs — and dropped: gpe_rnn_seq_bwd 1.00 -> 1.09 ms per step at cfg 2,
+// the atomics + the word memset + the split of 16 short slabs per workgroup cost more than the MFMAs they replace;
+// profiles/r04_e_recurrences.md.)
+template <int KS>
 __global__ __launch_bounds__(256) void gpe_rnn_wave_splitk_kernel(WvBwdParams p)
 {
     extern __shared__ __align__(16) float smem[];
@@ -592,7 +590,6 @@ __global__ __launch_bounds__(256) void gpe_rnn_wave_splitk_kernel(WvBwdParams p)
 #pragma unroll
     for (int n = 0; n < NT; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const bool split = rv <= 32;
-    float h3_inv = 1.f;
     // this workgroup's slabs ks = (z * jslabs + i) * KS, i < jslabs, while ks < K: the next slab's loads stay in flight
     // under the current slab's MFMAs (same pipeline as the forward)
     {
@@ -602,35 +599,25 @@ __global__ __launch_bounds__(256) void gpe_rnn_wave_splitk_kernel(WvBwdParams p)
         WvRegs<NT, KS> R;
         auto job_fetch = [&](int i) {
             const int ks = ks0 + i * KS;
-            if constexpr (H3) wv_fetch<NT, KS, true>(R, c.a[seg], c.as[seg], c.w[seg], p.K, p.Kpad_n, row0, rv, n0, ks);
-            else wv_fetch<NT, KS>(R, c.a[seg] + ks, c.as[seg], c.w[seg] + (long)(ks >> 4) * 4 * p.Kpad_n * 4, p.K - ks, p.Kpad_n, row0,
-                                  rv, n0, 0);
+            wv_fetch<NT, KS>(R, c.a[seg] + ks, c.as[seg], c.w[seg] + (long)(ks >> 4) * 4 * p.Kpad_n * 4, p.K - ks, p.Kpad_n, row0, rv,
+                             n0, 0);
         };
-        float sA = 1.f;
-        if constexpr (H3) {
-            float invA, sW, invW;
-            gpe_h3_scale_of(c.sa[seg][0], sA, invA);
-            gpe_h3_scale_of(c.sw[seg][0], sW, invW);
-            h3_inv = invA * invW;
-        }
         job_fetch(0);
         for (int i = 0; i < njobs; ++i) {
             const int ks = ks0 + i * KS;
             const int kslab = (p.K - ks < KS) ? (p.K - ks) : KS;
             __syncthreads();
-            if constexpr (H3) wv_commit<NT, KS, true>(R, p.K, p.Kpad_n, rv, n0, ks, As, Ws, lda);
-            else wv_commit<NT, KS>(R, p.K - ks, p.Kpad_n, rv, n0, 0, As, Ws, lda);
+            wv_commit<NT, KS>(R, p.K - ks, p.Kpad_n, rv, n0, 0, As, Ws, lda);
             __syncthreads();
             job_fetch(i + 1 < njobs ? i + 1 : i);
-            if constexpr (H3) wv_mma_h3<NT>(As, Ws, lda, (kslab + 31) & ~31, sA, acc, split);
-            else wv_mma<NT>(As, Ws, lda, (kslab + 15) & ~15, acc, split);
+            wv_mma<NT>(As, Ws, lda, (kslab + 15) & ~15, acc, split);
         }
     }
     __syncthreads();
 #pragma unroll
     for (int n = 0; n < NT; ++n)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) Cs[(16 * wave + 4 * g + r) * ldc + 16 * n + j] = H3 ? acc[n][r] * h3_inv : acc[n][r];
+        for (int r = 0; r < 4; ++r) Cs[(16 * wave + 4 * g + r) * ldc + 16 * n + j] = acc[n][r];
     __syncthreads();
     const int ncols = (p.H - n0 < 16 * NT) ? (p.H - n0) : 16 * NT;
     const int cq = lane << 2;
@@ -650,34 +637,12 @@ __global__ __launch_bounds__(256) void gpe_rnn_wave_splitk_kernel(WvBwdParams p)
     }
 }
 
-// largest magnitude of four values -> block maximum -> one atomicMax into the cell's amax word (H3 only: c.amax_out != NULL)
-__device__ __forceinline__ void wv_amax_out(unsigned* word, float a, float b, float c_, float d)
-{
-    __shared__ unsigned red[4];
-    unsigned m = __float_as_uint(fmaxf(fmaxf(fabsf(a), fabsf(b)), fmaxf(fabsf(c_), fabsf(d))));
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const unsigned t = (unsigned)__shfl_xor((int)m, o);
-        m = m > t ? m : t;
-    }
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const unsigned x = red[0] > red[1] ? red[0] : red[1], y = red[2] > red[3] ? red[2] : red[3];
-        const unsigned r = x > y ? x : y;
-        if (r) atomicMax(word, r);
-    }
-}
-
 template <int G>
-__global__ __launch_bounds__(256) void gpe_rnn_wave_cell_bwd_kernel(WvBwdParams p)
+__global__ void gpe_rnn_wave_cell_bwd_kernel(WvBwdParams p)
 {
     const WvBwdCell& c = p.cell[blockIdx.y];
     const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= (long)p.Bn * p.H) {
-        if (c.amax_out) wv_amax_out(c.amax_out, 0.f, 0.f, 0.f, 0.f);      // every thread of the block reaches the barrier
-        return;
-    }
+    if (e >= (long)p.Bn * p.H) return;
     const int H = p.H;
     const long b = e / H;
     const int u = (int)(e - b * H);
@@ -693,11 +658,11 @@ __global__ __launch_bounds__(256) void gpe_rnn_wave_cell_bwd_kernel(WvBwdParams 
         const float tc = tanhf(c.c[e]);
         float dc = dh * og * (1.f - tc * tc);
         if (c.carry_in) dc += c.carry_in[e];
-        const float g0 = dc * gg * ig * (1.f - ig), g1 = dc * c.c_prev[e] * fg * (1.f - fg);
-        const float g2 = dc * ig * (1.f - gg * gg), g3 = dh * tc * og * (1.f - og);
-        gx[u] = g0; gx[H + u] = g1; gx[2 * H + u] = g2; gx[3 * H + u] = g3;
+        gx[u] = dc * gg * ig * (1.f - ig);
+        gx[H + u] = dc * c.c_prev[e] * fg * (1.f - fg);
+        gx[2 * H + u] = dc * ig * (1.f - gg * gg);
+        gx[3 * H + u] = dh * tc * og * (1.f - og);
         c.carry_out[e] = dc * fg;
-        if (c.amax_out) wv_amax_out(c.amax_out, g0, g1, g2, g3);
     } else {
         if (c.carry_in) dh += c.carry_in[e];
         const float rg = sv[u], zg = sv[H + u], ng = sv[2 * H + u], hn = sv[3 * H + u];
@@ -709,7 +674,6 @@ __global__ __launch_bounds__(256) void gpe_rnn_wave_cell_bwd_kernel(WvBwdParams 
         gx[u] = dr_pre; gx[H + u] = dz_pre; gx[2 * H + u] = dn_pre;
         gh[u] = dr_pre; gh[H + u] = dz_pre; gh[2 * H + u] = dn_pre * rg;
         c.carry_out[e] = dh * zg;
-        if (c.amax_out) wv_amax_out(c.amax_out, dr_pre, dz_pre, dn_pre, 0.f);   // bounds the recurrent-side copy as well (0 < r < 1)
     }
 }
 
