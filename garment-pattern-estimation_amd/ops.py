@@ -47,17 +47,36 @@ def round_up(a, b):
     return (a + b - 1) // b * b
 
 
+_WS = {}                   # (device index, stream handle) -> uint8 tensor: the scratch of that stream's C-ABI calls
+
+
 def _workspace(nbytes, device):
-    """caller-owned scratch of a C-ABI call (include/gpe_hip.h: `ws`); torch's caching allocator recycles it stream-ordered"""
-    return torch.empty(max(int(nbytes), 16), device=device, dtype=torch.uint8)
+    """caller-owned scratch of a C-ABI call (include/gpe_hip.h: `ws`).  One grow-only buffer per (device, stream): launches of one
+    stream are ordered, so consecutive calls may share it, and two streams never do (the library's only rule for workspaces).
+    Re-allocation goes through torch's caching allocator, which keeps the old block alive until the stream has passed it."""
+    dev = torch.device(device)
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    key = (idx, torch.cuda.current_stream(idx).cuda_stream)
+    buf = _WS.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 1 << 20), device=torch.device('cuda', idx), dtype=torch.uint8)
+        _WS[key] = buf
+    return buf
+
+
+_EDGE_WS_BYTES = {}
 
 
 def edge_workspace(B, N, k, ldmax, device):
     """-> (ws, bytes) for gpe_edge_mlp_fwd / _bwd / gpe_edge_redgemm / gpe_edge_pq_amax calls on B clouds of N points, k
     neighbours, per-point output pitches <= ldmax floats."""
-    n = L.query('gpe_edge_ws_bytes', B, N, k, ldmax)
-    if n < 0:
-        raise RuntimeError('gpe_edge_ws_bytes failed with code %d' % n)
+    key = (B, N, k, ldmax)
+    n = _EDGE_WS_BYTES.get(key)
+    if n is None:
+        n = L.query('gpe_edge_ws_bytes', B, N, k, ldmax)
+        if n < 0:
+            raise RuntimeError('gpe_edge_ws_bytes failed with code %d' % n)
+        _EDGE_WS_BYTES[key] = n
     return _workspace(n, device), n
 
 
