@@ -161,8 +161,8 @@ _TRAFFIC_KERNELS = {
     'gpe_edge_mlp_fwd:dense': r'gpe_edgegemm(_sr)?_kernel<\d+, \d+, \d+, 0, 1(, [-\w]+)+>$|gpe_edgegemm_split_kernel<\w+, \d+, \d+, \d+, 0, 1(, [-\w]+)+>$',
     'gpe_edge_mlp_bwd:inplace': r'gpe_edgegemm(_sr)?_kernel<\d+, \d+, \d+, 0, 2(, [-\w]+)+>$|gpe_edgegemm_split_kernel<\w+, \d+, \d+, \d+, 0, 2(, [-\w]+)+>$',
     'gpe_edge_mlp_bwd:gather': r'gpe_edgegemm(_sr)?_kernel<\d+, \d+, \d+, 0, 3(, [-\w]+)+>$|gpe_edgegemm_split_kernel<\w+, \d+, \d+, \d+, 0, 3(, [-\w]+)+>$',
-    'gpe_edge_redgemm:gather': r'gpe_redgemm_(pc|b3)_kernel<\d+, \d+, 0(, \w+)?>$',
-    'gpe_edge_redgemm:dense': r'gpe_redgemm_(pc|b3)_kernel<\d+, \d+, 1(, \w+)?>$',
+    'gpe_edge_redgemm:gather': r'gpe_redgemm_(pc|b3)_kernel<\d+, \d+, 0(, \w+)*>$',
+    'gpe_edge_redgemm:dense': r'gpe_redgemm_(pc|b3)_kernel<\d+, \d+, 1(, \w+)*>$',
     'gpe_edge_gather_stats': r'gpe_gather_stats_kernel',
     'gpe_edge_dz3': r'gpe_dz3_kernel',
     'gpe_knn:filter': r'gpe_knn_mfma_kernel|gpe_knn_h3_kernel|gpe_knn_planes_kernel|gpe_knn_rerank_kernel|gpe_knn_norms_kernel|gpe_knn_cmax_kernel',

@@ -188,9 +188,13 @@ __device__ __forceinline__ int x6_scr(int row, int w, int b)
 //   2  ROTATED slabs: wave w walks the K slabs in the order w, w + 1, .. (mod KS), so that ITS left-over slabs are iterations 0
 //      and 4 of every wave — compile-time positions, no branch, no second read.  The resident weights are loaded in that order;
 //      a wave's accumulation order over K differs from its neighbours' (fixed per wave: still bit-reproducible).
-template <class SP, int AQ, int BQ, int KCH, int AMODE, int EMODE, bool K16, bool PSEUDO = false, int AGGT = -1, int LEFT = 0>
+// LAZY (k = 16 in-place backward only): the dense A operand is the stored activation of the aggregated block and dz3 is formed
+// from it in commit_row (RgParams::lz_*): 28 VALU per row quad instead of a separate 1.3 GB pass.
+template <class SP, int AQ, int BQ, int KCH, int AMODE, int EMODE, bool K16, bool PSEUDO = false, int AGGT = -1, int LEFT = 0,
+          bool LAZY = false>
 __global__ __launch_bounds__(256, 1) void gpe_edgegemm_split_kernel(RgParams p, int stats_nblk)
 {
+    static_assert(!LAZY || (K16 && AMODE == A_DENSE && EMODE == E_BWD_INPLACE && !PSEUDO), "lazy dz3: k = 16 in-place backward");
     constexpr bool TRACK = (EMODE == E_EDGE_FWD) && AGGT != 0;
     constexpr int NT = 4 * AQ + BQ;
     constexpr int KS = (KCH + 1) / 2;
@@ -323,6 +327,20 @@ __global__ __launch_bounds__(256, 1) void gpe_edgegemm_split_kernel(RgParams p, 
     long e_row0 = 0, e_pt0 = 0; int e_rv = 0;            // tile being finished
 
     float4 v[RBH];                                       // rows staged for the next tile (one batch)
+    // LAZY: coefficients of the BatchNorm behind the aggregation for this lane's K columns, and — per staged tile — the point's
+    // s * g quad and winning slots
+    float lzs[4] = {0.f, 0.f, 0.f, 0.f}, lzc1[4] = {0.f, 0.f, 0.f, 0.f}, lzk2[4] = {0.f, 0.f, 0.f, 0.f}, lzmu[4] = {0.f, 0.f, 0.f, 0.f};
+    float4 lz_gq = make_float4(0.f, 0.f, 0.f, 0.f);
+    uchar4 lz_sx = make_uchar4(0, 0, 0, 0), lz_sn = make_uchar4(0, 0, 0, 0);
+    if constexpr (LAZY) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            if (c + t < p.K) {
+                lzs[t] = p.lz_coef[c + t]; lzc1[t] = p.lz_coef[p.K + c + t];
+                lzk2[t] = p.lz_coef[2 * p.K + c + t]; lzmu[t] = p.lz_coef[3 * p.K + c + t];
+            }
+        }
+    }
     float4 pvs0, pvs1, pvs2, pvs3;                       // P rows of the points being staged (gather)
     pvs0 = pvs1 = pvs2 = pvs3 = make_float4(0.f, 0.f, 0.f, 0.f);
     float4 act[(EMODE != E_EDGE_FWD) ? X6_PB : 1];       // stored activations of the tile being finished (backward)
@@ -411,6 +429,14 @@ __global__ __launch_bounds__(256, 1) void gpe_edgegemm_split_kernel(RgParams p, 
                 v[uu] = ld4(p.a.base + (row0 + r) * p.a.stride_outer + ck);
             }
         }
+        if constexpr (LAZY) {
+            // the point of this wave's 16 rows (k = 16: one point per wave and tile), clamped into the last valid point
+            const long pt0 = (long)tile * PT + wave * npw, ptl = (long)tile * PT + ((last * rkl) >> 16);
+            const long pt = pt0 < ptl ? pt0 : ptl;
+            lz_gq = ld4(p.lz_g + pt * p.lz_ldg + ck);
+            lz_sx = *reinterpret_cast<const uchar4*>(p.lz_amx + pt * p.lz_ldagg + ck);
+            lz_sn = *reinterpret_cast<const uchar4*>(p.lz_amn + pt * p.lz_ldagg + ck);
+        }
         if (AMODE == A_GATHER) {
             const int pt0 = tile * PT + wave * npw + vz, ptl = tile * PT + ((last * rkl) >> 16);
             pvs0 = ld4(p.pq + x6_prow<PSEUDO>((pt0 + 0 < ptl) ? pt0 + 0 : ptl, p.pmagic) * p.ldpq + ck);
@@ -428,6 +454,20 @@ __global__ __launch_bounds__(256, 1) void gpe_edgegemm_split_kernel(RgParams p, 
             const float4 pv = K16 ? pvs0 : x6_sel4(pvs0, pvs1, pvs2, pvs3, (u * rkl) >> 16);
             o.x = fmaxf(o.x + pv.x, 0.f); o.y = fmaxf(o.y + pv.y, 0.f);
             o.z = fmaxf(o.z + pv.z, 0.f); o.w = fmaxf(o.w + pv.w, 0.f);
+        }
+        if constexpr (LAZY) {
+            // dz3 of slot u of the wave's point (gpe_dz3_kernel's arithmetic): the message that won the aggregation carries s * g
+            const float av[4] = {o.x, o.y, o.z, o.w};
+            const float gq[4] = {lz_gq.x, lz_gq.y, lz_gq.z, lz_gq.w};
+            const int sx[4] = {lz_sx.x, lz_sx.y, lz_sx.z, lz_sx.w}, sn[4] = {lz_sn.x, lz_sn.y, lz_sn.z, lz_sn.w};
+            float dz[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int sel = (lzs[t] >= 0.f) ? sx[t] : sn[t];
+                const float hit = (sel == u) ? lzs[t] * gq[t] : 0.f;
+                dz[t] = (av[t] > 0.f) ? hit - lzc1[t] - (av[t] - lzmu[t]) * lzk2[t] : 0.f;
+            }
+            o = make_float4(dz[0], dz[1], dz[2], dz[3]);
         }
         if (r >= s_rv) o = make_float4(0.f, 0.f, 0.f, 0.f);      // rows past the end of a partial last tile
         if constexpr (PLANES) {
@@ -811,7 +851,8 @@ static int x6_left_scheme(int amode, int emode)
     return tab[kind];
 }
 
-template <class SP, int AQ, int BQ, int KCH, int AMODE, int EMODE, bool K16, bool PSEUDO = false, int AGGT = -1, int LEFT = 0>
+template <class SP, int AQ, int BQ, int KCH, int AMODE, int EMODE, bool K16, bool PSEUDO = false, int AGGT = -1, int LEFT = 0,
+          bool LAZY = false>
 static int x6_launch_k(const RgParams& p, int stats_nblk, hipStream_t s)
 {
     constexpr int NT = 4 * AQ + BQ;
@@ -819,11 +860,11 @@ static int x6_launch_k(const RgParams& p, int stats_nblk, hipStream_t s)
     constexpr int AWORDS = SP::SCALED ? (2 * RG_BM * 16 * x6_pchunks(KCH)) / 4 : RG_BM * LDA;
     const size_t lds = (size_t)(2 * AWORDS + RG_BM * LDC) * sizeof(float);
     // 16 bytes of static __shared__ (amax_sh) sit beside the dynamic image
-    GPE_ENSURE_MAX_LDS_N((gpe_edgegemm_split_kernel<SP, AQ, BQ, KCH, AMODE, EMODE, K16, PSEUDO, AGGT, LEFT>), 160 * 1024 - 64);
+    GPE_ENSURE_MAX_LDS_N((gpe_edgegemm_split_kernel<SP, AQ, BQ, KCH, AMODE, EMODE, K16, PSEUDO, AGGT, LEFT, LAZY>), 160 * 1024 - 64);
     int gx = gpe_num_cus();
     if (gx > p.num_tiles) gx = p.num_tiles;
     if (stats_nblk > 0 && gx > stats_nblk) gx = stats_nblk;
-    hipLaunchKernelGGL((gpe_edgegemm_split_kernel<SP, AQ, BQ, KCH, AMODE, EMODE, K16, PSEUDO, AGGT, LEFT>), dim3(gx), dim3(256), lds, s, p, stats_nblk);
+    hipLaunchKernelGGL((gpe_edgegemm_split_kernel<SP, AQ, BQ, KCH, AMODE, EMODE, K16, PSEUDO, AGGT, LEFT, LAZY>), dim3(gx), dim3(256), lds, s, p, stats_nblk);
     GPE_CHECK_LAUNCH();
     return GPE_OK;
 }
@@ -849,6 +890,11 @@ static int x6_launch(const RgParams& p, int stats_nblk, hipStream_t s)
                 if (left == 2) return x6_launch_k<SP, AQ, BQ, KCH, AMODE, EMODE, true, false, 0, 2>(p, stats_nblk, s);
                 return x6_launch_k<SP, AQ, BQ, KCH, AMODE, EMODE, true, false, 0, 0>(p, stats_nblk, s);
             } else {
+                if constexpr (EMODE == E_BWD_INPLACE && AMODE == A_DENSE) {
+                    // lazy dz3: always the rotated-slab instance (the in-loop scheme spills 33 registers to scratch with the extra
+                    // per-lane coefficient quads; the rotated one does not)
+                    if (p.lz_g) return x6_launch_k<SP, AQ, BQ, KCH, AMODE, EMODE, true, false, -1, 2, true>(p, stats_nblk, s);
+                }
                 if (left == 2) return x6_launch_k<SP, AQ, BQ, KCH, AMODE, EMODE, true, false, -1, 2>(p, stats_nblk, s);
                 return x6_launch_k<SP, AQ, BQ, KCH, AMODE, EMODE, true, false, -1, 0>(p, stats_nblk, s);
             }

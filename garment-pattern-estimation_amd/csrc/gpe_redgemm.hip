@@ -43,6 +43,11 @@ struct RdParams {
     // f16x3 variant of the b3 kernel: bit patterns of the largest magnitudes of U and of V - shift (device memory)
     const unsigned* amax_u;
     const unsigned* amax_v;
+    // LAZY dz3 (f16x3, k = 16, dense V): U is the stored activation a3 of the aggregated block and the producers form dz3 from it
+    // (gpe_edge_dz3's arithmetic; RgParams::lz_* of the edge kernels has the same fields).  NULL = off.
+    const float* lz_g; int lz_ldg;
+    const uint8_t* lz_amx; const uint8_t* lz_amn; int lz_ldagg;
+    const float* lz_coef;                        // [4][Mg] = {s, c1, k2, mean}
 };
 
 __device__ __forceinline__ float4 rd_ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
@@ -592,9 +597,10 @@ template <int CT> struct RdB3Layout {                 // CT = number of 16-colum
     }
 };
 
-template <int MT, int NT, int VMODE, bool F16 = false>
+template <int MT, int NT, int VMODE, bool F16 = false, bool LAZY = false>
 __global__ __launch_bounds__(512, 2) void gpe_redgemm_b3_kernel(RdParams p)
 {
+    static_assert(!LAZY || (F16 && VMODE == V_DENSE), "lazy dz3: f16x3 reduce-GEMM with a dense V");
     float sU = 1.f, sV = 1.f, invU = 1.f, invV = 1.f;
     if constexpr (F16) {
         gpe_h3_scale_of(p.amax_u[0], sU, invU);
@@ -696,6 +702,20 @@ __global__ __launch_bounds__(512, 2) void gpe_redgemm_b3_kernel(RdParams p)
         for (int s_ = 0; s_ < (PMAX > 0 ? PMAX : 1); ++s_) accP[s_] = (f32x4){0.f, 0.f, 0.f, 0.f};
         double csd[4] = {0, 0, 0, 0};
         float4 ur[RQ], vr[RQ], vr2[VMODE == V_GATHER ? RQ : 1];
+        // LAZY: this lane's coefficient quads, and per fetched tile the s * g quad + winning slots of the wave's point (k = 16 and
+        // 32-row tiles aligned to points: a wave's 8 consecutive rows are slots 8 (w4 & 1) .. + 7 of ONE point)
+        float lzs[4] = {0.f, 0.f, 0.f, 0.f}, lzc1[4] = {0.f, 0.f, 0.f, 0.f}, lzk2[4] = {0.f, 0.f, 0.f, 0.f}, lzmu[4] = {0.f, 0.f, 0.f, 0.f};
+        float4 lz_gq = make_float4(0.f, 0.f, 0.f, 0.f);
+        uchar4 lz_sx = make_uchar4(0, 0, 0, 0), lz_sn = make_uchar4(0, 0, 0, 0);
+        if constexpr (LAZY) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                if (cq + t < p.Mg) {
+                    lzs[t] = p.lz_coef[cq + t]; lzc1[t] = p.lz_coef[p.Mg + cq + t];
+                    lzk2[t] = p.lz_coef[2 * p.Mg + cq + t]; lzmu[t] = p.lz_coef[3 * p.Mg + cq + t];
+                }
+            }
+        }
 
         int jgv = 0;                                // V_GATHER: lane q <-> neighbour row of this wave's q-th row
         // The producers' instruction diet of gpe_redgemm_pc_kernel, applied here in round 4: a partial last tile
@@ -715,6 +735,12 @@ __global__ __launch_bounds__(512, 2) void gpe_redgemm_b3_kernel(RdParams p)
             const long rb = tile_row0(tile) + RQ * w4;                      // 8 CONSECUTIVE rows per wave
             const float* up = p.u.base + rb * p.u.stride_outer + cu;
             const float* vp = p.v.base + rb * p.v.stride_outer + cv;
+            if constexpr (LAZY) {
+                const long pt = rb >> 4;                                    // k = 16 (host-checked); wave-uniform
+                lz_gq = rd_ld4(p.lz_g + pt * p.lz_ldg + cu);
+                lz_sx = *reinterpret_cast<const uchar4*>(p.lz_amx + pt * p.lz_ldagg + cu);
+                lz_sn = *reinterpret_cast<const uchar4*>(p.lz_amn + pt * p.lz_ldagg + cu);
+            }
 #pragma unroll
             for (int q = 0; q < RQ; ++q) {
                 ur[q] = rd_ld4(up + q * p.u.stride_outer);
@@ -733,6 +759,27 @@ __global__ __launch_bounds__(512, 2) void gpe_redgemm_b3_kernel(RdParams p)
             const long row0 = (long)tile * RD_RT;
             const int rv = (int)((p.rows - row0 < RD_RT) ? (p.rows - row0) : RD_RT);
             float c32[4] = {0.f, 0.f, 0.f, 0.f};
+            if constexpr (LAZY) {
+                // U row = dz3 of slot 8 (w4 & 1) + q of the wave's point, formed from the stored activation (gpe_dz3_kernel's arithmetic)
+                const float gq[4] = {lz_gq.x, lz_gq.y, lz_gq.z, lz_gq.w};
+                const int sx[4] = {lz_sx.x, lz_sx.y, lz_sx.z, lz_sx.w}, sn[4] = {lz_sn.x, lz_sn.y, lz_sn.z, lz_sn.w};
+                float sg[4];
+                int sel[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) { sel[t] = (lzs[t] >= 0.f) ? sx[t] : sn[t]; sg[t] = lzs[t] * gq[t]; }
+                const int slot0 = (w4 & 1) * RQ;
+#pragma unroll
+                for (int q = 0; q < RQ; ++q) {
+                    const float av[4] = {ur[q].x, ur[q].y, ur[q].z, ur[q].w};
+                    float dz[4];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const float hit = (sel[t] == slot0 + q) ? sg[t] : 0.f;
+                        dz[t] = (av[t] > 0.f) ? hit - lzc1[t] - (av[t] - lzmu[t]) * lzk2[t] : 0.f;
+                    }
+                    ur[q] = make_float4(dz[0], dz[1], dz[2], dz[3]);
+                }
+            }
             if (rv != RD_RT) {
                 // partial last tile (see fetch: it holds the operands' last 32 rows): rows of the previous tile and pad columns -> 0
 #pragma unroll
@@ -1258,12 +1305,12 @@ static int rd_pc_launch(const RdParams& p, int gx, hipStream_t s)
     return GPE_OK;
 }
 
-template <int MT, int NT, int VMODE, bool F16 = false>
+template <int MT, int NT, int VMODE, bool F16 = false, bool LAZY = false>
 static int rd_b3_launch(const RdParams& p, int gx, hipStream_t s)
 {
     const size_t lds = (size_t)2 * (RdB3Layout<MT>::BYTES + RdB3Layout<NT>::BYTES);
-    GPE_ENSURE_MAX_LDS((gpe_redgemm_b3_kernel<MT, NT, VMODE, F16>));
-    hipLaunchKernelGGL((gpe_redgemm_b3_kernel<MT, NT, VMODE, F16>), dim3(gx), dim3(512), lds, s, p);
+    GPE_ENSURE_MAX_LDS((gpe_redgemm_b3_kernel<MT, NT, VMODE, F16, LAZY>));
+    hipLaunchKernelGGL((gpe_redgemm_b3_kernel<MT, NT, VMODE, F16, LAZY>), dim3(gx), dim3(512), lds, s, p);
     GPE_CHECK_LAUNCH();
     return GPE_OK;
 }
@@ -1360,7 +1407,11 @@ static int rd_run(RdParams& p, int vmode, float* G, int ldG, float* colsum, floa
         if (rows_per_cloud % RD_RT == 0 && gx % GPE_NXCD == 0 && rows_per_cloud / RD_RT >= gx / GPE_NXCD)
             p.pin_tpc = (int)(rows_per_cloud / RD_RT);
     }
-    if (pc_ok && g_rd_math == 2 && p.amax_u && p.amax_v) {
+    if (p.lz_g) {
+        // lazy dz3: only the f16x3 dense-V kernel forms U on the fly; the caller asked gpe_edge_lazy_dz3_ok first
+        if (!(pc_ok && g_rd_math == 2 && p.amax_u && p.amax_v && vmode == V_DENSE && p.k == 16 && (p.rows & 15) == 0)) return GPE_EINVAL;
+        rc = (mt_all == 13) ? rd_b3_launch<13, 13, V_DENSE, true, true>(p, gx, s) : rd_b3_launch<10, 13, V_DENSE, true, true>(p, gx, s);
+    } else if (pc_ok && g_rd_math == 2 && p.amax_u && p.amax_v) {
         if (mt_all == 13 && vmode == V_DENSE) rc = rd_b3_launch<13, 13, V_DENSE, true>(p, gx, s);
         else if (mt_all == 13) rc = rd_b3_launch<13, 13, V_GATHER, true>(p, gx, s);
         else if (vmode == V_DENSE) rc = rd_b3_launch<10, 13, V_DENSE, true>(p, gx, s);
@@ -1402,7 +1453,8 @@ extern "C" int gpe_redgemm(const float* u, long u_so, long u_si, int u_inner, co
 extern "C" int gpe_edge_redgemm(const float* u, int ldu, int v_mode, const float* v, int ldv, const float* pq,
                                 int ldpq, const int32_t* jg, const float* v_shift, int B, int N, int k, int Mg,
                                 int Ng, float* G, int ldG, float* colsum, float* part, const uint32_t* amax_u,
-                                const uint32_t* amax_v, void* ws, long ws_bytes, void* stream)
+                                const uint32_t* amax_v, void* ws, long ws_bytes, const float* lz_g, int lz_ldg,
+                                const uint8_t* lz_amx, const uint8_t* lz_amn, int lz_ldagg, const float* lz_coef, void* stream)
 {
     if (!u || !G || !part || B <= 0 || N <= 0 || k <= 0 || Mg <= 0 || Ng <= 0 || Ng > 256 || ldG < Ng || ldu < Mg)
         return GPE_EINVAL;
@@ -1415,6 +1467,12 @@ extern "C" int gpe_edge_redgemm(const float* u, int ldu, int v_mode, const float
     p.v = GpeRows{v, ldv, 0, 0};
     p.pq = pq; p.ldpq = ldpq; p.H = Ng; p.jg = jg; p.k = k; p.rcp_k = 1.0 / k; p.kmagic = (unsigned)(((1ull << 32) + k - 1) / k); p.v_shift = v_shift;
     p.pin_clouds = B;
+    if (lz_g) {
+        if (!lz_amx || !lz_amn || !lz_coef || (lz_ldg & 3) || lz_ldg < ((Mg + 3) & ~3) || (lz_ldagg & 3) || lz_ldagg < ((Mg + 3) & ~3) ||
+            (((uintptr_t)lz_g) & 15) || k != 16 || v_mode != 1 || !amax_u || !amax_v)
+            return GPE_EINVAL;
+        p.lz_g = lz_g; p.lz_ldg = lz_ldg; p.lz_amx = lz_amx; p.lz_amn = lz_amn; p.lz_ldagg = lz_ldagg; p.lz_coef = lz_coef;
+    }
     if (g_rd_math == 2 && amax_u && p.rows >= gpe_h3_min_rows()) {
         // f16x3: the operand scales must be known without a pass over an E-row tensor — U (a dz tensor) through the caller's amax
         // word of it, V through the caller's word (dense: the amax the forward kernel measured; gathered: a bound of

@@ -46,6 +46,13 @@ struct RgParams {
     const unsigned* h3_amax_a;
     const unsigned* h3_amax_w;
     unsigned* amax_out;
+    // LAZY dz3 (f16x3, k = 16, in-place backward of the block under the aggregation): the A operand is the stored activation a3
+    // and the kernel forms dz3 = (a3 > 0) ? [slot == argsel] * s * g - c1 - (a3 - mean) * k2 : 0 while staging it — gpe_edge_dz3's
+    // arithmetic without its 1.3 GB round trip.  lz_g [B*N][lz_ldg] the layer-output gradient, lz_amx / lz_amn [B*N][lz_ldagg] the
+    // slots saved by the forward, lz_coef [4][K] = {s, c1, k2, mean} of the BatchNorm behind the aggregation.  NULL = off.
+    const float* lz_g; int lz_ldg;
+    const uint8_t* lz_amx; const uint8_t* lz_amn; int lz_ldagg;
+    const float* lz_coef;
     // host side only: what the CALLER passed (include/gpe_hip.h: amax_a / amax_out / ws of the edge entry points)
     const unsigned* user_amax_a;    // amax word of the A operand (gather: of relu(P_i + Q_j)); NULL = measure in-call
     unsigned* user_amax_out;        // receives the largest magnitude written to `out`; NULL = not wanted

@@ -213,6 +213,7 @@ size_t gpe_edge_pseudo_bytes(long npts, int k, int Cmax);   // gpe_edgegemm_sr.h
 static int g_gpe_dbg = 0;
 extern "C" int gpe_debug_set(int flags) { g_gpe_dbg = flags; return 0; }
 static int g_gpe_math = 0;
+extern "C" int gpe_edge_lazy_dz3_ok(int B, int N, int k, int F, int Cprev);
 extern "C" int gpe_math_get(void) { return g_gpe_math; }
 extern "C" int gpe_math_set(int mode)
 {
@@ -368,6 +369,77 @@ extern "C" int gpe_linear(const float* a, long a_so, long a_si, int a_inner, con
     return rg_dispatch_nt<A_DENSE, E_LINEAR>(NT, p, grid, (hipStream_t)stream);
 }
 
+// ---- lazy dz3 (round 4): the 1.3 GB in-place pass of gpe_edge_dz3 folded into its two consumers -----------------------------------
+// 1 when gpe_edge_mlp_bwd (act_mode 0) and gpe_edge_redgemm (v_mode 1) can form dz3 from the stored activation themselves for a
+// block F -> Cprev of B clouds x N points x k: f16x3 arithmetic, k = 16, both widths on the two-plane kernels' menu, above the
+// size gate.  Host only.
+extern "C" int gpe_edge_lazy_dz3_ok(int B, int N, int k, int F, int Cprev)
+{
+    static const int dbg_off = getenv("GPE_LAZY_DZ3") ? atoi(getenv("GPE_LAZY_DZ3")) == 0 : 0;   // A/B measurements
+    if (dbg_off || (g_gpe_dbg & 512) || g_gpe_math != 4 || k != 16 || B <= 0 || N <= 0) return 0;    // gpe_debug_set(512): eager dz3
+    if (F <= 96 || F > 208 || Cprev <= 96 || Cprev > 208 || (Cprev & 3)) return 0;
+    if (gpe_cdiv(Cprev, 16) != 13 || (gpe_cdiv(F, 16) != 10 && gpe_cdiv(F, 16) != 13)) return 0;   // the fp16 reduce-GEMM's instantiated shapes
+    const long rows = (long)B * N * k;
+    return rows >= gpe_h3_min_rows() && rows < (1L << 31) && rows / 32 >= 4L * 2 * gpe_num_cus();
+}
+
+// bound of |dz3| for its f16x3 scale: max_i,c |s_c g_ic| + max_c (|c1_c| + (amax(a3) + |mean_c|) |k2_c|), rounded up
+__global__ __launch_bounds__(256) void gpe_dz3_bound_kernel(const float* __restrict__ g, int ldg, const float* __restrict__ coef, int F,
+                                                            long rows, const unsigned* __restrict__ amax_a3, unsigned* __restrict__ out)
+{
+    __shared__ float red[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float m = 0.f;
+    const int fq = (F + 3) >> 2;
+    const long total = rows * fq;
+    for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long)gridDim.x * 256) {
+        const long r = t / fq;
+        const int c = (int)(t - r * fq) << 2;
+        const float4 v = *reinterpret_cast<const float4*>(g + r * ldg + c);
+        const float gv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (c + u < F) m = fmaxf(m, fabsf(coef[c + u] * gv[u]));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if (lane == 0) red[wave] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        float tail = 0.f;
+        if (blockIdx.x == 0) {                                      // the coefficient terms once
+            const float a3 = __uint_as_float(amax_a3[0]);
+            for (int c = 0; c < F; ++c) tail = fmaxf(tail, fabsf(coef[F + c]) + (a3 + fabsf(coef[3 * F + c])) * fabsf(coef[2 * F + c]));
+        }
+        // out[0] accumulates max |s g| over the blocks, out[1] = the coefficient terms; gpe_dz3_bound_finish adds the two
+        atomicMax(out, __float_as_uint(m));
+        if (blockIdx.x == 0) out[1] = __float_as_uint(tail);
+    }
+}
+__global__ void gpe_dz3_bound_finish(unsigned* out)
+{
+    const float b = (__uint_as_float(out[0]) + __uint_as_float(out[1])) * 1.000001f;
+    out[0] = __float_as_uint(b) & 0x7fffffffu;
+}
+// amax [2] uint32 (the bound lands in amax[0]; amax[1] is scratch); g rows 16-B aligned with ldg % 4 == 0
+extern "C" int gpe_edge_dz3_bound(const float* g, int ldg, const float* coef, int F, long rows, const uint32_t* amax_a3,
+                                  uint32_t* amax, void* stream)
+{
+    if (!g || !coef || !amax_a3 || !amax || F <= 0 || rows <= 0 || (ldg & 3) || ldg < ((F + 3) & ~3) || (((uintptr_t)g) & 15))
+        return GPE_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(amax, 0, 2 * sizeof(uint32_t), s) != hipSuccess) return GPE_ELAUNCH;
+    long gx = (rows * ((F + 3) >> 2) + 255) / 256;
+    const long cap = (long)gpe_num_cus() * 8;
+    if (gx > cap) gx = cap;
+    hipLaunchKernelGGL(gpe_dz3_bound_kernel, dim3((unsigned)gx), dim3(256), 0, s, g, ldg, coef, F, rows, amax_a3, amax);
+    GPE_CHECK_LAUNCH();
+    hipLaunchKernelGGL(gpe_dz3_bound_finish, dim3(1), dim3(1), 0, s, amax);
+    GPE_CHECK_LAUNCH();
+    return GPE_OK;
+}
+
 extern "C" int gpe_edge_mlp_fwd(int a_mode, const float* pq, int ldpq, const int32_t* jg, const float* a_in,
                                 int lda, int B, int N, int k, int Cin, int Cout, const float* wp,
                                 const float* bias, float* out, int ldo, double* stats_part, int agg, float* mx,
@@ -414,7 +486,8 @@ extern "C" int gpe_edge_mlp_fwd(int a_mode, const float* pq, int ldpq, const int
 extern "C" int gpe_edge_mlp_bwd(const float* a, int lda, int act_mode, const float* pq, int ldpq,
                                 const int32_t* jg, int B, int N, int k, int Cin, int Cout, const float* wp,
                                 const float* coef_out, float* dz_out, int ldo, float* dP, int lddp,
-                                const uint32_t* amax_a, uint32_t* amax_out, void* ws, long ws_bytes, void* stream)
+                                const uint32_t* amax_a, uint32_t* amax_out, void* ws, long ws_bytes, const float* lz_g, int lz_ldg,
+                                const uint8_t* lz_amx, const uint8_t* lz_amn, int lz_ldagg, const float* lz_coef, void* stream)
 {
     if (!a || !wp || !coef_out || !dz_out || B <= 0 || N <= 0 || k <= 0 || k > 64 || Cin <= 0 || Cout <= 0 ||
         (ldo & 3) || ldo < Cout || lda < Cin)
@@ -433,9 +506,18 @@ extern "C" int gpe_edge_mlp_bwd(const float* a, int lda, int act_mode, const flo
     hipStream_t s = (hipStream_t)stream;
     p.dbg = g_gpe_dbg; p.pin_clouds = B;
     p.user_amax_a = amax_a; p.user_amax_out = amax_out; p.ws = gpe_edge_ws(ws, ws_bytes);
+    if (lz_g) {
+        // lazy dz3: `a` is the stored activation of the aggregated block; only the f16x3 k = 16 in-place kernel forms dz3 from it
+        // (the caller asked gpe_edge_lazy_dz3_ok first and passes the bound of |dz3| as amax_a)
+        if (!lz_amx || !lz_amn || !lz_coef || (lz_ldg & 3) || lz_ldg < ((Cin + 3) & ~3) || (lz_ldagg & 3) || lz_ldagg < ((Cin + 3) & ~3) ||
+            (((uintptr_t)lz_g) & 15) || act_mode != 0 || !amax_a || !gpe_edge_lazy_dz3_ok(B, N, k, Cin, Cout) || !p.ws.h3)
+            return GPE_EINVAL;
+        p.lz_g = lz_g; p.lz_ldg = lz_ldg; p.lz_amx = lz_amx; p.lz_amn = lz_amn; p.lz_ldagg = lz_ldagg; p.lz_coef = lz_coef;
+    }
     int tracked = 0;
     p.tracked = &tracked;
     int rc = gpe_edgegemm_try(p, A_DENSE, act_mode == 1 ? E_BWD_GATHER : E_BWD_INPLACE, 0, s);
+    if (lz_g && rc != 1) return rc < 0 ? rc : GPE_EINVAL;          // no eager kernel may read a3 as if it were dz3
     if (rc == 0) {
         dim3 grid(p.num_tiles < 2048 ? p.num_tiles : 2048, ny);
         rc = (act_mode == 1) ? rg_dispatch_nt<A_DENSE, E_BWD_GATHER>(NT, p, grid, s)

@@ -590,7 +590,7 @@ class EdgeConvFn(torch.autograd.Function):
         # caller-owned state of the edge calls: one workspace, and in f16x3 mode the amax words of this layer's tensors —
         # [0] the bound of relu(P_i + Q_j), [l] activation a_l, [nb + l] dz_l (backward)
         ews, ews_n = edge_workspace(B, N, k, max(round_up(widths[-1], 4), 2 * H0), dev)
-        words = f16x3_words(2 * nb, E, dev)
+        words = f16x3_words(2 * nb + 1, E, dev)           # (+ 1: scratch word of gpe_edge_dz3_bound behind dz_{nb-1}'s)
         if words is not None:
             L.call('gpe_edge_pq_amax', PQ, 2 * H0, H0, BN, _word(words, 0), ews, ews_n)
         part = torch.empty(nblk, 2, H0, device=dev, dtype=torch.float64) if training else None
@@ -613,7 +613,7 @@ class EdgeConvFn(torch.autograd.Function):
                 amn = torch.empty(BN, ldo, device=dev, dtype=torch.uint8)
             wp = pack_weight(Ws[l], col_scale=stats[l - 1][2])
             bf = fold_bias(Ws[l], params[4 * l + 1], stats[l - 1][3])
-            w_out = None if last else _word(words, l)      # nobody scales by the last activation: dz overwrites it
+            w_out = _word(words, l)                        # (the last activation's word feeds the bound of a lazily formed dz)
             if l == 1:
                 L.call('gpe_edge_mlp_fwd', 0, PQ, 2 * H0, jg, None, 0, B, N, k, Cin, Cout, wp, bf, a, ldo, part,
                        agg, mx, mn, amx, amn, ldo, _word(words, 0), w_out, ews, ews_n)
@@ -675,12 +675,22 @@ class EdgeConvFn(torch.autograd.Function):
         part = torch.empty(psb, 2, Fo, device=dev, dtype=torch.float64)
         g_last, be_last = params[4 * (nb - 1) + 2], params[4 * (nb - 1) + 3]
         a_last = acts[-1]
+        lz = (None, 0, None, None, 0, None)                # lazy dz3 arguments of the two consumers (off)
         if aggr == 'max':
             mx, mn, amx, amn = tail
             L.call('gpe_edge_bwd_point_sums', g_out, ldg, mx, mn, ldF, stats[-1], BN, Fo, part)
             coef, dg, dbe = bn_bwd_coef(part, psb, stats[-1], Fo, E, g_last, be_last, training)
-            # dz in place over the stored activation (one coalesced pass)
-            L.call('gpe_edge_dz3', a_last, ldF, g_out, ldg, amx, amn, ldF, coef, B, N, k, Fo, _word(words, 2 * nb - 1))
+            if words is not None and nb >= 3 and L.query('gpe_edge_lazy_dz3_ok', B, N, k, Fo, widths[-2]) == 1:
+                # f16x3, k = 16: dz of the aggregated block is never materialised — the weight-gradient reduce-GEMM and the
+                # propagation below form it from the stored activation while staging it (the in-place pass is 1.3 GB at cfg 2).
+                # They need the gradient rows 16-B loadable (pad columns zero) and a bound of |dz| for the fp16 scale.
+                g_pad = torch.zeros(BN, ldF, device=dev, dtype=F32)
+                g_pad[:, :Fo].copy_(g_out)
+                L.call('gpe_edge_dz3_bound', g_pad, ldF, coef, Fo, BN, _word(words, nb - 1), words[2 * nb - 1: 2 * nb + 1])
+                lz = (g_pad, ldF, amx, amn, ldF, coef)
+            else:
+                # dz in place over the stored activation (one coalesced pass)
+                L.call('gpe_edge_dz3', a_last, ldF, g_out, ldg, amx, amn, ldF, coef, B, N, k, Fo, _word(words, 2 * nb - 1))
         else:
             # every message carries dy_e = w * g_i (w = 1/k mean, 1 add): sums over edges = (w*k) * per-point sums at
             # the mean activation of the point
@@ -708,11 +718,12 @@ class EdgeConvFn(torch.autograd.Function):
             w_dz = _word(words, nb + l)                    # dz_l: written by dz3 (l = nb - 1) or by the propagation below
             if l == 1:
                 L.call('gpe_edge_redgemm', dz, dz.stride(0), 0, None, 0, PQ, 2 * H0, jg, stats[0][0], B, N, k, Cl, Cp, G,
-                       Cp, db, ws, w_dz, _word(words, 0), ews, ews_n)
+                       Cp, db, ws, w_dz, _word(words, 0), ews, ews_n, None, 0, None, None, 0, None)
             else:
                 prev = acts[l - 1]
                 L.call('gpe_edge_redgemm', dz, dz.stride(0), 1, prev, prev.stride(0), None, 0, None, stats[l - 1][0],
-                       B, N, k, Cl, Cp, G, Cp, db, ws, w_dz, _word(words, l - 1), ews, ews_n)
+                       B, N, k, Cl, Cp, G, Cp, db, ws, w_dz, _word(words, l - 1), ews, ews_n,
+                       *(lz if l == nb - 1 else (None, 0, None, None, 0, None)))
             sums = torch.empty(1, 2, Cp, device=dev, dtype=torch.float64)
             dW = _gbuf(W)
             L.call('gpe_bn_bwd_from_G', G, Cp, db, W, W.stride(0), Cl, Cp, stats[l - 1], sums, dW, Cp)
@@ -726,12 +737,13 @@ class EdgeConvFn(torch.autograd.Function):
                 # In place over dz_1's buffer when the row pitch fits, else a fresh [E, H0]
                 dst = dz if dz.stride(0) == H0 else torch.empty(E, H0, device=dev, dtype=F32)
                 L.call('gpe_edge_mlp_bwd', dz, dz.stride(0), 1, PQ, 2 * H0, jg, B, N, k, Cl, Cp, wt, coef_p, dst, H0,
-                       dPQ, 2 * H0, w_dz, None, ews, ews_n)
+                       dPQ, 2 * H0, w_dz, None, ews, ews_n, None, 0, None, None, 0, None)
                 dz = dst
             else:
                 prev = acts[l - 1]
                 L.call('gpe_edge_mlp_bwd', dz, dz.stride(0), 0, None, 0, None, B, N, k, Cl, Cp, wt, coef_p, prev,
-                       prev.stride(0), None, 0, w_dz, _word(words, nb + l - 1), ews, ews_n)
+                       prev.stride(0), None, 0, w_dz, _word(words, nb + l - 1), ews, ews_n,
+                       *(lz if l == nb - 1 else (None, 0, None, None, 0, None)))
                 dz = prev
 
         # ---- block 0: gather backward = deterministic pull through the transposed graph -----------------
@@ -1092,7 +1104,8 @@ class DenseMLPFn(torch.autograd.Function):
                 else:
                     ws = torch.empty(L.query('gpe_redgemm_ws', C, Cp), device=dev, dtype=F32)
                     L.call('gpe_edge_redgemm', dz, dz.stride(0), 1, prev, prev.stride(0), None, 0, None, stp[0],
-                           1, M, 1, C, Cp, G, Cp, db, ws, _word(words, n + l), _word(words, l - 1), ews, ews_n)
+                           1, M, 1, C, Cp, G, Cp, db, ws, _word(words, n + l), _word(words, l - 1), ews, ews_n,
+                           None, 0, None, None, 0, None)
                 sums = torch.empty(1, 2, Cp, device=dev, dtype=torch.float64)
                 dW = _gbuf(W)
                 L.call('gpe_bn_bwd_from_G', G, Cp, db, W, W.stride(0), C, Cp, stp, sums, dW, Cp)
@@ -1100,7 +1113,7 @@ class DenseMLPFn(torch.autograd.Function):
                 coef_p, dgam_p, dbet_p = bn_bwd_coef(sums, 1, stp, Cp, M, gp, bp, training)
                 L.call('gpe_edge_mlp_bwd', dz, dz.stride(0), 0, None, 0, None, 1, M, 1, C, Cp,
                        pack_weight(W, transpose=True), coef_p, prev, prev.stride(0), None, 0,
-                       _word(words, n + l), _word(words, n + l - 1), ews, ews_n)
+                       _word(words, n + l), _word(words, n + l - 1), ews, ews_n, None, 0, None, None, 0, None)
                 grads[4 * l], grads[4 * l + 1] = _gret(W, dW), _gret(b, db)
                 grads[4 * (l - 1) + 2], grads[4 * (l - 1) + 3] = _gret(gp, dgam_p), _gret(bp, dbet_p)
             else:

@@ -36,7 +36,8 @@ extern "C" {
 
 /* version / capability probe (host only, no GPU needed) */
 int gpe_abi_version(void);
-/* profiling aid: ablation switches for the fused edge kernels (0 = production behaviour; results are WRONG otherwise) */
+/* profiling aid: ablation switches for the fused edge kernels (0 = production behaviour; results are WRONG otherwise, except
+ * bit 512, which only makes gpe_edge_lazy_dz3_ok answer 0 — the eager in-place dz3 pass, same results to rounding) */
 int gpe_debug_set(int flags);
 /* arithmetic of the fused per-edge GEMMs (gpe_edge_mlp_fwd / gpe_edge_mlp_bwd / gpe_edge_redgemm):
  *   0 = "f32"    exact fp32 matrix instruction (v_mfma_f32_16x16x4_f32)
@@ -206,7 +207,8 @@ int gpe_edge_dz3(float* a3, int lda3, const float* g, int ldg, const uint8_t* am
 int gpe_edge_redgemm(const float* u, int ldu, int v_mode, const float* v, int ldv, const float* pq, int ldpq,
                      const int32_t* jg, const float* v_shift, int B, int N, int k, int Mg, int Ng, float* G, int ldG,
                      float* colsum, float* part, const uint32_t* amax_u, const uint32_t* amax_v, void* ws, long ws_bytes,
-                     void* stream);
+                     const float* lz_g, int lz_ldg, const uint8_t* lz_amx, const uint8_t* lz_amn, int lz_ldagg,
+                     const float* lz_coef, void* stream);
 /* amax_u / amax_v: amax words of U and of V (v_mode 0: of relu(P_i+Q_j); NULL there = the bound passes run in `ws`).  f16x3 mode
  * runs the fp16-pipe kernel only when both are known, else the exact fp32 kernel. */
 
@@ -218,7 +220,19 @@ int gpe_edge_redgemm(const float* u, int ldu, int v_mode, const float* v, int ld
 int gpe_edge_mlp_bwd(const float* a, int lda, int act_mode, const float* pq, int ldpq, const int32_t* jg,
                      int B, int N, int k, int Cin, int Cout, const float* wp, const float* coef_out,
                      float* dz_out, int ldo, float* dP, int lddp, const uint32_t* amax_a, uint32_t* amax_out, void* ws,
-                     long ws_bytes, void* stream);
+                     long ws_bytes, const float* lz_g, int lz_ldg, const uint8_t* lz_amx, const uint8_t* lz_amn, int lz_ldagg,
+                     const float* lz_coef, void* stream);
+/* ---- lazy dz3 (ABI version 4): gpe_edge_dz3's in-place pass folded into its two consumers ---------------------------------
+ * With lz_g != NULL, gpe_edge_mlp_bwd (act_mode 0: `a`) and gpe_edge_redgemm (v_mode 1: `u`) take the STORED ACTIVATION a3 of the
+ * block under the max aggregation instead of dz3 and form dz3 = (a3>0) ? [slot==argsel]*s*g - c1 - (a3-mean)*k2 : 0 while staging
+ * it: lz_g [B*N][lz_ldg] the layer-output gradient (rows 16-B aligned, lz_ldg % 4 == 0, pad columns finite), lz_amx / lz_amn
+ * [B*N][lz_ldagg] the slots saved by gpe_edge_mlp_fwd, lz_coef [4][F] from gpe_bn_bwd_coef.  a3 is not modified.  Only where
+ * gpe_edge_lazy_dz3_ok(...) == 1 (f16x3 arithmetic, k = 16, widths on the two-plane kernels' menu, above the size gate); amax_a /
+ * amax_u must then be a bound of |dz3| (gpe_edge_dz3_bound) and amax_v the word of V.  Anything else returns -22. */
+int gpe_edge_lazy_dz3_ok(int B, int N, int k, int F, int Cprev);
+/* amax[0] = bits of a bound of |dz3| = max |s*g| + max_c (|c1| + (amax(a3) + |mean|) |k2|); amax[1] is scratch (two words) */
+int gpe_edge_dz3_bound(const float* g, int ldg, const float* coef, int F, long rows, const uint32_t* amax_a3, uint32_t* amax,
+                       void* stream);
 
 /* dQ[j] = sum over incoming edges e of dz1[e]  (deterministic pull through the reverse adjacency) */
 int gpe_edge_pull_dq(const float* dz, int lddz, const int32_t* rev_off, const int32_t* rev_edge,

@@ -35,7 +35,7 @@ def run():
     L.call('gpe_edge_mlp_fwd', 0, PQ, 2 * H, jg, None, 0, B, N, k, H, H, w2p, b2, a2, H, part2, 0, None, None, None, None, 0, None, None, EWS, NWS)
     L.call('gpe_edge_mlp_fwd', 1, None, 0, None, a2, H, B, N, k, H, Fo, w3p, b3, a3, 152, part3, 1, mx, mn, amx, amn, 152, None, None, EWS, NWS)
     d2 = a2.clone()
-    L.call('gpe_edge_mlp_bwd', dz3, 152, 0, None, 0, None, B, N, k, Fo, H, w3t, coef, d2, H, None, 0, None, None, EWS, NWS)
+    L.call('gpe_edge_mlp_bwd', dz3, 152, 0, None, 0, None, B, N, k, Fo, H, w3t, coef, d2, H, None, 0, None, None, EWS, NWS, None, 0, None, None, 0, None)
     return a2, a3, mx, part2.sum(0), d2
 
 
@@ -62,7 +62,7 @@ mx = torch.empty(B * N, 152, device=dev); mn = torch.empty_like(mx)
 amx = torch.empty(B * N, 152, device=dev, dtype=torch.uint8); amn = torch.empty_like(amx)
 def f2(): L.call('gpe_edge_mlp_fwd', 0, PQ, 2 * H, jg, None, 0, B, N, k, H, H, w2p, b2, a2, H, part, 0, None, None, None, None, 0, None, None, EWS, NWS)
 def f3(): L.call('gpe_edge_mlp_fwd', 1, None, 0, None, a2, H, B, N, k, H, Fo, w3p, b3, a3, 152, part, 1, mx, mn, amx, amn, 152, None, None, EWS, NWS)
-def b2a(): L.call('gpe_edge_mlp_bwd', a3, 152, 0, None, 0, None, B, N, k, Fo, H, w3t, coef, a2, H, None, 0, None, None, EWS, NWS)
+def b2a(): L.call('gpe_edge_mlp_bwd', a3, 152, 0, None, 0, None, B, N, k, Fo, H, w3t, coef, a2, H, None, 0, None, None, EWS, NWS, None, 0, None, None, 0, None)
 for mode in ['f32', 'bf16x3']:
     gpe_amd.set_math(mode)
     for flags in [0, 16, 3]:
@@ -82,8 +82,8 @@ G = torch.empty(H, H, device=dev); cs = torch.empty(H, device=dev)
 ws = torch.empty(L.query('gpe_redgemm_ws', H, H), device=dev)
 shift = torch.randn(H, device=dev)
 a2r = torch.randn(E, H, device=dev); a3r = torch.randn(E, 152, device=dev); a3r[:, 150:] = 0
-def rg(): L.call('gpe_edge_redgemm', a2r, H, 0, None, 0, PQ, 2 * H, jg, shift, B, N, k, H, H, G, H, cs, ws, None, None, EWS, NWS)
-def rd(): L.call('gpe_edge_redgemm', a3r, 152, 1, a2r, H, None, 0, None, shift, B, N, k, Fo, H, G[:Fo], H, cs, ws, None, None, EWS, NWS)
+def rg(): L.call('gpe_edge_redgemm', a2r, H, 0, None, 0, PQ, 2 * H, jg, shift, B, N, k, H, H, G, H, cs, ws, None, None, EWS, NWS, None, 0, None, None, 0, None)
+def rd(): L.call('gpe_edge_redgemm', a3r, 152, 1, a2r, H, None, 0, None, shift, B, N, k, Fo, H, G[:Fo], H, cs, ws, None, None, EWS, NWS, None, 0, None, None, 0, None)
 res = {}
 for mode in ['f32', 'bf16x3']:
     gpe_amd.set_math(mode)

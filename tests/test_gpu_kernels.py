@@ -287,12 +287,12 @@ def test_edge_redgemm_producer_consumer_tiles(gpe, mode, B, N, k, Mg, Ng):
         pv = Ng + 8
         vbuf = torch.full((E, pv), float('nan')).cuda()
         vbuf[:, :Ng] = torch.randn(E, Ng, generator=g).cuda()
-        L.call('gpe_edge_redgemm', ubuf, pu, 1, vbuf, pv, None, 0, None, shift, B, N, k, Mg, Ng, G, Ng, cs, ws, None, None, None, 0)
+        L.call('gpe_edge_redgemm', ubuf, pu, 1, vbuf, pv, None, 0, None, shift, B, N, k, Mg, Ng, G, Ng, cs, ws, None, None, None, 0, None, 0, None, None, 0, None)
         vref = vbuf[:, :Ng].double() - shift.double()
     else:
         pq = torch.randn(B * N, 2 * Ng, generator=g).cuda()
         jg = (torch.randint(0, N, (B, N, k), generator=g) + torch.arange(B).view(B, 1, 1) * N).int().cuda()
-        L.call('gpe_edge_redgemm', ubuf, pu, 0, None, 0, pq, 2 * Ng, jg, shift, B, N, k, Mg, Ng, G, Ng, cs, ws, None, None, None, 0)
+        L.call('gpe_edge_redgemm', ubuf, pu, 0, None, 0, pq, 2 * Ng, jg, shift, B, N, k, Mg, Ng, G, Ng, cs, ws, None, None, None, 0, None, 0, None, None, 0, None)
         i = torch.arange(B * N, device='cuda').repeat_interleave(k)
         vref = torch.relu(pq[i, :Ng].double() + pq[jg.view(-1).long(), Ng:].double()) - shift.double()
     uref = ubuf[:, :Mg].double()
@@ -872,7 +872,7 @@ def test_f16x3_edge_redgemm_with_words(gpe, f16x3_ungated, v_mode):
         vref = v.double() - shift.double()
         variants = [words[1:2]]
         run = lambda wv: L.call('gpe_edge_redgemm', u, 152, 1, v, Ng, None, 0, None, shift, B, N, k, Mg, Ng, G, Ng, cs, part,
-                                words[0:1], wv, ws, nws)
+                                words[0:1], wv, ws, nws, None, 0, None, None, 0, None)
     else:
         pq = torch.randn(B * N, 2 * Ng, generator=g).cuda()
         jg = (torch.randint(0, N, (B, N, k), generator=g) + torch.arange(B).view(B, 1, 1) * N).int().cuda()
@@ -883,7 +883,7 @@ def test_f16x3_edge_redgemm_with_words(gpe, f16x3_ungated, v_mode):
         vref = a0 - shift.double()
         variants = [words[2:3], None]
         run = lambda wv: L.call('gpe_edge_redgemm', u, 152, 0, None, 0, pq, 2 * Ng, jg, shift, B, N, k, Mg, Ng, G, Ng, cs, part,
-                                words[0:1], wv, ws, nws)
+                                words[0:1], wv, ws, nws, None, 0, None, None, 0, None)
     uref = u[:, :Mg].double()
     for wv in variants:
         G.zero_(); cs.zero_()
@@ -1081,6 +1081,50 @@ def test_stitch_losses_and_renumbering(gpe, hardnet, origin, order, supervised):
     # before the switch-over epoch nothing of this runs and the dict has the four main keys only
     lo0, do0, upd0 = ours(views(pd.detach(), qd.detach()), {k: v.clone() for k, v in gt.items()}, epoch=39)
     assert set(do0.keys()) == {'pattern_loss', 'loop_loss', 'rotation_loss', 'translation_loss'} and upd0 == bool(order and 0 == 39)
+
+
+def test_lazy_dz3_matches_the_in_place_pass(gpe):
+    """f16x3, k = 16, above the size gate: the backward of the aggregated block never materialises dz3 — the weight-gradient
+    reduce-GEMM and the propagation kernel form it from the stored activation while staging it (include/gpe_hip.h "lazy dz3").
+    Same gradients as with the separate in-place pass (gpe_debug_set(512) keeps it), to rounding: both run the fp16 pipe, only
+    the scale word differs (a bound instead of the measured maximum) — and both meet the fp64 oracle at the layer test's bars."""
+    L = gpe._lib
+    B, N, C, k = 8, 512, 3, 16                                   # E = 65 536 rows: the smallest launch the lazy path takes
+    oconv = _oracle_conv(C, 200, 150, k, seed=5)                 # includes negative BatchNorm scales: the min side
+    conv = _product_conv(gpe, oconv, C, 200, 150, k).train()
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(B * N, C, generator=g)
+    wgt = torch.randn(B * N, 150, generator=g)
+    prev = gpe.set_math('f16x3')
+    try:
+        assert L.query('gpe_edge_lazy_dz3_ok', B, N, k, 150, 200) == 1
+        res = {}
+        for flag in (0, 512):
+            L.query('gpe_debug_set', flag)
+            assert L.query('gpe_edge_lazy_dz3_ok', B, N, k, 150, 200) == (0 if flag else 1)
+            for p_ in conv.parameters():
+                p_.grad = None
+            xd = x.cuda().requires_grad_()
+            y = conv(xd, B, N)
+            (y * wgt.cuda()).sum().backward()
+            res[flag] = (y.detach().clone(), xd.grad.clone(), {n: p_.grad.clone() for n, p_ in conv.named_parameters()})
+    finally:
+        L.query('gpe_debug_set', 0)
+        gpe.set_math(prev)
+    assert torch.equal(res[0][0], res[512][0])                   # same forward
+    assert relerr(res[0][1], res[512][1]) < 2e-6
+    for n in res[0][2]:
+        assert relerr(res[0][2][n], res[512][2][n]) < 2e-5, n
+    # against the fp64 oracle on the build's graph
+    o64 = copy.deepcopy(oconv).double().train()
+    o64.knn_override = conv.last_knn.cpu().view(-1, k).long()
+    xr = x.double().requires_grad_()
+    yr = o64(xr, torch.arange(B).repeat_interleave(N))
+    (yr * wgt.double()).sum().backward()
+    assert relerr(res[0][0], yr) < 5e-5
+    assert relerr(res[0][1], xr.grad) < 2e-4
+    for n, p_ in o64.named_parameters():
+        assert relerr(res[0][2][n], p_.grad) < 3e-4, n
 
 
 def test_two_streams_one_device(gpe):
