@@ -1350,7 +1350,7 @@ static int rd_run(RdParams& p, int vmode, float* G, int ldG, float* colsum, floa
     p.part = part;
     // row-poor dense products (fewer than 64 row tiles per workgroup of the big-block grid) with a 16-B loadable U
     // thin products: stream U once (Ng <= 4, plain 16-B loadable U rows, single-level rows on both sides)
-    if (vmode == V_DENSE && p.Ng <= 4 && p.Mg <= 1024 && p.rows >= 4096 && p.u.inner <= 0 && p.v.inner <= 0 &&
+    if (vmode == V_DENSE && !p.lz_g && p.Ng <= 4 && p.Mg <= 1024 && p.rows >= 4096 && p.u.inner <= 0 && p.v.inner <= 0 &&
         rd_rows_vec(p.u, p.Mg)) {
         const int gxt = (int)(p.rows / 64 < RDT_GX ? p.rows / 64 : RDT_GX);
         p.MgPad = gpe_round_up(p.Mg, 4); p.NgPad = 4;
@@ -1370,7 +1370,7 @@ static int rd_run(RdParams& p, int vmode, float* G, int ldG, float* colsum, floa
         return GPE_OK;
     }
     const long in_max = (p.u.inner > p.v.inner ? p.u.inner : p.v.inner) > 1 ? (p.u.inner > p.v.inner ? p.u.inner : p.v.inner) : 1;
-    if (vmode == V_DENSE && g_rd_math != 1 && p.num_tiles > 0 && p.num_tiles < 64L * gx && p.rows * in_max < (1L << 32) &&
+    if (vmode == V_DENSE && g_rd_math != 1 && !p.lz_g && p.num_tiles > 0 && p.num_tiles < 64L * gx && p.rows * in_max < (1L << 32) &&
         p.rows < (1L << 31) && rd_rows_vec2(p.u, p.Mg)) {
         p.umagic = p.u.inner > 1 ? (unsigned)(((1ull << 32) + p.u.inner - 1) / p.u.inner) : 0;
         p.vmagic = p.v.inner > 1 ? (unsigned)(((1ull << 32) + p.v.inner - 1) / p.v.inner) : 0;
