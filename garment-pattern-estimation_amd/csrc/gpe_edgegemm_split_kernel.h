@@ -433,7 +433,11 @@ __global__ __launch_bounds__(256, 1) void gpe_edgegemm_split_kernel(RgParams p, 
             // the point of this wave's 16 rows (k = 16: one point per wave and tile), clamped into the last valid point
             const long pt0 = (long)tile * PT + wave * npw, ptl = (long)tile * PT + ((last * rkl) >> 16);
             const long pt = pt0 < ptl ? pt0 : ptl;
-            lz_gq = ld4(p.lz_g + pt * p.lz_ldg + ck);
+            // (dword loads at clamped columns: the gradient rows are the caller's [B*N, K] tensor as it is — no 16-B alignment, no
+            // pad columns; the pad lanes' coefficients are 0)
+            const float* gr = p.lz_g + pt * p.lz_ldg + ck;
+            const int rem = p.K - 1 - ck;
+            lz_gq = make_float4(gr[0], gr[rem < 1 ? rem : 1], gr[rem < 2 ? rem : 2], gr[rem < 3 ? rem : 3]);
             lz_sx = *reinterpret_cast<const uchar4*>(p.lz_amx + pt * p.lz_ldagg + ck);
             lz_sn = *reinterpret_cast<const uchar4*>(p.lz_amn + pt * p.lz_ldagg + ck);
         }

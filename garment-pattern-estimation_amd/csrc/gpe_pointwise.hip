@@ -496,10 +496,12 @@ __global__ __launch_bounds__(256) void gpe_point_sums_kernel(const float* __rest
                                                              const float* __restrict__ mx,
                                                              const float* __restrict__ mn, int ldagg,
                                                              const float* __restrict__ stats, long rows, int C,
-                                                             double* __restrict__ part)
+                                                             double* __restrict__ part, unsigned* __restrict__ amax_sg)
 {
+    // amax_sg (may be NULL): receives max |s_c g_ic| — the data term of the bound of a lazily formed dz3 (gpe_edge_dz3_bound)
     const int c = blockIdx.y * 256 + threadIdx.x;
     double s1 = 0, s2 = 0;
+    float gm = 0.f, sabs = 0.f;
     if (c < C) {
         const float mean = stats[c], rstd = stats[C + c], s = stats[2 * C + c];
         // 8 rows in flight per thread (a load per dependent fp64 add was a 512-deep latency chain: 0.4 TB/s)
@@ -514,6 +516,7 @@ __global__ __launch_bounds__(256) void gpe_point_sums_kernel(const float* __rest
             for (int u = 0; u < 8; ++u) {
                 s1 += (double)gv[u];
                 s2 += (double)gv[u] * (double)((sv[u] - mean) * rstd);
+                gm = fmaxf(gm, fabsf(gv[u]));
             }
         }
         for (; r < rows; r += st) {
@@ -521,20 +524,29 @@ __global__ __launch_bounds__(256) void gpe_point_sums_kernel(const float* __rest
             const float sel = sp[r * ldagg + c];
             s1 += (double)gv;
             s2 += (double)gv * (double)((sel - mean) * rstd);
+            gm = fmaxf(gm, fabsf(gv));
         }
         part[(size_t)blockIdx.x * 2 * C + c] = s1;
         part[(size_t)blockIdx.x * 2 * C + C + c] = s2;
+        sabs = fabsf(s);
+    }
+    if (amax_sg) {                                   // uniform branch; every wave of the block arrives here
+        float m = gm * sabs;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+        if ((threadIdx.x & 63) == 0) atomicMax(amax_sg, __float_as_uint(m * 1.0000002f));   // |s| * max|g| rounds once more than |s g|
     }
 }
 
 extern "C" int gpe_point_sums_blocks(void) { return PS_BLOCKS; }
 
 extern "C" int gpe_edge_bwd_point_sums(const float* g, int ldg, const float* mx, const float* mn, int ldagg,
-                                       const float* stats, long rows, int C, double* part, void* stream)
+                                       const float* stats, long rows, int C, double* part, uint32_t* amax_sg, void* stream)
 {
     if (!g || !mx || !mn || !stats || !part || rows <= 0 || C <= 0) return GPE_EINVAL;
+    if (amax_sg && hipMemsetAsync(amax_sg, 0, sizeof(uint32_t), (hipStream_t)stream) != hipSuccess) return GPE_ELAUNCH;
     hipLaunchKernelGGL(gpe_point_sums_kernel, dim3(PS_BLOCKS, gpe_cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, g, ldg, mx, mn,
-                       ldagg, stats, rows, C, part);
+                       ldagg, stats, rows, C, part, amax_sg);
     GPE_CHECK_LAUNCH();
     return GPE_OK;
 }

@@ -737,7 +737,9 @@ __global__ __launch_bounds__(512, 2) void gpe_redgemm_b3_kernel(RdParams p)
             const float* vp = p.v.base + rb * p.v.stride_outer + cv;
             if constexpr (LAZY) {
                 const long pt = rb >> 4;                                    // k = 16 (host-checked); wave-uniform
-                lz_gq = rd_ld4(p.lz_g + pt * p.lz_ldg + cu);
+                const float* gr = p.lz_g + pt * p.lz_ldg + cu;                  // dword loads at clamped columns: any row pitch
+                const int rem = p.Mg - 1 - cu;
+                lz_gq = make_float4(gr[0], gr[rem < 1 ? rem : 1], gr[rem < 2 ? rem : 2], gr[rem < 3 ? rem : 3]);
                 lz_sx = *reinterpret_cast<const uchar4*>(p.lz_amx + pt * p.lz_ldagg + cu);
                 lz_sn = *reinterpret_cast<const uchar4*>(p.lz_amn + pt * p.lz_ldagg + cu);
             }
@@ -1468,8 +1470,8 @@ extern "C" int gpe_edge_redgemm(const float* u, int ldu, int v_mode, const float
     p.pq = pq; p.ldpq = ldpq; p.H = Ng; p.jg = jg; p.k = k; p.rcp_k = 1.0 / k; p.kmagic = (unsigned)(((1ull << 32) + k - 1) / k); p.v_shift = v_shift;
     p.pin_clouds = B;
     if (lz_g) {
-        if (!lz_amx || !lz_amn || !lz_coef || (lz_ldg & 3) || lz_ldg < ((Mg + 3) & ~3) || (lz_ldagg & 3) || lz_ldagg < ((Mg + 3) & ~3) ||
-            (((uintptr_t)lz_g) & 15) || k != 16 || v_mode != 1 || !amax_u || !amax_v)
+        if (!lz_amx || !lz_amn || !lz_coef || lz_ldg < Mg || (lz_ldagg & 3) || lz_ldagg < ((Mg + 3) & ~3) || k != 16 || v_mode != 1 ||
+            !amax_u || !amax_v)
             return GPE_EINVAL;
         p.lz_g = lz_g; p.lz_ldg = lz_ldg; p.lz_amx = lz_amx; p.lz_amn = lz_amn; p.lz_ldagg = lz_ldagg; p.lz_coef = lz_coef;
     }

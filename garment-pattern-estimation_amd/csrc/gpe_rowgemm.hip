@@ -383,59 +383,32 @@ extern "C" int gpe_edge_lazy_dz3_ok(int B, int N, int k, int F, int Cprev)
     return rows >= gpe_h3_min_rows() && rows < (1L << 31) && rows / 32 >= 4L * 2 * gpe_num_cus();
 }
 
-// bound of |dz3| for its f16x3 scale: max_i,c |s_c g_ic| + max_c (|c1_c| + (amax(a3) + |mean_c|) |k2_c|), rounded up
-__global__ __launch_bounds__(256) void gpe_dz3_bound_kernel(const float* __restrict__ g, int ldg, const float* __restrict__ coef, int F,
-                                                            long rows, const unsigned* __restrict__ amax_a3, unsigned* __restrict__ out)
+// bound of |dz3| for its f16x3 scale: max_i,c |s_c g_ic| (measured by gpe_edge_bwd_point_sums while it reads g: amax_sg) +
+// max_c (|c1_c| + (amax(a3) + |mean_c|) |k2_c|), rounded up.  One workgroup over the F coefficient columns.
+__global__ __launch_bounds__(256) void gpe_dz3_bound_kernel(const unsigned* __restrict__ amax_sg, const float* __restrict__ coef, int F,
+                                                            const unsigned* __restrict__ amax_a3, unsigned* __restrict__ out)
 {
     __shared__ float red[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float m = 0.f;
-    const int fq = (F + 3) >> 2;
-    const long total = rows * fq;
-    for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long)gridDim.x * 256) {
-        const long r = t / fq;
-        const int c = (int)(t - r * fq) << 2;
-        const float4 v = *reinterpret_cast<const float4*>(g + r * ldg + c);
-        const float gv[4] = {v.x, v.y, v.z, v.w};
+    const float a3 = __uint_as_float(amax_a3[0]);
+    float tail = 0.f;
+    for (int c = threadIdx.x; c < F; c += 256)
+        tail = fmaxf(tail, fabsf(coef[F + c]) + (a3 + fabsf(coef[3 * F + c])) * fabsf(coef[2 * F + c]));
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
-            if (c + u < F) m = fmaxf(m, fabsf(coef[c + u] * gv[u]));
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-    if (lane == 0) red[wave] = m;
+    for (int o = 32; o > 0; o >>= 1) tail = fmaxf(tail, __shfl_xor(tail, o));
+    if (lane == 0) red[wave] = tail;
     __syncthreads();
     if (threadIdx.x == 0) {
-        m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-        float tail = 0.f;
-        if (blockIdx.x == 0) {                                      // the coefficient terms once
-            const float a3 = __uint_as_float(amax_a3[0]);
-            for (int c = 0; c < F; ++c) tail = fmaxf(tail, fabsf(coef[F + c]) + (a3 + fabsf(coef[3 * F + c])) * fabsf(coef[2 * F + c]));
-        }
-        // out[0] accumulates max |s g| over the blocks, out[1] = the coefficient terms; gpe_dz3_bound_finish adds the two
-        atomicMax(out, __float_as_uint(m));
-        if (blockIdx.x == 0) out[1] = __float_as_uint(tail);
+        tail = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        const float b = (__uint_as_float(amax_sg[0]) + tail) * 1.000001f;
+        out[0] = __float_as_uint(b) & 0x7fffffffu;
     }
 }
-__global__ void gpe_dz3_bound_finish(unsigned* out)
+extern "C" int gpe_edge_dz3_bound(const uint32_t* amax_sg, const float* coef, int F, const uint32_t* amax_a3, uint32_t* amax_out,
+                                  void* stream)
 {
-    const float b = (__uint_as_float(out[0]) + __uint_as_float(out[1])) * 1.000001f;
-    out[0] = __float_as_uint(b) & 0x7fffffffu;
-}
-// amax [2] uint32 (the bound lands in amax[0]; amax[1] is scratch); g rows 16-B aligned with ldg % 4 == 0
-extern "C" int gpe_edge_dz3_bound(const float* g, int ldg, const float* coef, int F, long rows, const uint32_t* amax_a3,
-                                  uint32_t* amax, void* stream)
-{
-    if (!g || !coef || !amax_a3 || !amax || F <= 0 || rows <= 0 || (ldg & 3) || ldg < ((F + 3) & ~3) || (((uintptr_t)g) & 15))
-        return GPE_EINVAL;
-    hipStream_t s = (hipStream_t)stream;
-    if (hipMemsetAsync(amax, 0, 2 * sizeof(uint32_t), s) != hipSuccess) return GPE_ELAUNCH;
-    long gx = (rows * ((F + 3) >> 2) + 255) / 256;
-    const long cap = (long)gpe_num_cus() * 8;
-    if (gx > cap) gx = cap;
-    hipLaunchKernelGGL(gpe_dz3_bound_kernel, dim3((unsigned)gx), dim3(256), 0, s, g, ldg, coef, F, rows, amax_a3, amax);
-    GPE_CHECK_LAUNCH();
-    hipLaunchKernelGGL(gpe_dz3_bound_finish, dim3(1), dim3(1), 0, s, amax);
+    if (!amax_sg || !coef || !amax_a3 || !amax_out || F <= 0) return GPE_EINVAL;
+    hipLaunchKernelGGL(gpe_dz3_bound_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, amax_sg, coef, F, amax_a3, amax_out);
     GPE_CHECK_LAUNCH();
     return GPE_OK;
 }
@@ -509,8 +482,8 @@ extern "C" int gpe_edge_mlp_bwd(const float* a, int lda, int act_mode, const flo
     if (lz_g) {
         // lazy dz3: `a` is the stored activation of the aggregated block; only the f16x3 k = 16 in-place kernel forms dz3 from it
         // (the caller asked gpe_edge_lazy_dz3_ok first and passes the bound of |dz3| as amax_a)
-        if (!lz_amx || !lz_amn || !lz_coef || (lz_ldg & 3) || lz_ldg < ((Cin + 3) & ~3) || (lz_ldagg & 3) || lz_ldagg < ((Cin + 3) & ~3) ||
-            (((uintptr_t)lz_g) & 15) || act_mode != 0 || !amax_a || !gpe_edge_lazy_dz3_ok(B, N, k, Cin, Cout) || !p.ws.h3)
+        if (!lz_amx || !lz_amn || !lz_coef || lz_ldg < Cin || (lz_ldagg & 3) || lz_ldagg < ((Cin + 3) & ~3) || act_mode != 0 || !amax_a ||
+            !gpe_edge_lazy_dz3_ok(B, N, k, Cin, Cout) || !p.ws.h3)
             return GPE_EINVAL;
         p.lz_g = lz_g; p.lz_ldg = lz_ldg; p.lz_amx = lz_amx; p.lz_amn = lz_amn; p.lz_ldagg = lz_ldagg; p.lz_coef = lz_coef;
     }

@@ -590,7 +590,7 @@ class EdgeConvFn(torch.autograd.Function):
         # caller-owned state of the edge calls: one workspace, and in f16x3 mode the amax words of this layer's tensors —
         # [0] the bound of relu(P_i + Q_j), [l] activation a_l, [nb + l] dz_l (backward)
         ews, ews_n = edge_workspace(B, N, k, max(round_up(widths[-1], 4), 2 * H0), dev)
-        words = f16x3_words(2 * nb + 1, E, dev)           # (+ 1: scratch word of gpe_edge_dz3_bound behind dz_{nb-1}'s)
+        words = f16x3_words(2 * nb + 1, E, dev)           # (+ 1: max |s g| of the layer-output gradient, lazy dz3)
         if words is not None:
             L.call('gpe_edge_pq_amax', PQ, 2 * H0, H0, BN, _word(words, 0), ews, ews_n)
         part = torch.empty(nblk, 2, H0, device=dev, dtype=torch.float64) if training else None
@@ -678,16 +678,16 @@ class EdgeConvFn(torch.autograd.Function):
         lz = (None, 0, None, None, 0, None)                # lazy dz3 arguments of the two consumers (off)
         if aggr == 'max':
             mx, mn, amx, amn = tail
-            L.call('gpe_edge_bwd_point_sums', g_out, ldg, mx, mn, ldF, stats[-1], BN, Fo, part)
+            lazy = words is not None and nb >= 3 and L.query('gpe_edge_lazy_dz3_ok', B, N, k, Fo, widths[-2]) == 1
+            L.call('gpe_edge_bwd_point_sums', g_out, ldg, mx, mn, ldF, stats[-1], BN, Fo, part,
+                   _word(words, 2 * nb) if lazy else None)
             coef, dg, dbe = bn_bwd_coef(part, psb, stats[-1], Fo, E, g_last, be_last, training)
-            if words is not None and nb >= 3 and L.query('gpe_edge_lazy_dz3_ok', B, N, k, Fo, widths[-2]) == 1:
+            if lazy:
                 # f16x3, k = 16: dz of the aggregated block is never materialised — the weight-gradient reduce-GEMM and the
                 # propagation below form it from the stored activation while staging it (the in-place pass is 1.3 GB at cfg 2).
-                # They need the gradient rows 16-B loadable (pad columns zero) and a bound of |dz| for the fp16 scale.
-                g_pad = torch.zeros(BN, ldF, device=dev, dtype=F32)
-                g_pad[:, :Fo].copy_(g_out)
-                L.call('gpe_edge_dz3_bound', g_pad, ldF, coef, Fo, BN, _word(words, nb - 1), words[2 * nb - 1: 2 * nb + 1])
-                lz = (g_pad, ldF, amx, amn, ldF, coef)
+                # Its fp16 scale comes from a bound of |dz|: max |s g| (measured by the point sums above) + the coefficient terms.
+                L.call('gpe_edge_dz3_bound', _word(words, 2 * nb), coef, Fo, _word(words, nb - 1), _word(words, 2 * nb - 1))
+                lz = (g_out, ldg, amx, amn, ldF, coef)
             else:
                 # dz in place over the stored activation (one coalesced pass)
                 L.call('gpe_edge_dz3', a_last, ldF, g_out, ldg, amx, amn, ldF, coef, B, N, k, Fo, _word(words, 2 * nb - 1))
@@ -699,7 +699,7 @@ class EdgeConvFn(torch.autograd.Function):
             if aggr == 'add':
                 gs = torch.empty(BN, Fo, device=dev, dtype=F32)
                 L.call('gpe_scale', g_out.contiguous(), float(k), gs, gs.numel())
-            L.call('gpe_edge_bwd_point_sums', gs, gs.stride(0), abar, abar, ldF, stats[-1], BN, Fo, part)
+            L.call('gpe_edge_bwd_point_sums', gs, gs.stride(0), abar, abar, ldF, stats[-1], BN, Fo, part, None)
             coef, dg, dbe = bn_bwd_coef(part, psb, stats[-1], Fo, E, g_last, be_last, training)
             L.call('gpe_edge_dz3_all', a_last, ldF, g_out, ldg, 1.0 / k if aggr == 'mean' else 1.0, coef, B, N, k, Fo,
                    _word(words, 2 * nb - 1))
@@ -1083,7 +1083,7 @@ class DenseMLPFn(torch.autograd.Function):
         g_l, be_l = params[4 * (n - 1) + 2], params[4 * (n - 1) + 3]
         psb = L.query('gpe_point_sums_blocks')
         part = torch.empty(psb, 2, C, device=dev, dtype=torch.float64)
-        L.call('gpe_edge_bwd_point_sums', gy, C, a, a, a.stride(0), st, M, C, part)
+        L.call('gpe_edge_bwd_point_sums', gy, C, a, a, a.stride(0), st, M, C, part, None)
         coef, dgam, dbet = bn_bwd_coef(part, psb, st, C, M, g_l, be_l, training)
         words = ctx.words
         ews, ews_n = edge_workspace(1, M, 1, 4, dev)

@@ -182,7 +182,9 @@ int gpe_edge_finish(const float* mx, const float* mn, int ldagg, const float* st
  * part [gpe_point_sums_blocks()][2][C]: sum_i g, sum_i g*xhat_sel */
 int gpe_point_sums_blocks(void);
 int gpe_edge_bwd_point_sums(const float* g, int ldg, const float* mx, const float* mn, int ldagg,
-                            const float* stats, long rows, int C, double* part, void* stream);
+                            const float* stats, long rows, int C, double* part, uint32_t* amax_sg, void* stream);
+/* amax_sg (may be NULL): receives the bits of max |s_c * g_ic| (s = the BatchNorm scale in `stats`), measured while g is read —
+ * the data term of gpe_edge_dz3_bound */
 /* coefficient vectors for "dz = (a>0) ? s*dy - c1 - (a-mean)*k2 : 0":  coef [4][C] = {s, c1 = s*mean(dy),
  * k2 = s*rstd*mean(dy*xhat), mean} from partial sums part [nblk][2][C]; also the BatchNorm parameter gradients
  * dgamma = sum dy*xhat, dbeta = sum dy (may be NULL) */
@@ -225,14 +227,14 @@ int gpe_edge_mlp_bwd(const float* a, int lda, int act_mode, const float* pq, int
 /* ---- lazy dz3 (ABI version 4): gpe_edge_dz3's in-place pass folded into its two consumers ---------------------------------
  * With lz_g != NULL, gpe_edge_mlp_bwd (act_mode 0: `a`) and gpe_edge_redgemm (v_mode 1: `u`) take the STORED ACTIVATION a3 of the
  * block under the max aggregation instead of dz3 and form dz3 = (a3>0) ? [slot==argsel]*s*g - c1 - (a3-mean)*k2 : 0 while staging
- * it: lz_g [B*N][lz_ldg] the layer-output gradient (rows 16-B aligned, lz_ldg % 4 == 0, pad columns finite), lz_amx / lz_amn
+ * it: lz_g [B*N][lz_ldg] the layer-output gradient as it arrives (any pitch >= F, no alignment requirement), lz_amx / lz_amn
  * [B*N][lz_ldagg] the slots saved by gpe_edge_mlp_fwd, lz_coef [4][F] from gpe_bn_bwd_coef.  a3 is not modified.  Only where
  * gpe_edge_lazy_dz3_ok(...) == 1 (f16x3 arithmetic, k = 16, widths on the two-plane kernels' menu, above the size gate); amax_a /
  * amax_u must then be a bound of |dz3| (gpe_edge_dz3_bound) and amax_v the word of V.  Anything else returns -22. */
 int gpe_edge_lazy_dz3_ok(int B, int N, int k, int F, int Cprev);
-/* amax[0] = bits of a bound of |dz3| = max |s*g| + max_c (|c1| + (amax(a3) + |mean|) |k2|); amax[1] is scratch (two words) */
-int gpe_edge_dz3_bound(const float* g, int ldg, const float* coef, int F, long rows, const uint32_t* amax_a3, uint32_t* amax,
-                       void* stream);
+/* amax_out = bits of a bound of |dz3| = max |s*g| (amax_sg, from gpe_edge_bwd_point_sums) + max_c (|c1| + (amax(a3) + |mean|) |k2|)
+ * with coef [4][F] from gpe_bn_bwd_coef and amax_a3 the word of the stored activation (gpe_edge_mlp_fwd's amax_out) */
+int gpe_edge_dz3_bound(const uint32_t* amax_sg, const float* coef, int F, const uint32_t* amax_a3, uint32_t* amax_out, void* stream);
 
 /* dQ[j] = sum over incoming edges e of dz1[e]  (deterministic pull through the reverse adjacency) */
 int gpe_edge_pull_dq(const float* dz, int lddz, const int32_t* rev_off, const int32_t* rev_edge,
