@@ -416,6 +416,20 @@ __global__ __launch_bounds__(256, 1) void gpe_edgegemm_split_kernel(RgParams p, 
         const long row0 = (long)tile * p.R;
         s_rv = (int)((p.M - row0 < p.R) ? (p.M - row0) : p.R);
         const int last = s_rv - 1;
+        if constexpr (LAZY) if (h == 0) {                 // once per tile: the second batch keeps the registers
+            // (issued AHEAD of the row loads: the memory counter retires in order, so commit_row's wait for its row covers these —
+            // behind them, the first commit had to wait for every row of the batch)
+            // the point of this wave's 16 rows (k = 16: one point per wave and tile), clamped into the last valid point
+            const long pt0 = (long)tile * PT + wave * npw, ptl = (long)tile * PT + ((last * rkl) >> 16);
+            const long pt = pt0 < ptl ? pt0 : ptl;
+            // (dword loads at clamped columns: the gradient rows are the caller's [B*N, K] tensor as it is — no 16-B alignment, no
+            // pad columns; the pad lanes' coefficients are 0)
+            const float* gr = p.lz_g + pt * p.lz_ldg + ck;
+            const int rem = p.K - 1 - ck;
+            lz_gq = make_float4(gr[0], gr[rem < 1 ? rem : 1], gr[rem < 2 ? rem : 2], gr[rem < 3 ? rem : 3]);
+            lz_sx = *reinterpret_cast<const uchar4*>(p.lz_amx + pt * p.lz_ldagg + ck);
+            lz_sn = *reinterpret_cast<const uchar4*>(p.lz_amn + pt * p.lz_ldagg + ck);
+        }
 #pragma unroll
         for (int uu = 0; uu < RBH; ++uu) {
             const int u = h * RBH + uu;
@@ -428,18 +442,6 @@ __global__ __launch_bounds__(256, 1) void gpe_edgegemm_split_kernel(RgParams p, 
                 // rows are 16-B aligned and padded to a multiple of 4 columns (checked by the dispatcher)
                 v[uu] = ld4(p.a.base + (row0 + r) * p.a.stride_outer + ck);
             }
-        }
-        if constexpr (LAZY) {
-            // the point of this wave's 16 rows (k = 16: one point per wave and tile), clamped into the last valid point
-            const long pt0 = (long)tile * PT + wave * npw, ptl = (long)tile * PT + ((last * rkl) >> 16);
-            const long pt = pt0 < ptl ? pt0 : ptl;
-            // (dword loads at clamped columns: the gradient rows are the caller's [B*N, K] tensor as it is — no 16-B alignment, no
-            // pad columns; the pad lanes' coefficients are 0)
-            const float* gr = p.lz_g + pt * p.lz_ldg + ck;
-            const int rem = p.K - 1 - ck;
-            lz_gq = make_float4(gr[0], gr[rem < 1 ? rem : 1], gr[rem < 2 ? rem : 2], gr[rem < 3 ? rem : 3]);
-            lz_sx = *reinterpret_cast<const uchar4*>(p.lz_amx + pt * p.lz_ldagg + ck);
-            lz_sn = *reinterpret_cast<const uchar4*>(p.lz_amn + pt * p.lz_ldagg + ck);
         }
         if (AMODE == A_GATHER) {
             const int pt0 = tile * PT + wave * npw + vz, ptl = tile * PT + ((last * rkl) >> 16);
