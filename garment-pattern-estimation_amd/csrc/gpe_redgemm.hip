@@ -1372,7 +1372,14 @@ static int rd_run(RdParams& p, int vmode, float* G, int ldG, float* colsum, floa
         return GPE_OK;
     }
     const long in_max = (p.u.inner > p.v.inner ? p.u.inner : p.v.inner) > 1 ? (p.u.inner > p.v.inner ? p.u.inner : p.v.inner) : 1;
-    if (vmode == V_DENSE && g_rd_math != 1 && !p.lz_g && p.num_tiles > 0 && p.num_tiles < 64L * gx && p.rows * in_max < (1L << 32) &&
+    static const int dbg_deep = getenv("GPE_RD_DEEP") ? atoi(getenv("GPE_RD_DEEP")) : -1;   // measurement override: 0 = never the deep kernel
+    // the edge weight-gradient shapes (<= 208 x 208 outputs, plain 16-B rows, >= 4 row tiles per workgroup) stay on the
+    // producer/consumer kernels below at every size: measured (profiles/r04_h_rd_paths.md, dense V, 150 x 200) 48 / 64 / 106 / 206 us
+    // against the deep kernel's 70 / 107 / 204 / 403 us at E = 41 k / 66 k / 131 k / 262 k rows (f16x3: 46 / 53 / 70 / 127 us); the deep
+    // kernel keeps the row-poor decoder products it was built for (10 k rows x 1000 x 250: 79 against 154 us)
+    const bool edge_shape = gpe_cdiv(p.Ng, 16) == 13 && (gpe_cdiv(p.Mg, 16) == 13 || gpe_cdiv(p.Mg, 16) == 10) && gy == 1 &&
+                            rd_rows_vec(p.u, p.Mg) && rd_rows_vec(p.v, p.Ng) && p.num_tiles >= 4L * gx;
+    if (vmode == V_DENSE && g_rd_math != 1 && !p.lz_g && !edge_shape && dbg_deep != 0 && p.num_tiles > 0 && p.num_tiles < 64L * gx && p.rows * in_max < (1L << 32) &&
         p.rows < (1L << 31) && rd_rows_vec2(p.u, p.Mg)) {
         p.umagic = p.u.inner > 1 ? (unsigned)(((1ull << 32) + p.u.inner - 1) / p.u.inner) : 0;
         p.vmagic = p.v.inner > 1 ? (unsigned)(((1ull << 32) + p.v.inner - 1) / p.v.inner) : 0;
