@@ -100,17 +100,20 @@ def call_work(name, a):
     if name == 'gpe_edge_mlp_fwd':          # a_mode, ldpq, lda, B, N, k, Cin, Cout, ...
         B, N, k, Cin, Cout = a[3], a[4], a[5], a[6], a[7]
         E = float(B) * N * k
-        by = E * Cout * 4 + (B * N * 2.0 * Cin * 4 + E * 4 if a[0] == 0 else E * Cin * 4)
+        so = 2 if a[-1] == 1 else 4         # last int = out_half: the aggregated block's activation stored in fp16 (row g)
+        by = E * Cout * so + (B * N * 2.0 * Cin * 4 + E * 4 if a[0] == 0 else E * Cin * 4)
         return 2.0 * E * Cin * Cout, by
-    if name == 'gpe_edge_mlp_bwd':          # lda, act_mode, ldpq, B, N, k, Cin, Cout
+    if name == 'gpe_edge_mlp_bwd':          # lda, act_mode, ldpq, B, N, k, Cin, Cout, ldo, lddp, ws_bytes, lz_ldg, lz_ldagg
         B, N, k, Cin, Cout = a[3], a[4], a[5], a[6], a[7]
         E = float(B) * N * k
-        by = E * Cin * 4 + E * Cout * 4 + (B * N * 2.0 * Cout * 4 + E * 4 if a[1] == 1 else E * Cout * 4)
+        si = 2 if a[-1] > 0 else 4          # lazy dz3: the A operand is the fp16 activation
+        by = E * Cin * si + E * Cout * 4 + (B * N * 2.0 * Cout * 4 + E * 4 if a[1] == 1 else E * Cout * 4)
         return 2.0 * E * Cin * Cout, by
-    if name == 'gpe_edge_redgemm':          # ldu, v_mode, ldv, ldpq, B, N, k, Mg, Ng
+    if name == 'gpe_edge_redgemm':          # ldu, v_mode, ldv, ldpq, B, N, k, Mg, Ng, ldG, ws_bytes, lz_ldg, lz_ldagg
         B, N, k, Mg, Ng = a[4], a[5], a[6], a[7], a[8]
         E = float(B) * N * k
-        return 2.0 * E * Mg * Ng, E * Mg * 4 + (B * N * 2.0 * Ng * 4 + E * 4 if a[1] == 0 else E * Ng * 4)
+        su = 2 if a[-1] > 0 else 4
+        return 2.0 * E * Mg * Ng, E * Mg * su + (B * N * 2.0 * Ng * 4 + E * 4 if a[1] == 0 else E * Ng * 4)
     if name == 'gpe_edge_dz3':              # lda3, ldg, ldagg, B, N, k, F : the activation read and overwritten
         B, N, k, F = a[3], a[4], a[5], a[6]
         return 0.0, 2.0 * B * N * k * F * 4

@@ -576,6 +576,8 @@ int gpe_edgegemm_try(const RgParams& p, int amode, int emode, int stats_nblk, hi
         const int r = gpe_edgegemm_h3_try(p, amode, emode, stats_nblk, s);
         if (r != 0) return r;
     }
+    // fp16 activation rows / a lazily formed dz3 exist only in the f16x3 single-role kernels: nothing below may touch such buffers
+    if (p.out_half || p.lz_g) return GPE_EINVAL;
     if ((math == 0 || g_eg_math >= 2) && !(p.dbg & 64)) {   // exact fp32: the single-role software-pipelined kernel
         const int r = gpe_edgegemm_sr_try(p, amode, emode, stats_nblk, s);
         if (r != 0) return r;

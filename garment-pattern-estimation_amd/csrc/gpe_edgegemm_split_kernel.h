@@ -177,7 +177,8 @@ __device__ __forceinline__ int x6_scr(int row, int w, int b)
 // division (the non-k16 gather-backward variants sit at the register limit)
 // AGGT (forward only): 1 / 0 = the per-point max / min / argmax / argmin tracking of the aggregated last block is compiled in /
 // out; -1 = decided at run time by p.agg (the tracking then always runs: 24 VALU per row, only the stores are skipped).  The
-// k = 16 instances of the benchmark configuration are instantiated with 0 and 1.
+// k = 16 instances of the benchmark configuration are instantiated with 0 and 1, and with 2 = tracked AND the activation rows stored
+// as _Float16 (RgParams::out_half: the aggregated block whose backward forms dz3 lazily, DESIGN.md 8 row g).
 // LEFT (two-plane policy only): where a wave multiplies its K slabs (wave, wave + 4) of the BQ left-over tiles.
 //   0  inside the slot loop under the wave-dependent `(sl & 3) == wave` — every slot becomes a conditional block that modifies accL,
 //      which the compiler merges with up to 48 register copies per join and runs through accumulation registers with `s_nop 7` +
@@ -196,6 +197,7 @@ __global__ __launch_bounds__(256, 1) void gpe_edgegemm_split_kernel(RgParams p, 
 {
     static_assert(!LAZY || (K16 && AMODE == A_DENSE && EMODE == E_BWD_INPLACE && !PSEUDO), "lazy dz3: k = 16 in-place backward");
     constexpr bool TRACK = (EMODE == E_EDGE_FWD) && AGGT != 0;
+    constexpr bool OUTH = AGGT == 2;                     // 2 = tracked AND the activation rows stored in fp16 (RgParams::out_half)
     constexpr int NT = 4 * AQ + BQ;
     constexpr int KS = (KCH + 1) / 2;
     constexpr bool KTAIL = (KCH & 1) != 0;               // last slab holds only 16 k: lane groups g >= 2 contribute zeros
@@ -440,7 +442,12 @@ __global__ __launch_bounds__(256, 1) void gpe_edgegemm_split_kernel(RgParams p, 
                 v[uu] = ld4(p.pq + (long)jj * p.ldpq + p.H + ck);
             } else {
                 // rows are 16-B aligned and padded to a multiple of 4 columns (checked by the dispatcher)
-                v[uu] = ld4(p.a.base + (row0 + r) * p.a.stride_outer + ck);
+                if constexpr (LAZY) {
+                    // the stored activation is fp16 (8 bytes per quad; pitch in halves): the raw words travel in v[].x / .y
+                    const uint2 hq = *reinterpret_cast<const uint2*>(reinterpret_cast<const _Float16*>(p.a.base) + (row0 + r) * p.a.stride_outer + ck);
+                    v[uu].x = __uint_as_float(hq.x); v[uu].y = __uint_as_float(hq.y);
+                } else
+                    v[uu] = ld4(p.a.base + (row0 + r) * p.a.stride_outer + ck);
             }
         }
         if (AMODE == A_GATHER) {
@@ -463,7 +470,9 @@ __global__ __launch_bounds__(256, 1) void gpe_edgegemm_split_kernel(RgParams p, 
         }
         if constexpr (LAZY) {
             // dz3 of slot u of the wave's point (gpe_dz3_kernel's arithmetic): the message that won the aggregation carries s * g
-            const float av[4] = {o.x, o.y, o.z, o.w};
+            const x6_f32x2 a01 = __builtin_convertvector(__builtin_bit_cast(x6_f16x2, __float_as_uint(o.x)), x6_f32x2);
+            const x6_f32x2 a23 = __builtin_convertvector(__builtin_bit_cast(x6_f16x2, __float_as_uint(o.y)), x6_f32x2);
+            const float av[4] = {a01[0], a01[1], a23[0], a23[1]};
             const float gq[4] = {lz_gq.x, lz_gq.y, lz_gq.z, lz_gq.w};
             const int sx[4] = {lz_sx.x, lz_sx.y, lz_sx.z, lz_sx.w}, sn[4] = {lz_sn.x, lz_sn.y, lz_sn.z, lz_sn.w};
             float dz[4];
@@ -504,7 +513,13 @@ __global__ __launch_bounds__(256, 1) void gpe_edgegemm_split_kernel(RgParams p, 
                 // gather variant: the activation rows stream out past L2 so that they do not evict the cloud's Q table
                 // (counter fetch of this kernel 199 -> <145 MB against 109 MB compulsory, same run time: profiles/r02_b)
                 if (AMODE == A_GATHER) st4_stream(p.out + (e_row0 + r) * p.ldo + c, make_float4(vv[0], vv[1], vv[2], vv[3]));
-                else st4(p.out + (e_row0 + r) * p.ldo + c, make_float4(vv[0], vv[1], vv[2], vv[3]));
+                else if constexpr (OUTH) {
+                    // fp16 rows (RNE), 8 bytes per quad: the backward only forms dz3 from this tensor (mask + a tiny-coefficient term)
+                    const x6_f32x2 v01 = {vv[0], vv[1]}, v23 = {vv[2], vv[3]};
+                    *reinterpret_cast<uint2*>(reinterpret_cast<_Float16*>(p.out) + (e_row0 + r) * p.ldo + c) =
+                        make_uint2(__builtin_bit_cast(unsigned, __builtin_convertvector(v01, x6_f16x2)),
+                                   __builtin_bit_cast(unsigned, __builtin_convertvector(v23, x6_f16x2)));
+                } else st4(p.out + (e_row0 + r) * p.ldo + c, make_float4(vv[0], vv[1], vv[2], vv[3]));
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
                     s32[t] += vv[t];
@@ -535,7 +550,7 @@ __global__ __launch_bounds__(256, 1) void gpe_edgegemm_split_kernel(RgParams p, 
         if (K16 ? (u == X6_PB - 1) : (++es == p.k)) {        // a point is complete (K16: compile-time)
             if (n_on) {
                 const long gpt = e_pt0 + (K16 ? 0 : ept);
-                if (TRACK && (AGGT == 1 || p.agg)) {
+                if (TRACK && (AGGT >= 1 || p.agg)) {
                     const long o = gpt * p.oldagg + c;
                     st4(p.mx + o, make_float4(vmx[0], vmx[1], vmx[2], vmx[3]));
                     st4(p.mn + o, make_float4(vmn[0], vmn[1], vmn[2], vmn[3]));
@@ -878,6 +893,9 @@ static int x6_launch_k(const RgParams& p, int stats_nblk, hipStream_t s)
 template <class SP, int AQ, int BQ, int KCH, int AMODE, int EMODE>
 static int x6_launch(const RgParams& p, int stats_nblk, hipStream_t s)
 {
+    // only the k = 16 aggregated dense forward of the scaled policy stores fp16 rows / only its in-place backward forms dz3 lazily
+    if (p.out_half && !(SP::SCALED && EMODE == E_EDGE_FWD && AMODE == A_DENSE && p.k == 16 && p.agg && !p.pmagic)) return GPE_EINVAL;
+    if (p.lz_g && !(SP::SCALED && EMODE == E_BWD_INPLACE && AMODE == A_DENSE && p.k == 16)) return GPE_EINVAL;
     if constexpr (EMODE != E_BWD_INPLACE) {          // the in-place backward needs nothing per point: never pseudo-points
         if (p.pmagic)
             return p.k == 16 ? x6_launch_k<SP, AQ, BQ, KCH, AMODE, EMODE, true, true>(p, stats_nblk, s)
@@ -890,6 +908,13 @@ static int x6_launch(const RgParams& p, int stats_nblk, hipStream_t s)
             const int left = x6_left_scheme(AMODE, EMODE);
             if constexpr (EMODE == E_EDGE_FWD) {
                 if (p.agg) {
+                    if constexpr (AMODE == A_DENSE) {
+                        // fp16 activation rows (row g): the aggregated dense forward only
+                        if (p.out_half) {
+                            if (left == 2) return x6_launch_k<SP, AQ, BQ, KCH, AMODE, EMODE, true, false, 2, 2>(p, stats_nblk, s);
+                            return x6_launch_k<SP, AQ, BQ, KCH, AMODE, EMODE, true, false, 2, 0>(p, stats_nblk, s);
+                        }
+                    }
                     if (left == 2) return x6_launch_k<SP, AQ, BQ, KCH, AMODE, EMODE, true, false, 1, 2>(p, stats_nblk, s);
                     return x6_launch_k<SP, AQ, BQ, KCH, AMODE, EMODE, true, false, 1, 0>(p, stats_nblk, s);
                 }

@@ -745,7 +745,12 @@ __global__ __launch_bounds__(512, 2) void gpe_redgemm_b3_kernel(RdParams p)
             }
 #pragma unroll
             for (int q = 0; q < RQ; ++q) {
-                ur[q] = rd_ld4(up + q * p.u.stride_outer);
+                if constexpr (LAZY) {
+                    // fp16 rows of the stored activation (pitch in halves): the raw words travel in ur[].x / .y
+                    const uint2 hq = *reinterpret_cast<const uint2*>(reinterpret_cast<const _Float16*>(p.u.base) + (rb + q) * p.u.stride_outer + cu);
+                    ur[q].x = __uint_as_float(hq.x); ur[q].y = __uint_as_float(hq.y);
+                } else
+                    ur[q] = rd_ld4(up + q * p.u.stride_outer);
                 if (VMODE == V_DENSE) vr[q] = rd_ld4(vp + q * p.v.stride_outer);
                 else {
                     const long i = (long)__umulhi((unsigned)(rb + q), p.kmagic);
@@ -772,7 +777,11 @@ __global__ __launch_bounds__(512, 2) void gpe_redgemm_b3_kernel(RdParams p)
                 const int slot0 = (w4 & 1) * RQ;
 #pragma unroll
                 for (int q = 0; q < RQ; ++q) {
-                    const float av[4] = {ur[q].x, ur[q].y, ur[q].z, ur[q].w};
+                    typedef _Float16 rd_h2 __attribute__((ext_vector_type(2)));
+                    typedef float rd_f2 __attribute__((ext_vector_type(2)));
+                    const rd_f2 a01 = __builtin_convertvector(__builtin_bit_cast(rd_h2, __float_as_uint(ur[q].x)), rd_f2);
+                    const rd_f2 a23 = __builtin_convertvector(__builtin_bit_cast(rd_h2, __float_as_uint(ur[q].y)), rd_f2);
+                    const float av[4] = {a01[0], a01[1], a23[0], a23[1]};
                     float dz[4];
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {

@@ -53,6 +53,9 @@ struct RgParams {
     const float* lz_g; int lz_ldg;
     const uint8_t* lz_amx; const uint8_t* lz_amn; int lz_ldagg;
     const float* lz_coef;
+    // fp16 storage of the aggregated block's activation (row g): out_half = the forward stores `out` as _Float16 rows
+    // (ldo in halves); the lazy consumers always read their A operand that way (a.stride_outer in halves)
+    int out_half;
     // host side only: what the CALLER passed (include/gpe_hip.h: amax_a / amax_out / ws of the edge entry points)
     const unsigned* user_amax_a;    // amax word of the A operand (gather: of relu(P_i + Q_j)); NULL = measure in-call
     unsigned* user_amax_out;        // receives the largest magnitude written to `out`; NULL = not wanted

@@ -390,7 +390,7 @@ __global__ __launch_bounds__(256) void gpe_dz3_bound_kernel(const unsigned* __re
 {
     __shared__ float red[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const float a3 = __uint_as_float(amax_a3[0]);
+    const float a3 = __uint_as_float(amax_a3[0]) * 1.001f;           // (the stored activation may be fp16-rounded: + 2^-11)
     float tail = 0.f;
     for (int c = threadIdx.x; c < F; c += 256)
         tail = fmaxf(tail, fabsf(coef[F + c]) + (a3 + fabsf(coef[3 * F + c])) * fabsf(coef[2 * F + c]));
@@ -417,10 +417,13 @@ extern "C" int gpe_edge_mlp_fwd(int a_mode, const float* pq, int ldpq, const int
                                 int lda, int B, int N, int k, int Cin, int Cout, const float* wp,
                                 const float* bias, float* out, int ldo, double* stats_part, int agg, float* mx,
                                 float* mn, uint8_t* amx, uint8_t* amn, int ldagg, const uint32_t* amax_a,
-                                uint32_t* amax_out, void* ws, long ws_bytes, void* stream)
+                                uint32_t* amax_out, void* ws, long ws_bytes, int out_half, void* stream)
 {
     if (!wp || !out || B <= 0 || N <= 0 || k <= 0 || k > 64 || Cin <= 0 || Cout <= 0 || (ldo & 3) || ldo < Cout)
         return GPE_EINVAL;
+    // out_half: `out` is a _Float16 [E][ldo] tensor (the aggregated block's activation when its backward will form dz3 lazily):
+    // only the dense f16x3 forward of a max-aggregated block above the size gate stores it (gpe_edge_lazy_dz3_ok)
+    if (out_half && (a_mode != 1 || !agg || !gpe_edge_lazy_dz3_ok(B, N, k, Cout, Cin))) return GPE_EINVAL;
     // the gather producer builds one <= 256-wide K slab; dense rows stream any K in 256-wide slabs
     if (a_mode == 0 && (!pq || !jg || (ldpq & 3) || (Cin & 3) || Cin > RG_KSLAB)) return GPE_EINVAL;
     if (a_mode == 1 && (!a_in || lda < Cin)) return GPE_EINVAL;
@@ -441,6 +444,7 @@ extern "C" int gpe_edge_mlp_fwd(int a_mode, const float* pq, int ldpq, const int
     p.agg = agg; p.mx = mx; p.mn = mn; p.oamx = amx; p.oamn = amn; p.oldagg = ldagg;
     p.dbg = g_gpe_dbg; p.pin_clouds = B;
     p.user_amax_a = amax_a; p.user_amax_out = amax_out; p.ws = gpe_edge_ws(ws, ws_bytes);
+    p.out_half = out_half;
     int tracked = 0;
     p.tracked = &tracked;
     int rc = gpe_edgegemm_try(p, a_mode == 0 ? A_GATHER : A_DENSE, E_EDGE_FWD,
@@ -452,6 +456,7 @@ extern "C" int gpe_edge_mlp_fwd(int a_mode, const float* pq, int ldpq, const int
     } else
         rc = rc == 1 ? GPE_OK : rc;
     // the caller asked for the largest magnitude written and the kernel that ran did not track it: one streaming pass
+    if (rc == GPE_OK && out_half && !tracked) return GPE_EINVAL;       // (cannot happen: the f16x3 kernels track what they store)
     if (rc == GPE_OK && amax_out && !tracked) rc = gpe_h3_absmax(amax_out, out, p.M, Cout, ldo, (hipStream_t)stream);
     return rc;
 }

@@ -603,7 +603,11 @@ class EdgeConvFn(torch.autograd.Function):
             Cin, Cout = widths[l - 1], widths[l]
             ldo = round_up(Cout, 4)
             last = l == nb - 1
-            a = torch.empty(E, ldo, device=dev, dtype=F32)
+            # row g: the aggregated block's activation is kept in fp16 when its backward will form dz3 lazily — its
+            # only readers then (include/gpe_hip.h "out_half"; gradients move by 2e-6 / 5e-6 of their maximum)
+            half = bool(last and training and aggr == 'max' and words is not None and nb >= 3 and
+                        L.query('gpe_edge_lazy_dz3_ok', B, N, k, Cout, Cin) == 1)
+            a = torch.empty(E, ldo, device=dev, dtype=torch.float16 if half else F32)
             part = torch.empty(nblk, 2, Cout, device=dev, dtype=torch.float64) if training else None
             agg = int(last and aggr == 'max')
             if agg:
@@ -616,11 +620,11 @@ class EdgeConvFn(torch.autograd.Function):
             w_out = _word(words, l)                        # (the last activation's word feeds the bound of a lazily formed dz)
             if l == 1:
                 L.call('gpe_edge_mlp_fwd', 0, PQ, 2 * H0, jg, None, 0, B, N, k, Cin, Cout, wp, bf, a, ldo, part,
-                       agg, mx, mn, amx, amn, ldo, _word(words, 0), w_out, ews, ews_n)
+                       agg, mx, mn, amx, amn, ldo, _word(words, 0), w_out, ews, ews_n, 0)
             else:
                 prev = acts[l - 1]
                 L.call('gpe_edge_mlp_fwd', 1, None, 0, None, prev, prev.stride(0), B, N, k, Cin, Cout, wp, bf, a, ldo,
-                       part, agg, mx, mn, amx, amn, ldo, _word(words, l - 1), w_out, ews, ews_n)
+                       part, agg, mx, mn, amx, amn, ldo, _word(words, l - 1), w_out, ews, ews_n, int(half))
             acts.append(a)
             stats.append(stats_of(part, l))
         Fo = widths[-1]
@@ -678,7 +682,11 @@ class EdgeConvFn(torch.autograd.Function):
         lz = (None, 0, None, None, 0, None)                # lazy dz3 arguments of the two consumers (off)
         if aggr == 'max':
             mx, mn, amx, amn = tail
-            lazy = words is not None and nb >= 3 and L.query('gpe_edge_lazy_dz3_ok', B, N, k, Fo, widths[-2]) == 1
+            # (the forward stored a3 in fp16 exactly when it found the lazy path open; should the mode have changed since — a debug
+            # flag, another arithmetic — the eager pass below runs on an fp32 copy)
+            lazy = a_last.dtype == torch.float16 and L.query('gpe_edge_lazy_dz3_ok', B, N, k, Fo, widths[-2]) == 1
+            if a_last.dtype == torch.float16 and not lazy:
+                a_last = a_last.float()
             L.call('gpe_edge_bwd_point_sums', g_out, ldg, mx, mn, ldF, stats[-1], BN, Fo, part,
                    _word(words, 2 * nb) if lazy else None)
             coef, dg, dbe = bn_bwd_coef(part, psb, stats[-1], Fo, E, g_last, be_last, training)
@@ -1048,7 +1056,7 @@ class DenseMLPFn(torch.autograd.Function):
             L.call('gpe_edge_mlp_fwd', 1, None, 0, None, a_in, a_in.stride(0), 1, M, 1, Cin, Cout,
                    pack_weight(W, col_scale=scale), b if tvec is None else fold_bias(W, b, tvec), a, ldo, part,
                    0, None, None, None, None, 0, _word(words, l - 1) if l > 0 else None,
-                   _word(words, l) if l < n_blocks - 1 else None, ews, ews_n)
+                   _word(words, l) if l < n_blocks - 1 else None, ews, ews_n, 0)
             st = bn_finalize(part, nblk, Cout, M, g, be, eps, momentum, rm, rv, nb) if training \
                 else bn_from_running(rm, rv, g, be, eps)
             acts.append(a)

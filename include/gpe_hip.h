@@ -162,7 +162,13 @@ int gpe_edge_mlp_fwd(int a_mode, const float* pq, int ldpq, const int32_t* jg, c
                      int B, int N, int k, int Cin, int Cout, const float* wp, const float* bias,
                      float* out, int ldo, double* stats_part,
                      int agg, float* mx, float* mn, uint8_t* amx, uint8_t* amn, int ldagg,
-                     const uint32_t* amax_a, uint32_t* amax_out, void* ws, long ws_bytes, void* stream);
+                     const uint32_t* amax_a, uint32_t* amax_out, void* ws, long ws_bytes, int out_half, void* stream);
+/* out_half != 0: `out` is a _Float16 [E][ldo] tensor (ldo in halves, % 4 == 0; values rounded to nearest even) — the storage of the
+ * aggregated block's activation when its backward forms dz3 lazily (below): that backward only needs the ReLU side of a3 and
+ * the term (a3 - mean) * k2 with a coefficient of order 1e-3, gradients move by 2e-6 / 5e-6 of their maximum
+ * (profiles/r04_h_row_g_probe.txt), and the step loses 0.96 GB of traffic per layer.  Only where gpe_edge_lazy_dz3_ok(B, N, k, Cout,
+ * Cin) == 1 with a_mode 1 and agg != 0; anything else returns -22.  mx / mn, the statistics and amax_out are taken from the fp32
+ * values before rounding. */
 /* amax_a: amax word of the A operand (a_mode 0: of relu(P_i+Q_j), e.g. from gpe_edge_pq_amax; a_mode 1: of a_in), amax_out: word
  * that receives the largest |out| — see Conventions.  ws: gpe_edge_ws_bytes(B, N, k, ldagg) bytes, 16-B aligned: the store image
  * of the straight-line kernels, the in-call f16x3 words, the per-pseudo-point rows of a k > 16 launch.  NULL / too small: the
@@ -226,7 +232,8 @@ int gpe_edge_mlp_bwd(const float* a, int lda, int act_mode, const float* pq, int
                      const float* lz_coef, void* stream);
 /* ---- lazy dz3 (ABI version 4): gpe_edge_dz3's in-place pass folded into its two consumers ---------------------------------
  * With lz_g != NULL, gpe_edge_mlp_bwd (act_mode 0: `a`) and gpe_edge_redgemm (v_mode 1: `u`) take the STORED ACTIVATION a3 of the
- * block under the max aggregation instead of dz3 and form dz3 = (a3>0) ? [slot==argsel]*s*g - c1 - (a3-mean)*k2 : 0 while staging
+ * block under the max aggregation — as the _Float16 [E][lda / ldu] tensor gpe_edge_mlp_fwd stored with out_half = 1 (pitch in
+ * halves, % 4 == 0, rows 8-B aligned) — instead of dz3 and form dz3 = (a3>0) ? [slot==argsel]*s*g - c1 - (a3-mean)*k2 : 0 while staging
  * it: lz_g [B*N][lz_ldg] the layer-output gradient as it arrives (any pitch >= F, no alignment requirement), lz_amx / lz_amn
  * [B*N][lz_ldagg] the slots saved by gpe_edge_mlp_fwd, lz_coef [4][F] from gpe_bn_bwd_coef.  a3 is not modified.  Only where
  * gpe_edge_lazy_dz3_ok(...) == 1 (f16x3 arithmetic, k = 16, widths on the two-plane kernels' menu, above the size gate); amax_a /

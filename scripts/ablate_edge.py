@@ -40,8 +40,8 @@ def timeit(fn, n=5):
     return e0.elapsed_time(e1) / n
 
 
-def f2(): L.call('gpe_edge_mlp_fwd', 0, PQ, 2 * H, jg, None, 0, B, N, k, H, H, w2p, b2, a2, H, part, 0, None, None, None, None, 0, None, None, EWS, NWS)
-def f3(): L.call('gpe_edge_mlp_fwd', 1, None, 0, None, a2, H, B, N, k, H, Fo, w3p, b3, a3, 152, part, 1, mx, mn, amx, amn, 152, None, None, EWS, NWS)
+def f2(): L.call('gpe_edge_mlp_fwd', 0, PQ, 2 * H, jg, None, 0, B, N, k, H, H, w2p, b2, a2, H, part, 0, None, None, None, None, 0, None, None, EWS, NWS, 0)
+def f3(): L.call('gpe_edge_mlp_fwd', 1, None, 0, None, a2, H, B, N, k, H, Fo, w3p, b3, a3, 152, part, 1, mx, mn, amx, amn, 152, None, None, EWS, NWS, 0)
 def b2a(): L.call('gpe_edge_mlp_bwd', a3, 152, 0, None, 0, None, B, N, k, Fo, H, w3t, coef, a2, H, None, 0, None, None, EWS, NWS, None, 0, None, None, 0, None)
 def rg(): L.call('gpe_edge_redgemm', a2, H, 0, None, 0, PQ, 2 * H, jg, shift, B, N, k, H, H, G, H, cs, ws, None, None, EWS, NWS, None, 0, None, None, 0, None)
 def rd(): L.call('gpe_edge_redgemm', a3, 152, 1, a2, H, None, 0, None, shift, B, N, k, Fo, H, G[:Fo], H, cs, ws, None, None, EWS, NWS, None, 0, None, None, 0, None)

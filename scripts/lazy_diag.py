@@ -38,7 +38,12 @@ L.call('gpe_edge_redgemm', dz, 152, 1, a2, Cp, None, 0, None, shift, B, N, k, F,
        None, 0, None, None, 0, None)
 Gr = dzr.t() @ (a2.double() - shift.double())
 print('eager redgemm G', rel(Ge, Gr), 'cs', rel(cse, dzr.sum(0)))
-# lazy
+# lazy (reads the activation as the fp16 tensor the forward stores with out_half = 1)
+a3h = a3.half()
+# the reference for the lazy consumers: dz3 from the ROUNDED activation
+a3d = a3h[:, :F].double()
+dzr = torch.where(a3d > 0, torch.where(sel == slot, sg, torch.zeros_like(sg)) - coef[1].double() - (a3d - coef[3].double()) * coef[2].double(), torch.zeros_like(sg))
+Gr = dzr.t() @ (a2.double() - shift.double())
 gu = gp[:, :F].contiguous()                                   # the gradient as autograd hands it over: pitch F, no padding
 stats = torch.zeros(4, F, device='cuda'); stats[2] = coef[0]; stats[1] = 1
 mxx = torch.zeros(BN, 152, device='cuda')
@@ -50,7 +55,7 @@ L.call('gpe_edge_dz3_bound', words[4:5], coef, F, words[2:3], words[3:4])
 wv = lambda w: torch.tensor([w.item()], dtype=torch.int32).view(torch.float32).item()
 print('bound', wv(words[3]), 'measured', wv(words[0]), 'true', dzr.abs().max().item())
 Gl, csl = torch.zeros(F, Cp).cuda(), torch.zeros(F).cuda()
-L.call('gpe_edge_redgemm', a3, 152, 1, a2, Cp, None, 0, None, shift, B, N, k, F, Cp, Gl, Cp, csl, part, words[3:4], words[1:2], ws, nws,
+L.call('gpe_edge_redgemm', a3h, 152, 1, a2, Cp, None, 0, None, shift, B, N, k, F, Cp, Gl, Cp, csl, part, words[3:4], words[1:2], ws, nws,
        gu, F, amx, amn, 152, coef)
 print('lazy  redgemm G', rel(Gl, Gr), 'cs', rel(csl, dzr.sum(0)))
 # propagation
@@ -58,7 +63,7 @@ wt = ops.pack_weight(W, transpose=True)
 oe = a2.clone(); ol = a2.clone()
 L.call('gpe_edge_mlp_bwd', dz, 152, 0, None, 0, None, B, N, k, F, Cp, wt, coef_p, oe, Cp, None, 0, words[0:1], words[5:6], ws, nws,
        None, 0, None, None, 0, None)
-L.call('gpe_edge_mlp_bwd', a3, 152, 0, None, 0, None, B, N, k, F, Cp, wt, coef_p, ol, Cp, None, 0, words[3:4], words[6:7], ws, nws,
+L.call('gpe_edge_mlp_bwd', a3h, 152, 0, None, 0, None, B, N, k, F, Cp, wt, coef_p, ol, Cp, None, 0, words[3:4], words[6:7], ws, nws,
        gu, F, amx, amn, 152, coef)
 y = dzr @ W.double()
 ref = torch.where(a2.double() > 0, coef_p[0].double() * y - coef_p[1].double() - (a2.double() - coef_p[3].double()) * coef_p[2].double(), torch.zeros_like(y))

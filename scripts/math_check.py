@@ -32,8 +32,8 @@ def run():
     part3 = torch.zeros(nblk, 2, Fo, device=dev, dtype=torch.float64)
     mx = torch.zeros(B * N, 152, device=dev); mn = torch.zeros_like(mx)
     amx = torch.zeros(B * N, 152, device=dev, dtype=torch.uint8); amn = torch.zeros_like(amx)
-    L.call('gpe_edge_mlp_fwd', 0, PQ, 2 * H, jg, None, 0, B, N, k, H, H, w2p, b2, a2, H, part2, 0, None, None, None, None, 0, None, None, EWS, NWS)
-    L.call('gpe_edge_mlp_fwd', 1, None, 0, None, a2, H, B, N, k, H, Fo, w3p, b3, a3, 152, part3, 1, mx, mn, amx, amn, 152, None, None, EWS, NWS)
+    L.call('gpe_edge_mlp_fwd', 0, PQ, 2 * H, jg, None, 0, B, N, k, H, H, w2p, b2, a2, H, part2, 0, None, None, None, None, 0, None, None, EWS, NWS, 0)
+    L.call('gpe_edge_mlp_fwd', 1, None, 0, None, a2, H, B, N, k, H, Fo, w3p, b3, a3, 152, part3, 1, mx, mn, amx, amn, 152, None, None, EWS, NWS, 0)
     d2 = a2.clone()
     L.call('gpe_edge_mlp_bwd', dz3, 152, 0, None, 0, None, B, N, k, Fo, H, w3t, coef, d2, H, None, 0, None, None, EWS, NWS, None, 0, None, None, 0, None)
     return a2, a3, mx, part2.sum(0), d2
@@ -60,8 +60,8 @@ a2 = torch.empty(E, H, device=dev); a3 = torch.empty(E, 152, device=dev)
 part = torch.empty(nblk, 2, H, device=dev, dtype=torch.float64)
 mx = torch.empty(B * N, 152, device=dev); mn = torch.empty_like(mx)
 amx = torch.empty(B * N, 152, device=dev, dtype=torch.uint8); amn = torch.empty_like(amx)
-def f2(): L.call('gpe_edge_mlp_fwd', 0, PQ, 2 * H, jg, None, 0, B, N, k, H, H, w2p, b2, a2, H, part, 0, None, None, None, None, 0, None, None, EWS, NWS)
-def f3(): L.call('gpe_edge_mlp_fwd', 1, None, 0, None, a2, H, B, N, k, H, Fo, w3p, b3, a3, 152, part, 1, mx, mn, amx, amn, 152, None, None, EWS, NWS)
+def f2(): L.call('gpe_edge_mlp_fwd', 0, PQ, 2 * H, jg, None, 0, B, N, k, H, H, w2p, b2, a2, H, part, 0, None, None, None, None, 0, None, None, EWS, NWS, 0)
+def f3(): L.call('gpe_edge_mlp_fwd', 1, None, 0, None, a2, H, B, N, k, H, Fo, w3p, b3, a3, 152, part, 1, mx, mn, amx, amn, 152, None, None, EWS, NWS, 0)
 def b2a(): L.call('gpe_edge_mlp_bwd', a3, 152, 0, None, 0, None, B, N, k, Fo, H, w3t, coef, a2, H, None, 0, None, None, EWS, NWS, None, 0, None, None, 0, None)
 for mode in ['f32', 'bf16x3']:
     gpe_amd.set_math(mode)

@@ -765,7 +765,7 @@ def _f16x3_dense_block(gpe, a_in, Wm, bias, B, N, k, amax_a=None, amax_out=None)
     out = torch.empty(E, (Cout + 3) // 4 * 4, device='cuda')
     ws, nws = gpe.ops.edge_workspace(B, N, k, 4, 'cuda')
     L.call('gpe_edge_mlp_fwd', 1, None, 0, None, a_in, a_in.stride(0), B, N, k, Cin, Cout, gpe.ops.pack_weight(Wm), bias, out,
-           out.stride(0), None, 0, None, None, None, None, 0, amax_a, amax_out, ws, nws)
+           out.stride(0), None, 0, None, None, None, None, 0, amax_a, amax_out, ws, nws, 0)
     return out[:, :Cout]
 
 
@@ -1084,7 +1084,8 @@ def test_stitch_losses_and_renumbering(gpe, hardnet, origin, order, supervised):
 
 
 def test_lazy_dz3_matches_the_in_place_pass(gpe):
-    """f16x3, k = 16, above the size gate: the backward of the aggregated block never materialises dz3 — the weight-gradient
+    """f16x3, k = 16, above the size gate: the aggregated block's activation is stored in fp16 and its backward never materialises
+    dz3 — the weight-gradient
     reduce-GEMM and the propagation kernel form it from the stored activation while staging it (include/gpe_hip.h "lazy dz3").
     Same gradients as with the separate in-place pass (gpe_debug_set(512) keeps it), to rounding: both run the fp16 pipe, only
     the scale word differs (a bound instead of the measured maximum) — and both meet the fp64 oracle at the layer test's bars."""
@@ -1112,9 +1113,11 @@ def test_lazy_dz3_matches_the_in_place_pass(gpe):
         L.query('gpe_debug_set', 0)
         gpe.set_math(prev)
     assert torch.equal(res[0][0], res[512][0])                   # same forward
-    assert relerr(res[0][1], res[512][1]) < 2e-6
+    # (the lazy run also keeps a3 in fp16 — include/gpe_hip.h "out_half" — which moves the gradients by 2e-6 / 5e-6 of their
+    # maximum at the encoder's sizes, profiles/r04_h_row_g_probe.txt)
+    assert relerr(res[0][1], res[512][1]) < 1e-5
     for n in res[0][2]:
-        assert relerr(res[0][2][n], res[512][2][n]) < 2e-5, n
+        assert relerr(res[0][2][n], res[512][2][n]) < 3e-5, n
     # against the fp64 oracle on the build's graph
     o64 = copy.deepcopy(oconv).double().train()
     o64.knn_override = conv.last_knn.cpu().view(-1, k).long()
