@@ -331,15 +331,22 @@ __global__ __launch_bounds__(256, 1) void gpe_edgegemm_split_kernel(RgParams p, 
     float4 v[RBH];                                       // rows staged for the next tile (one batch)
     // LAZY: coefficients of the BatchNorm behind the aggregation for this lane's K columns, and — per staged tile — the point's
     // s * g quad and winning slots
-    float lzs[4] = {0.f, 0.f, 0.f, 0.f}, lzc1[4] = {0.f, 0.f, 0.f, 0.f}, lzk2[4] = {0.f, 0.f, 0.f, 0.f}, lzmu[4] = {0.f, 0.f, 0.f, 0.f};
+    // dz3 = (a>0) ? [slot wins] s g - c1 - (a - mean) k2 : 0, evaluated as fma(-k2, a, base) with base = s g + (mean k2 - c1) for the
+    // winning slot, (mean k2 - c1) for the others: lzs = s, lznc = mean k2 - c1, lznk = -k2 per column; lz_sel / lz_won per staged tile
+    float lzs[4] = {0.f, 0.f, 0.f, 0.f}, lznc[4] = {0.f, 0.f, 0.f, 0.f}, lznk[4] = {0.f, 0.f, 0.f, 0.f};
+    int lz_sel[4] = {0, 0, 0, 0};
+    float lz_won[4] = {0.f, 0.f, 0.f, 0.f};
     float4 lz_gq = make_float4(0.f, 0.f, 0.f, 0.f);
     uchar4 lz_sx = make_uchar4(0, 0, 0, 0), lz_sn = make_uchar4(0, 0, 0, 0);
     if constexpr (LAZY) {
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             if (c + t < p.K) {
-                lzs[t] = p.lz_coef[c + t]; lzc1[t] = p.lz_coef[p.K + c + t];
-                lzk2[t] = p.lz_coef[2 * p.K + c + t]; lzmu[t] = p.lz_coef[3 * p.K + c + t];
+                // (all three carry the operand scale sA — a power of two, exact — so that commit_row's split needs no multiply)
+                const float k2 = p.lz_coef[2 * p.K + c + t];
+                lzs[t] = p.lz_coef[c + t] * sA;
+                lznc[t] = __builtin_fmaf(p.lz_coef[3 * p.K + c + t], k2, -p.lz_coef[p.K + c + t]) * sA;
+                lznk[t] = -k2 * sA;
             }
         }
     }
@@ -473,14 +480,20 @@ __global__ __launch_bounds__(256, 1) void gpe_edgegemm_split_kernel(RgParams p, 
             const x6_f32x2 a01 = __builtin_convertvector(__builtin_bit_cast(x6_f16x2, __float_as_uint(o.x)), x6_f32x2);
             const x6_f32x2 a23 = __builtin_convertvector(__builtin_bit_cast(x6_f16x2, __float_as_uint(o.y)), x6_f32x2);
             const float av[4] = {a01[0], a01[1], a23[0], a23[1]};
-            const float gq[4] = {lz_gq.x, lz_gq.y, lz_gq.z, lz_gq.w};
-            const int sx[4] = {lz_sx.x, lz_sx.y, lz_sx.z, lz_sx.w}, sn[4] = {lz_sn.x, lz_sn.y, lz_sn.z, lz_sn.w};
+            if (u == 0) {                                    // (u is a compile-time constant at every call site) once per tile
+                const float gq[4] = {lz_gq.x, lz_gq.y, lz_gq.z, lz_gq.w};
+                const int sx[4] = {lz_sx.x, lz_sx.y, lz_sx.z, lz_sx.w}, sn[4] = {lz_sn.x, lz_sn.y, lz_sn.z, lz_sn.w};
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    lz_sel[t] = (lzs[t] >= 0.f) ? sx[t] : sn[t];
+                    lz_won[t] = __builtin_fmaf(lzs[t], gq[t], lznc[t]);
+                }
+            }
             float dz[4];
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                const int sel = (lzs[t] >= 0.f) ? sx[t] : sn[t];
-                const float hit = (sel == u) ? lzs[t] * gq[t] : 0.f;
-                dz[t] = (av[t] > 0.f) ? hit - lzc1[t] - (av[t] - lzmu[t]) * lzk2[t] : 0.f;
+                const float base = (lz_sel[t] == u) ? lz_won[t] : lznc[t];
+                dz[t] = (av[t] > 0.f) ? __builtin_fmaf(lznk[t], av[t], base) : 0.f;
             }
             o = make_float4(dz[0], dz[1], dz[2], dz[3]);
         }
@@ -488,8 +501,9 @@ __global__ __launch_bounds__(256, 1) void gpe_edgegemm_split_kernel(RgParams p, 
         if constexpr (PLANES) {
             // the row's quad, normalised and split once: 4 values -> 8 bytes in each plane
             unsigned q0[SP::P], q1[SP::P];
-            SP::split2(o.x * sA, o.y * sA, q0);
-            SP::split2(o.z * sA, o.w * sA, q1);
+            const float sc = LAZY ? 1.f : sA;                    // LAZY: dz3 was formed from pre-scaled coefficients
+            SP::split2(o.x * sc, o.y * sc, q0);
+            SP::split2(o.z * sc, o.w * sc, q1);
             char* row = reinterpret_cast<char*>(An) + r * PPITCH + 2 * c;
             *reinterpret_cast<uint2*>(row) = make_uint2(q0[0], q1[0]);
             *reinterpret_cast<uint2*>(row + PLANE) = make_uint2(q0[1], q1[1]);

@@ -704,15 +704,18 @@ __global__ __launch_bounds__(512, 2) void gpe_redgemm_b3_kernel(RdParams p)
         float4 ur[RQ], vr[RQ], vr2[VMODE == V_GATHER ? RQ : 1];
         // LAZY: this lane's coefficient quads, and per fetched tile the s * g quad + winning slots of the wave's point (k = 16 and
         // 32-row tiles aligned to points: a wave's 8 consecutive rows are slots 8 (w4 & 1) .. + 7 of ONE point)
-        float lzs[4] = {0.f, 0.f, 0.f, 0.f}, lzc1[4] = {0.f, 0.f, 0.f, 0.f}, lzk2[4] = {0.f, 0.f, 0.f, 0.f}, lzmu[4] = {0.f, 0.f, 0.f, 0.f};
+        // (dz3 = fma(-k2, a, base), base = s g + (mean k2 - c1) for the winning slot, mean k2 - c1 for the others: gpe_edgegemm_split_kernel.h)
+        float lzs[4] = {0.f, 0.f, 0.f, 0.f}, lznc[4] = {0.f, 0.f, 0.f, 0.f}, lznk[4] = {0.f, 0.f, 0.f, 0.f};
         float4 lz_gq = make_float4(0.f, 0.f, 0.f, 0.f);
         uchar4 lz_sx = make_uchar4(0, 0, 0, 0), lz_sn = make_uchar4(0, 0, 0, 0);
         if constexpr (LAZY) {
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 if (cq + t < p.Mg) {
-                    lzs[t] = p.lz_coef[cq + t]; lzc1[t] = p.lz_coef[p.Mg + cq + t];
-                    lzk2[t] = p.lz_coef[2 * p.Mg + cq + t]; lzmu[t] = p.lz_coef[3 * p.Mg + cq + t];
+                    const float k2 = p.lz_coef[2 * p.Mg + cq + t];
+                    lzs[t] = p.lz_coef[cq + t];
+                    lznc[t] = __builtin_fmaf(p.lz_coef[3 * p.Mg + cq + t], k2, -p.lz_coef[p.Mg + cq + t]);
+                    lznk[t] = -k2;
                 }
             }
         }
@@ -773,7 +776,7 @@ __global__ __launch_bounds__(512, 2) void gpe_redgemm_b3_kernel(RdParams p)
                 float sg[4];
                 int sel[4];
 #pragma unroll
-                for (int t = 0; t < 4; ++t) { sel[t] = (lzs[t] >= 0.f) ? sx[t] : sn[t]; sg[t] = lzs[t] * gq[t]; }
+                for (int t = 0; t < 4; ++t) { sel[t] = (lzs[t] >= 0.f) ? sx[t] : sn[t]; sg[t] = __builtin_fmaf(lzs[t], gq[t], lznc[t]); }
                 const int slot0 = (w4 & 1) * RQ;
 #pragma unroll
                 for (int q = 0; q < RQ; ++q) {
@@ -785,8 +788,8 @@ __global__ __launch_bounds__(512, 2) void gpe_redgemm_b3_kernel(RdParams p)
                     float dz[4];
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
-                        const float hit = (sel[t] == slot0 + q) ? sg[t] : 0.f;
-                        dz[t] = (av[t] > 0.f) ? hit - lzc1[t] - (av[t] - lzmu[t]) * lzk2[t] : 0.f;
+                        const float base = (sel[t] == slot0 + q) ? sg[t] : lznc[t];
+                        dz[t] = (av[t] > 0.f) ? __builtin_fmaf(lznk[t], av[t], base) : 0.f;
                     }
                     ur[q] = make_float4(dz[0], dz[1], dz[2], dz[3]);
                 }

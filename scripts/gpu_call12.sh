@@ -5,7 +5,7 @@ mkdir -p gpurun_out
 timeout 300 python scripts/lazy_diag.py 8 2>&1 | grep -E "eager|lazy|bound|bad" | head -12
 timeout 900 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider -k "lazy_dz3 or (f16x3 and (cfg2 or cfg1 or cfg4 or att_k20 or edgeconv or redgemm or amax or full3d or segment3d)) or two_streams or trajectory" > gpurun_out/r04i_tests.log 2>&1
 tail -6 gpurun_out/r04i_tests.log
-for V in 1 0; do
+for V in 1; do
   GPE_LAZY_DZ3=$V timeout 300 python bench.py --steps 60 --warmup 5 --no-cpu-baseline --no-fast-math-line > gpurun_out/r04i_lazy_$V.log 2>&1
   grep '^{' gpurun_out/r04i_lazy_$V.log | tail -1 > gpurun_out/r04i_lazy_$V.json
   python - <<PY
