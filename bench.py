@@ -72,6 +72,15 @@ def parse():
     return ap.parse_args()
 
 
+def parse_defaults():
+    import sys
+    argv, sys.argv = sys.argv, sys.argv[:1]
+    try:
+        return parse()
+    finally:
+        sys.argv = argv
+
+
 def synthetic(B, N, data_config, seed, device):
     g = torch.Generator().manual_seed(seed)
     P, Lp = data_config['max_pattern_len'], data_config['max_panel_len']
@@ -186,10 +195,17 @@ def csrc_sha():
     return h.hexdigest()[:16]
 
 
+# the committed PMC passes are runs of the DEFAULT workload (scripts/collect_profiles.sh): any other shape / model / loss epoch /
+# arithmetic quotes algorithmic bytes instead (set by main() from the arguments)
+_PMC_APPLIES = [True, None]
+
+
 def _pmc_doc():
     """(doc, source, why-not) of the newest profiles/*_hbm_traffic.json — only if it records the csrc hash of THIS tree
-    (profiles/summarize_pmc.py writes it); a summary made from other kernel sources is refused."""
+    (profiles/summarize_pmc.py writes it) and this run is the workload it was measured on; anything else is refused."""
     import glob
+    if not _PMC_APPLIES[0]:
+        return None, None, _PMC_APPLIES[1]
     files = sorted(glob.glob(os.path.join(REPO, 'profiles', '*_hbm_traffic.json')))
     if not files:
         return None, None, 'no profiles/*_hbm_traffic.json'
@@ -380,6 +396,11 @@ def roofline_tables(rec, nsteps, args, step_s, f16_rows):
 
 def main():
     args = parse()
+    d = parse_defaults()
+    off = [k for k in ('batch', 'points', 'k', 'model', 'epoch', 'math') if getattr(args, k) != getattr(d, k)]
+    if off:
+        _PMC_APPLIES[0] = False
+        _PMC_APPLIES[1] = 'not quoted: the committed PMC passes measure the default workload, this run changes ' + ', '.join('--' + k for k in off)
     import gpe_amd
     from gpe_amd import _lib, configs, nets, parallel
     if args.edge_dbg:
