@@ -317,8 +317,14 @@ __global__ __launch_bounds__(256, 1) void gpe_edgegemm_split_kernel(RgParams p, 
             }
         } else {                                         // N % 4 == 0 guaranteed by the dispatcher
             cs4 = ld4(p.coef_out + c); c14 = ld4(p.coef_out + p.N + c);
-            if (SP::SCALED) cs4 = x6_scale4(cs4, invW);  // the weight scale is undone in the BatchNorm-backward factor of z
+            // both operand scales (powers of two) are undone in the BatchNorm-backward factor of z: the epilogue multiplies the RAW
+            // accumulator
+            if (SP::SCALED) cs4 = x6_scale4(cs4, invW * invA);
             k24 = ld4(p.coef_out + 2 * p.N + c); mu4 = ld4(p.coef_out + 3 * p.N + c);
+            // dz = (a>0) ? fma(z, s', fma(-k2, a, mean k2 - c1)) : 0 — two fmas per element (c14 := mean k2 - c1, k24 := -k2)
+            c14 = make_float4(__builtin_fmaf(mu4.x, k24.x, -c14.x), __builtin_fmaf(mu4.y, k24.y, -c14.y),
+                              __builtin_fmaf(mu4.z, k24.z, -c14.z), __builtin_fmaf(mu4.w, k24.w, -c14.w));
+            k24 = make_float4(-k24.x, -k24.y, -k24.z, -k24.w);
         }
     }
     float amax_run = 0.f;                                // SplitF16x2: largest magnitude written to p.out (-> RgParams::amax_out)
@@ -513,7 +519,8 @@ __global__ __launch_bounds__(256, 1) void gpe_edgegemm_split_kernel(RgParams p, 
     // ---- epilogue of row u (compile-time u) of the tile being finished ------------------------------------------------
     auto epi_row = [&](int u, const float4 zraw) {
         if (!K16 && u >= rwl) return;
-        const float4 z = SP::SCALED ? x6_scale4(zraw, invA) : zraw;     // undo the activation scale (exact: a power of two)
+        // forward: undo the activation scale here (exact: a power of two); backward: folded into cs4 above
+        const float4 z = (SP::SCALED && EMODE == E_EDGE_FWD) ? x6_scale4(zraw, invA) : zraw;
         const int r = rbl + u;
         if (r >= e_rv) return;               // K16: all 16 rows of the wave's point are valid or none is (uniform)
         const int slot = K16 ? u : es;
@@ -551,10 +558,10 @@ __global__ __launch_bounds__(256, 1) void gpe_edgegemm_split_kernel(RgParams p, 
                     av.z = fmaxf(av.z + pv.z, 0.f); av.w = fmaxf(av.w + pv.w, 0.f);
                 }
                 float4 o;
-                o.x = (av.x > 0.f) ? z.x * cs4.x - c14.x - (av.x - mu4.x) * k24.x : 0.f;
-                o.y = (av.y > 0.f) ? z.y * cs4.y - c14.y - (av.y - mu4.y) * k24.y : 0.f;
-                o.z = (av.z > 0.f) ? z.z * cs4.z - c14.z - (av.z - mu4.z) * k24.z : 0.f;
-                o.w = (av.w > 0.f) ? z.w * cs4.w - c14.w - (av.w - mu4.w) * k24.w : 0.f;
+                o.x = (av.x > 0.f) ? __builtin_fmaf(z.x, cs4.x, __builtin_fmaf(k24.x, av.x, c14.x)) : 0.f;
+                o.y = (av.y > 0.f) ? __builtin_fmaf(z.y, cs4.y, __builtin_fmaf(k24.y, av.y, c14.y)) : 0.f;
+                o.z = (av.z > 0.f) ? __builtin_fmaf(z.z, cs4.z, __builtin_fmaf(k24.z, av.z, c14.z)) : 0.f;
+                o.w = (av.w > 0.f) ? __builtin_fmaf(z.w, cs4.w, __builtin_fmaf(k24.w, av.w, c14.w)) : 0.f;
                 st4(p.out + (e_row0 + r) * p.ldo + c, o);
                 if (SP::SCALED && EMODE == E_BWD_INPLACE)
                     amax_run = fmaxf(fmaxf(amax_run, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
