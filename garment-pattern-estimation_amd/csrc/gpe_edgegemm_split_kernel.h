@@ -327,6 +327,7 @@ __global__ __launch_bounds__(256, 1) void gpe_edgegemm_split_kernel(RgParams p, 
             k24 = make_float4(-k24.x, -k24.y, -k24.z, -k24.w);
         }
     }
+    const float invAW = invA * invW;
     float amax_run = 0.f;                                // SplitF16x2: largest magnitude written to p.out (-> RgParams::amax_out)
     float s32[4], q32[4], vmx[4], vmn[4];
     int imx[4], imn[4];
@@ -519,18 +520,19 @@ __global__ __launch_bounds__(256, 1) void gpe_edgegemm_split_kernel(RgParams p, 
     // ---- epilogue of row u (compile-time u) of the tile being finished ------------------------------------------------
     auto epi_row = [&](int u, const float4 zraw) {
         if (!K16 && u >= rwl) return;
-        // forward: undo the activation scale here (exact: a power of two); backward: folded into cs4 above
-        const float4 z = (SP::SCALED && EMODE == E_EDGE_FWD) ? x6_scale4(zraw, invA) : zraw;
+        // the operand scales (powers of two) are undone inside the epilogue's fma: forward through invAW, backward through cs4
+        const float4 z = zraw;
         const int r = rbl + u;
         if (r >= e_rv) return;               // K16: all 16 rows of the wave's point are valid or none is (uniform)
         const int slot = K16 ? u : es;
         if (n_on) {
             if (EMODE == E_EDGE_FWD) {
-                const float vv[4] = {fmaxf(SP::SCALED ? __builtin_fmaf(z.x, invW, bias4.x) : z.x + bias4.x, 0.f),
-                                     fmaxf(SP::SCALED ? __builtin_fmaf(z.y, invW, bias4.y) : z.y + bias4.y, 0.f),
-                                     fmaxf(SP::SCALED ? __builtin_fmaf(z.z, invW, bias4.z) : z.z + bias4.z, 0.f),
-                                     fmaxf(SP::SCALED ? __builtin_fmaf(z.w, invW, bias4.w) : z.w + bias4.w, 0.f)};
-                if (SP::SCALED) amax_run = fmaxf(fmaxf(amax_run, fmaxf(vv[0], vv[1])), fmaxf(vv[2], vv[3]));
+                const float vv[4] = {fmaxf(SP::SCALED ? __builtin_fmaf(z.x, invAW, bias4.x) : z.x + bias4.x, 0.f),
+                                     fmaxf(SP::SCALED ? __builtin_fmaf(z.y, invAW, bias4.y) : z.y + bias4.y, 0.f),
+                                     fmaxf(SP::SCALED ? __builtin_fmaf(z.z, invAW, bias4.z) : z.z + bias4.z, 0.f),
+                                     fmaxf(SP::SCALED ? __builtin_fmaf(z.w, invAW, bias4.w) : z.w + bias4.w, 0.f)};
+                // largest magnitude written: per row here — or, where the per-point maxima are tracked anyway, once per point below
+                if (SP::SCALED && !TRACK) amax_run = fmaxf(fmaxf(amax_run, fmaxf(vv[0], vv[1])), fmaxf(vv[2], vv[3]));
                 // gather variant: the activation rows stream out past L2 so that they do not evict the cloud's Q table
                 // (counter fetch of this kernel 199 -> <145 MB against 109 MB compulsory, same run time: profiles/r02_b)
                 if (AMODE == A_GATHER) st4_stream(p.out + (e_row0 + r) * p.ldo + c, make_float4(vv[0], vv[1], vv[2], vv[3]));
@@ -571,6 +573,7 @@ __global__ __launch_bounds__(256, 1) void gpe_edgegemm_split_kernel(RgParams p, 
         if (K16 ? (u == X6_PB - 1) : (++es == p.k)) {        // a point is complete (K16: compile-time)
             if (n_on) {
                 const long gpt = e_pt0 + (K16 ? 0 : ept);
+                if constexpr (TRACK && SP::SCALED) amax_run = fmaxf(fmaxf(amax_run, fmaxf(vmx[0], vmx[1])), fmaxf(vmx[2], vmx[3]));
                 if (TRACK && (AGGT >= 1 || p.agg)) {
                     const long o = gpt * p.oldagg + c;
                     st4(p.mx + o, make_float4(vmx[0], vmx[1], vmx[2], vmx[3]));
