@@ -1,5 +1,6 @@
 // Internal helpers shared by the gfx950 kernels of libgpe_hip.so (not part of the C ABI).
 #pragma once
+#include <cstdlib>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -170,20 +171,40 @@ __device__ __forceinline__ long gpe_walk_point(const GpePointWalk& w, long u, in
 //   pinned: XCD x = blockIdx.x % 8 takes clouds x, x+8, ...; its gridDim.x/8 workgroups stride through each cloud's tiles.
 // Requires (host-checked) gridDim.x % 8 == 0, B % 8 == 0, gridDim.x / 8 <= tpc.  Positions past the end give tile numbers
 // >= num_tiles in both modes, so `tile < num_tiles` stays the loop condition.
-struct GpeTileSeq { int t, c, step, tpc; };
-__device__ __forceinline__ GpeTileSeq gpe_tile_seq(int tpc)
+struct GpeTileSeq { int t, c, step, tpc, rev, nt; };
+// Direction policy of the persistent edge kernels (host side): the kernels of an EdgeConv layer hand 0.6 - 0.8 GB tensors to each
+// other, and the last ~ 200 MB a kernel touched are the part of them the memory-side cache (256 MB) can still hold.  Fixed per
+// entry point, so that every producer / consumer pair walks in opposite directions — forward: F2 (gather) up, F3 (dense) down;
+// backward: dense reduce-GEMM up, B3 (in place) down, gathered reduce-GEMM up, B2 (gathered) down, pull_dq up.
+// GPE_REV=0 keeps every kernel walking up (A/B measurements).
+static inline int gpe_walk_rev(int down)
+{
+    static const int off = getenv("GPE_REV") ? atoi(getenv("GPE_REV")) == 0 : 0;
+    return off ? 0 : down;
+}
+// rev != 0 walks the same sequence from the far end: pinned — XCD x takes its clouds in the order x + 8 (ncl - 1), ..., x + 8, x
+// (a cloud stays on its XCD); unpinned — mirrored tile numbers nt - 1 - t.  Consecutive kernels that hand a tensor on walk in
+// opposite directions, so that the consumer starts on what the producer touched last (gpe_walk_direction below).
+__device__ __forceinline__ GpeTileSeq gpe_tile_seq(int tpc, int rev = 0, int clouds = 0, int num_tiles = 0)
 {
     GpeTileSeq s;
     s.tpc = tpc;
+    s.rev = rev;
+    s.nt = num_tiles;
     s.step = tpc ? (int)(gridDim.x >> 3) : (int)gridDim.x;
     s.t = tpc ? (int)(blockIdx.x >> 3) : (int)blockIdx.x;
     s.c = tpc ? (int)(blockIdx.x & (GPE_NXCD - 1)) : 0;
+    if (tpc && rev) s.c += GPE_NXCD * (clouds / GPE_NXCD - 1);
     return s;
 }
-__device__ __forceinline__ int gpe_seq_tile(const GpeTileSeq& s) { return s.tpc ? s.c * s.tpc + s.t : s.t; }
+__device__ __forceinline__ int gpe_seq_tile(const GpeTileSeq& s)
+{
+    if (s.tpc) return (s.c < 0) ? 0x7fffffff : s.c * s.tpc + s.t;
+    return (s.rev && s.t < s.nt) ? s.nt - 1 - s.t : s.t;
+}
 __device__ __forceinline__ void gpe_seq_advance(GpeTileSeq& s)
 {
     s.t += s.step;
-    if (s.tpc && s.t >= s.tpc) { s.t -= s.tpc; s.c += GPE_NXCD; }
+    if (s.tpc && s.t >= s.tpc) { s.t -= s.tpc; s.c += s.rev ? -GPE_NXCD : GPE_NXCD; }
 }
 

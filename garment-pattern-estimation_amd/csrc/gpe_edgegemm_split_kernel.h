@@ -601,14 +601,11 @@ __global__ __launch_bounds__(256, 1) void gpe_edgegemm_split_kernel(RgParams p, 
     // clouds): this workgroup sits on XCD x = blockIdx.x % 8 and takes every (gridDim.x/8)-th tile of clouds x, x+8, ... —
     // the gathered Q table of a cloud (3.3 MB at the shipped sizes) is then read through ONE 4 MiB L2 instead of eight.
     // Sequence positions past the end map to tile numbers >= num_tiles in both modes.
-    const int seq_step = p.pin_tpc ? (int)(gridDim.x >> 3) : (int)gridDim.x;
-    int seq_t = p.pin_tpc ? (int)(blockIdx.x >> 3) : (int)blockIdx.x;      // pinned: tile inside the cloud
-    int seq_c = p.pin_tpc ? (int)(blockIdx.x & 7) : 0;                     // pinned: cloud
-    auto seq_tile = [&]() -> int { return p.pin_tpc ? seq_c * p.pin_tpc + seq_t : seq_t; };
-    auto seq_advance = [&]() {
-        seq_t += seq_step;
-        if (p.pin_tpc && seq_t >= p.pin_tpc) { seq_t -= p.pin_tpc; seq_c += GPE_NXCD; }   // host: seq_step <= pin_tpc
-    };
+    // p.rev: the same sequence from the far end (pinned: the XCD's clouds last to first; unpinned: mirrored tile numbers) — the
+    // kernel that consumes a tensor starts on what its producer touched last (gpe_common.h)
+    GpeTileSeq sq = gpe_tile_seq(p.pin_tpc, p.rev, p.pin_clouds, p.num_tiles);
+    auto seq_tile = [&]() -> int { return gpe_seq_tile(sq); };
+    auto seq_advance = [&]() { gpe_seq_advance(sq); };                        // host: gridDim.x / 8 <= pin_tpc
 
     // ---- prologue: stage tile 0 ---------------------------------------------------------------------------------------
     __syncthreads();                                     // A buffers zeroed

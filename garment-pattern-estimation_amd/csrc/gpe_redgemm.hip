@@ -38,6 +38,7 @@ struct RdParams {
     const float* v_shift;                        // optional [Ng]: V := V - shift on valid rows (BN centring)
     int vec;                                     // rows aligned to 16 B and padded to 4 columns: plain 16-B loads
     int pin_tpc;                                 // gather variants of the pc/b3 kernels: tiles per cloud when pinned (gpe_common.h)
+    int rev;                                     // walk the tile sequence from the far end (gpe_common.h GpeTileSeq)
     float* part;                                 // [gridDim.x][MgPad][NgPad]
     double* part_cs;                             // [gridDim.x][MgPad]
     // f16x3 variant of the b3 kernel: bit patterns of the largest magnitudes of U and of V - shift (device memory)
@@ -316,7 +317,7 @@ __global__ __launch_bounds__(512, 2) void gpe_redgemm_pc_kernel(RdParams p)
             for (int n = 0; n < NB; ++n) acc[q][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
         __syncthreads();                           // prologue: tile 0 staged
         int buf = 0;
-        GpeTileSeq sq = gpe_tile_seq(p.pin_tpc);
+        GpeTileSeq sq = gpe_tile_seq(p.pin_tpc, p.rev, p.pin_clouds, p.num_tiles);
         for (int tile = gpe_seq_tile(sq); tile < p.num_tiles; gpe_seq_advance(sq), tile = gpe_seq_tile(sq)) {
             const float* ub = Us + buf * RD_RT * LDU;
             const float* vb = Vs + buf * RD_RT * LDV;
@@ -475,7 +476,7 @@ __global__ __launch_bounds__(512, 2) void gpe_redgemm_pc_kernel(RdParams p)
             for (int t = 0; t < 4; ++t) csd[t] += (double)c32[t];
         };
 
-        GpeTileSeq sq = gpe_tile_seq(p.pin_tpc);
+        GpeTileSeq sq = gpe_tile_seq(p.pin_tpc, p.rev, p.pin_clouds, p.num_tiles);
         int tile = gpe_seq_tile(sq);
         gpe_seq_advance(sq);
         int next = gpe_seq_tile(sq);
@@ -641,7 +642,7 @@ __global__ __launch_bounds__(512, 2) void gpe_redgemm_b3_kernel(RdParams p)
             for (int n = 0; n < NB; ++n) acc[q][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
         __syncthreads();                           // prologue: tile 0 staged
         int buf = 0;
-        GpeTileSeq sq = gpe_tile_seq(p.pin_tpc);
+        GpeTileSeq sq = gpe_tile_seq(p.pin_tpc, p.rev, p.pin_clouds, p.num_tiles);
         for (int tile = gpe_seq_tile(sq); tile < p.num_tiles; gpe_seq_advance(sq), tile = gpe_seq_tile(sq)) {
             const char* ub = Ub + buf * LU::BYTES;
             const char* vb = Vb + buf * LV::BYTES;
@@ -846,7 +847,7 @@ __global__ __launch_bounds__(512, 2) void gpe_redgemm_b3_kernel(RdParams p)
             for (int t = 0; t < 4; ++t) csd[t] += (double)c32[t];
         };
 
-        GpeTileSeq sq = gpe_tile_seq(p.pin_tpc);
+        GpeTileSeq sq = gpe_tile_seq(p.pin_tpc, p.rev, p.pin_clouds, p.num_tiles);
         int tile = gpe_seq_tile(sq);
         gpe_seq_advance(sq);
         int next = gpe_seq_tile(sq);

@@ -34,6 +34,7 @@ struct RgParams {
     // cloud -> XCD pinning of the persistent edge kernels (gpe_common.h): tiles of cloud c are processed by the workgroups
     // of XCD c % 8.  tpc = tiles per cloud (N*k / R, exact); 0 = off.
     int pin_tpc;
+    int rev;                                     // walk the tile sequence from the far end (gpe_common.h GpeTileSeq)
     int pin_clouds;         // B when the caller's rows are B equal clouds (edge kernels), else 0
     // k > 16 on the single-role kernels: a point's k rows are handled as f pseudo-points of k/f rows (gpe_edgegemm_sr.hip);
     // the P row of pseudo-point x is then x / f = umulhi(x, pmagic).  0 = pseudo-points are points.

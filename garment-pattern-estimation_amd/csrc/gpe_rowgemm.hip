@@ -445,6 +445,7 @@ extern "C" int gpe_edge_mlp_fwd(int a_mode, const float* pq, int ldpq, const int
     p.dbg = g_gpe_dbg; p.pin_clouds = B;
     p.user_amax_a = amax_a; p.user_amax_out = amax_out; p.ws = gpe_edge_ws(ws, ws_bytes);
     p.out_half = out_half;
+    p.rev = gpe_walk_rev(a_mode == 1);                 // F2 walks up, F3 down (gpe_common.h)
     int tracked = 0;
     p.tracked = &tracked;
     int rc = gpe_edgegemm_try(p, a_mode == 0 ? A_GATHER : A_DENSE, E_EDGE_FWD,
@@ -484,6 +485,7 @@ extern "C" int gpe_edge_mlp_bwd(const float* a, int lda, int act_mode, const flo
     hipStream_t s = (hipStream_t)stream;
     p.dbg = g_gpe_dbg; p.pin_clouds = B;
     p.user_amax_a = amax_a; p.user_amax_out = amax_out; p.ws = gpe_edge_ws(ws, ws_bytes);
+    p.rev = gpe_walk_rev(1);                           // B3 and B2 walk down: behind a reduce-GEMM that walked up
     if (lz_g) {
         // lazy dz3: `a` is the stored activation of the aggregated block; only the f16x3 k = 16 in-place kernel forms dz3 from it
         // (the caller asked gpe_edge_lazy_dz3_ok first and passes the bound of |dz3| as amax_a)
