@@ -836,57 +836,11 @@ __global__ __launch_bounds__(256) void gpe_knn_planes_kernel(const float* __rest
     }
 }
 
-// Seeded insertion bound (round 4): the caller may hand over ANY k distinct points of the query's cloud (`seed` [nq][seed_ld], local
-// indices; e.g. the previous layer's neighbour list).  The exact k-th neighbour distance cannot exceed D = max over the seeds of the
-// exact distance, so no candidate with d~ > D + E is ever needed: out[q] = D (1 + 2^-20) — the filter adds its 2E.  A loose seed set
-// only makes the bound useless, never wrong.  One wave per query; lane (s, g): seed s = lane % 16 (+ 16 per round), channels
-// [g CQ, (g + 1) CQ) as float4 (rows 16-B aligned, ldx >= round4(C): host-checked).
-__global__ __launch_bounds__(256) void gpe_knn_seed_kernel(const float* __restrict__ x, int ldx, int C, int N, long nq,
-                                                           const int32_t* __restrict__ seed, int seed_ld, int ks,
-                                                           float* __restrict__ out)
-{
-    const int lane = threadIdx.x & 63;
-    const long q = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (q >= nq) return;
-    const long base = (q / N) * N;                                     // first row of the query's cloud
-    const int s = lane & 15, g = lane >> 4;
-    const int C4 = (C + 3) >> 2;                                       // float4 pieces of a row
-    const int CQ = (C4 + 3) >> 2;                                      // pieces per lane group
-    const float* qrow = x + q * ldx;
-    float D = 0.f;
-    for (int s0 = 0; s0 < ks; s0 += 16) {
-        const int si = (s0 + s < ks) ? s0 + s : ks - 1;                // clamped: a repeated seed changes nothing
-        int j = seed[q * seed_ld + si];
-        j = (j < 0) ? 0 : (j >= N ? N - 1 : j);                        // a corrupt list costs tightness, not safety of the loads
-        const float* prow = x + (base + j) * ldx;
-        float acc = 0.f;
-        for (int i = 0; i < CQ; ++i) {
-            const int c4 = g * CQ + i;
-            if (c4 < C4) {
-                const float4 a = *reinterpret_cast<const float4*>(qrow + 4 * c4);
-                const float4 b = *reinterpret_cast<const float4*>(prow + 4 * c4);
-                const int c = 4 * c4;
-                const float d0 = a.x - b.x, d1 = (c + 1 < C) ? a.y - b.y : 0.f, d2 = (c + 2 < C) ? a.z - b.z : 0.f,
-                            d3 = (c + 3 < C) ? a.w - b.w : 0.f;
-                acc = __builtin_fmaf(d0, d0, acc); acc = __builtin_fmaf(d1, d1, acc);
-                acc = __builtin_fmaf(d2, d2, acc); acc = __builtin_fmaf(d3, d3, acc);
-            }
-        }
-        acc += __shfl_xor(acc, 16);
-        acc += __shfl_xor(acc, 32);
-        D = fmaxf(D, acc);
-    }
-#pragma unroll
-    for (int o = 8; o > 0; o >>= 1) D = fmaxf(D, __shfl_xor(D, o));
-    if (lane == 0) out[q] = D * 1.000001f;                             // summation order differs from the defined chain: (C + 2) u
-}
-
 template <int NBMAX>
 __global__ __launch_bounds__(256, 2) void gpe_knn_h3_kernel(const _Float16* __restrict__ pl, const float* __restrict__ isc, int N,
                                                             int CP, int kk, int K2, const float* __restrict__ norms,
                                                             const int* __restrict__ cmax, float ce, int B, int tiles, int pin,
-                                                            int nsplit, unsigned long long* __restrict__ part, int probe,
-                                                            const float* __restrict__ seed_thr)
+                                                            int nsplit, unsigned long long* __restrict__ part, int probe)
 {
     extern __shared__ __align__(16) float smem[];
     constexpr int PLANE_B = KNN_TC * KNN_H3_PITCH;
@@ -928,7 +882,6 @@ __global__ __launch_bounds__(256, 2) void gpe_knn_h3_kernel(const _Float16* __re
 #pragma unroll
     for (int i = 0; i < 16; ++i) { ld_[i] = INFINITY; li_[i] = -1; }
     float thrq = INFINITY;
-    float seedq = INFINITY;                               // seeded bound of this lane's query (lane % 16), in d~ terms
 
     const int j = lane & 15, g = lane >> 4;
     const int myq = (q0 + 16 * wave + j < N) ? q0 + 16 * wave + j : N - 1;
@@ -939,10 +892,7 @@ __global__ __launch_bounds__(256, 2) void gpe_knn_h3_kernel(const _Float16* __re
     {
         const int qi = (q0 + 16 * wave + (lane & 15) < N) ? q0 + 16 * wave + (lane & 15) : N - 1;
         m2e_of = 2.02f * ce * (cnorm[qi] + cm);
-        // every candidate of the exact top-k has d <= D (seed kernel) and therefore d~ <= D + E: insert only below D + 2E
-        if (seed_thr) { seedq = seed_thr[(size_t)b * N + qi] + m2e_of; thrq = seedq; }
     }
-    const bool seeded = seed_thr != nullptr;              // uniform: the first tile then runs the insertion path too
     // ---- the wave's 16 queries: resident B fragments (lane (j, g): query j, halves 32 blk + 8 g .. + 7 of both planes) ----
     const int NB = CP >> 5;
     knn_u32x4 qh[NBMAX], ql[NBMAX];
@@ -1055,7 +1005,7 @@ __global__ __launch_bounds__(256, 2) void gpe_knn_h3_kernel(const _Float16* __re
                     dmin = fminf(fminf(dmin, fminf(d.x, d.y)), fminf(d.z, d.w));
                 }
                 unsigned qm = 0xffffu;
-                if (c0 != c_first || seeded) {
+                if (c0 != c_first) {
                     const unsigned long long hm = __ballot(dmin < thrq);
                     qm = (unsigned)((hm | (hm >> 16) | (hm >> 32) | (hm >> 48)) & 0xffffull);
                 }
@@ -1072,10 +1022,10 @@ __global__ __launch_bounds__(256, 2) void gpe_knn_h3_kernel(const _Float16* __re
                         const float d = dW[i * KNN_LDD + lane];
                         float ldv = ld_[i];
                         int liv = li_[i];
-                        const float t = knn_select_mf(c0 == c_first && !seeded, d, lane, cand, K2, kk, knn_readlane_f(m2e_of, i),
+                        const float t = knn_select_mf(c0 == c_first, d, lane, cand, K2, kk, knn_readlane_f(m2e_of, i),
                                                       knn_readlane_f(thrq, i), mW, ldv, liv);
                         ld_[i] = ldv; li_[i] = liv;
-                        thrq = ((lane & 15) == i) ? fminf(t, seedq) : thrq;
+                        thrq = ((lane & 15) == i) ? t : thrq;
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
@@ -1263,11 +1213,11 @@ extern "C" long gpe_knn_ws_bytes(int B, int N, int C, int k)
     // fp16-pipe filter (16 <= C <= 256): two fp16 planes of the table (C rounded up to 32) + one inverse scale per row
     const size_t CP = ((size_t)C + 31) & ~(size_t)31;
     const size_t plane_bytes = (C >= KNN_MF_MINC && C <= KNN_H3_MAXC) ? ((nq * 2 * CP * sizeof(_Float16) + 255) & ~(size_t)255) + norm_bytes : 0;
-    return (long)(lists + norm_bytes + ((size_t)B * sizeof(int) + 255 & ~(size_t)255) + plane_bytes + norm_bytes + 256);   // (+ seeded bounds)
+    return (long)(lists + norm_bytes + ((size_t)B * sizeof(int) + 255 & ~(size_t)255) + plane_bytes + 256);
 }
 
-extern "C" int gpe_knn(const float* x, int B, int N, int C, int ldx, int k, int32_t* idx, int32_t* idx_glob,
-                       const int32_t* seed_idx, int seed_k, void* ws, long ws_bytes, void* stream)
+extern "C" int gpe_knn(const float* x, int B, int N, int C, int ldx, int k, int32_t* idx, int32_t* idx_glob, void* ws,
+                       long ws_bytes, void* stream)
 {
     if (!x || !idx || B < 0 || N <= 0 || C <= 0 || ldx < C || k <= 0 || k > 64 || k > N || (long)B * N * k >= (1L << 31)) return GPE_EINVAL;
     if (B == 0) return GPE_OK;
@@ -1300,11 +1250,6 @@ extern "C" int gpe_knn(const float* x, int B, int N, int C, int ldx, int k, int3
     size_t need = part_bytes + norm_bytes + cmax_bytes + 256;
     if (h3 && (!ws || (size_t)ws_bytes < need + pl_bytes + norm_bytes)) h3 = false;      // workspace sized by an older query
     if (h3) need += pl_bytes + norm_bytes;
-    // seeded bound (fp16-pipe filter only): needs >= k seeds per query, 16-B loadable rows and room for one float per query
-    static const int dbg_noseed = getenv("GPE_KNN_NOSEED") ? atoi(getenv("GPE_KNN_NOSEED")) : 0;     // A/B measurements
-    bool seeded = h3 && seed_idx && seed_k >= k && !dbg_noseed && nsplit == 1 && ldx % 4 == 0 && ((uintptr_t)x % 16) == 0 &&
-                  ((C + 3) & ~3) <= ldx && ws && (size_t)ws_bytes >= need + norm_bytes;
-    if (seeded) need += norm_bytes;
     char* scratch = (ws && !(((uintptr_t)ws) & 15) && (size_t)ws_bytes >= need) ? (char*)ws : nullptr;
     if (!scratch) return knn_exact(x, B, N, C, ldx, k, idx, idx_glob, nullptr, 0, stream);   // no workspace: the all-exact kernel
     unsigned long long* part = (unsigned long long*)scratch;
@@ -1312,7 +1257,6 @@ extern "C" int gpe_knn(const float* x, int B, int N, int C, int ldx, int k, int3
     int* cmax = (int*)(scratch + part_bytes + norm_bytes);
     _Float16* planes = (_Float16*)(scratch + part_bytes + norm_bytes + cmax_bytes);
     float* iscale = (float*)(scratch + part_bytes + norm_bytes + cmax_bytes + pl_bytes);
-    float* seed_thr = seeded ? (float*)(scratch + part_bytes + norm_bytes + cmax_bytes + pl_bytes + norm_bytes) : nullptr;
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(gpe_knn_norms_kernel, dim3((unsigned)gpe_cdiv((long)nq, 4 * KNN_NORM_ROWS)), dim3(256), 0, s, x, (long)nq, N, C, ldx, norms,
                        cmax);
@@ -1337,21 +1281,16 @@ extern "C" int gpe_knn(const float* x, int B, int N, int C, int ldx, int k, int3
         GPE_CHECK_LAUNCH();
         const size_t lds3 = (size_t)2 * 2 * KNN_TC * KNN_H3_PITCH + (size_t)4 * 16 * KNN_LDD * sizeof(float) +
                             4 * 64 * sizeof(unsigned long long) + 4 * KNN_TC * sizeof(float);
-        if (seeded) {
-            hipLaunchKernelGGL(gpe_knn_seed_kernel, dim3((unsigned)gpe_cdiv((long)nq, 4)), dim3(256), 0, s, x, ldx, C, N, (long)nq, seed_idx,
-                               seed_k, k, seed_thr);
-            GPE_CHECK_LAUNCH();
-        }
         const int NB = CP >> 5;
         if (NB <= 2)
             hipLaunchKernelGGL((gpe_knn_h3_kernel<2>), dim3((unsigned)nblocks), dim3(256), lds3, s, planes, iscale, N, CP, k, K2, norms,
-                               cmax, ce, B, tiles, pin, nsplit, part, mprobe, seed_thr);
+                               cmax, ce, B, tiles, pin, nsplit, part, mprobe);
         else if (NB <= 5)
             hipLaunchKernelGGL((gpe_knn_h3_kernel<5>), dim3((unsigned)nblocks), dim3(256), lds3, s, planes, iscale, N, CP, k, K2, norms,
-                               cmax, ce, B, tiles, pin, nsplit, part, mprobe, seed_thr);
+                               cmax, ce, B, tiles, pin, nsplit, part, mprobe);
         else
             hipLaunchKernelGGL((gpe_knn_h3_kernel<8>), dim3((unsigned)nblocks), dim3(256), lds3, s, planes, iscale, N, CP, k, K2, norms,
-                               cmax, ce, B, tiles, pin, nsplit, part, mprobe, seed_thr);
+                               cmax, ce, B, tiles, pin, nsplit, part, mprobe);
     } else if (vec == 4)
         hipLaunchKernelGGL((gpe_knn_mfma_kernel<4>), dim3((unsigned)nblocks), dim3(256), lds, s, x, N, C, ldx, k, K2, norms, cmax, ce,
                            B, tiles, pin, nsplit, part, mprobe);

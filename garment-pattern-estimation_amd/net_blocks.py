@@ -38,10 +38,7 @@ class DynamicEdgeConv(nn.Module):
         for b in blocks[1:]:
             plan.add_linear(b[0].weight, fwd=False, bwd=True)     # forward packs carry the folded BatchNorm scale
 
-    def forward(self, x, n_clouds, n_points, knn_seed=None):
-        """knn_seed: the neighbour lists of another graph over the same points (EdgeConvFeatures hands layer l - 1's to layer l):
-        k distinct points per query bound its k-th distance from above, so the search can discard most candidates at once
-        (ops.knn; the result is the same bit-exact graph with or without it)."""
+    def forward(self, x, n_clouds, n_points):
         nb = len(self.nn)
         blocks = [self.nn[i] for i in range(nb)]
         lin = [b[0] for b in blocks]
@@ -57,11 +54,7 @@ class DynamicEdgeConv(nn.Module):
             # a first-block width the fused P|Q kernels do not take: the general (explicit-message) formulation
             out, idx = ops.edge_conv_general(x, n_clouds, n_points, self.k, self.training, eps, mom, nb, self.aggr, args)
         else:
-            ops._KNN_SEED[0] = knn_seed
-            try:
-                out, idx = ops.EdgeConvFn.apply(x, n_clouds, n_points, self.k, self.training, eps, mom, nb, self.aggr, *args)
-            finally:
-                ops._KNN_SEED[0] = None
+            out, idx = ops.EdgeConvFn.apply(x, n_clouds, n_points, self.k, self.training, eps, mom, nb, self.aggr, *args)
         self.last_knn = idx
         return out
 
@@ -118,10 +111,8 @@ class EdgeConvFeatures(nn.Module):
         # batch vector of the reference (nn/net_blocks.py:165-167); the kernels only need (B, N)
         batch = torch.arange(B, device=positions.device).repeat_interleave(N)
         out = pos_flat
-        prev = None
         for conv in self.conv_layers:
-            out = conv(out, B, N, knn_seed=prev)
-            prev = conv.last_knn                           # this layer's graph seeds the next layer's search
+            out = conv(out, B, N)
         if self.config['skip_connections']:
             out = torch.cat([out, pos_flat], dim=-1)
         if global_pool:

@@ -390,25 +390,15 @@ def redgemm_raw(u_desc, v_desc, rows, Mg, Ng, want_colsum=True, accumulate_into=
     return G, cs
 
 
-# seed lists for the next knn() call of this thread's forward (set by net_blocks.DynamicEdgeConv around EdgeConvFn.apply: the
-# previous layer's graph is a set of k distinct points per query, i.e. a valid upper bound of the k-th distance, include/gpe_hip.h)
-_KNN_SEED = [None]
-
-
-def knn(x, B, N, k, want_global=False, seed=None):
+def knn(x, B, N, k, want_global=False):
     """x: [B*N, C] rows (ld = x.stride(0)).  -> int32 [B, N, k] local neighbour indices (and, optionally, the same
-    graph as global row numbers b*N + idx, the form the gather kernels consume).  seed: int32 [B, N, ks >= k] of DISTINCT local
-    indices per query (any such set bounds the search; a good one — the previous layer's graph — shortens it; result unchanged).
+    graph as global row numbers b*N + idx, the form the gather kernels consume).
     Replaces torch_cluster.knn under DynamicEdgeConv (nn/net_blocks.py:127-135)."""
     _dev_check(x)
     idx = torch.empty(B, N, k, device=x.device, dtype=torch.int32)
     jg = torch.empty(B, N, k, device=x.device, dtype=torch.int32) if want_global else None
     nws = L.query('gpe_knn_ws_bytes', B, N, x.shape[1], k)
-    if seed is not None and not (seed.dtype == torch.int32 and seed.is_contiguous() and seed.dim() == 3 and seed.shape[0] == B and
-                                 seed.shape[1] == N and seed.shape[2] >= k and seed.device == x.device):
-        seed = None
-    L.call('gpe_knn', x, B, N, x.shape[1], x.stride(0), k, idx, jg, seed, seed.shape[2] if seed is not None else 0,
-           _workspace(nws, x.device), nws)
+    L.call('gpe_knn', x, B, N, x.shape[1], x.stride(0), k, idx, jg, _workspace(nws, x.device), nws)
     return (idx, jg) if want_global else idx
 
 
@@ -585,8 +575,7 @@ class EdgeConvFn(torch.autograd.Function):
                              '(got %d): use ops.edge_conv_general' % H0)
         E = BN * k
         nblk = L.query('gpe_stats_blocks')
-        seed, _KNN_SEED[0] = _KNN_SEED[0], None
-        idx, jg = knn(x, B, N, k, want_global=True, seed=seed)
+        idx, jg = knn(x, B, N, k, want_global=True)
         wpq_p, _, bpq = edge_first_operands(Ws[0], params[1])
         PQ = torch.empty(BN, 2 * H0, device=dev, dtype=F32)
         linear_raw(_rows2d(x), wpq_p, bpq, BN, 2 * H0, C, _rows2d(PQ))

@@ -74,12 +74,8 @@ long gpe_f16x3_min_rows_set(long rows);
  * Limits: 1 <= k <= min(64, N) (the k-list of a query lives one entry per lane of its wavefront; torch_cluster's own device
  * kernel stops at k = 100, the reference's configurations use k = 5 .. 20), B*N*k < 2^31; anything else returns -22. */
 long gpe_knn_ws_bytes(int B, int N, int C, int k);
-int gpe_knn(const float* x, int B, int N, int C, int ldx, int k, int32_t* idx, int32_t* idx_glob, const int32_t* seed_idx,
-            int seed_k, void* ws, long ws_bytes, void* stream);
-/* seed_idx (may be NULL) [B][N][seed_k] int32, seed_k >= k: per query k (the first k are used) DISTINCT local indices of its own
- * cloud — e.g. the previous layer's neighbour list.  The k-th neighbour distance cannot exceed the largest distance to them, so the
- * matrix-pipe filter (16 <= C <= 256) starts with that bound instead of ranking its first tile; the result is the same bit-exact
- * graph, found sooner the better the seeds are.  The caller vouches for distinctness: repeated seeds make the bound too small. */
+int gpe_knn(const float* x, int B, int N, int C, int ldx, int k, int32_t* idx, int32_t* idx_glob, void* ws, long ws_bytes,
+            void* stream);
 /* idx_glob (may be NULL) [B][N][k] = b*N + idx: the GLOBAL row of each neighbour, which is what the gather kernels
  * below take as `jg` (B*N*k must be < 2^31).  ws: gpe_knn_ws_bytes(B, N, C, k) bytes, 16-B aligned (squared norms, per-cloud
  * maxima, candidate lists of the matrix-pipe filter / of a split candidate range); NULL or too small: the all-exact kernel

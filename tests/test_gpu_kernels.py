@@ -105,41 +105,6 @@ def test_knn_wide_rows_hard_data(gpe, B, N, C, ld, k, data):
     assert bad == 0, '%d / %d queries differ' % (bad, B * N)
 
 
-@pytest.mark.parametrize('B,N,C,ld,k', [(2, 300, 150, 152, 16), (1, 2048, 33, 36, 16), (8, 512, 150, 152, 16), (2, 513, 256, 256, 20),
-                                        (3, 97, 32, 32, 5)])
-@pytest.mark.parametrize('data', ['gauss', 'clusters', 'lattice'])
-@pytest.mark.parametrize('seeds', ['good', 'random', 'far', 'long'])
-def test_knn_seeded_bound_keeps_the_graph_bit_exact(gpe, B, N, C, ld, k, data, seeds):
-    """gpe_knn with seed lists (include/gpe_hip.h): ANY k distinct points of the query's cloud bound its k-th distance, so the fp16-pipe
-    filter may start from that bound — the graph must stay bit-exact whether the seeds are the true neighbours in a related metric
-    ('good': the graph over the first 3 channels, what EdgeConvFeatures hands from layer to layer), arbitrary ('random'), the k
-    FARTHEST points ('far': a useless bound) or a longer list of which the first k count ('long')."""
-    from oracle import ref_path as O
-    g = torch.Generator().manual_seed(B * 7 + N + C + k)
-    if data == 'gauss':
-        x = torch.randn(B * N, C, generator=g)
-    elif data == 'clusters':
-        cen = torch.randn(8, C, generator=g) * 20
-        x = cen[torch.randint(0, 8, (B * N,), generator=g)] + 1e-2 * torch.randn(B * N, C, generator=g)
-    else:
-        x = torch.randint(0, 3, (B * N, C), generator=g).float()
-        x[:, 8:] = 0
-    buf = torch.zeros(B * N, ld)
-    buf[:, :C] = x
-    ref = O.knn_local(x.contiguous(), B, k).to(torch.int32).view(B, N, k)
-    ks = k + 7 if seeds == 'long' else k
-    if seeds in ('good', 'long'):
-        seed = O.knn_local(x[:, :3].contiguous(), B, ks).to(torch.int32).view(B, N, ks)
-    elif seeds == 'random':
-        seed = torch.stack([torch.stack([torch.randperm(N, generator=g)[:ks] for _ in range(N)]) for _ in range(B)]).to(torch.int32)
-    else:
-        d = torch.cdist(x.view(B, N, C).double(), x.view(B, N, C).double())
-        seed = d.topk(ks, dim=-1, largest=True).indices.to(torch.int32)
-    got = gpe.ops.knn(buf.cuda()[:, :C], B, N, k, seed=seed.contiguous().cuda()).cpu()
-    bad = (got != ref).any(-1).sum().item()
-    assert bad == 0, '%d / %d queries differ' % (bad, B * N)
-
-
 _KNN_ALT_WORKER = '''
 import sys, torch
 sys.path.insert(0, %r)
