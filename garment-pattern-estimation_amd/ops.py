@@ -14,7 +14,6 @@ Two per-model services live here as well (both optional; without them every Func
                 straight into the arena's gradient buffer (no per-parameter tensors, no cat/copy for the all-reduce
                 buckets, one fused Adam launch).
 """
-import os
 import weakref
 
 import numpy as np
@@ -284,70 +283,6 @@ def _gret(param, buf):
 
 
 # -------------------------------------------------------------------------------------------------
-# weight gradients off the critical path
-# -------------------------------------------------------------------------------------------------
-# The decoders' backward is a chain of small launches (recurrent diagonals on 32 .. 288 workgroups, row GEMMs of a few hundred
-# rows) that leaves most of the chip idle, and the weight-gradient reduce-GEMMs of those layers (0.8 ms per step at BASELINE cfg 2)
-# feed nothing but the optimizer.  With the gradient arena registered they are issued on a SIDE stream, ordered behind everything
-# enqueued so far, while the main stream carries on with the input-gradient chain; the main stream waits for them — and only then
-# tells the arena that those gradients exist (so a data-parallel bucket cannot leave early) — when the first EdgeConv layer's
-# backward starts (6 ms of full-chip kernels follow: nothing to gain from overlapping into them) or, at the latest, in an
-# end-of-backward callback of the autograd engine.  GPE_WGRAD_OVERLAP=0 keeps everything on one stream (A/B measurements).
-_WGRAD_OVERLAP = os.environ.get('GPE_WGRAD_OVERLAP', '1') != '0'
-_SIDE = {}                 # device index -> {'stream', 'pending': [params], 'armed': end-of-backward callback queued}
-
-
-def _in_arena(p):
-    hit = _SINK.get(p.data_ptr())
-    return hit is not None and hit[0]() is not None
-
-
-def flush_wgrads():
-    """Join the side streams: the current stream waits for the deferred weight-gradient launches, then the arena learns of them."""
-    for dev, st in _SIDE.items():
-        st['armed'] = False
-        if not st['pending']:
-            continue
-        with torch.cuda.device(dev):
-            torch.cuda.current_stream().wait_stream(st['stream'])
-        pend, st['pending'] = st['pending'], []
-        for p in pend:
-            hit = _SINK.get(p.data_ptr())
-            arena = hit[0]() if hit is not None else None
-            if arena is not None:
-                arena.mark_written(p)
-
-
-def _wgrad(run, params, tensors):
-    """run(): the launches that write the gradients of `params` (all of them) into their buffers, reading `tensors`.
-    -> True when they were deferred to the side stream (the caller then returns None for these parameters WITHOUT _gret: the
-    arena is told at the join), False when they ran inline."""
-    if not (_WGRAD_OVERLAP and tensors and tensors[0].is_cuda and all(_in_arena(p) for p in params)):
-        run()
-        return False
-    dev = tensors[0].device.index
-    st = _SIDE.get(dev)
-    if st is None:
-        st = _SIDE[dev] = {'stream': torch.cuda.Stream(device=dev), 'pending': [], 'armed': False}
-    main = torch.cuda.current_stream()
-    side = st['stream']
-    side.wait_stream(main)
-    with torch.cuda.stream(side):
-        run()
-    for t in tensors:
-        if t is not None:
-            t.record_stream(side)                          # the allocator must not hand their memory out before the side stream is done
-    st['pending'].extend(params)
-    if not st['armed']:
-        try:
-            torch.autograd.Variable._execution_engine.queue_callback(flush_wgrads)
-            st['armed'] = True
-        except RuntimeError:                               # not inside a backward pass (a Function called by hand): join now
-            flush_wgrads()
-    return True
-
-
-# -------------------------------------------------------------------------------------------------
 # raw wrappers
 # -------------------------------------------------------------------------------------------------
 def pack_weight(w, transpose=False, col_scale=None):
@@ -536,12 +471,9 @@ class LinearFn(torch.autograd.Function):
         if ctx.needs_input_grad[1] or bias is not None:
             gw = _gbuf(weight)
             gb = _gbuf(bias) if bias is not None else torch.empty(N, device=x.device, dtype=F32)
-            if _wgrad(lambda: redgemm_raw(_rows2d(gy), xd, M, N, K, out=(gw, gb)), [weight] + ([bias] if bias is not None else []),
-                      [gy, x] + ([] if bias is not None else [gb])):
-                gw = gb = None                             # in the arena; reported at the join (flush_wgrads)
-            else:
-                gw = _gret(weight, gw)
-                gb = _gret(bias, gb) if bias is not None else None
+            redgemm_raw(_rows2d(gy), xd, M, N, K, out=(gw, gb))
+            gw = _gret(weight, gw)
+            gb = _gret(bias, gb) if bias is not None else None
         return gx, gw, gb
 
 
@@ -722,7 +654,6 @@ class EdgeConvFn(torch.autograd.Function):
             raise RuntimeError('EdgeConvFn.backward ran twice on the same graph: the stored activations are overwritten '
                                'in place by the first pass (retain_graph is not supported)')
         ctx.done = True
-        flush_wgrads()                                     # deferred weight gradients of the decoders: join before the full-chip kernels
         B, N, k, C, nb, aggr, training = ctx.dims
         widths = ctx.widths
         sv = ctx.saved_tensors
@@ -1001,28 +932,25 @@ class RNNStackFn(torch.autograd.Function):
         d_h0 = torch.empty(Lr, Bn, Hh, device=dev, dtype=F32) if want_h0 else None
         d_c0 = carry[0].clone() if want_c0 else None
         nz = (GH + 255) // 256
-        wjobs, wbufs, wtens = [], [], [x, hs, dgx, dgh]    # the weight-gradient products: off the critical path (_wgrad)
         for l in range(Lr):
             w_ih, w_hh, b_ih, b_hh = params[4 * l: 4 * l + 4]
             gx_rows, gh_rows = _rows3d(dgx[l][:, :, :GH]), _rows3d(dgh[l][:, :, :GH])
             d_whh, d_bhh = _gbuf(w_hh), _gbuf(b_hh)
-            wjobs.append((gh_rows, _rows3d(hs[l][:, :T, :Hh]), Bn * T, GH, Hh, (d_whh, d_bhh)))
+            redgemm_raw(gh_rows, _rows3d(hs[l][:, :T, :Hh]), Bn * T, GH, Hh, out=(d_whh, d_bhh))
             d_wih, d_bih = _gbuf(w_ih), _gbuf(b_ih)
-            wbufs.append((d_wih, d_whh, d_bih, d_bhh))
             if l == 0 and not seq:
                 # the same input row feeds every step: sum the gate gradients over T first, then ONE Bn-row product
                 # (T times fewer rows than dG^T x over the repeated input)
                 dGs = torch.empty(Bn, GH, device=dev, dtype=F32)
                 L.call('gpe_reduce_inner', dgx[0], T * GHp, GHp, T, Bn, GH, dGs, GH, 0)
-                wjobs.append((_rows2d(dGs), _rows2d(x), Bn, GH, In, (d_wih, d_bih)))
-                wtens.append(dGs)
+                redgemm_raw(_rows2d(dGs), _rows2d(x), Bn, GH, In, out=(d_wih, d_bih))
                 if ctx.needs_input_grad[0]:
                     d_x = torch.empty(Bn, In, device=dev, dtype=F32)
                     linear_raw(_rows2d(dGs), pack_weight(w_ih, transpose=True), None, Bn, In, GH, _rows2d(d_x))
             else:
                 Kin = In if l == 0 else Hh
                 src = _rows3d(x) if l == 0 else _rows3d(hs[l - 1][:, 1:, :Hh])
-                wjobs.append((gx_rows, src, Bn * T, GH, Kin, (d_wih, d_bih)))
+                redgemm_raw(gx_rows, src, Bn * T, GH, Kin, out=(d_wih, d_bih))
                 if l == 0 and ctx.needs_input_grad[0]:
                     d_x = torch.empty(Bn, T, In, device=dev, dtype=F32)
                     linear_raw(gx_rows, pack_weight(w_ih, transpose=True), None, Bn * T, In, GH, (d_x, In, 0, 0))
@@ -1033,13 +961,8 @@ class RNNStackFn(torch.autograd.Function):
                 L.call('gpe_reduce_inner', rec, Hh, Bn * Hh, nz, Bn, Hh, d_h0[l], Hh, 0)
                 if not lstm:
                     L.call('gpe_add', d_h0[l], carry[0][l], d_h0[l], Bn * Hh)
-
-        def run_wjobs():
-            for u, v, rows, Mg, Ng, out in wjobs:
-                redgemm_raw(u, v, rows, Mg, Ng, out=out)
-        if not _wgrad(run_wjobs, [p_ for p_ in params if p_ is not None], wtens):
-            for l in range(Lr):
-                grads[4 * l: 4 * l + 4] = [_gret(p_, b_) for p_, b_ in zip(params[4 * l: 4 * l + 4], wbufs[l])]
+            grads[4 * l: 4 * l + 4] = [_gret(w_ih, d_wih), _gret(w_hh, d_whh), _gret(b_ih, d_bih),
+                                       _gret(b_hh, d_bhh)]
         return (d_x, d_h0, d_c0, None, None, None, None, *grads)
 
 
