@@ -196,3 +196,30 @@ def test_bench_workload_names():
     assert bench._workload_name(mk('lstm', 8192, 64, 16)).startswith('BASELINE cfg 5')
     assert bench._workload_name(mk('lstm', 1000, 3, 10)).startswith('custom shape')
     assert 'N=1000, batch 3/GPU, k=10' in bench._workload_name(mk('lstm', 1000, 3, 10))
+
+
+def test_bench_quotes_counter_traffic_only_for_what_it_measured(monkeypatch):
+    """bench.py's `traffic` fields come from the committed PMC passes: refused when the kernel sources changed since (csrc hash)
+    and — since round 4 — when the run is not the workload those passes measured (another shape / model / loss epoch / arithmetic),
+    and the per-call work model follows the arguments the lazy-dz3 / fp16-activation paths add."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('bench_mod2', os.path.join(os.path.dirname(os.path.dirname(__file__)), 'bench.py'))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    doc, src, why = bench._pmc_doc()
+    assert doc is not None and src.startswith('profiles/') and why is None, why     # the committed file matches this tree's csrc
+    assert doc['csrc_sha'] == bench.csrc_sha()
+    per_launch, _ = bench.pmc_traffic('gpe_edge_mlp_bwd:inplace', 2.0)
+    assert 1.5e9 < per_launch < 3e9                           # the lazy B3: a3 (fp16) + a2 in, dz2 out
+    assert bench.pmc_traffic('gpe_edge_dz3')[0] is None       # no such launch in the benched mode any more
+    bench._PMC_APPLIES[0], bench._PMC_APPLIES[1] = False, 'not quoted: other workload'
+    assert bench._pmc_doc() == (None, None, 'not quoted: other workload')
+    assert bench.pmc_step_bytes() == (None, None)
+    # algorithmic bytes: fp16 rows where the arguments say so (last int of the call: out_half / lz_ldagg)
+    E = 32 * 2048 * 16
+    fwd32 = bench.call_work('gpe_edge_mlp_fwd', (1, 0, 200, 32, 2048, 16, 200, 150, 152, 1, 152, 4096, 0))[1]
+    fwd16 = bench.call_work('gpe_edge_mlp_fwd', (1, 0, 200, 32, 2048, 16, 200, 150, 152, 1, 152, 4096, 1))[1]
+    assert fwd32 - fwd16 == E * 150 * 2
+    b32 = bench.call_work('gpe_edge_mlp_bwd', (152, 0, 0, 32, 2048, 16, 150, 200, 200, 0, 4096, 0, 0))[1]
+    b16 = bench.call_work('gpe_edge_mlp_bwd', (152, 0, 0, 32, 2048, 16, 150, 200, 200, 0, 4096, 150, 152))[1]
+    assert b32 - b16 == E * 150 * 2
