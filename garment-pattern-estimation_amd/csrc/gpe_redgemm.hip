@@ -598,13 +598,8 @@ template <int CT> struct RdB3Layout {                 // CT = number of 16-colum
     }
 };
 
-// PW = producer waves (4 or 8; the workgroup is 256 + 64 PW threads).  The four consumers need 0.7 us of MFMAs per 32-row tile; four
-// producers needed 2.5 us for its loads, the (lazy dz3 +) split arithmetic and the LDS writes — ~800 instructions per wave and tile at
-// the ~7 cycles an instruction costs next to a consumer's MFMAs on the same SIMD — so the consumers idled 75 % of the time
-// (profiles/r04_l_sq_wave_states.md: 0.43 - 0.45 parked over all waves).  Eight producers take 4 consecutive rows each (half of an
-// 8-row LDS group: 8-byte plane writes).
-template <int MT, int NT, int VMODE, bool F16 = false, bool LAZY = false, int PW = 4>
-__global__ __launch_bounds__(256 + 64 * PW, 1) void gpe_redgemm_b3_kernel(RdParams p)   // (100 - 118 KB of LDS: one workgroup per CU either way)
+template <int MT, int NT, int VMODE, bool F16 = false, bool LAZY = false>
+__global__ __launch_bounds__(512, 1) void gpe_redgemm_b3_kernel(RdParams p)   // (100 - 118 KB of LDS: one workgroup per CU either way)
 {
     static_assert(!LAZY || (F16 && VMODE == V_DENSE), "lazy dz3: f16x3 reduce-GEMM with a dense V");
     float sU = 1.f, sV = 1.f, invU = 1.f, invV = 1.f;
@@ -622,12 +617,11 @@ __global__ __launch_bounds__(256 + 64 * PW, 1) void gpe_redgemm_b3_kernel(RdPara
     static_assert(RD_RT == 32, "one v_mfma_f32_16x16x32_bf16 reduces exactly one row tile");
     constexpr int MB = MT / 2, NB = NT / 2;
     constexpr int LEFT = (MT & 1) * NT + (NT & 1) * (MT - (MT & 1));     // left-over tiles
-    constexpr int PMAX = (LEFT + PW - 1) / PW;
+    constexpr int PMAX = (LEFT + 3) / 4;
     constexpr int UC = 16 * MT, VC = 16 * NT;
     using LU = RdB3Layout<MT>;
     using LV = RdB3Layout<NT>;
-    static_assert(PW == 4 || PW == 8, "4 or 8 producer waves");
-    constexpr int RQ = RD_RT / PW;                    // 8 (4) consecutive rows per producer wave
+    constexpr int RQ = RD_RT / 4;                     // 8 consecutive rows per producer wave
     extern __shared__ __align__(16) char smem_b3[];
     char* const Ub = smem_b3;                         // [2][LU::BYTES]
     char* const Vb = smem_b3 + 2 * LU::BYTES;         // [2][LV::BYTES]
@@ -635,9 +629,6 @@ __global__ __launch_bounds__(256 + 64 * PW, 1) void gpe_redgemm_b3_kernel(RdPara
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int w4 = wave & 3;
-    const int wp = wave - 4;                          // producer index 0 .. PW-1 (waves >= 4)
-    const int rg = (PW == 4) ? wp : (wp >> 1);        // the 8-row LDS group a producer writes into, and (PW == 8) which half of it
-    const int rh = (PW == 4) ? 0 : (wp & 1);
     const int j = lane & 15, g = lane >> 4;
     float* dst = p.part + (size_t)blockIdx.x * p.MgPad * p.NgPad;
 
@@ -693,12 +684,12 @@ __global__ __launch_bounds__(256 + 64 * PW, 1) void gpe_redgemm_b3_kernel(RdPara
 #pragma unroll
             for (int t = 0; t < 4; ++t) if (cq + t < p.Ng) sh[t] = p.v_shift[cq + t];
         }
-        // my left-over tiles: list index t = wp, wp + PW, ...  ->  (m, n)
+        // my left-over tiles: list index t = w4, w4+4, ...  ->  (m, n)
         int offU[PMAX > 0 ? PMAX : 1], offV[PMAX > 0 ? PMAX : 1];
         int my_count = 0;
 #pragma unroll
         for (int s_ = 0; s_ < PMAX; ++s_) {
-            const int t = wp + PW * s_;
+            const int t = w4 + 4 * s_;
             int m = 0, n = 0;
             if (t < LEFT) {
                 ++my_count;
@@ -721,10 +712,10 @@ __global__ __launch_bounds__(256 + 64 * PW, 1) void gpe_redgemm_b3_kernel(RdPara
         };
         // two sets where they fit without spilling (measured with hipcc -S: the dense-V 10 x 13 instances; the gathered-V ones hold a
         // third row array and spill 136 - 336 bytes of scratch with two sets)
-        constexpr bool DEEP = PW == 8 || (VMODE == V_DENSE && MT <= 10);
+        constexpr bool DEEP = VMODE == V_DENSE && MT <= 10;
         Stage S0, S1;
         // LAZY: this lane's coefficient quads, and per fetched tile the s * g quad + winning slots of the wave's point (k = 16 and
-        // 32-row tiles aligned to points: a wave's RQ consecutive rows are slots (RQ wp) % 16 .. of ONE point)
+        // 32-row tiles aligned to points: a wave's 8 consecutive rows are slots 8 (w4 & 1) .. + 7 of ONE point)
         // (dz3 = fma(-k2, a, base), base = s g + (mean k2 - c1) for the winning slot, mean k2 - c1 for the others: gpe_edgegemm_split_kernel.h)
         float lzs[4] = {0.f, 0.f, 0.f, 0.f}, lznc[4] = {0.f, 0.f, 0.f, 0.f}, lznk[4] = {0.f, 0.f, 0.f, 0.f};
         S0.lz_gq = S1.lz_gq = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -752,10 +743,10 @@ __global__ __launch_bounds__(256 + 64 * PW, 1) void gpe_redgemm_b3_kernel(RdPara
             return (row0 + RD_RT <= p.rows) ? row0 : p.rows - RD_RT;
         };
         auto load_jgv = [&](int tile) -> int {
-            return p.jg[tile_row0(tile) + RQ * wp + ((lane < RQ) ? lane : RQ - 1)];
+            return p.jg[tile_row0(tile) + RQ * w4 + ((lane < RQ) ? lane : RQ - 1)];
         };
         auto fetch = [&](Stage& S, int tile, int jgv) __attribute__((always_inline)) {
-            const long rb = tile_row0(tile) + RQ * wp;                      // RQ CONSECUTIVE rows per wave
+            const long rb = tile_row0(tile) + RQ * w4;                      // 8 CONSECUTIVE rows per wave
             const float* up = p.u.base + rb * p.u.stride_outer + cu;
             const float* vp = p.v.base + rb * p.v.stride_outer + cv;
             if constexpr (LAZY) {
@@ -790,14 +781,14 @@ __global__ __launch_bounds__(256 + 64 * PW, 1) void gpe_redgemm_b3_kernel(RdPara
             const int rv = (int)((p.rows - row0 < RD_RT) ? (p.rows - row0) : RD_RT);
             float c32[4] = {0.f, 0.f, 0.f, 0.f};
             if constexpr (LAZY) {
-                // U row = dz3 of slot slot0 + q of the wave's point, formed from the stored activation (gpe_dz3_kernel's arithmetic)
+                // U row = dz3 of slot 8 (w4 & 1) + q of the wave's point, formed from the stored activation (gpe_dz3_kernel's arithmetic)
                 const float gq[4] = {S.lz_gq.x, S.lz_gq.y, S.lz_gq.z, S.lz_gq.w};
                 const int sx[4] = {S.lz_sx.x, S.lz_sx.y, S.lz_sx.z, S.lz_sx.w}, sn[4] = {S.lz_sn.x, S.lz_sn.y, S.lz_sn.z, S.lz_sn.w};
                 float sg[4];
                 int sel[4];
 #pragma unroll
                 for (int t = 0; t < 4; ++t) { sel[t] = (lzs[t] >= 0.f) ? sx[t] : sn[t]; sg[t] = __builtin_fmaf(lzs[t], gq[t], lznc[t]); }
-                const int slot0 = (RQ * wp) & 15;                  // first slot of the wave's rows inside their point (k = 16)
+                const int slot0 = (w4 & 1) * RQ;
 #pragma unroll
                 for (int q = 0; q < RQ; ++q) {
                     typedef _Float16 rd_h2 __attribute__((ext_vector_type(2)));
@@ -818,7 +809,7 @@ __global__ __launch_bounds__(256 + 64 * PW, 1) void gpe_redgemm_b3_kernel(RdPara
                 // partial last tile (see fetch: it holds the operands' last 32 rows): rows of the previous tile and pad columns -> 0
 #pragma unroll
                 for (int q = 0; q < RQ; ++q) {
-                    const bool ok = RQ * wp + q >= RD_RT - rv;
+                    const bool ok = RQ * w4 + q >= RD_RT - rv;
                     if (!(ok && u_on)) S.ur[q] = make_float4(0.f, 0.f, 0.f, 0.f);
                     else {
                         if (cq + 1 >= p.Mg) S.ur[q].y = 0.f;
@@ -833,17 +824,12 @@ __global__ __launch_bounds__(256 + 64 * PW, 1) void gpe_redgemm_b3_kernel(RdPara
                 for (int q = 0; q < RQ; ++q) { c32[0] += S.ur[q].x; c32[1] += S.ur[q].y; c32[2] += S.ur[q].z; c32[3] += S.ur[q].w; }
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
-                    unsigned hw[RQ / 2], lw[RQ / 2];
+                    unsigned hw[4], lw[4];
 #pragma unroll
-                    for (int e = 0; e < RQ / 2; ++e)
+                    for (int e = 0; e < 4; ++e)
                         rd_split_pair_p<F16>(rd_comp(S.ur[2 * e], t) * sU, rd_comp(S.ur[2 * e + 1], t) * sU, hw[e], lw[e]);
-                    if constexpr (PW == 4) {
-                        *reinterpret_cast<uint4*>(ub + LU::slot(0, rg, cq + t)) = make_uint4(hw[0], hw[1], hw[2], hw[3]);
-                        *reinterpret_cast<uint4*>(ub + LU::slot(1, rg, cq + t)) = make_uint4(lw[0], lw[1], lw[2], lw[3]);
-                    } else {                               // this wave's 4 rows: one half of the group's 16-byte slot
-                        *reinterpret_cast<uint2*>(ub + LU::slot(0, rg, cq + t) + 8 * rh) = make_uint2(hw[0], hw[1]);
-                        *reinterpret_cast<uint2*>(ub + LU::slot(1, rg, cq + t) + 8 * rh) = make_uint2(lw[0], lw[1]);
-                    }
+                    *reinterpret_cast<uint4*>(ub + LU::slot(0, w4, cq + t)) = make_uint4(hw[0], hw[1], hw[2], hw[3]);
+                    *reinterpret_cast<uint4*>(ub + LU::slot(1, w4, cq + t)) = make_uint4(lw[0], lw[1], lw[2], lw[3]);
                 }
             }
             if (cq < VC) {
@@ -859,17 +845,12 @@ __global__ __launch_bounds__(256 + 64 * PW, 1) void gpe_redgemm_b3_kernel(RdPara
                 }
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
-                    unsigned hw[RQ / 2], lw[RQ / 2];
+                    unsigned hw[4], lw[4];
 #pragma unroll
-                    for (int e = 0; e < RQ / 2; ++e)
+                    for (int e = 0; e < 4; ++e)
                         rd_split_pair_p<F16>(rd_comp(S.vr[2 * e], t) * sV, rd_comp(S.vr[2 * e + 1], t) * sV, hw[e], lw[e]);
-                    if constexpr (PW == 4) {
-                        *reinterpret_cast<uint4*>(vb + LV::slot(0, rg, cq + t)) = make_uint4(hw[0], hw[1], hw[2], hw[3]);
-                        *reinterpret_cast<uint4*>(vb + LV::slot(1, rg, cq + t)) = make_uint4(lw[0], lw[1], lw[2], lw[3]);
-                    } else {
-                        *reinterpret_cast<uint2*>(vb + LV::slot(0, rg, cq + t) + 8 * rh) = make_uint2(hw[0], hw[1]);
-                        *reinterpret_cast<uint2*>(vb + LV::slot(1, rg, cq + t) + 8 * rh) = make_uint2(lw[0], lw[1]);
-                    }
+                    *reinterpret_cast<uint4*>(vb + LV::slot(0, w4, cq + t)) = make_uint4(hw[0], hw[1], hw[2], hw[3]);
+                    *reinterpret_cast<uint4*>(vb + LV::slot(1, w4, cq + t)) = make_uint4(lw[0], lw[1], lw[2], lw[3]);
                 }
             }
 #pragma unroll
@@ -959,18 +940,17 @@ __global__ __launch_bounds__(256 + 64 * PW, 1) void gpe_redgemm_b3_kernel(RdPara
                     dst[(size_t)(offU[s_] + 4 * g + r) * p.NgPad + offV[s_] + j] = accP[s_][r] * invU * invV;
             }
         }
-        double* red = reinterpret_cast<double*>(smem_b3);       // [PW][UC]
+        double* red = reinterpret_cast<double*>(smem_b3);       // [4][UC]
         if (cq < UC) {
 #pragma unroll
-            for (int t = 0; t < 4; ++t) red[wp * UC + cq + t] = csd[t];
+            for (int t = 0; t < 4; ++t) red[w4 * UC + cq + t] = csd[t];
         }
         __syncthreads();                           // tail
     }
     if (tid < p.Mg) {
         const double* red = reinterpret_cast<const double*>(smem_b3);
-        double a = (red[tid] + red[UC + tid]) + (red[2 * UC + tid] + red[3 * UC + tid]);
-        if constexpr (PW == 8) a += (red[4 * UC + tid] + red[5 * UC + tid]) + (red[6 * UC + tid] + red[7 * UC + tid]);
-        p.part_cs[(size_t)blockIdx.x * p.MgPad + tid] = a;
+        p.part_cs[(size_t)blockIdx.x * p.MgPad + tid] =
+            (red[tid] + red[UC + tid]) + (red[2 * UC + tid] + red[3 * UC + tid]);
     }
 }
 
@@ -1395,16 +1375,6 @@ template <int MT, int NT, int VMODE, bool F16 = false, bool LAZY = false>
 static int rd_b3_launch(const RdParams& p, int gx, hipStream_t s)
 {
     const size_t lds = (size_t)2 * (RdB3Layout<MT>::BYTES + RdB3Layout<NT>::BYTES);
-    // the fp16-pipe instances run eight producer waves (768 threads; GPE_RD_PW=4 keeps four for A/B measurements)
-    static const int dbg_pw = getenv("GPE_RD_PW") ? atoi(getenv("GPE_RD_PW")) : 8;
-    if constexpr (F16) {
-        if (dbg_pw == 8) {
-            GPE_ENSURE_MAX_LDS((gpe_redgemm_b3_kernel<MT, NT, VMODE, F16, LAZY, 8>));
-            hipLaunchKernelGGL((gpe_redgemm_b3_kernel<MT, NT, VMODE, F16, LAZY, 8>), dim3(gx), dim3(768), lds, s, p);
-            GPE_CHECK_LAUNCH();
-            return GPE_OK;
-        }
-    }
     GPE_ENSURE_MAX_LDS((gpe_redgemm_b3_kernel<MT, NT, VMODE, F16, LAZY>));
     hipLaunchKernelGGL((gpe_redgemm_b3_kernel<MT, NT, VMODE, F16, LAZY>), dim3(gx), dim3(512), lds, s, p);
     GPE_CHECK_LAUNCH();
