@@ -599,7 +599,7 @@ template <int CT> struct RdB3Layout {                 // CT = number of 16-colum
 };
 
 template <int MT, int NT, int VMODE, bool F16 = false, bool LAZY = false>
-__global__ __launch_bounds__(512, 1) void gpe_redgemm_b3_kernel(RdParams p)   // (100 - 118 KB of LDS: one workgroup per CU either way)
+__global__ __launch_bounds__(512, 2) void gpe_redgemm_b3_kernel(RdParams p)
 {
     static_assert(!LAZY || (F16 && VMODE == V_DENSE), "lazy dz3: f16x3 reduce-GEMM with a dense V");
     float sU = 1.f, sV = 1.f, invU = 1.f, invV = 1.f;
@@ -702,24 +702,13 @@ __global__ __launch_bounds__(512, 1) void gpe_redgemm_b3_kernel(RdParams p)   //
 #pragma unroll
         for (int s_ = 0; s_ < (PMAX > 0 ? PMAX : 1); ++s_) accP[s_] = (f32x4){0.f, 0.f, 0.f, 0.f};
         double csd[4] = {0, 0, 0, 0};
-        // Staged rows of ONE tile.  Two of them alternate: the loads of tile t + 2 are issued before tile t + 1 is committed, so a
-        // commit finds its rows (issued a whole iteration earlier) arrived — with one set every iteration paid a full memory
-        // round trip between its fetch and its commit (2.76 us per tile for 1.4 us of bytes, profiles/r04_l_kernel_trace.md)
-        struct Stage {
-            float4 ur[RQ], vr[RQ], vr2[VMODE == V_GATHER ? RQ : 1];
-            float4 lz_gq;
-            uchar4 lz_sx, lz_sn;
-        };
-        // two sets where they fit without spilling (measured with hipcc -S: the dense-V 10 x 13 instances; the gathered-V ones hold a
-        // third row array and spill 136 - 336 bytes of scratch with two sets)
-        constexpr bool DEEP = VMODE == V_DENSE && MT <= 10;
-        Stage S0, S1;
+        float4 ur[RQ], vr[RQ], vr2[VMODE == V_GATHER ? RQ : 1];
         // LAZY: this lane's coefficient quads, and per fetched tile the s * g quad + winning slots of the wave's point (k = 16 and
         // 32-row tiles aligned to points: a wave's 8 consecutive rows are slots 8 (w4 & 1) .. + 7 of ONE point)
         // (dz3 = fma(-k2, a, base), base = s g + (mean k2 - c1) for the winning slot, mean k2 - c1 for the others: gpe_edgegemm_split_kernel.h)
         float lzs[4] = {0.f, 0.f, 0.f, 0.f}, lznc[4] = {0.f, 0.f, 0.f, 0.f}, lznk[4] = {0.f, 0.f, 0.f, 0.f};
-        S0.lz_gq = S1.lz_gq = make_float4(0.f, 0.f, 0.f, 0.f);
-        S0.lz_sx = S0.lz_sn = S1.lz_sx = S1.lz_sn = make_uchar4(0, 0, 0, 0);
+        float4 lz_gq = make_float4(0.f, 0.f, 0.f, 0.f);
+        uchar4 lz_sx = make_uchar4(0, 0, 0, 0), lz_sn = make_uchar4(0, 0, 0, 0);
         if constexpr (LAZY) {
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
@@ -732,6 +721,7 @@ __global__ __launch_bounds__(512, 1) void gpe_redgemm_b3_kernel(RdParams p)   //
             }
         }
 
+        int jgv = 0;                                // V_GATHER: lane q <-> neighbour row of this wave's q-th row
         // The producers' instruction diet of gpe_redgemm_pc_kernel, applied here in round 4: a partial last tile
         // is fetched as the LAST 32 rows of the operands (in bounds: the launcher guarantees rows >= 32; row order inside a
         // tile is irrelevant to the sums; the rows that belong to the previous tile are zeroed by commit's slow path), so every
@@ -745,7 +735,7 @@ __global__ __launch_bounds__(512, 1) void gpe_redgemm_b3_kernel(RdParams p)   //
         auto load_jgv = [&](int tile) -> int {
             return p.jg[tile_row0(tile) + RQ * w4 + ((lane < RQ) ? lane : RQ - 1)];
         };
-        auto fetch = [&](Stage& S, int tile, int jgv) __attribute__((always_inline)) {
+        auto fetch = [&](int tile) {
             const long rb = tile_row0(tile) + RQ * w4;                      // 8 CONSECUTIVE rows per wave
             const float* up = p.u.base + rb * p.u.stride_outer + cu;
             const float* vp = p.v.base + rb * p.v.stride_outer + cv;
@@ -753,28 +743,28 @@ __global__ __launch_bounds__(512, 1) void gpe_redgemm_b3_kernel(RdParams p)   //
                 const long pt = rb >> 4;                                    // k = 16 (host-checked); wave-uniform
                 const float* gr = p.lz_g + pt * p.lz_ldg + cu;                  // dword loads at clamped columns: any row pitch
                 const int rem = p.Mg - 1 - cu;
-                S.lz_gq = make_float4(gr[0], gr[rem < 1 ? rem : 1], gr[rem < 2 ? rem : 2], gr[rem < 3 ? rem : 3]);
-                S.lz_sx = *reinterpret_cast<const uchar4*>(p.lz_amx + pt * p.lz_ldagg + cu);
-                S.lz_sn = *reinterpret_cast<const uchar4*>(p.lz_amn + pt * p.lz_ldagg + cu);
+                lz_gq = make_float4(gr[0], gr[rem < 1 ? rem : 1], gr[rem < 2 ? rem : 2], gr[rem < 3 ? rem : 3]);
+                lz_sx = *reinterpret_cast<const uchar4*>(p.lz_amx + pt * p.lz_ldagg + cu);
+                lz_sn = *reinterpret_cast<const uchar4*>(p.lz_amn + pt * p.lz_ldagg + cu);
             }
 #pragma unroll
             for (int q = 0; q < RQ; ++q) {
                 if constexpr (LAZY) {
-                    // fp16 rows of the stored activation (pitch in halves): the raw words travel in S.ur[].x / .y
+                    // fp16 rows of the stored activation (pitch in halves): the raw words travel in ur[].x / .y
                     const uint2 hq = *reinterpret_cast<const uint2*>(reinterpret_cast<const _Float16*>(p.u.base) + (rb + q) * p.u.stride_outer + cu);
-                    S.ur[q].x = __uint_as_float(hq.x); S.ur[q].y = __uint_as_float(hq.y);
+                    ur[q].x = __uint_as_float(hq.x); ur[q].y = __uint_as_float(hq.y);
                 } else
-                    S.ur[q] = rd_ld4(up + q * p.u.stride_outer);
-                if (VMODE == V_DENSE) S.vr[q] = rd_ld4(vp + q * p.v.stride_outer);
+                    ur[q] = rd_ld4(up + q * p.u.stride_outer);
+                if (VMODE == V_DENSE) vr[q] = rd_ld4(vp + q * p.v.stride_outer);
                 else {
                     const long i = (long)__umulhi((unsigned)(rb + q), p.kmagic);
                     const long jj = __builtin_amdgcn_readlane(jgv, q);       // prefetched one tile ahead (load_jgv)
-                    S.vr[q] = rd_ld4(p.pq + i * p.ldpq + cv);
-                    S.vr2[q] = rd_ld4(p.pq + jj * p.ldpq + p.H + cv);
+                    vr[q] = rd_ld4(p.pq + i * p.ldpq + cv);
+                    vr2[q] = rd_ld4(p.pq + jj * p.ldpq + p.H + cv);
                 }
             }
         };
-        auto commit = [&](Stage& S, int buf, int tile) __attribute__((always_inline)) {
+        auto commit = [&](int buf, int tile) {
             char* ub = Ub + buf * LU::BYTES;
             char* vb = Vb + buf * LV::BYTES;
             const long row0 = (long)tile * RD_RT;
@@ -782,8 +772,8 @@ __global__ __launch_bounds__(512, 1) void gpe_redgemm_b3_kernel(RdParams p)   //
             float c32[4] = {0.f, 0.f, 0.f, 0.f};
             if constexpr (LAZY) {
                 // U row = dz3 of slot 8 (w4 & 1) + q of the wave's point, formed from the stored activation (gpe_dz3_kernel's arithmetic)
-                const float gq[4] = {S.lz_gq.x, S.lz_gq.y, S.lz_gq.z, S.lz_gq.w};
-                const int sx[4] = {S.lz_sx.x, S.lz_sx.y, S.lz_sx.z, S.lz_sx.w}, sn[4] = {S.lz_sn.x, S.lz_sn.y, S.lz_sn.z, S.lz_sn.w};
+                const float gq[4] = {lz_gq.x, lz_gq.y, lz_gq.z, lz_gq.w};
+                const int sx[4] = {lz_sx.x, lz_sx.y, lz_sx.z, lz_sx.w}, sn[4] = {lz_sn.x, lz_sn.y, lz_sn.z, lz_sn.w};
                 float sg[4];
                 int sel[4];
 #pragma unroll
@@ -793,8 +783,8 @@ __global__ __launch_bounds__(512, 1) void gpe_redgemm_b3_kernel(RdParams p)   //
                 for (int q = 0; q < RQ; ++q) {
                     typedef _Float16 rd_h2 __attribute__((ext_vector_type(2)));
                     typedef float rd_f2 __attribute__((ext_vector_type(2)));
-                    const rd_f2 a01 = __builtin_convertvector(__builtin_bit_cast(rd_h2, __float_as_uint(S.ur[q].x)), rd_f2);
-                    const rd_f2 a23 = __builtin_convertvector(__builtin_bit_cast(rd_h2, __float_as_uint(S.ur[q].y)), rd_f2);
+                    const rd_f2 a01 = __builtin_convertvector(__builtin_bit_cast(rd_h2, __float_as_uint(ur[q].x)), rd_f2);
+                    const rd_f2 a23 = __builtin_convertvector(__builtin_bit_cast(rd_h2, __float_as_uint(ur[q].y)), rd_f2);
                     const float av[4] = {a01[0], a01[1], a23[0], a23[1]};
                     float dz[4];
 #pragma unroll
@@ -802,7 +792,7 @@ __global__ __launch_bounds__(512, 1) void gpe_redgemm_b3_kernel(RdParams p)   //
                         const float base = (sel[t] == slot0 + q) ? sg[t] : lznc[t];
                         dz[t] = (av[t] > 0.f) ? __builtin_fmaf(lznk[t], av[t], base) : 0.f;
                     }
-                    S.ur[q] = make_float4(dz[0], dz[1], dz[2], dz[3]);
+                    ur[q] = make_float4(dz[0], dz[1], dz[2], dz[3]);
                 }
             }
             if (rv != RD_RT) {
@@ -810,24 +800,24 @@ __global__ __launch_bounds__(512, 1) void gpe_redgemm_b3_kernel(RdParams p)   //
 #pragma unroll
                 for (int q = 0; q < RQ; ++q) {
                     const bool ok = RQ * w4 + q >= RD_RT - rv;
-                    if (!(ok && u_on)) S.ur[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (!(ok && u_on)) ur[q] = make_float4(0.f, 0.f, 0.f, 0.f);
                     else {
-                        if (cq + 1 >= p.Mg) S.ur[q].y = 0.f;
-                        if (cq + 2 >= p.Mg) S.ur[q].z = 0.f;
-                        if (cq + 3 >= p.Mg) S.ur[q].w = 0.f;
+                        if (cq + 1 >= p.Mg) ur[q].y = 0.f;
+                        if (cq + 2 >= p.Mg) ur[q].z = 0.f;
+                        if (cq + 3 >= p.Mg) ur[q].w = 0.f;
                     }
                     // (V needs no mask: a zero U row contributes 0 * finite to every product and nothing to the column sums)
                 }
             }
             if (cq < UC) {
 #pragma unroll
-                for (int q = 0; q < RQ; ++q) { c32[0] += S.ur[q].x; c32[1] += S.ur[q].y; c32[2] += S.ur[q].z; c32[3] += S.ur[q].w; }
+                for (int q = 0; q < RQ; ++q) { c32[0] += ur[q].x; c32[1] += ur[q].y; c32[2] += ur[q].z; c32[3] += ur[q].w; }
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
                     unsigned hw[4], lw[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
-                        rd_split_pair_p<F16>(rd_comp(S.ur[2 * e], t) * sU, rd_comp(S.ur[2 * e + 1], t) * sU, hw[e], lw[e]);
+                        rd_split_pair_p<F16>(rd_comp(ur[2 * e], t) * sU, rd_comp(ur[2 * e + 1], t) * sU, hw[e], lw[e]);
                     *reinterpret_cast<uint4*>(ub + LU::slot(0, w4, cq + t)) = make_uint4(hw[0], hw[1], hw[2], hw[3]);
                     *reinterpret_cast<uint4*>(ub + LU::slot(1, w4, cq + t)) = make_uint4(lw[0], lw[1], lw[2], lw[3]);
                 }
@@ -835,20 +825,20 @@ __global__ __launch_bounds__(512, 1) void gpe_redgemm_b3_kernel(RdParams p)   //
             if (cq < VC) {
 #pragma unroll
                 for (int q = 0; q < RQ; ++q) {
-                    float4 v = S.vr[q];
+                    float4 v = vr[q];
                     if (VMODE == V_GATHER) {
-                        v.x = fmaxf(v.x + S.vr2[q].x, 0.f); v.y = fmaxf(v.y + S.vr2[q].y, 0.f);
-                        v.z = fmaxf(v.z + S.vr2[q].z, 0.f); v.w = fmaxf(v.w + S.vr2[q].w, 0.f);
+                        v.x = fmaxf(v.x + vr2[q].x, 0.f); v.y = fmaxf(v.y + vr2[q].y, 0.f);
+                        v.z = fmaxf(v.z + vr2[q].z, 0.f); v.w = fmaxf(v.w + vr2[q].w, 0.f);
                     }
                     v.x -= sh[0]; v.y -= sh[1]; v.z -= sh[2]; v.w -= sh[3];
-                    S.vr[q] = v;
+                    vr[q] = v;
                 }
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
                     unsigned hw[4], lw[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
-                        rd_split_pair_p<F16>(rd_comp(S.vr[2 * e], t) * sV, rd_comp(S.vr[2 * e + 1], t) * sV, hw[e], lw[e]);
+                        rd_split_pair_p<F16>(rd_comp(vr[2 * e], t) * sV, rd_comp(vr[2 * e + 1], t) * sV, hw[e], lw[e]);
                     *reinterpret_cast<uint4*>(vb + LV::slot(0, w4, cq + t)) = make_uint4(hw[0], hw[1], hw[2], hw[3]);
                     *reinterpret_cast<uint4*>(vb + LV::slot(1, w4, cq + t)) = make_uint4(lw[0], lw[1], lw[2], lw[3]);
                 }
@@ -863,23 +853,14 @@ __global__ __launch_bounds__(512, 1) void gpe_redgemm_b3_kernel(RdParams p)   //
         int next = gpe_seq_tile(sq);
         gpe_seq_advance(sq);
         int next2 = gpe_seq_tile(sq);
-        gpe_seq_advance(sq);
-        int next3 = gpe_seq_tile(sq);
-        const int nt = p.num_tiles;
-        // V_GATHER: the neighbour rows of a tile are loaded one fetch ahead of the fetch that uses them (jg0: of the tile fetched
-        // next, jg1: of the one after)
-        int jg0 = 0, jg1 = 0;
-        if (VMODE == V_GATHER) jg0 = load_jgv(tile < nt ? tile : 0);
-        if (tile < nt) {
-            fetch(S0, tile, jg0);
-            if (VMODE == V_GATHER) jg0 = load_jgv(next < nt ? next : tile);
-            commit(S0, 0, tile);
-            fetch(S0, next < nt ? next : tile, jg0);           // tile + 1: in flight across the prologue barrier
-            if (VMODE == V_GATHER) jg1 = load_jgv(next2 < nt ? next2 : tile);
-        }
+        if (VMODE == V_GATHER) jgv = load_jgv(tile < p.num_tiles ? tile : 0);
+        if (tile < p.num_tiles) { fetch(tile); commit(0, tile); }
+        if (VMODE == V_GATHER && tile < p.num_tiles) jgv = load_jgv(next < p.num_tiles ? next : tile);
         __syncthreads();                           // prologue
         int buf = 0;
-        auto left_over = [&]() __attribute__((always_inline)) {
+        for (; tile < p.num_tiles; tile = next, next = next2, gpe_seq_advance(sq), next2 = gpe_seq_tile(sq)) {
+            fetch(next < p.num_tiles ? next : tile);          // unconditional, clamped (see gpe_redgemm_pc_kernel)
+            if (VMODE == V_GATHER) jgv = load_jgv(next2 < p.num_tiles ? next2 : tile);
             if (PMAX > 0) {
                 const char* ub = Ub + buf * LU::BYTES;
                 const char* vb = Vb + buf * LV::BYTES;
@@ -896,41 +877,9 @@ __global__ __launch_bounds__(512, 1) void gpe_redgemm_b3_kernel(RdParams p)   //
                     }
                 }
             }
-        };
-        // one iteration = one tile = one barrier (the consumers' loop above runs the same count); the two halves differ only in
-        // which register set holds tile + 1 (committed now) and which receives tile + 2 (fetched now)
-        auto step = [&](Stage& Sc, Stage& Sf) __attribute__((always_inline)) {
-            fetch(Sf, next2 < nt ? next2 : tile, jg1);          // unconditional, clamped (see gpe_redgemm_pc_kernel)
-            if (VMODE == V_GATHER) { jg0 = jg1; jg1 = load_jgv(next3 < nt ? next3 : tile); }
-            left_over();
-            if (next < nt) commit(Sc, buf ^ 1, next);
+            if (next < p.num_tiles) commit(buf ^ 1, next);
             __syncthreads();
             buf ^= 1;
-            tile = next; next = next2; next2 = next3;
-            gpe_seq_advance(sq);
-            next3 = gpe_seq_tile(sq);
-        };
-        // one set only (DEEP = false: the instances whose two sets would not fit the register file): tile + 1 is fetched at the top
-        // of the iteration that commits it
-        auto step1 = [&]() __attribute__((always_inline)) {
-            left_over();
-            if (next < nt) commit(S0, buf ^ 1, next);
-            __syncthreads();
-            buf ^= 1;
-            tile = next; next = next2; next2 = next3;
-            gpe_seq_advance(sq);
-            next3 = gpe_seq_tile(sq);
-            fetch(S0, next < nt ? next : tile, jg1);
-            if (VMODE == V_GATHER) jg1 = load_jgv(next2 < nt ? next2 : tile);
-        };
-        if constexpr (DEEP) {
-            while (tile < nt) {
-                step(S0, S1);
-                if (!(tile < nt)) break;
-                step(S1, S0);
-            }
-        } else {
-            while (tile < nt) step1();
         }
 #pragma unroll
         for (int s_ = 0; s_ < PMAX; ++s_) {
