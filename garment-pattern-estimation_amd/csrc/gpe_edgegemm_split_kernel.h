@@ -126,11 +126,9 @@ struct SplitF16x2 {
     {
         const x6_f32x2 v = {a, b};
         const x6_f16x2 h = __builtin_convertvector(v, x6_f16x2);                   // v_cvt_pk_f16_f32, RNE
-        // low plane = fp16(v - h): v_fma_mixlo/hi_f16 read the fp16 halves of h as they are and round the exact difference once —
-        // 3 instructions per pair instead of 5
+        const x6_f32x2 r = v - __builtin_convertvector(h, x6_f32x2);               // exact in fp32
         o[0] = __builtin_bit_cast(unsigned, h);
-        asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(o[1]) : "v"(o[0]), "v"(a));
-        asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(o[1]) : "v"(o[0]), "v"(b));
+        o[1] = __builtin_bit_cast(unsigned, __builtin_convertvector(r, x6_f16x2));
     }
     __device__ static __forceinline__ f32x4 mfma(const x6_u32x4 a, const x6_u32x4 b, const f32x4 c)
     {

@@ -572,11 +572,9 @@ __device__ __forceinline__ void rd_split_pair_p(float x0, float x1, unsigned& hw
     if constexpr (F16) {
         const rd_f32x2_t x = {x0, x1};
         const rd_f16x2_t h = __builtin_convertvector(x, rd_f16x2_t);
-        // low plane = fp16(x - h): v_fma_mixlo/hi_f16 read the fp16 halves of h as they are and round the exact difference once —
-        // 3 instructions per pair instead of 5 (two conversions back, a packed subtract, a packed conversion)
+        const rd_f32x2_t r = x - __builtin_convertvector(h, rd_f32x2_t);
         hw = __builtin_bit_cast(unsigned, h);
-        asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(lw) : "v"(hw), "v"(x0));
-        asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lw) : "v"(hw), "v"(x1));
+        lw = __builtin_bit_cast(unsigned, __builtin_convertvector(r, rd_f16x2_t));
     } else
         rd_split_pair(x0, x1, hw, lw);
 }
@@ -681,10 +679,10 @@ __global__ __launch_bounds__(512, 2) void gpe_redgemm_b3_kernel(RdParams p)
         const int cq = lane << 2;
         const bool u_on = cq < p.Mg, v_on = cq < p.Ng;
         const int cu = u_on ? cq : 0, cv = v_on ? cq : 0;
-        float nsh[4] = {0.f, 0.f, 0.f, 0.f};             // - shift * sV
+        float sh[4] = {0.f, 0.f, 0.f, 0.f};
         if (p.v_shift && v_on) {
 #pragma unroll
-            for (int t = 0; t < 4; ++t) if (cq + t < p.Ng) nsh[t] = -p.v_shift[cq + t] * sV;
+            for (int t = 0; t < 4; ++t) if (cq + t < p.Ng) sh[t] = p.v_shift[cq + t];
         }
         // my left-over tiles: list index t = w4, w4+4, ...  ->  (m, n)
         int offU[PMAX > 0 ? PMAX : 1], offV[PMAX > 0 ? PMAX : 1];
@@ -715,12 +713,10 @@ __global__ __launch_bounds__(512, 2) void gpe_redgemm_b3_kernel(RdParams p)
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 if (cq + t < p.Mg) {
-                    // (all three carry the operand scale sU — a power of two, exact: the split below needs no multiply, the column sums
-                    // are rescaled once at the end)
                     const float k2 = p.lz_coef[2 * p.Mg + cq + t];
-                    lzs[t] = p.lz_coef[cq + t] * sU;
-                    lznc[t] = __builtin_fmaf(p.lz_coef[3 * p.Mg + cq + t], k2, -p.lz_coef[p.Mg + cq + t]) * sU;
-                    lznk[t] = -k2 * sU;
+                    lzs[t] = p.lz_coef[cq + t];
+                    lznc[t] = __builtin_fmaf(p.lz_coef[3 * p.Mg + cq + t], k2, -p.lz_coef[p.Mg + cq + t]);
+                    lznk[t] = -k2;
                 }
             }
         }
@@ -774,7 +770,6 @@ __global__ __launch_bounds__(512, 2) void gpe_redgemm_b3_kernel(RdParams p)
             const long row0 = (long)tile * RD_RT;
             const int rv = (int)((p.rows - row0 < RD_RT) ? (p.rows - row0) : RD_RT);
             float c32[4] = {0.f, 0.f, 0.f, 0.f};
-            const float sUc = LAZY ? 1.f : sU;                 // LAZY: dz3 was formed from pre-scaled coefficients
             if constexpr (LAZY) {
                 // U row = dz3 of slot 8 (w4 & 1) + q of the wave's point, formed from the stored activation (gpe_dz3_kernel's arithmetic)
                 const float gq[4] = {lz_gq.x, lz_gq.y, lz_gq.z, lz_gq.w};
@@ -822,7 +817,7 @@ __global__ __launch_bounds__(512, 2) void gpe_redgemm_b3_kernel(RdParams p)
                     unsigned hw[4], lw[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
-                        rd_split_pair_p<F16>(rd_comp(ur[2 * e], t) * sUc, rd_comp(ur[2 * e + 1], t) * sUc, hw[e], lw[e]);
+                        rd_split_pair_p<F16>(rd_comp(ur[2 * e], t) * sU, rd_comp(ur[2 * e + 1], t) * sU, hw[e], lw[e]);
                     *reinterpret_cast<uint4*>(ub + LU::slot(0, w4, cq + t)) = make_uint4(hw[0], hw[1], hw[2], hw[3]);
                     *reinterpret_cast<uint4*>(ub + LU::slot(1, w4, cq + t)) = make_uint4(lw[0], lw[1], lw[2], lw[3]);
                 }
@@ -835,9 +830,7 @@ __global__ __launch_bounds__(512, 2) void gpe_redgemm_b3_kernel(RdParams p)
                         v.x = fmaxf(v.x + vr2[q].x, 0.f); v.y = fmaxf(v.y + vr2[q].y, 0.f);
                         v.z = fmaxf(v.z + vr2[q].z, 0.f); v.w = fmaxf(v.w + vr2[q].w, 0.f);
                     }
-                    // (v - shift) * sV in one fma (sV is a power of two: bit-identical)
-                    v.x = __builtin_fmaf(v.x, sV, nsh[0]); v.y = __builtin_fmaf(v.y, sV, nsh[1]);
-                    v.z = __builtin_fmaf(v.z, sV, nsh[2]); v.w = __builtin_fmaf(v.w, sV, nsh[3]);
+                    v.x -= sh[0]; v.y -= sh[1]; v.z -= sh[2]; v.w -= sh[3];
                     vr[q] = v;
                 }
 #pragma unroll
@@ -845,7 +838,7 @@ __global__ __launch_bounds__(512, 2) void gpe_redgemm_b3_kernel(RdParams p)
                     unsigned hw[4], lw[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
-                        rd_split_pair_p<F16>(rd_comp(vr[2 * e], t), rd_comp(vr[2 * e + 1], t), hw[e], lw[e]);
+                        rd_split_pair_p<F16>(rd_comp(vr[2 * e], t) * sV, rd_comp(vr[2 * e + 1], t) * sV, hw[e], lw[e]);
                     *reinterpret_cast<uint4*>(vb + LV::slot(0, w4, cq + t)) = make_uint4(hw[0], hw[1], hw[2], hw[3]);
                     *reinterpret_cast<uint4*>(vb + LV::slot(1, w4, cq + t)) = make_uint4(lw[0], lw[1], lw[2], lw[3]);
                 }
@@ -899,7 +892,7 @@ __global__ __launch_bounds__(512, 2) void gpe_redgemm_b3_kernel(RdParams p)
         double* red = reinterpret_cast<double*>(smem_b3);       // [4][UC]
         if (cq < UC) {
 #pragma unroll
-            for (int t = 0; t < 4; ++t) red[w4 * UC + cq + t] = LAZY ? csd[t] * (double)invU : csd[t];   // LAZY: sums of scaled rows
+            for (int t = 0; t < 4; ++t) red[w4 * UC + cq + t] = csd[t];
         }
         __syncthreads();                           // tail
     }
