@@ -538,7 +538,9 @@ __global__ __launch_bounds__(256, 1) void gpe_edgegemm_split_kernel(RgParams p, 
                 if (AMODE == A_GATHER) st4_stream(p.out + (e_row0 + r) * p.ldo + c, make_float4(vv[0], vv[1], vv[2], vv[3]));
                 else if constexpr (OUTH) {
                     // fp16 rows (RNE), 8 bytes per quad: the backward only forms dz3 from this tensor (mask + a tiny-coefficient term)
-                    const x6_f32x2 v01 = {vv[0], vv[1]}, v23 = {vv[2], vv[3]};
+                    // (clamped to the largest finite fp16: an activation beyond 65504 must not become inf in the stored copy — the
+                    // backward would turn it into NaN gradients; mx / mn, the statistics and the amax word keep the fp32 value)
+                    const x6_f32x2 v01 = {fminf(vv[0], 65504.f), fminf(vv[1], 65504.f)}, v23 = {fminf(vv[2], 65504.f), fminf(vv[3], 65504.f)};
                     *reinterpret_cast<uint2*>(reinterpret_cast<_Float16*>(p.out) + (e_row0 + r) * p.ldo + c) =
                         make_uint2(__builtin_bit_cast(unsigned, __builtin_convertvector(v01, x6_f16x2)),
                                    __builtin_bit_cast(unsigned, __builtin_convertvector(v23, x6_f16x2)));

@@ -163,7 +163,7 @@ int gpe_edge_mlp_fwd(int a_mode, const float* pq, int ldpq, const int32_t* jg, c
                      float* out, int ldo, double* stats_part,
                      int agg, float* mx, float* mn, uint8_t* amx, uint8_t* amn, int ldagg,
                      const uint32_t* amax_a, uint32_t* amax_out, void* ws, long ws_bytes, int out_half, void* stream);
-/* out_half != 0: `out` is a _Float16 [E][ldo] tensor (ldo in halves, % 4 == 0; values rounded to nearest even) — the storage of the
+/* out_half != 0: `out` is a _Float16 [E][ldo] tensor (ldo in halves, % 4 == 0; values rounded to nearest even, clamped at 65504) — the storage of the
  * aggregated block's activation when its backward forms dz3 lazily (below): that backward only needs the ReLU side of a3 and
  * the term (a3 - mean) * k2 with a coefficient of order 1e-3, gradients move by 2e-6 / 5e-6 of their maximum
  * (profiles/r04_h_row_g_probe.txt), and the step loses 0.96 GB of traffic per layer.  Only where gpe_edge_lazy_dz3_ok(B, N, k, Cout,

@@ -1083,6 +1083,40 @@ def test_stitch_losses_and_renumbering(gpe, hardnet, origin, order, supervised):
     assert set(do0.keys()) == {'pattern_loss', 'loop_loss', 'rotation_loss', 'translation_loss'} and upd0 == bool(order and 0 == 39)
 
 
+def test_fp16_activation_store_is_clamped_not_inf(gpe):
+    """gpe_edge_mlp_fwd(out_half = 1): an activation beyond the fp16 range is stored as 65504, never as inf (the lazily formed dz3
+    would turn inf into NaN gradients); the per-point maxima, and the amax word, keep the fp32 value."""
+    ops, L = gpe.ops, gpe._lib
+    B, N, k, Cin, Cout = 8, 512, 16, 200, 150
+    E, BN = B * N * k, B * N
+    g = torch.Generator().manual_seed(23)
+    a2 = torch.randn(E, Cin, generator=g).abs().cuda()
+    W = torch.randn(Cout, Cin, generator=g).cuda() * 0.05
+    W[7] = 600.0                                                # column 7: sums of 200 half-normal values x 600 ~ 1e5 > 65504
+    bias = torch.zeros(Cout).cuda()
+    prev = gpe.set_math('f16x3')
+    try:
+        assert L.query('gpe_edge_lazy_dz3_ok', B, N, k, Cout, Cin) == 1
+        a3h = torch.empty(E, 152, device='cuda', dtype=torch.float16)
+        mx = torch.empty(BN, 152, device='cuda'); mn = torch.empty_like(mx)
+        amx = torch.empty(BN, 152, device='cuda', dtype=torch.uint8); amn = torch.empty_like(amx)
+        words = torch.zeros(2, dtype=torch.int32, device='cuda')
+        ws, nws = ops.edge_workspace(B, N, k, 2 * Cin, 'cuda')
+        L.call('gpe_edge_mlp_fwd', 1, None, 0, None, a2, Cin, B, N, k, Cin, Cout, ops.pack_weight(W), bias, a3h, 152, None,
+               1, mx, mn, amx, amn, 152, None, words[0:1], ws, nws, 1)
+    finally:
+        gpe.set_math(prev)
+    ref = torch.relu(a2.double() @ W.double().t())
+    assert ref[:, 7].max().item() > 65504
+    got = a3h[:, :Cout].float()
+    assert torch.isfinite(got).all()
+    assert got[:, 7].max().item() == 65504.0
+    small = ref < 6e4
+    assert ((got.double() - ref).abs()[small] <= ref[small] * 2.0 ** -10 + 1e-6).all()   # everything in range: fp16 rounding of the fp32 value
+    assert relerr(mx[:, 7], ref.view(BN, k, Cout)[:, :, 7].max(1).values) < 1e-6         # the aggregate is not clamped
+    assert _word_value(words[0:1]) > 65504
+
+
 @pytest.mark.parametrize('B,N', [(8, 512), (9, 457)])
 def test_lazy_dz3_matches_the_in_place_pass(gpe, B, N):
     """f16x3, k = 16, above the size gate: the aggregated block's activation is stored in fp16 and its backward never materialises
