@@ -67,7 +67,7 @@ def parse():
                     help="arithmetic of the fused edge GEMMs for the timed region (gpe_math_set); 'f32' = exact")
     ap.add_argument('--no-fast-math-line', action='store_true', help='skip the extra mixed / bf16x3 measurements')
     ap.add_argument('--call-shapes', default=None, metavar='FILE', help='write per-(entry, int args) launch counts and mean durations')
-    ap.add_argument('--edge-dbg', type=int, default=0, help='measurement aid: gpe_debug_set flags for the edge kernels (0 = product path)')
+    ap.add_argument('--edge-dbg', type=int, default=int(os.environ.get('GPE_EDGE_DBG', '0')), help='measurement aid: gpe_debug_set flags for the edge kernels (0 = product path)')
     ap.add_argument('--torch-adam', action='store_true', help='torch.optim.Adam instead of the fused arena optimizer')
     return ap.parse_args()
 

@@ -21,7 +21,11 @@ EXTRA_FLAGS = {'gpe_edgegemm_sr_dense.hip': ['-mllvm', '-amdgpu-sched-strategy=m
                # the bf16x6 mode's forward edge kernels 2.94 -> 2.89 ms per step
                'gpe_edgegemm_x6.hip': ['-mllvm', '-amdgpu-sched-strategy=max-memory-clause'],
                # the f16x3 mode's edge kernels: forward 2.50 -> 2.43, backward 2.24 -> 2.05 ms per step (with the slot fences off)
-               'gpe_edgegemm_h3.hip': ['-mllvm', '-amdgpu-sched-strategy=max-ilp']}
+               'gpe_edgegemm_h3.hip': ['-mllvm', '-amdgpu-sched-strategy=max-ilp'],
+               # the two-waves-per-SIMD instances of the same kernels: F2 / B2 (gpe_edgegemm_w8.hip) under the default scheduler,
+               # F3 and B3 under max-ilp (without / with the slot fence: set in the files) — table in gpe_edgegemm_w8.hip
+               'gpe_edgegemm_w8_f3.hip': ['-mllvm', '-amdgpu-sched-strategy=max-ilp'],
+               'gpe_edgegemm_w8_b3.hip': ['-mllvm', '-amdgpu-sched-strategy=max-ilp']}
 
 
 def _sources():

@@ -151,6 +151,8 @@ int gpe_h3_absmax(unsigned* out, const float* x, long rows, int cols, long ld, h
     return GPE_OK;
 }
 
+int gpe_edgegemm_w8_dispatch(int amode, int emode, int NT, int KCH, const RgParams& p, int stats_nblk, hipStream_t s);   // gpe_edgegemm_w8.hip
+
 template <int AMODE, int EMODE>
 static int h3_dispatch(int NT, int KCH, const RgParams& p, int stats_nblk, hipStream_t s)
 {
@@ -207,8 +209,10 @@ int gpe_edgegemm_h3_try(const RgParams& p_in, int amode, int emode, int stats_nb
     p.h3_amax_w = slots + 1;
     p.amax_out = tracks ? p.user_amax_out : nullptr;
 
-    int rc = GPE_EINVAL;
-    if (amode == A_GATHER && emode == E_EDGE_FWD) rc = h3_dispatch<A_GATHER, E_EDGE_FWD>(NT, KCH, p, stats_nblk, s);
+    // k = 16 at the shipped widths: two waves per SIMD (gpe_edgegemm_w8.hip); everything else the single-role kernel
+    int rc = gpe_edgegemm_w8_dispatch(amode, emode, NT, KCH, p, stats_nblk, s);
+    if (rc != GPE_ENOTSUP_SHAPE) { /* launched (or refused with an error) */ }
+    else if (amode == A_GATHER && emode == E_EDGE_FWD) rc = h3_dispatch<A_GATHER, E_EDGE_FWD>(NT, KCH, p, stats_nblk, s);
     else if (amode == A_DENSE && emode == E_EDGE_FWD) rc = h3_dispatch<A_DENSE, E_EDGE_FWD>(NT, KCH, p, stats_nblk, s);
     else if (amode == A_DENSE && emode == E_BWD_INPLACE) rc = h3_dispatch<A_DENSE, E_BWD_INPLACE>(NT, KCH, p, stats_nblk, s);
     else if (amode == A_DENSE && emode == E_BWD_GATHER) rc = h3_dispatch<A_DENSE, E_BWD_GATHER>(NT, KCH, p, stats_nblk, s);
