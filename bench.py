@@ -2,10 +2,12 @@
 """bench.py — garments/sec of one training step (fwd -> loss -> bwd [-> grad all-reduce] -> Adam) of the
 NeuralTailor LSTM model (GarmentFullPattern3D, reference nn/nets.py:41-184 driven as nn/trainer.py:92-99) on
 synthetic point clouds, BASELINE.json config 2 per GPU:  N=2048 points, batch 32, k=16, EdgeConv encoder + LSTM
-decoders.  fp32 storage; arithmetic of the timed region = --math, default 'f16x3': every product of the fused edge GEMMs as
-three fp16 MFMAs on tensor-normalised two-term splits (23 mantissa bits), fp32 accumulate — the parity-grade mode (every
--m gpu test holds it to the exact mode's bars).  The exact-fp32-MFMA step is measured in the same run and reported as
-`exact_f32` (for every world size); tensors stay fp32 in HBM (DESIGN.md 8, row g).
+decoders.  Arithmetic of the timed region = --math, default 'f16x3': every product of the fused edge GEMMs, of their
+weight-gradient reduce-GEMMs and of the forward recurrences as three fp16 MFMAs on tensor-normalised two-term splits (23 mantissa
+bits), fp32 accumulate; the kNN filter runs on fp16 planes in every mode (exact after its rerank) — the parity-grade mode (every
+-m gpu test holds it to the exact mode's bars).  Storage: fp32 tensors in HBM, except the aggregated block's activation a3, which
+the f16x3 mode keeps in fp16 where its backward forms dz3 lazily (k = 16 above the size gate; DESIGN.md 8 row g).  The
+exact-fp32-MFMA step is measured in the same run and reported as `exact_f32` and inside `config` (for every world size).
 
     python bench.py --gpus 1 --steps 20 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
@@ -60,7 +62,7 @@ def parse():
                          'stitch + free-class terms are active as well (synthetic stitches) — an extra measurement')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-batch', type=int, default=0, help='batch of the CPU baseline sample; 0 = the benchmarked batch (capped at 32)')
-    ap.add_argument('--cpu-steps', type=int, default=2)
+    ap.add_argument('--cpu-steps', type=int, default=3)
     ap.add_argument('--cpu-threads', type=int, default=0, help='0 = all host cores (nproc)')
     ap.add_argument('--no-kernel-timing', action='store_true')
     ap.add_argument('--math', choices=['f32', 'f16x3', 'bf16x6', 'mixed', 'bf16x3'], default='f16x3',
@@ -298,26 +300,27 @@ def cpu_baseline(args, data_config, nn_cfg):
         return sum(times[1:]) / len(times[1:])
 
     # Thread count: torch's intra-op pool does not scale to a 256-thread host on this op mix, so the baseline picks its
-    # thread count by MEASUREMENT inside this run: one timed step of a small sample (B=2 at the benchmarked N, k) at
-    # 16 / 32 / 64 threads (and nproc, under a time cap), then runs the baseline at the fastest.  --cpu-threads overrides.
+    # thread count by MEASUREMENT inside this run, AT THE BENCHMARKED BATCH (round 4 probed a B=2 sample, which favours few
+    # threads): one timed step (after one warm-up at the first setting) at 16 / 64 / nproc threads, then >= 3 timed steps at the
+    # fastest.  --cpu-threads overrides.
     nproc = os.cpu_count() or 1
     probe = {}
+    cpu_batch = args.cpu_batch if args.cpu_batch > 0 else min(args.batch, 32)
     if args.cpu_threads > 0:
         ncores = args.cpu_threads
     else:
-        for nt in sorted({min(n, nproc) for n in (16, 32, 64)}):
+        for nt in sorted({min(n, nproc) for n in (16, 64, nproc)}):
             torch.set_num_threads(nt)
-            probe[str(nt)] = round(timed(2, args.points, args.k, 1), 3)
+            probe[str(nt)] = round(timed(cpu_batch, args.points, args.k, 1), 3)
         ncores = int(min(probe, key=probe.get))
-        probe['note'] = 's/step of a B=2 sample at N=%d, k=%d (1 warm-up + 1 timed), measured in this run' % (args.points, args.k)
+        probe['note'] = 's/step at B=%d, N=%d, k=%d (1 warm-up + 1 timed per setting), measured in this run' % (cpu_batch, args.points, args.k)
     torch.set_num_threads(ncores)
-    cpu_batch = args.cpu_batch if args.cpu_batch > 0 else min(args.batch, 32)
-    t2 = timed(cpu_batch, args.points, args.k, args.cpu_steps)
+    t2 = timed(cpu_batch, args.points, args.k, max(args.cpu_steps, 3))
     t1 = timed(8, 1024, 5, max(args.cpu_steps, 5))          # BASELINE cfg 1: the reference's own CPU-runnable case
     O.KNN_IMPL = 'c'
     return {'value': cpu_batch / t2, 'unit': 'garments/s', 'cores': ncores, 'kind': 'port',
             'sample': 'oracle/ref_path.py (kNN by cdist+topk) fwd+loss+bwd, B=%d N=%d k=%d fp32, 1 warm-up + %d timed '
-                      'steps, %.2f s/step' % (cpu_batch, args.points, args.k, args.cpu_steps, t2),
+                      'steps, %.2f s/step' % (cpu_batch, args.points, args.k, max(args.cpu_steps, 3), t2),
             'cfg1': {'value': 8 / t1, 'unit': 'garments/s',
                      'sample': 'BASELINE cfg 1 (N=1024, B=8, k=5), 1 warm-up + %d timed steps, %.3f s/step'
                                % (max(args.cpu_steps, 5), t1)},
@@ -591,10 +594,19 @@ def main():
             'value': garments / elapsed, 'unit': 'garments/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f32',
+            # the arithmetic type of the timed region (not a storage claim): 'f16x3' = fp16 MFMA on two-term splits, fp32 accumulate
+            'dtype': {'f32': 'f32', 'f16x3': 'f16x3 (fp16 MFMA x3 per product, fp32 accumulate)', 'bf16x6': 'bf16x6',
+                      'mixed': 'bf16x3/f32', 'bf16x3': 'bf16x3'}[args.math],
             'math_mode': args.math, 'data': 'synthetic',
+            # (the driver's parsed record keeps `config`, `roofline` and `cpu_baseline` and drops other top-level keys: what a
+            # reader needs to interpret `value` is repeated here)
             'config': {'workload': _workload_name(args),
                        'global_batch': args.batch * world, 'parallelism': 'dp%d' % world,
+                       'math_mode': args.math,
+                       'storage': 'fp32 tensors in HBM' + ('; the aggregated block\'s activation a3 in fp16 (lazy dz3, k = 16 above the '
+                                                            'size gate)' if args.math == 'f16x3' and args.k == 16 else ''),
+                       'exact_f32': ({'value': fast['f32']['value'], 'ms_per_step': fast['f32']['ms_per_step']}
+                                     if fast and fast.get('f32') else None),
                        'loss_epoch': args.epoch,
                        'step': 'fwd + ComposedPatternLoss + bwd' + (' + RCCL grad all-reduce' if world > 1 else '')
                                + (' + Adam (torch)' if args.torch_adam else ' + fused Adam (flat arena)'),

@@ -334,6 +334,11 @@ __global__ __launch_bounds__(256, 1) void gpe_edgegemm_split_kernel(RgParams p, 
     float4 dp;
     int es = 0, ept = 0;                                 // row inside the current point, point inside this wave's share
     long e_row0 = 0, e_pt0 = 0; int e_rv = 0;            // tile being finished
+    // gather forward: the activation rows leave through a buffer descriptor of the tile's `out` rows (scalar row offset, constant
+    // lane offset) with the sc1 flavour as the instruction's aux bit.  Round 3 / 4 wrote this store as `asm volatile
+    // ("global_store_dwordx4 … sc1")`: in the register-tight instances the compiler then waits `vmcnt(0)` in front of every row — for
+    // the previous row's write acknowledgement (found in round 5 on the two-waves-per-SIMD kernel, profiles/r05_a_w8_schedules.md)
+    __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, 0, 0x00020000);
 
     float4 v[RBH];                                       // rows staged for the next tile (one batch)
     // LAZY: coefficients of the BatchNorm behind the aggregation for this lane's K columns, and — per staged tile — the point's
@@ -408,6 +413,8 @@ __global__ __launch_bounds__(256, 1) void gpe_edgegemm_split_kernel(RgParams p, 
         e_pt0 = (long)tile * PT + wave * npw;
         e_rv = (int)((p.M - e_row0 < p.R) ? (p.M - e_row0) : p.R);
         es = 0; ept = 0;
+        if (EMODE == E_EDGE_FWD && AMODE == A_GATHER)
+            orsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(p.out) + e_row0 * p.ldo * 4, 0, RG_BM * p.ldo * 4, 0x00020000);
 #pragma unroll
         for (int t = 0; t < 4; ++t) { s32[t] = 0.f; q32[t] = 0.f; vmx[t] = -INFINITY; vmn[t] = INFINITY; imx[t] = 0; imn[t] = 0; }
         dp = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -535,8 +542,10 @@ __global__ __launch_bounds__(256, 1) void gpe_edgegemm_split_kernel(RgParams p, 
                 if (SP::SCALED && !TRACK) amax_run = fmaxf(fmaxf(amax_run, fmaxf(vv[0], vv[1])), fmaxf(vv[2], vv[3]));
                 // gather variant: the activation rows stream out past L2 so that they do not evict the cloud's Q table
                 // (counter fetch of this kernel 199 -> <145 MB against 109 MB compulsory, same run time: profiles/r02_b)
-                if (AMODE == A_GATHER) st4_stream(p.out + (e_row0 + r) * p.ldo + c, make_float4(vv[0], vv[1], vv[2], vv[3]));
-                else if constexpr (OUTH) {
+                if (AMODE == A_GATHER) {
+                    const x6_u32x4 oq = {__float_as_uint(vv[0]), __float_as_uint(vv[1]), __float_as_uint(vv[2]), __float_as_uint(vv[3])};
+                    __builtin_amdgcn_raw_buffer_store_b128(oq, orsrc, c * 4, r * p.ldo * 4, 16);
+                } else if constexpr (OUTH) {
                     // fp16 rows (RNE), 8 bytes per quad: the backward only forms dz3 from this tensor (mask + a tiny-coefficient term)
                     // (clamped to the largest finite fp16: an activation beyond 65504 must not become inf in the stored copy — the
                     // backward would turn it into NaN gradients; mx / mn, the statistics and the amax word keep the fp32 value)

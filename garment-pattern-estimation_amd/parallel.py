@@ -31,6 +31,8 @@ class DistributedHotPath(nn.Module):
         self.device_ids = list(device_ids) if device_ids is not None else []
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        # ReduceOp.AVG exists on the nccl (= RCCL) backend only
+        self._avg_op = dist.is_initialized() and dist.get_backend(process_group) == 'nccl'
         self.arena = arena if arena is not None else FlatArena(module)
         a = self.arena
         # buckets = consecutive parameter ranges of the arena (already in gradient-ready order)
@@ -103,8 +105,13 @@ class DistributedHotPath(nn.Module):
         self._launched.add(bi)
         _, _, lo, hi = self._buckets[bi]
         flat = self.arena.grad[lo:hi]
-        flat.div_(self.world)
-        self._inflight.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        if self._avg_op:
+            # RCCL averages inside the collective: no extra elementwise launch per bucket and step
+            self._inflight.append(dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=self.group, async_op=True))
+        else:
+            # gloo (the CPU tests) has no AVG: pre-divide, then SUM
+            flat.div_(self.world)
+            self._inflight.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def _on_written(self, i):
         self._on_ready(i)

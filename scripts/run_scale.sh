@@ -5,8 +5,13 @@
 # Each line carries dist_world (what the process group reported), allreduce_bytes, allreduce_ms_per_step (the exchange on its
 # own, all buckets back to back) and exchange.exposed_ms_per_step (what backward did not hide), so the table can be checked
 # against RCCL having really connected N ranks.  No such curve has been measured yet.
+# BATCH (env, default 32 = BASELINE's per-GPU share) sets the garments per GPU.  A data-parallel job that may choose its global batch
+# should give each GPU 128 - 256 garments: measured on one MI355X (profiles/r04_k_batch_scaling.md) 2953 / 3246 / 3456 / 3583
+# garments/s per GPU at 32 / 64 / 128 / 256 — the ~2 ms of latency-bound launches per step are constant, the edge kernels linear —
+# and the gradient exchange stays 11 MB per step whatever the batch (RCCL ReduceOp.AVG on in-place arena slices).
 STEPS=${1:-20}
 WARMUP=${2:-5}
+BATCH=${BATCH:-32}
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out
 mkdir -p "$OUT"
@@ -14,10 +19,10 @@ cd "$ROOT"
 export HSA_ENABLE_IPC_MODE_LEGACY=0
 for N in 1 2 4 8; do
   if [ "$N" = 1 ]; then
-    python bench.py --gpus 1 --steps "$STEPS" --warmup "$WARMUP" --no-cpu-baseline --no-fast-math-line > "$OUT/scale_N1.log" 2>&1
+    python bench.py --gpus 1 --batch "$BATCH" --steps "$STEPS" --warmup "$WARMUP" --no-cpu-baseline --no-fast-math-line > "$OUT/scale_N1.log" 2>&1
   else
     python -m torch.distributed.run --nnodes=1 --nproc-per-node "$N" --master-addr 127.0.0.1 --master-port $((29500 + N)) \
-        bench.py --gpus "$N" --steps "$STEPS" --warmup "$WARMUP" > "$OUT/scale_N$N.log" 2>&1
+        bench.py --gpus "$N" --batch "$BATCH" --steps "$STEPS" --warmup "$WARMUP" > "$OUT/scale_N$N.log" 2>&1
   fi
   grep '^{' "$OUT/scale_N$N.log" | tail -1 > "$OUT/scale_N$N.json"
 done
