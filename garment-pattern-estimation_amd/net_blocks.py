@@ -31,6 +31,7 @@ class DynamicEdgeConv(nn.Module):
         self.k = k
         self.aggr = aggr
         self.last_knn = None
+        self.half_act_guard = ops.HalfActGuard()             # f16x3: watches the fp16-stored activation (ops.set_half_act_guard)
 
     def register_packs(self, plan):
         blocks = [self.nn[i] for i in range(len(self.nn))]
@@ -54,7 +55,8 @@ class DynamicEdgeConv(nn.Module):
             # a first-block width the fused P|Q kernels do not take: the general (explicit-message) formulation
             out, idx = ops.edge_conv_general(x, n_clouds, n_points, self.k, self.training, eps, mom, nb, self.aggr, args)
         else:
-            out, idx = ops.EdgeConvFn.apply(x, n_clouds, n_points, self.k, self.training, eps, mom, nb, self.aggr, *args)
+            out, idx = ops.EdgeConvFn.apply(x, n_clouds, n_points, self.k, self.training, eps, mom, nb, self.aggr,
+                                            self.half_act_guard, *args)
         self.last_knn = idx
         return out
 
@@ -312,7 +314,7 @@ class LSTMEncoderModule(nn.Module):
         c0 = _init_tenzor(self.n_layers, bs, self.encoding_size, device=device, init_type=self.custom_init)
         seq = batch_sequence if batch_sequence.stride(-1) == 1 else batch_sequence.contiguous()
         _, hN, _ = ops.rnn_stack(seq, h0, c0, seq.size(1), self.n_layers, 'lstm', _rnn_params(self.lstm, self.n_layers),
-                                 want_state=True, dropout=self.dropout, training=self.training)
+                                 want_state=True, dropout=self.dropout, training=self.training, h0_bounded=True)
         return hN[-1]
 
 
@@ -347,7 +349,7 @@ class LSTMDecoderModule(nn.Module):
         self.last_states = (h0, c0)
         enc = batch_enc if batch_enc.is_contiguous() else batch_enc.contiguous()
         top, _, _ = ops.rnn_stack(enc, h0, c0, out_len, self.n_layers, 'lstm', _rnn_params(self.lstm, self.n_layers),
-                                  dropout=self.dropout, training=self.training)
+                                  dropout=self.dropout, training=self.training, h0_bounded=True)
         return ops.linear(top, self.lin.weight, self.lin.bias).view(bs, out_len, -1)
 
 
@@ -386,12 +388,12 @@ class LSTMDoubleReverseDecoderModule(nn.Module):
         enc = batch_enc if batch_enc.is_contiguous() else batch_enc.contiguous()
         out, hN, cN = ops.rnn_stack(enc, h0, c0, out_len, self.n_layers, 'lstm',
                                     _rnn_params(self.lstm_reverse, self.n_layers), want_state=True,
-                                    dropout=self.dropout, training=self.training)
+                                    dropout=self.dropout, training=self.training, h0_bounded=True)
         dec_input = enc.unsqueeze(1).expand(-1, out_len, -1)
         seq = torch.cat([torch.flip(out, [1]), dec_input], -1)            # skip connection with the original input
         top, _, _ = ops.rnn_stack(seq, hN, cN, out_len, self.n_layers, 'lstm',
                                   _rnn_params(self.lstm_forward, self.n_layers), dropout=self.dropout,
-                                  training=self.training)
+                                  training=self.training, h0_bounded=True)      # (states of the first LSTM: |h| < 1)
         return ops.linear(top, self.lin.weight, self.lin.bias).view(bs, out_len, -1)
 
 
@@ -424,7 +426,7 @@ class GRUDecoderModule(nn.Module):
         enc = batch_enc if batch_enc.is_contiguous() else batch_enc.contiguous()
         top, _, _ = ops.rnn_stack(enc, h0, None, out_len, self.n_layers, 'gru',
                                   _rnn_params(self.recurrent_cell, self.n_layers), dropout=self.dropout,
-                                  training=self.training)
+                                  training=self.training, h0_bounded=True)
         return ops.linear(top, self.lin.weight, self.lin.bias).view(bs, out_len, -1)
 
 

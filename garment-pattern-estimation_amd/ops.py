@@ -14,6 +14,8 @@ Two per-model services live here as well (both optional; without them every Func
                 straight into the arena's gradient buffer (no per-parameter tensors, no cat/copy for the all-reduce
                 buckets, one fused Adam launch).
 """
+import os
+import warnings
 import weakref
 
 import numpy as np
@@ -119,7 +121,12 @@ class PackPlan:
     `p.data` (an EMA of the weights, a hand-written `p.data.copy_()`, a foreign optimizer working on raw storage), and a stale
     pack gives silently wrong numbers.  In training the weights change every step anyway.  A caller whose weights are truly
     constant (inference loops) may set `plan.frozen = True` after the first forward: the launch is then skipped while the
-    version counters and WEIGHTS_EPOCH stand still — that caller vouches for not touching `p.data`."""
+    version counters and WEIGHTS_EPOCH stand still — that caller vouches for not touching `p.data`.
+
+    A plan — and therefore the module that owns it — is SINGLE-STREAM: its outputs and amax words are rewritten by every refresh,
+    so two streams driving the same module at the same time would race (the C library itself is stream-safe: all state is the
+    caller's).  Use one module copy per stream (tests/test_gpu_kernels.py::test_two_streams_one_device).  A module that moves from
+    one stream to another between forwards is handled: refresh() makes the new stream wait for the previous one."""
 
     def __init__(self):
         self.specs = []        # (param, param2, kind, N, K, aux)
@@ -131,6 +138,8 @@ class PackPlan:
         self.home = None
         self.keys = []
         self.frozen = False
+        self.h3_current = False
+        self._stream = None
         self._keys_box = box = []              # shared with the finalizer: the keys this plan currently owns in _PACKS
         me = weakref.ref(self)
         # pop only entries that are still THIS plan's: a newer plan over the same parameters may have re-registered the keys
@@ -219,6 +228,16 @@ class PackPlan:
             self._keys_box.append(key)
         self.blocks = blk
         self.table = torch.from_numpy(tab.view(np.uint8).copy()).to(dev)
+        # the same table without the fp16-plane jobs, for every arithmetic mode but f16x3 (their outputs and amax words are only
+        # read by the f16x3 recurrences: ADVICE r4 — two launches and the plane arithmetic per step for nothing)
+        keep = [i for i in range(len(self.specs)) if i not in h3]
+        tab2 = tab[keep].copy()
+        blk2 = 0
+        for j in range(len(keep)):
+            tab2[j]['first_block'] = blk2
+            blk2 += (int(tab2[j]['total']) + 1023) // 1024
+        self.table_noh3 = torch.from_numpy(tab2.view(np.uint8).copy()).to(dev) if h3 else self.table
+        self.blocks_noh3, self.n_noh3 = (blk2, len(keep)) if h3 else (blk, len(self.specs))
         self.home = self._home()
 
     def _home(self):
@@ -232,14 +251,23 @@ class PackPlan:
         if not self.specs:
             return
         vers = self._versions()
+        if self.specs[0][0].is_cuda:
+            st = torch.cuda.current_stream(self.specs[0][0].device)
+            if self._stream is not None and st != self._stream:
+                st.wait_stream(self._stream)     # the packs / words the previous stream's launches still read are about to change
+            self._stream = st
         if self.table is None or self.home != self._home():
             self._build()                      # first use, or a parameter moved (.to(device), arena re-homing)
-        elif self.frozen and self.vers == vers and self.epoch == WEIGHTS_EPOCH:
+        elif (self.frozen and self.vers == vers and self.epoch == WEIGHTS_EPOCH and
+              self.h3_current == (self.pre_table is not None and L.get_math() == 'f16x3')):   # (a mode change re-runs the packs)
             return
-        if self.pre_table is not None:
+        self.h3_current = self.pre_table is not None and L.get_math() == 'f16x3'
+        if self.h3_current:
             self.words.zero_()
             L.call('gpe_pack_multi', self.pre_table, self.pre_table.numel() // 64, self.pre_blocks)
-        L.call('gpe_pack_multi', self.table, len(self.specs), self.blocks)
+            L.call('gpe_pack_multi', self.table, len(self.specs), self.blocks)
+        else:
+            L.call('gpe_pack_multi', self.table_noh3, self.n_noh3, self.blocks_noh3)
         self.vers, self.epoch = vers, WEIGHTS_EPOCH
 
 
@@ -317,7 +345,7 @@ def planned_planes(w, kind):
         return None, None
     plan = hit[0]()
     out = _planned(w, kind)
-    if plan is None or out is None:
+    if plan is None or out is None or not plan.h3_current:   # (planes are only rebuilt by a refresh that ran in f16x3 mode)
         return None, None
     return out, plan.word_of.get((w.data_ptr(), kind))
 
@@ -549,6 +577,86 @@ segment_mean.pool_mode, segment_max.pool_mode, segment_add.pool_mode = 0, 1, 2
 # -------------------------------------------------------------------------------------------------
 # EdgeConv layer
 # -------------------------------------------------------------------------------------------------
+_HALF_ACT_GUARD = os.environ.get('GPE_HALF_ACT_GUARD', 'fallback')
+
+
+def set_half_act_guard(mode):
+    """What watches the fp16 storage of the aggregated block's activation (f16x3 mode, lazy dz3; DESIGN.md 8 row g).  The stored
+    copy is clamped at 65504 and flushes positives below 6e-8; the forward measures the activation's true largest magnitude
+    (an amax word on the device) — this guard reads it:
+      'fallback' (default)  asynchronously, one step late and without a host synchronisation: a layer whose activation reached
+                            the fp16 limit switches to fp32 storage + the eager dz3 pass for every later step, with a RuntimeWarning
+                            (the step that tripped the guard ran with clamped values: its gradient elements of the clamped
+                            activations are off);
+      'strict'              synchronously inside the forward (one host read per EdgeConv layer and step): the launch is repeated
+                            with fp32 storage before anything consumes the clamped rows — exact at every step;
+      'off'                 no check (rounds 3 - 4 behaviour).
+    Returns the previous mode."""
+    global _HALF_ACT_GUARD
+    if mode not in ('fallback', 'strict', 'off'):
+        raise ValueError("half-activation guard mode must be 'fallback', 'strict' or 'off'")
+    prev, _HALF_ACT_GUARD = _HALF_ACT_GUARD, mode
+    return prev
+
+
+class HalfActGuard:
+    """Per-layer state of set_half_act_guard: owned by the module that owns the layer (net_blocks.DynamicEdgeConv)."""
+    LIMIT = 65504.0
+
+    def __init__(self):
+        self.disabled = False
+        self.last_amax = None
+        self._pending = None
+
+    def __getstate__(self):                              # copies / pickles of the owning module carry the decision, not the
+        return {'disabled': self.disabled, 'last_amax': self.last_amax, '_pending': None}    # in-flight read (pinned buffer + event)
+
+    def __deepcopy__(self, memo):
+        g = HalfActGuard()
+        g.disabled, g.last_amax = self.disabled, self.last_amax
+        return g
+
+    @staticmethod
+    def _value(host):
+        return float(np.array([int(host[0])], dtype=np.int32).view(np.float32)[0])
+
+    def _trip(self, v):
+        self.disabled = True
+        warnings.warn('f16x3: the aggregated EdgeConv activation reached %.3g (fp16 storage clamps at 65504): this layer keeps it '
+                      'in fp32 and forms dz3 eagerly from now on (gpe_amd.ops.set_half_act_guard)' % v, RuntimeWarning, stacklevel=3)
+
+    def allow(self):
+        """May the coming forward store the activation in fp16?  Polls the previous step's word without blocking."""
+        if _HALF_ACT_GUARD == 'off':
+            return True
+        if self._pending is not None and self._pending[1].query():
+            v = self._value(self._pending[0])
+            self._pending = None
+            self.last_amax = v
+            if not v < self.LIMIT:                      # (also true for NaN)
+                self._trip(v)
+        return not self.disabled
+
+    def watch(self, word):
+        """After the forward launch that filled `word` (int32[1], the activation's amax bits).  'strict': returns False when the
+        launch must be repeated with fp32 storage."""
+        if _HALF_ACT_GUARD == 'off':
+            return True
+        if _HALF_ACT_GUARD == 'strict':
+            v = self._value(word.cpu())
+            self.last_amax = v
+            if not v < self.LIMIT:
+                self._trip(v)
+                return False
+            return True
+        host = torch.empty(1, dtype=torch.int32, pin_memory=True)
+        host.copy_(word, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._pending = (host, ev)
+        return True
+
+
 class EdgeConvFn(torch.autograd.Function):
     """One DynamicEdgeConv(MLP([2C, H, .., H, F]), k, aggr) layer (nn/net_blocks.py:43-47,124-135,174):
     kNN graph on the input features -> per-edge [Linear->ReLU->BatchNorm] x nb -> max / mean / add over the k messages.
@@ -560,7 +668,7 @@ class EdgeConvFn(torch.autograd.Function):
     nb = EConv_hidden_depth + 1 >= 2; the shipped configs use nb = 3, aggr = 'max'."""
 
     @staticmethod
-    def forward(ctx, x, B, N, k, training, eps, momentum, nb, aggr, *tensors):
+    def forward(ctx, x, B, N, k, training, eps, momentum, nb, aggr, guard, *tensors):
         _dev_check(x)
         dev = x.device
         BN, C = x.shape
@@ -606,7 +714,7 @@ class EdgeConvFn(torch.autograd.Function):
             # row g: the aggregated block's activation is kept in fp16 when its backward will form dz3 lazily — its
             # only readers then (include/gpe_hip.h "out_half"; gradients move by 2e-6 / 5e-6 of their maximum)
             half = bool(last and training and aggr == 'max' and words is not None and nb >= 3 and
-                        L.query('gpe_edge_lazy_dz3_ok', B, N, k, Cout, Cin) == 1)
+                        L.query('gpe_edge_lazy_dz3_ok', B, N, k, Cout, Cin) == 1 and (guard is None or guard.allow()))
             a = torch.empty(E, ldo, device=dev, dtype=torch.float16 if half else F32)
             part = torch.empty(nblk, 2, Cout, device=dev, dtype=torch.float64) if training else None
             agg = int(last and aggr == 'max')
@@ -625,6 +733,12 @@ class EdgeConvFn(torch.autograd.Function):
                 prev = acts[l - 1]
                 L.call('gpe_edge_mlp_fwd', 1, None, 0, None, prev, prev.stride(0), B, N, k, Cin, Cout, wp, bf, a, ldo,
                        part, agg, mx, mn, amx, amn, ldo, _word(words, l - 1), w_out, ews, ews_n, int(half))
+                if half and guard is not None and not guard.watch(w_out):
+                    # 'strict' guard: the activation does not fit fp16 — the same launch once more with fp32 rows (nothing has
+                    # consumed the clamped copy; statistics, maxima and the amax word are rewritten with the same values)
+                    a = torch.empty(E, ldo, device=dev, dtype=F32)
+                    L.call('gpe_edge_mlp_fwd', 1, None, 0, None, prev, prev.stride(0), B, N, k, Cin, Cout, wp, bf, a, ldo,
+                           part, agg, mx, mn, amx, amn, ldo, _word(words, l - 1), w_out, ews, ews_n, 0)
             acts.append(a)
             stats.append(stats_of(part, l))
         Fo = widths[-1]
@@ -769,7 +883,7 @@ class EdgeConvFn(torch.autograd.Function):
             _, wpq_t, _ = edge_first_operands(W1, b1)
             gx = torch.empty(BN, C, device=dev, dtype=F32)
             linear_raw(_rows2d(dPQ), wpq_t, None, BN, C, 2 * H0, _rows2d(gx))
-        return (gx, None, None, None, None, None, None, None, None, *grads, *([None] * (3 * nb)))
+        return (gx, None, None, None, None, None, None, None, None, None, *grads, *([None] * (3 * nb)))
 
 
 class EdgeInputsFn(torch.autograd.Function):
@@ -835,7 +949,7 @@ class RNNStackFn(torch.autograd.Function):
     second), final states too."""
 
     @staticmethod
-    def forward(ctx, x, h0, c0, T, n_layers, kind, want_state, *params):
+    def forward(ctx, x, h0, c0, T, n_layers, kind, want_state, h0_ok, *params):
         _dev_check(x)
         ctx.set_materialize_grads(False)
         dev = x.device
@@ -881,7 +995,9 @@ class RNNStackFn(torch.autograd.Function):
             if l > 0:
                 a, b = planned_planes(w_ih, K_GATES_H3)
                 pl_ih.append(a); am_ih.append(b)
-        h3 = all(t is not None for t in pl_hh + am_hh + pl_ih[1:] + am_ih[1:])
+        # (h0_ok: the fp16-pipe kernels scale the state rows by 2^12 before the fp16 split — a start state of magnitude >= 16 would
+        # overflow to inf; rnn_stack decides)
+        h3 = bool(h0_ok) and all(t is not None for t in pl_hh + am_hh + pl_ih[1:] + am_ih[1:])
         keep = (whh, wih, biases, pl_hh, am_hh, pl_ih, am_ih)   # operands stay referenced until the launches are queued
         L.call('gpe_rnn_seq_fwd', G, Lr, T, Bn, Hh, xproj, xp_sb, xp_st, _ptr_array(whh), _ptr_array(wih),
                _ptr_array(biases), None if lstm else _ptr_array(bhns), hs, hs.stride(0), hs.stride(1), hs.stride(2),
@@ -963,7 +1079,7 @@ class RNNStackFn(torch.autograd.Function):
                     L.call('gpe_add', d_h0[l], carry[0][l], d_h0[l], Bn * Hh)
             grads[4 * l: 4 * l + 4] = [_gret(w_ih, d_wih), _gret(w_hh, d_whh), _gret(b_ih, d_bih),
                                        _gret(b_hh, d_bhh)]
-        return (d_x, d_h0, d_c0, None, None, None, None, *grads)
+        return (d_x, d_h0, d_c0, None, None, None, None, None, *grads)
 
 
 class DropoutMulFn(torch.autograd.Function):
@@ -999,17 +1115,26 @@ def _dropout_mask(T, Bn, H, p, device):
     return noise.transpose(0, 1).contiguous().to(device, non_blocking=True)
 
 
-def rnn_stack(x, h0, c0, T, n_layers, kind, params, want_state=False, dropout=0.0, training=False):
+def rnn_stack(x, h0, c0, T, n_layers, kind, params, want_state=False, dropout=0.0, training=False, h0_bounded=False):
     """nn.LSTM / nn.GRU(batch_first=True, num_layers, dropout).  Without dropout (or in eval mode, or with one layer) the whole
     stack runs in wavefront order (RNNStackFn).  With dropout the layers run one after the other — the mask sits between them —
-    each as a one-layer RNNStackFn over the masked output sequence of the layer below."""
+    each as a one-layer RNNStackFn over the masked output sequence of the layer below.
+
+    f16x3 arithmetic (gpe_amd.set_math): the forward gate products run on the fp16 pipe with the state rows scaled by 2^12, which
+    is exact for every state a cell produces (|h| < 1) and for start states below 16.  h0_bounded=True promises |h0| < 16 (the
+    package's own modules: the reference's zero / kaiming start states, nn/net_blocks.py:308-315, and chained decoder states);
+    otherwise the largest |h0| is READ BACK here (one host synchronisation per call, f16x3 mode only) and a start state of
+    magnitude >= 16 takes the exact fp32 kernels for the whole sequence."""
+    h0_ok = True
+    if not h0_bounded and L.get_math() == 'f16x3' and h0 is not None:
+        h0_ok = bool(h0.abs().max().item() < 16.0)
     if not (dropout > 0 and training and n_layers > 1):
-        out = RNNStackFn.apply(x, h0, c0, T, n_layers, kind, want_state, *params)
+        out = RNNStackFn.apply(x, h0, c0, T, n_layers, kind, want_state, h0_ok, *params)
         return out if kind == 'lstm' else (out[0], out[1], None)
     lstm = kind == 'lstm'
     inp, hs, cs = x, [], []
     for l in range(n_layers):
-        out = RNNStackFn.apply(inp, h0[l:l + 1], c0[l:l + 1] if lstm else None, T, 1, kind, want_state, *params[4 * l:4 * l + 4])
+        out = RNNStackFn.apply(inp, h0[l:l + 1], c0[l:l + 1] if lstm else None, T, 1, kind, want_state, h0_ok, *params[4 * l:4 * l + 4])
         top = out[0]
         if want_state:
             hs.append(out[1])

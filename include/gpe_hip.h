@@ -59,8 +59,17 @@ int gpe_debug_set(int flags);
  *                workgroup), activations / dz tensors by the kernel that stores them, the gathered operand by a bound over the
  *                [P|Q] table (gpe_edge_pq_amax, or in-call).  Launches with fewer than gpe_f16x3_min_rows() rows run the exact
  *                kernels (the scale passes cost more than the fp16 pipe saves there).  The mode bench.py times.
- * Returns the previous mode, or -22 for an unknown one.  kNN, BatchNorm statistics, the LSTM decoder and every
- * elementwise op are fp32 (fp64 for reductions) in every mode. */
+ *                Mode 4 also (since round 4): the FORWARD gate products of the recurrences (gpe_rnn_seq_fwd with plane packs:
+ *                state rows scaled by 2^12 — start states must stay below 16 in magnitude, the Python side checks) and, where
+ *                the caller asks for it (out_half of gpe_edge_mlp_fwd), fp16 STORAGE of the aggregated block's activation:
+ *                rows clamped at 65504, positives below 6e-8 flushed — the forward still reports the activation's true
+ *                largest magnitude in amax_out, and a caller must not keep the fp16 copy when that word reaches 65504
+ *                (gpe_amd.ops.set_half_act_guard does this on the Python side).  For k = 16 at the shipped widths (200 / 200 /
+ *                150) the four edge launches run the two-waves-per-SIMD kernel (gpe_edgegemm_w8_kernel.h), else the
+ *                single-role one.
+ * Returns the previous mode, or -22 for an unknown one.  The kNN result is exact in every mode (its FILTER runs on fp16 planes
+ * in every mode, followed by an exact fp32 recheck); BatchNorm statistics, the backward recurrences and every elementwise op
+ * are fp32 (fp64 for reductions) in every mode. */
 int gpe_math_set(int mode);
 int gpe_math_get(void);
 /* f16x3 size gate (part of the arithmetic mode): edge launches with fewer rows use the exact fp32 kernels.  Default 65536;
