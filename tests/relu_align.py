@@ -68,7 +68,7 @@ def capture_relu_masks():
 def align_relus(model, masks):
     """Hooks every nn.ReLU of the oracle `model`: the i-th ReLU evaluated takes the i-th captured mask.  Returns a dict
     that is filled during the forward: flips (count), max_z (largest |z| of a flipped element), n (elements seen)."""
-    stats = {'flips': 0, 'max_z': 0.0, 'n': 0, 'used': 0}
+    stats = {'flips': 0, 'max_z': 0.0, 'n': 0, 'used': 0, 'per_relu': []}
     queue = list(masks)
 
     def hook(_m, inp, _out):
@@ -80,9 +80,13 @@ def align_relus(model, masks):
         flip = (z.detach() > 0) != m
         nf = int(flip.sum())
         stats['n'] += z.numel()
+        mz = 0.0
         if nf:
             stats['flips'] += nf
-            stats['max_z'] = max(stats['max_z'], z.detach()[flip].abs().max().item())
+            mz = z.detach()[flip].abs().max().item()
+            stats['max_z'] = max(stats['max_z'], mz)
+        # per-ReLU record (printed by the whole-batch tests): elements, flips, largest |z| among them, rms of z
+        stats['per_relu'].append((stats['used'], z.numel(), nf, mz, float(z.detach().double().pow(2).mean().sqrt())))
         return z * m.to(z.dtype)
 
     handles = [mod.register_forward_hook(hook) for mod in model.modules() if isinstance(mod, torch.nn.ReLU)]
@@ -97,6 +101,9 @@ def check_alignment(stats, n_masks, z_tol=FLIP_Z_TOL, max_frac=2e-5):
     build and oracle differ by the drift of the weights, not only by rounding.)"""
     for h in stats['handles']:
         h.remove()
+    for i, n, nf, mz, rms in stats['per_relu']:
+        if nf:
+            print('relu_align (%s): ReLU #%d  %d elements, %d decisions differ from the build, largest |z| among them %.2e (rms z %.2e)' % (stats.get('tag', 'oracle'), i, n, nf, mz, rms))
     assert stats['used'] == n_masks and not stats['pending'], (stats['used'], n_masks)
     assert stats['max_z'] < z_tol, 'a ReLU decision differs where |z_fp64| = %.2e' % stats['max_z']
     assert stats['flips'] <= max(4, max_frac * stats['n']), (stats['flips'], stats['n'])

@@ -1152,7 +1152,7 @@ def test_fp16_activation_store_is_clamped_not_inf(gpe):
 
 def test_half_activation_guard(gpe):
     """ops.set_half_act_guard (VERDICT r4 #7-ii): the f16x3 mode keeps the aggregated block's activation in fp16 (clamped
-    at 65504).  A layer whose activation outgrows fp16 — here: the last Linear scaled by 3e3 — must not train on clamped values:
+    at 65504).  A layer whose activation outgrows fp16 — here: the last Linear scaled by 1e5 — must not train on clamped values:
     'strict' repeats the launch with fp32 rows inside the same forward (gradients = the eager fp32-storage pass, and the fp64
     oracle's at the usual bar); 'fallback' notices one step late without a host synchronisation, warns, and stores fp32 from then
     on; a layer in range keeps the fp16 storage."""
@@ -1161,7 +1161,7 @@ def test_half_activation_guard(gpe):
     B, N, C, k = 8, 512, 3, 16
     oconv = _oracle_conv(C, 200, 150, k, seed=5)
     with torch.no_grad():
-        oconv.nn[2][0].weight *= 3e3
+        oconv.nn[2][0].weight *= 1e5
     g = torch.Generator().manual_seed(6)
     x = torch.randn(B * N, C, generator=g)
     wgt = torch.randn(B * N, 150, generator=g)
