@@ -50,6 +50,21 @@ struct RdParams {
     const uint8_t* lz_amx; const uint8_t* lz_amn; int lz_ldagg;
     const float* lz_coef;                        // [4][Mg] = {s, c1, k2, mean}
 };
+// b3 kernel, compile-time switches (A/B builds through scripts/ab_build.sh; run-time flags cost this kernel registers it does not
+// have: a run-time `pipe` flag spilled 120 of them in the gathered 13 x 13 instance):
+//   RD_B3_PIPE  producers' order: 0 (default) = fetch tile t + 1 ... left-over MFMAs ... commit it (round 4); 1 = the two operands
+//               alternate commit / fetch one tile further ahead, so that every load has most of an iteration to land (round 5).
+//               MEASURED SLOWER: gathered 13 x 13 383 / 391 -> 425 / 416 us, dense 10 x 13 376 / 379 -> 382 / 378 (one session, twice
+//               each, profiles/r05_b_redgemm_probe.md) — the producers are not waiting for memory: per tile and SIMD the kernel
+//               issues 129 MFMAs (2.1 k cycles) next to ~510 producer VALU + 60 LDS / VMEM instructions, and those add up
+//   RD_B3_DBG   timing-only ablation (WRONG RESULTS): 1 = no commit (split + LDS writes), 2 = no row loads, 4 = no consumer MFMAs,
+//               8 = no left-over MFMAs
+#ifndef RD_B3_PIPE
+#define RD_B3_PIPE 0
+#endif
+#ifndef RD_B3_DBG
+#define RD_B3_DBG 0
+#endif
 
 __device__ __forceinline__ float4 rd_ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 
@@ -652,6 +667,7 @@ __global__ __launch_bounds__(512, 2) void gpe_redgemm_b3_kernel(RdParams p)
                 bh[n] = *reinterpret_cast<const uint4*>(vb + LV::slot(0, g, 16 * (nt0 + n) + j));
                 bl[n] = *reinterpret_cast<const uint4*>(vb + LV::slot(1, g, 16 * (nt0 + n) + j));
             }
+            if (!(RD_B3_DBG & 4))
 #pragma unroll
             for (int q = 0; q < MB; ++q) {
                 const uint4 ah = *reinterpret_cast<const uint4*>(ub + LU::slot(0, g, 16 * (mt0 + q) + j));
@@ -735,10 +751,10 @@ __global__ __launch_bounds__(512, 2) void gpe_redgemm_b3_kernel(RdParams p)
         auto load_jgv = [&](int tile) -> int {
             return p.jg[tile_row0(tile) + RQ * w4 + ((lane < RQ) ? lane : RQ - 1)];
         };
-        auto fetch = [&](int tile) {
+        // U rows first, then V rows: the memory counter retires in order, so a commit of U can wait for "all but the V loads"
+        auto fetchU = [&](int tile) {
             const long rb = tile_row0(tile) + RQ * w4;                      // 8 CONSECUTIVE rows per wave
             const float* up = p.u.base + rb * p.u.stride_outer + cu;
-            const float* vp = p.v.base + rb * p.v.stride_outer + cv;
             if constexpr (LAZY) {
                 const long pt = rb >> 4;                                    // k = 16 (host-checked); wave-uniform
                 const float* gr = p.lz_g + pt * p.lz_ldg + cu;                  // dword loads at clamped columns: any row pitch
@@ -755,6 +771,13 @@ __global__ __launch_bounds__(512, 2) void gpe_redgemm_b3_kernel(RdParams p)
                     ur[q].x = __uint_as_float(hq.x); ur[q].y = __uint_as_float(hq.y);
                 } else
                     ur[q] = rd_ld4(up + q * p.u.stride_outer);
+            }
+        };
+        auto fetchV = [&](int tile) {
+            const long rb = tile_row0(tile) + RQ * w4;
+            const float* vp = p.v.base + rb * p.v.stride_outer + cv;
+#pragma unroll
+            for (int q = 0; q < RQ; ++q) {
                 if (VMODE == V_DENSE) vr[q] = rd_ld4(vp + q * p.v.stride_outer);
                 else {
                     const long i = (long)__umulhi((unsigned)(rb + q), p.kmagic);
@@ -764,9 +787,8 @@ __global__ __launch_bounds__(512, 2) void gpe_redgemm_b3_kernel(RdParams p)
                 }
             }
         };
-        auto commit = [&](int buf, int tile) {
+        auto commitU = [&](int buf, int tile) {
             char* ub = Ub + buf * LU::BYTES;
-            char* vb = Vb + buf * LV::BYTES;
             const long row0 = (long)tile * RD_RT;
             const int rv = (int)((p.rows - row0 < RD_RT) ? (p.rows - row0) : RD_RT);
             float c32[4] = {0.f, 0.f, 0.f, 0.f};
@@ -822,6 +844,11 @@ __global__ __launch_bounds__(512, 2) void gpe_redgemm_b3_kernel(RdParams p)
                     *reinterpret_cast<uint4*>(ub + LU::slot(1, w4, cq + t)) = make_uint4(lw[0], lw[1], lw[2], lw[3]);
                 }
             }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) csd[t] += (double)c32[t];
+        };
+        auto commitV = [&](int buf) {
+            char* vb = Vb + buf * LV::BYTES;
             if (cq < VC) {
 #pragma unroll
                 for (int q = 0; q < RQ; ++q) {
@@ -843,25 +870,47 @@ __global__ __launch_bounds__(512, 2) void gpe_redgemm_b3_kernel(RdParams p)
                     *reinterpret_cast<uint4*>(vb + LV::slot(1, w4, cq + t)) = make_uint4(lw[0], lw[1], lw[2], lw[3]);
                 }
             }
-#pragma unroll
-            for (int t = 0; t < 4; ++t) csd[t] += (double)c32[t];
         };
 
+
+        // Order of a producer wave's iteration: see RD_B3_PIPE above.  Phase switches (RD_B3_DBG builds, us per launch at cfg 2,
+        // gathered / dense, stand-alone launches on random data): production 527 / 426, no commit 399 / 320, no row loads 378 / 301,
+        // neither 253 / 202, no consumer MFMAs 446 / 354, no MFMAs at all 394 / 331, nothing at all 94 / 85 — the phases ADD UP.
         GpeTileSeq sq = gpe_tile_seq(p.pin_tpc, p.rev, p.pin_clouds, p.num_tiles);
         int tile = gpe_seq_tile(sq);
         gpe_seq_advance(sq);
         int next = gpe_seq_tile(sq);
         gpe_seq_advance(sq);
         int next2 = gpe_seq_tile(sq);
+        gpe_seq_advance(sq);
+        int next3 = gpe_seq_tile(sq);
+        constexpr bool pipe = RD_B3_PIPE != 0;
         if (VMODE == V_GATHER) jgv = load_jgv(tile < p.num_tiles ? tile : 0);
-        if (tile < p.num_tiles) { fetch(tile); commit(0, tile); }
+        if (tile < p.num_tiles) { fetchU(tile); fetchV(tile); commitU(0, tile); commitV(0); }
         if (VMODE == V_GATHER && tile < p.num_tiles) jgv = load_jgv(next < p.num_tiles ? next : tile);
+        if (pipe && tile < p.num_tiles) {
+            fetchU(next < p.num_tiles ? next : tile);                       // committed in the first iteration
+            fetchV(next < p.num_tiles ? next : tile);
+            if (VMODE == V_GATHER) jgv = load_jgv(next2 < p.num_tiles ? next2 : tile);
+        }
         __syncthreads();                           // prologue
         int buf = 0;
-        for (; tile < p.num_tiles; tile = next, next = next2, gpe_seq_advance(sq), next2 = gpe_seq_tile(sq)) {
-            fetch(next < p.num_tiles ? next : tile);          // unconditional, clamped (see gpe_redgemm_pc_kernel)
-            if (VMODE == V_GATHER) jgv = load_jgv(next2 < p.num_tiles ? next2 : tile);
-            if (PMAX > 0) {
+        for (; tile < p.num_tiles; tile = next, next = next2, next2 = next3, gpe_seq_advance(sq), next3 = gpe_seq_tile(sq)) {
+            if constexpr (pipe) {
+                // U of tile t + 1 (fetched during iteration t - 1) -> LDS, U of tile t + 2 requested; then the same for V: each set
+                // of loads has the other operand's commit, the left-over MFMAs and the barrier to land
+                const bool cm = next < p.num_tiles && !(RD_B3_DBG & 1);
+                const int t2 = next2 < p.num_tiles ? next2 : tile;           // clamped: unconditional loads
+                if (cm) commitU(buf ^ 1, next);
+                if (!(RD_B3_DBG & 2)) fetchU(t2);
+                if (cm) commitV(buf ^ 1);
+                if (!(RD_B3_DBG & 2)) fetchV(t2);
+                if (VMODE == V_GATHER) jgv = load_jgv(next3 < p.num_tiles ? next3 : tile);
+            } else {
+                if (!(RD_B3_DBG & 2)) { fetchU(next < p.num_tiles ? next : tile); fetchV(next < p.num_tiles ? next : tile); }
+                if (VMODE == V_GATHER) jgv = load_jgv(next2 < p.num_tiles ? next2 : tile);
+            }
+            if (PMAX > 0 && !(RD_B3_DBG & 8)) {
                 const char* ub = Ub + buf * LU::BYTES;
                 const char* vb = Vb + buf * LV::BYTES;
 #pragma unroll
@@ -877,7 +926,7 @@ __global__ __launch_bounds__(512, 2) void gpe_redgemm_b3_kernel(RdParams p)
                     }
                 }
             }
-            if (next < p.num_tiles) commit(buf ^ 1, next);
+            if (!pipe && next < p.num_tiles && !(RD_B3_DBG & 1)) { commitU(buf ^ 1, next); commitV(buf ^ 1); }
             __syncthreads();
             buf ^= 1;
         }
