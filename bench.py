@@ -70,6 +70,7 @@ def parse():
     ap.add_argument('--no-fast-math-line', action='store_true', help='skip the extra mixed / bf16x3 measurements')
     ap.add_argument('--call-shapes', default=None, metavar='FILE', help='write per-(entry, int args) launch counts and mean durations')
     ap.add_argument('--edge-dbg', type=int, default=int(os.environ.get('GPE_EDGE_DBG', '0')), help='measurement aid: gpe_debug_set flags for the edge kernels (0 = product path)')
+    ap.add_argument('--f16x3-min-rows', type=int, default=-1, help='measurement aid: override the f16x3 size gate (gpe_f16x3_min_rows_set); -1 = library default')
     ap.add_argument('--torch-adam', action='store_true', help='torch.optim.Adam instead of the fused arena optimizer')
     return ap.parse_args()
 
@@ -408,6 +409,8 @@ def main():
     from gpe_amd import _lib, configs, nets, parallel
     if args.edge_dbg:
         _lib.query('gpe_debug_set', args.edge_dbg)
+    if args.f16x3_min_rows >= 0:
+        gpe_amd.set_f16x3_min_rows(args.f16x3_min_rows)
 
     rank, local, world = parallel.init_distributed()
     if world != args.gpus:

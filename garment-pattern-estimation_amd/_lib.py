@@ -105,12 +105,21 @@ def _conv(a):
 TIMING = None
 
 
+# the raw handle of torch's current stream without building a torch.cuda.Stream object per call (a small step — cfg 1, the att
+# k = 5 shape — issues ~100 launches in 4 - 7 ms: the host side of a call is part of the step there)
+_raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+_cur_device = getattr(torch._C, '_cuda_getDevice', None) or torch.cuda.current_device
+_FN = {}
+
+
 def call(name, *args):
     """Invoke a C-ABI entry point on torch's current HIP stream (appended as the trailing `stream` argument)."""
-    fn = getattr(lib(), name)
+    fn = _FN.get(name)
+    if fn is None:
+        fn = _FN[name] = getattr(lib(), name)
     # kernels run on the CURRENT device's stream: refuse tensors that live elsewhere (a model on cuda:1 while cuda:0 is
     # current would otherwise hand foreign pointers to the wrong device's queue)
-    cur = torch.cuda.current_device()
+    cur = _cur_device()
     for a in args:
         if isinstance(a, torch.Tensor):
             if not a.is_cuda or a.device.index != cur:
@@ -118,11 +127,15 @@ def call(name, *args):
                                    'torch.cuda.device(...) (one process per GPU is the supported layout)'
                                    % (name, a.device, cur))
             break
-    stream = torch.cuda.current_stream()
+    if TIMING is not None or _raw_stream is None:
+        stream = torch.cuda.current_stream()
+        handle = stream.cuda_stream
+    else:
+        handle = _raw_stream(cur)
     if TIMING is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(stream)
-    rc = fn(*[_conv(a) for a in args], stream.cuda_stream)
+    rc = fn(*[a.data_ptr() if isinstance(a, torch.Tensor) else a for a in args], handle)
     if TIMING is not None:
         e1.record(stream)
         TIMING.append((name, tuple(a for a in args if isinstance(a, (int, float))), e0, e1))

@@ -4,6 +4,8 @@
 //   F3  dense forward 200 -> 150 + max / min (10 x 13; activation rows as fp32 or, for the lazy-dz3 backward, fp16)
 //   B3  in-place backward 150 -> 200         (13 x 10; dz3 given, or formed from the stored fp16 activation: LAZY)
 //   B2  gathered backward 200 -> 200         (13 x 13)
+// ... and the same four for k = 5, the neighbourhood size of the shipped YAMLs (gpe_edgegemm_w8_k5.hip: three points per wave,
+// 60-row tiles; fp32 activation rows and the eager dz3 pass — the lazy path is k = 16 only).
 // Everything else stays on the single-role kernel (gpe_edgegemm_h3.hip).  GPE_W8 = four digits "F2 F3 B3 B2" (1 = this kernel,
 // 0 = the single-role one) or a single 0 / 1 for all four: A/B measurements inside one session.
 //
@@ -18,6 +20,7 @@
 #include "gpe_edgegemm_w8_kernel.h"
 
 int gpe_w8_launch_f3(const RgParams& p, int stats_nblk, hipStream_t s);     // gpe_edgegemm_w8_f3.hip
+int gpe_w8_dispatch_k5(int amode, int emode, int NT, int KCH, const RgParams& p, int stats_nblk, hipStream_t s);   // gpe_edgegemm_w8_k5.hip
 int gpe_w8_launch_b3(const RgParams& p, int stats_nblk, hipStream_t s);     // gpe_edgegemm_w8_b3.hip
 
 static int w8_enabled(int kind)
@@ -39,10 +42,16 @@ static int w8_enabled(int kind)
 // launch is not on this kernel's menu.
 int gpe_edgegemm_w8_dispatch(int amode, int emode, int NT, int KCH, const RgParams& p, int stats_nblk, hipStream_t s)
 {
-    if (p.k != 16 || p.pmagic || p.R != RG_BM || (p.M & 15)) return GPE_ENOTSUP_SHAPE;
+    // k = 16 (64-row tiles) or k = 5 (60-row tiles: gpe_edgegemm_w8_k5.hip); whole points only
+    if (p.pmagic || !((p.k == 16 && p.R == 64) || (p.k == 5 && p.R == 60)) || p.M % p.k) return GPE_ENOTSUP_SHAPE;
     // the K-partials of the split tiles lie in the first 384 / 256 bytes of a plane row: bytes every commit rewrites
     const int kbytes = 2 * ((p.K + 3) & ~3);
     if (kbytes < (KCH == 13 ? 384 : 256)) return GPE_ENOTSUP_SHAPE;
+    if (p.k == 5) {
+        const int kind = (emode == E_EDGE_FWD) ? (amode == A_GATHER ? 0 : 1) : (emode == E_BWD_INPLACE ? 2 : 3);
+        if (p.out_half || p.lz_g) return GPE_EINVAL;
+        return w8_enabled(kind) ? gpe_w8_dispatch_k5(amode, emode, NT, KCH, p, stats_nblk, s) : GPE_ENOTSUP_SHAPE;
+    }
     if (p.out_half && !(emode == E_EDGE_FWD && amode == A_DENSE && p.agg)) return GPE_EINVAL;
     if (p.lz_g && !(emode == E_BWD_INPLACE && amode == A_DENSE)) return GPE_EINVAL;
     if (amode == A_GATHER && emode == E_EDGE_FWD && NT == 13 && KCH == 13 && !p.agg && w8_enabled(0))

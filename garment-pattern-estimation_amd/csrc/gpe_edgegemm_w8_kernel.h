@@ -34,6 +34,9 @@
 #define W8_RING 8          // stored-activation rows in flight per finisher (backward variants)
 typedef unsigned w8_u32x2 __attribute__((ext_vector_type(2)));
 // keeps a loaded quad (and therefore its load) in front of this point: see the finisher's epilogue
+#ifndef W8_B2_SC1
+#define W8_B2_SC1 1
+#endif
 #ifndef W8_BUFSTORE
 // bit 0 F2, 1 F3, 2 B3, 3 B2: row stores through the buffer descriptor.  NOT the in-place backward (B3): it loads the rows it later
 // overwrites through plain global pointers, the compiler takes buffer accesses and global accesses for disjoint memory, and the
@@ -43,10 +46,19 @@ typedef unsigned w8_u32x2 __attribute__((ext_vector_type(2)));
 #endif
 __device__ __forceinline__ void w8_pin4(float4& v) { asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w)); }
 
-template <int NT, int KCH, int AMODE, int EMODE, int AGGT, bool LAZY>
+// KK = neighbours per point, compile time: 16 (BASELINE cfg 2 / 3 / 5: one point of 16 rows per wave and tile) or 5 (the shipped YAMLs,
+// models/att/att.yaml:94: three points of 5 rows per wave, 60-row tiles — rows 60..63 of the LDS tile belong to nobody: they are
+// multiplied like the others and never read).  Every per-row decision (which point, which slot, where a point ends) is a
+// compile-time function of the row number u, so the slots stay straight-line code for both.
+template <int NT, int KCH, int AMODE, int EMODE, int AGGT, bool LAZY, int KK = 16>
 __global__ __launch_bounds__(512) void gpe_edgegemm_w8_kernel(RgParams p, int stats_nblk)
 {
     using SP = SplitF16x2;
+    static_assert(KK == 16 || KK == 5, "neighbourhood sizes with a compile-time row schedule");
+    static_assert(!LAZY || KK == 16, "lazy dz3 needs one point per wave");
+    constexpr int NPW = 16 / KK;                         // points per wave and tile
+    constexpr int RW = NPW * KK;                         // rows a wave stages / finishes per tile (16 or 15)
+    constexpr int TR = 4 * RW;                           // rows per tile (64 or 60)
     static_assert(NT == 13 || (NT == 10 && KCH == 13), "shapes of the shipped edge MLPs");
     static_assert(KCH == 13 || KCH == 10, "K = 200 / 150");
     static_assert(!LAZY || (AMODE == A_DENSE && EMODE == E_BWD_INPLACE), "lazy dz3: in-place backward");
@@ -89,7 +101,7 @@ __global__ __launch_bounds__(512) void gpe_edgegemm_w8_kernel(RgParams p, int st
     const int role = wave >> 2, pt = wave & 3;           // role 0 stages, role 1 finishes; both for point `pt` of a tile
     const int j = lane & 15, g = lane >> 4;
     const int g_tail = (g >= 2) ? (g & 1) : g;
-    const int rb = 16 * pt;
+    const int rb = RW * pt;
     const int c = lane << 2;                             // this lane's column quad
     const bool n_on = c < p.N;
     // staging is branch-free: lanes past the last K quad repeat that quad (same address, same data) instead of being masked — a load
@@ -174,11 +186,11 @@ __global__ __launch_bounds__(512) void gpe_edgegemm_w8_kernel(RgParams p, int st
         asm volatile("s_mov_b32 %0, 0" : "=s"(sz_));           \
         rbl = rb + sz_;                                        \
     }
-    // neighbour rows of this wave's point in `tile`, lane-distributed: lane L <-> row rb + min(L, 15) (clamped into the tile)
+    // neighbour rows of this wave's points in `tile`, lane-distributed: lane L <-> row rb + min(L, RW - 1) (clamped into the tile)
     auto load_jgv = [&](int tile) -> int {
-        const long row0 = (long)tile * RG_BM;
-        const int rv = (int)((p.M - row0 < RG_BM) ? (p.M - row0) : RG_BM);
-        int r = rbl + ((lane < 16) ? lane : 15);
+        const long row0 = (long)tile * TR;
+        const int rv = (int)((p.M - row0 < TR) ? (p.M - row0) : TR);
+        int r = rbl + ((lane < RW) ? lane : RW - 1);
         r = (r < rv - 1) ? r : rv - 1;
         return p.jg[row0 + r];
     };
@@ -192,7 +204,9 @@ __global__ __launch_bounds__(512) void gpe_edgegemm_w8_kernel(RgParams p, int st
 
         // ---- stager state ----
         float4 v[8];
-        float4 pvs0 = zero4;
+        float4 pvs[NPW];                                 // gather: P rows of the points being staged
+#pragma unroll
+        for (int q = 0; q < NPW; ++q) pvs[q] = zero4;
         int s_rv = 0, jgv_a = 0, jgv_b = 0;              // neighbour rows of the tile being staged / of the one after it
         float lzs[4] = {0.f, 0.f, 0.f, 0.f}, lznc[4] = {0.f, 0.f, 0.f, 0.f}, lznk[4] = {0.f, 0.f, 0.f, 0.f};
         int lz_sel[4] = {0, 0, 0, 0};
@@ -244,8 +258,10 @@ __global__ __launch_bounds__(512) void gpe_edgegemm_w8_kernel(RgParams p, int st
         for (int t = 0; t < 4; ++t) { vmx[t] = -INFINITY; vmn[t] = INFINITY; imx[t] = 0; imn[t] = 0; }
         float4 dp = zero4;
         float4 act[(ROLE == 1 && !FWD) ? W8_RING : 1];
-        float4 pve0 = zero4;                             // P row of the point being finished (E_BWD_GATHER)
-        long e_row0 = 0, e_pt = 0; int e_rv = 0;         // tile being finished
+        float4 pve[NPW];                                 // P rows of the points being finished (E_BWD_GATHER)
+#pragma unroll
+        for (int q = 0; q < NPW; ++q) pve[q] = zero4;
+        long e_row0 = 0, e_pt = 0; int e_rv = 0;         // tile being finished; e_pt = this wave's first point
         // The epilogue of a row sits under ONE wave-uniform branch (nothing to finish in the first iteration and for an absent point of
         // a ragged last tile).  The compiler sinks a load whose only use lies in a conditional block INTO the block, where it then
         // waits for its own round trip — so the row's C quad and stored activation are pinned (w8_pin4) in front of the branch: the
@@ -261,11 +277,11 @@ __global__ __launch_bounds__(512) void gpe_edgegemm_w8_kernel(RgParams p, int st
 
         // ---- stager: VMEM issue + LDS commit --------------------------------------------------------------------------------
         auto issue_stage_loads = [&](int tile_s, int h) {
-            const long row0 = (long)tile_s * RG_BM;
-            s_rv = (int)((p.M - row0 < RG_BM) ? (p.M - row0) : RG_BM);
+            const long row0 = (long)tile_s * TR;
+            s_rv = (int)((p.M - row0 < TR) ? (p.M - row0) : TR);
             const int last = s_rv - 1;
-            // the point of this wave's 16 rows, clamped into the last valid point of the tile
-            const long pt0 = (long)tile_s * 4 + pt, ptl = (long)tile_s * 4 + (last >> 4);
+            // the first point of this wave's rows, clamped into the last valid point of the tile
+            const long pt0 = (long)tile_s * (4 * NPW) + pt * NPW, ptl = (long)tile_s * (4 * NPW) + last / KK;
             const long ptc = pt0 < ptl ? pt0 : ptl;
             if (h == 0) {
                 if constexpr (LAZY) {
@@ -277,11 +293,14 @@ __global__ __launch_bounds__(512) void gpe_edgegemm_w8_kernel(RgParams p, int st
                     lz_sx = *reinterpret_cast<const uchar4*>(p.lz_amx + ptc * p.lz_ldagg + ck);
                     lz_sn = *reinterpret_cast<const uchar4*>(p.lz_amn + ptc * p.lz_ldagg + ck);
                 }
-                if constexpr (AMODE == A_GATHER) pvs0 = ld4(p.pq + (ptc + vz) * p.ldpq + ck);
+                if constexpr (AMODE == A_GATHER) {
+#pragma unroll
+                    for (int q = 0; q < NPW; ++q) pvs[q] = ld4(p.pq + ((pt0 + q < ptl ? pt0 + q : ptl) + vz) * p.ldpq + ck);
+                }
             }
 #pragma unroll
             for (int uu = 0; uu < 8; ++uu) {
-                const int u = 8 * h + uu;
+                const int u = (8 * h + uu < RW) ? 8 * h + uu : RW - 1;     // (KK = 5: the 16th row does not exist — loaded twice, committed never)
                 int r = rbl + u;
                 r = (r < last) ? r : last;
                 if constexpr (AMODE == A_GATHER) {
@@ -296,11 +315,13 @@ __global__ __launch_bounds__(512) void gpe_edgegemm_w8_kernel(RgParams p, int st
             }
         };
         auto commit_row = [&](float* An, int u) {
+            if (u >= RW) return;                         // (compile time)
             const int r = rbl + u;
             float4 o = v[u & 7];
             if constexpr (AMODE == A_GATHER) {
-                o.x = fmaxf(o.x + pvs0.x, 0.f); o.y = fmaxf(o.y + pvs0.y, 0.f);
-                o.z = fmaxf(o.z + pvs0.z, 0.f); o.w = fmaxf(o.w + pvs0.w, 0.f);
+                const float4 pv = pvs[u / KK];
+                o.x = fmaxf(o.x + pv.x, 0.f); o.y = fmaxf(o.y + pv.y, 0.f);
+                o.z = fmaxf(o.z + pv.z, 0.f); o.w = fmaxf(o.w + pv.w, 0.f);
             }
             if constexpr (LAZY) {
                 // dz3 of slot u of the wave's point (gpe_dz3_kernel's arithmetic): the message that won the aggregation carries s * g
@@ -347,8 +368,9 @@ __global__ __launch_bounds__(512) void gpe_edgegemm_w8_kernel(RgParams p, int st
         // stored activation of row u of `tile_e` (whose neighbour rows are jv) -> ring entry u % W8_RING
         auto issue_act_load = [&](int u, int tile_e, int jv) {
             if constexpr (ROLE == 1 && !FWD) {
-                const long row0 = (long)tile_e * RG_BM;
-                const int rv = (int)((p.M - row0 < RG_BM) ? (p.M - row0) : RG_BM);
+                const long row0 = (long)tile_e * TR;
+                const int rv = (int)((p.M - row0 < TR) ? (p.M - row0) : TR);
+                if (u >= RW) u = RW - 1;                 // (KK = 5: no 16th row)
                 int r = rbl + u;
                 r = (r < rv - 1) ? r : rv - 1;           // clamp: unconditional loads
                 if constexpr (EMODE == E_BWD_INPLACE) act[u % W8_RING] = ld4(p.out + (row0 + r) * p.ldo + cn);
@@ -359,10 +381,10 @@ __global__ __launch_bounds__(512) void gpe_edgegemm_w8_kernel(RgParams p, int st
             }
         };
         auto begin_epi = [&](int tile_e, bool on) {
-            e_row0 = (long)tile_e * RG_BM;
-            e_pt = (long)tile_e * 4 + pt;
-            e_rv = (int)((p.M - e_row0 < RG_BM) ? (p.M - e_row0) : RG_BM);
-            epi_on = on && rbl < e_rv;                   // all 16 rows of the wave's point are valid or none is
+            e_row0 = (long)tile_e * TR;
+            e_pt = (long)tile_e * (4 * NPW) + pt * NPW;
+            e_rv = (int)((p.M - e_row0 < TR) ? (p.M - e_row0) : TR);
+            epi_on = on && rbl < e_rv;                   // KK = 16: all rows of the wave's point are valid or none is
             constexpr int ES = OUTH ? 2 : 4;             // bytes per stored element
             orsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(p.out) + e_row0 * p.ldo * ES, 0, RG_BM * p.ldo * ES, 0x00020000);
 #pragma unroll
@@ -370,15 +392,20 @@ __global__ __launch_bounds__(512) void gpe_edgegemm_w8_kernel(RgParams p, int st
             dp = zero4;
             amax_t = 0.f;
             if constexpr (GATHER_ACT) {
-                const long ptl = (long)tile_e * 4 + ((e_rv - 1) >> 4);
-                pve0 = ld4(p.pq + ((e_pt < ptl ? e_pt : ptl) + vz) * p.ldpq + cn);
+                const long ptl = (long)tile_e * (4 * NPW) + (e_rv - 1) / KK;
+#pragma unroll
+                for (int q = 0; q < NPW; ++q) pve[q] = ld4(p.pq + ((e_pt + q < ptl ? e_pt + q : ptl) + vz) * p.ldpq + cn);
             }
         };
         auto epi_row = [&](int u, float4 z) {
+            if (u >= RW) return;                         // (compile time)
             w8_pin4(z);
             if constexpr (!FWD) w8_pin4(act[u % W8_RING]);
             if (!epi_on) return;
             const int r = rbl + u;                       // row inside the tile: wave-uniform -> the descriptor's scalar offset
+            if constexpr (KK != 16) {
+                if (r >= e_rv) return;                   // a ragged last tile ends between the points of a wave
+            }
             if constexpr (FWD) {
                 const float vv[4] = {fmaxf(__builtin_fmaf(z.x, invAW, bias4.x), 0.f), fmaxf(__builtin_fmaf(z.y, invAW, bias4.y), 0.f),
                                      fmaxf(__builtin_fmaf(z.z, invAW, bias4.z), 0.f), fmaxf(__builtin_fmaf(z.w, invAW, bias4.w), 0.f)};
@@ -405,15 +432,16 @@ __global__ __launch_bounds__(512) void gpe_edgegemm_w8_kernel(RgParams p, int st
                     s32[t] += vv[t];
                     q32[t] = __builtin_fmaf(vv[t], vv[t], q32[t]);
                     if constexpr (TRACK) {
-                        if (vv[t] > vmx[t]) { vmx[t] = vv[t]; imx[t] = u; }
-                        if (vv[t] < vmn[t]) { vmn[t] = vv[t]; imn[t] = u; }
+                        if (vv[t] > vmx[t]) { vmx[t] = vv[t]; imx[t] = u % KK; }
+                        if (vv[t] < vmn[t]) { vmn[t] = vv[t]; imn[t] = u % KK; }
                     }
                 }
             } else {
                 float4 av = act[u % W8_RING];
                 if constexpr (GATHER_ACT) {
-                    av.x = fmaxf(av.x + pve0.x, 0.f); av.y = fmaxf(av.y + pve0.y, 0.f);
-                    av.z = fmaxf(av.z + pve0.z, 0.f); av.w = fmaxf(av.w + pve0.w, 0.f);
+                    const float4 pv = pve[u / KK];
+                    av.x = fmaxf(av.x + pv.x, 0.f); av.y = fmaxf(av.y + pv.y, 0.f);
+                    av.z = fmaxf(av.z + pv.z, 0.f); av.w = fmaxf(av.w + pv.w, 0.f);
                 }
                 float4 o;
                 o.x = (av.x > 0.f) ? __builtin_fmaf(z.x, cs4.x, __builtin_fmaf(k24.x, av.x, c14.x)) : 0.f;
@@ -421,30 +449,40 @@ __global__ __launch_bounds__(512) void gpe_edgegemm_w8_kernel(RgParams p, int st
                 o.z = (av.z > 0.f) ? __builtin_fmaf(z.z, cs4.z, __builtin_fmaf(k24.z, av.z, c14.z)) : 0.f;
                 o.w = (av.w > 0.f) ? __builtin_fmaf(z.w, cs4.w, __builtin_fmaf(k24.w, av.w, c14.w)) : 0.f;
                 const x6_u32x4 oq = {__float_as_uint(o.x), __float_as_uint(o.y), __float_as_uint(o.z), __float_as_uint(o.w)};
+                // (gathered backward: sc1 like the gather forward — its dz rows are read by another kernel much later, and kept in L2 they
+                // evict the cloud's Q table this kernel's epilogue keeps re-reading: round 3 measured 1122 -> 974 MB fetched per launch
+                // for that change but lost 6 % to the `asm volatile` store it needed then)
                 if constexpr ((W8_BUFSTORE & (EMODE == E_BWD_INPLACE ? 4 : 8)) != 0)
-                    __builtin_amdgcn_raw_buffer_store_b128(oq, orsrc, cn * 4, r * p.ldo * 4, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(oq, orsrc, cn * 4, r * p.ldo * 4, (GATHER_ACT && W8_B2_SC1) ? 16 : 0);
                 else
                     st4(p.out + (e_row0 + r) * p.ldo + cn, o);
                 if constexpr (EMODE == E_BWD_INPLACE)
                     amax_t = fmaxf(fmaxf(amax_t, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
                 dp.x += o.x; dp.y += o.y; dp.z += o.z; dp.w += o.w;
             }
-            if (u == 15) {                               // the point is complete (compile time)
-                if constexpr (TRACK) amax_t = fmaxf(fmaxf(vmx[0], vmx[1]), fmaxf(vmx[2], vmx[3]));
+            if (u % KK == KK - 1) {                      // a point is complete (compile time)
+                if constexpr (TRACK) amax_t = fmaxf(amax_t, fmaxf(fmaxf(vmx[0], vmx[1]), fmaxf(vmx[2], vmx[3])));
                 {
+                    const long gpt = e_pt + u / KK;
                     if constexpr (TRACK) {
-                        const long o = e_pt * p.oldagg + cn;
+                        const long o = gpt * p.oldagg + cn;
                         st4(p.mx + o, make_float4(vmx[0], vmx[1], vmx[2], vmx[3]));
                         st4(p.mn + o, make_float4(vmn[0], vmn[1], vmn[2], vmn[3]));
                         *reinterpret_cast<uchar4*>(p.oamx + o) = make_uchar4(imx[0], imx[1], imx[2], imx[3]);
                         *reinterpret_cast<uchar4*>(p.oamn + o) = make_uchar4(imn[0], imn[1], imn[2], imn[3]);
                     }
-                    if constexpr (GATHER_ACT) st4(p.dP + e_pt * p.lddp + cn, dp);
+                    if constexpr (GATHER_ACT) st4(p.dP + gpt * p.lddp + cn, dp);
                 }
+                // (per point, not per wave: a ragged last tile can end between the points of a KK = 5 wave)
                 amax_run = fmaxf(amax_run, amax_t);
                 if constexpr (FWD) {
 #pragma unroll
                     for (int t = 0; t < 4; ++t) { stS[t] += (double)s32[t]; stQ[t] += (double)q32[t]; }
+                }
+                if constexpr (NPW > 1) {                 // the next point of this wave starts clean
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) { vmx[t] = -INFINITY; vmn[t] = INFINITY; imx[t] = 0; imn[t] = 0; s32[t] = 0.f; q32[t] = 0.f; }
+                    dp = zero4;
                 }
             }
         };
@@ -531,7 +569,7 @@ __global__ __launch_bounds__(512) void gpe_edgegemm_w8_kernel(RgParams p, int st
                         if (q >= EP0 && q < EP0 + 8) issue_act_load(q - EP0 + 8, tile_e, jgv_cur);
                         if (q >= EP0 + 8) issue_act_load(q - EP0 - 8, tile, jgv_e);
                         if (q + 1 >= EP0 && q + 1 < NSLOT) {         // C row of the NEXT slot's epilogue (LDS prefetch)
-                            const int rr = rbl + (q + 1 - EP0);
+                            const int rr = rbl + ((q + 1 - EP0 < RW) ? q + 1 - EP0 : RW - 1);
                             zq = ld4(&Cs[rr * LDC + cn]);
                         }
                     }
@@ -586,7 +624,8 @@ __global__ __launch_bounds__(512) void gpe_edgegemm_w8_kernel(RgParams p, int st
             __syncthreads();                             // (2) C complete, partials complete, next A tile complete
             if constexpr (ROLE == 1) {
                 // fold the partials of this point's 16 rows into C, in slot order (bit-reproducible), then release the rows
-                const int ur = lane >> 2, cq = (lane & 3) << 2;
+                // (KK = 5: a wave owns 15 rows — the 16th lane group repeats the 15th row's fold: same values, same addresses)
+                const int ur = (lane >> 2) < RW ? (lane >> 2) : RW - 1, cq = (lane & 3) << 2;
                 const int row = rbl + ur;
                 if constexpr (PAIRS) {
 #pragma unroll
@@ -631,7 +670,7 @@ __global__ __launch_bounds__(512) void gpe_edgegemm_w8_kernel(RgParams p, int st
                 jgv_cur = jgv_e;
                 // rows 0..7 were requested in the last iteration; rows 8..15 as the ring frees
 #pragma unroll
-                for (int u = 0; u < 16; ++u) {
+                for (int u = 0; u < RW; ++u) {
                     epi_row(u, ld4(&Cs[(rbl + u) * LDC + cn]));
                     if (u < 8) issue_act_load(u + 8, prev >= 0 ? prev : 0, jgv_cur);
                 }
@@ -688,18 +727,18 @@ __global__ __launch_bounds__(512) void gpe_edgegemm_w8_kernel(RgParams p, int st
 #undef W8_REFRESH_SCALARS
 }
 
-template <int NT, int KCH, int AMODE, int EMODE, int AGGT, bool LAZY>
+template <int NT, int KCH, int AMODE, int EMODE, int AGGT, bool LAZY, int KK = 16>
 static int w8_launch(const RgParams& p, int stats_nblk, hipStream_t s)
 {
     constexpr int LDC = 16 * NT + 4;
     constexpr int AWORDS = (2 * RG_BM * 16 * x6_pchunks(KCH)) / 4;
     const size_t lds = (size_t)(2 * AWORDS + RG_BM * LDC) * sizeof(float);
     // 32 bytes of static __shared__ (amax_sh, flag_sh) sit beside the dynamic image
-    GPE_ENSURE_MAX_LDS_N((gpe_edgegemm_w8_kernel<NT, KCH, AMODE, EMODE, AGGT, LAZY>), 160 * 1024 - 64);
+    GPE_ENSURE_MAX_LDS_N((gpe_edgegemm_w8_kernel<NT, KCH, AMODE, EMODE, AGGT, LAZY, KK>), 160 * 1024 - 64);
     int gx = gpe_num_cus();
     if (gx > p.num_tiles) gx = p.num_tiles;
     if (stats_nblk > 0 && gx > stats_nblk) gx = stats_nblk;
-    hipLaunchKernelGGL((gpe_edgegemm_w8_kernel<NT, KCH, AMODE, EMODE, AGGT, LAZY>), dim3(gx), dim3(512), lds, s, p, stats_nblk);
+    hipLaunchKernelGGL((gpe_edgegemm_w8_kernel<NT, KCH, AMODE, EMODE, AGGT, LAZY, KK>), dim3(gx), dim3(512), lds, s, p, stats_nblk);
     GPE_CHECK_LAUNCH();
     return GPE_OK;
 }

@@ -107,6 +107,12 @@ _JOB = np.dtype([('w', '<u8'), ('w2', '<u8'), ('out', '<u8'), ('total', '<i8'), 
 assert _JOB.itemsize == 64
 
 
+# PackPlan.refresh on a side stream under the layer-1 kNN search: built in round 5 and MEASURED SLOWER (cfg 2, one session, twice each:
+# 10.19 / 10.17 ms per step without, 10.34 / 10.34 with — the stream fork / join costs more than the 0.09 ms of pack launches it hides).
+# Off; GPE_PACK_ASYNC=1 turns it on for A/B runs.
+PACK_ASYNC = os.environ.get('GPE_PACK_ASYNC', '0') == '1'
+
+
 def bump_weights_epoch():
     global WEIGHTS_EPOCH
     WEIGHTS_EPOCH += 1
@@ -140,6 +146,8 @@ class PackPlan:
         self.frozen = False
         self.h3_current = False
         self._stream = None
+        self._side = None
+        self._ready = None
         self._keys_box = box = []              # shared with the finalizer: the keys this plan currently owns in _PACKS
         me = weakref.ref(self)
         # pop only entries that are still THIS plan's: a newer plan over the same parameters may have re-registered the keys
@@ -262,13 +270,38 @@ class PackPlan:
               self.h3_current == (self.pre_table is not None and L.get_math() == 'f16x3')):   # (a mode change re-runs the packs)
             return
         self.h3_current = self.pre_table is not None and L.get_math() == 'f16x3'
-        if self.h3_current:
-            self.words.zero_()
-            L.call('gpe_pack_multi', self.pre_table, self.pre_table.numel() // 64, self.pre_blocks)
-            L.call('gpe_pack_multi', self.table, len(self.specs), self.blocks)
+
+        def launches():
+            if self.h3_current:
+                self.words.zero_()
+                L.call('gpe_pack_multi', self.pre_table, self.pre_table.numel() // 64, self.pre_blocks)
+                L.call('gpe_pack_multi', self.table, len(self.specs), self.blocks)
+            else:
+                L.call('gpe_pack_multi', self.table_noh3, self.n_noh3, self.blocks_noh3)
+
+        if PACK_ASYNC and self.specs[0][0].is_cuda:
+            # The pack launches (two or three small grids, ~0.09 ms per step at cfg 2) run on a side stream: the first thing a model
+            # forward does after this call is the layer-1 kNN search, which reads no pack — the first consumer of a pack makes its
+            # stream wait for `_ready` (see _planned).  The side stream first waits for everything queued so far (the optimizer's
+            # update of the parameters, last step's readers of the old packs).
+            main = self._stream
+            if self._side is None or self._side.device != main.device:
+                self._side = torch.cuda.Stream(device=main.device)
+            self._side.wait_stream(main)
+            with torch.cuda.stream(self._side):
+                launches()
+                self._ready = torch.cuda.Event()
+                self._ready.record(self._side)
         else:
-            L.call('gpe_pack_multi', self.table_noh3, self.n_noh3, self.blocks_noh3)
+            launches()
+            self._ready = None
         self.vers, self.epoch = vers, WEIGHTS_EPOCH
+
+    def _await(self):
+        """Called by the accessors of this plan's packs: the consumer's stream waits for an in-flight refresh (once)."""
+        if self._ready is not None:
+            torch.cuda.current_stream().wait_event(self._ready)
+            self._ready = None
 
 
 def _planned(t, kind, t2=None):
@@ -282,6 +315,7 @@ def _planned(t, kind, t2=None):
         return None
     if plan.vers[i] != t._version + (t2._version if t2 is not None else 0):
         return None
+    plan._await()
     return out
 
 
