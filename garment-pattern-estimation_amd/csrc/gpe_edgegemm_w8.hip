@@ -21,6 +21,7 @@
 
 int gpe_w8_launch_f3(const RgParams& p, int stats_nblk, hipStream_t s);     // gpe_edgegemm_w8_f3.hip
 int gpe_w8_dispatch_k5(int amode, int emode, int NT, int KCH, const RgParams& p, int stats_nblk, hipStream_t s);   // gpe_edgegemm_w8_k5.hip
+int gpe_w8_dispatch_k4(int amode, int emode, int NT, int KCH, const RgParams& p, int stats_nblk, hipStream_t s);   // gpe_edgegemm_w8_k4.hip
 int gpe_w8_launch_b3(const RgParams& p, int stats_nblk, hipStream_t s);     // gpe_edgegemm_w8_b3.hip
 
 static int w8_enabled(int kind)
@@ -42,15 +43,18 @@ static int w8_enabled(int kind)
 // launch is not on this kernel's menu.
 int gpe_edgegemm_w8_dispatch(int amode, int emode, int NT, int KCH, const RgParams& p, int stats_nblk, hipStream_t s)
 {
-    // k = 16 (64-row tiles) or k = 5 (60-row tiles: gpe_edgegemm_w8_k5.hip); whole points only
-    if (p.pmagic || !((p.k == 16 && p.R == 64) || (p.k == 5 && p.R == 60)) || p.M % p.k) return GPE_ENOTSUP_SHAPE;
+    // k = 16 (64-row tiles), k = 5 (60-row tiles: gpe_edgegemm_w8_k5.hip) or four-row (pseudo-)points (k = 20 as 5 x 4, and the rows
+    // of any k > 16 that need nothing per point: gpe_edgegemm_w8_k4.hip); whole points only
+    if (!((p.k == 16 && p.R == 64 && !p.pmagic) || (p.k == 5 && p.R == 60 && !p.pmagic) || (p.k == 4 && p.R == 64)) || p.M % p.k)
+        return GPE_ENOTSUP_SHAPE;
     // the K-partials of the split tiles lie in the first 384 / 256 bytes of a plane row: bytes every commit rewrites
     const int kbytes = 2 * ((p.K + 3) & ~3);
     if (kbytes < (KCH == 13 ? 384 : 256)) return GPE_ENOTSUP_SHAPE;
-    if (p.k == 5) {
+    if (p.k != 16) {
         const int kind = (emode == E_EDGE_FWD) ? (amode == A_GATHER ? 0 : 1) : (emode == E_BWD_INPLACE ? 2 : 3);
         if (p.out_half || p.lz_g) return GPE_EINVAL;
-        return w8_enabled(kind) ? gpe_w8_dispatch_k5(amode, emode, NT, KCH, p, stats_nblk, s) : GPE_ENOTSUP_SHAPE;
+        if (!w8_enabled(kind)) return GPE_ENOTSUP_SHAPE;
+        return p.k == 5 ? gpe_w8_dispatch_k5(amode, emode, NT, KCH, p, stats_nblk, s) : gpe_w8_dispatch_k4(amode, emode, NT, KCH, p, stats_nblk, s);
     }
     if (p.out_half && !(emode == E_EDGE_FWD && amode == A_DENSE && p.agg)) return GPE_EINVAL;
     if (p.lz_g && !(emode == E_BWD_INPLACE && amode == A_DENSE)) return GPE_EINVAL;

@@ -31,7 +31,6 @@
 #ifndef W8_SLOT_FENCE
 #define W8_SLOT_FENCE 1
 #endif
-#define W8_RING 8          // stored-activation rows in flight per finisher (backward variants)
 typedef unsigned w8_u32x2 __attribute__((ext_vector_type(2)));
 // keeps a loaded quad (and therefore its load) in front of this point: see the finisher's epilogue
 #ifndef W8_B2_SC1
@@ -46,15 +45,17 @@ typedef unsigned w8_u32x2 __attribute__((ext_vector_type(2)));
 #endif
 __device__ __forceinline__ void w8_pin4(float4& v) { asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w)); }
 
-// KK = neighbours per point, compile time: 16 (BASELINE cfg 2 / 3 / 5: one point of 16 rows per wave and tile) or 5 (the shipped YAMLs,
+// KK = rows per point, compile time: 16 (BASELINE cfg 2 / 3 / 5: one point of 16 rows per wave and tile), 5 (the shipped YAMLs,
 // models/att/att.yaml:94: three points of 5 rows per wave, 60-row tiles — rows 60..63 of the LDS tile belong to nobody: they are
-// multiplied like the others and never read).  Every per-row decision (which point, which slot, where a point ends) is a
+// multiplied like the others and never read) or 4 (BASELINE cfg 4, k = 20: a point runs as five PSEUDO-points of four rows whose
+// per-point results are folded afterwards — gpe_edge_pseudo_setup / _fold, gpe_edgegemm_sr.hip; RgParams::pmagic != 0 then turns
+// a pseudo-point number into its P row; rows that need nothing per point are simply tiled by four).  Every per-row decision (which point, which slot, where a point ends) is a
 // compile-time function of the row number u, so the slots stay straight-line code for both.
 template <int NT, int KCH, int AMODE, int EMODE, int AGGT, bool LAZY, int KK = 16>
 __global__ __launch_bounds__(512) void gpe_edgegemm_w8_kernel(RgParams p, int stats_nblk)
 {
     using SP = SplitF16x2;
-    static_assert(KK == 16 || KK == 5, "neighbourhood sizes with a compile-time row schedule");
+    static_assert(KK == 16 || KK == 5 || KK == 4, "neighbourhood sizes with a compile-time row schedule");
     static_assert(!LAZY || KK == 16, "lazy dz3 needs one point per wave");
     constexpr int NPW = 16 / KK;                         // points per wave and tile
     constexpr int RW = NPW * KK;                         // rows a wave stages / finishes per tile (16 or 15)
@@ -88,6 +89,9 @@ __global__ __launch_bounds__(512) void gpe_edgegemm_w8_kernel(RgParams p, int st
     constexpr int C1 = (NSLOT >= 28) ? 22 : 16;
     // finisher: one row per slot in the last 16 slots
     constexpr int EP0 = NSLOT - 16;
+    // stored-activation rows in flight per finisher (backward variants): a ring; the gathered backward with several points per wave
+    // (three or four P rows, per-point sums) has 8 registers fewer to give
+    constexpr int RING = (GATHER_ACT && NPW > 1) ? 6 : 8;
 
     extern __shared__ __align__(16) float smem[];
     __shared__ unsigned amax_sh[4];
@@ -194,6 +198,9 @@ __global__ __launch_bounds__(512) void gpe_edgegemm_w8_kernel(RgParams p, int st
         r = (r < rv - 1) ? r : rv - 1;
         return p.jg[row0 + r];
     };
+    // P row of (pseudo-)point x (wave-uniform): x itself, or x / f when a k > 16 point runs as f pseudo-points
+    // (only the four-row instances are ever launched with pseudo-points)
+    auto prow = [&](long x) -> long { return (KK == 4 && p.pmagic) ? (long)__umulhi((unsigned)x, p.pmagic) : x; };
     // float index, inside an A buffer, of partial slot s of row `row`
     auto scr = [&](int row, int s) -> int { return ((s >= SPP ? PLANE + (s - SPP) * 64 : s * 64) + row * PPITCH) >> 2; };
 
@@ -204,9 +211,11 @@ __global__ __launch_bounds__(512) void gpe_edgegemm_w8_kernel(RgParams p, int st
 
         // ---- stager state ----
         float4 v[8];
-        float4 pvs[NPW];                                 // gather: P rows of the points being staged
+        // gather: P rows of the (at most two) points a batch of 8 rows touches — batch h covers points (8 h) / KK and the next one
+        constexpr int NPB = NPW > 1 ? 2 : 1;
+        float4 pvs[NPB];
 #pragma unroll
-        for (int q = 0; q < NPW; ++q) pvs[q] = zero4;
+        for (int q = 0; q < NPB; ++q) pvs[q] = zero4;
         int s_rv = 0, jgv_a = 0, jgv_b = 0;              // neighbour rows of the tile being staged / of the one after it
         float lzs[4] = {0.f, 0.f, 0.f, 0.f}, lznc[4] = {0.f, 0.f, 0.f, 0.f}, lznk[4] = {0.f, 0.f, 0.f, 0.f};
         int lz_sel[4] = {0, 0, 0, 0};
@@ -257,10 +266,13 @@ __global__ __launch_bounds__(512) void gpe_edgegemm_w8_kernel(RgParams p, int st
 #pragma unroll
         for (int t = 0; t < 4; ++t) { vmx[t] = -INFINITY; vmn[t] = INFINITY; imx[t] = 0; imn[t] = 0; }
         float4 dp = zero4;
-        float4 act[(ROLE == 1 && !FWD) ? W8_RING : 1];
-        float4 pve[NPW];                                 // P rows of the points being finished (E_BWD_GATHER)
+        float4 act[(ROLE == 1 && !FWD) ? RING : 1];
+        // P rows of the points being finished (E_BWD_GATHER): the current point's and the next one's (ring of two)
+        constexpr int NPE = NPW > 3 ? 2 : NPW;           // (three rows fit: the ring costs the k = 5 instance more registers than it saves)
+        float4 pve[NPE];
+        long e_ptl = 0;
 #pragma unroll
-        for (int q = 0; q < NPW; ++q) pve[q] = zero4;
+        for (int q = 0; q < NPE; ++q) pve[q] = zero4;
         long e_row0 = 0, e_pt = 0; int e_rv = 0;         // tile being finished; e_pt = this wave's first point
         // The epilogue of a row sits under ONE wave-uniform branch (nothing to finish in the first iteration and for an absent point of
         // a ragged last tile).  The compiler sinks a load whose only use lies in a conditional block INTO the block, where it then
@@ -293,9 +305,13 @@ __global__ __launch_bounds__(512) void gpe_edgegemm_w8_kernel(RgParams p, int st
                     lz_sx = *reinterpret_cast<const uchar4*>(p.lz_amx + ptc * p.lz_ldagg + ck);
                     lz_sn = *reinterpret_cast<const uchar4*>(p.lz_amn + ptc * p.lz_ldagg + ck);
                 }
-                if constexpr (AMODE == A_GATHER) {
+            }
+            if constexpr (AMODE == A_GATHER) {
+                const int pb = (8 * h) / KK;             // first point of this batch (wave-relative)
 #pragma unroll
-                    for (int q = 0; q < NPW; ++q) pvs[q] = ld4(p.pq + ((pt0 + q < ptl ? pt0 + q : ptl) + vz) * p.ldpq + ck);
+                for (int q = 0; q < NPB; ++q) {
+                    const long pg = pt0 + ((pb + q < NPW) ? pb + q : NPW - 1);
+                    pvs[q] = ld4(p.pq + (prow(pg < ptl ? pg : ptl) + vz) * p.ldpq + ck);
                 }
             }
 #pragma unroll
@@ -319,7 +335,7 @@ __global__ __launch_bounds__(512) void gpe_edgegemm_w8_kernel(RgParams p, int st
             const int r = rbl + u;
             float4 o = v[u & 7];
             if constexpr (AMODE == A_GATHER) {
-                const float4 pv = pvs[u / KK];
+                const float4 pv = pvs[u / KK - (8 * (u / 8)) / KK];
                 o.x = fmaxf(o.x + pv.x, 0.f); o.y = fmaxf(o.y + pv.y, 0.f);
                 o.z = fmaxf(o.z + pv.z, 0.f); o.w = fmaxf(o.w + pv.w, 0.f);
             }
@@ -365,7 +381,7 @@ __global__ __launch_bounds__(512) void gpe_edgegemm_w8_kernel(RgParams p, int st
         };
 
         // ---- finisher: VMEM issue + epilogue of one row -------------------------------------------------------------------------
-        // stored activation of row u of `tile_e` (whose neighbour rows are jv) -> ring entry u % W8_RING
+        // stored activation of row u of `tile_e` (whose neighbour rows are jv) -> ring entry u % RING
         auto issue_act_load = [&](int u, int tile_e, int jv) {
             if constexpr (ROLE == 1 && !FWD) {
                 const long row0 = (long)tile_e * TR;
@@ -373,10 +389,10 @@ __global__ __launch_bounds__(512) void gpe_edgegemm_w8_kernel(RgParams p, int st
                 if (u >= RW) u = RW - 1;                 // (KK = 5: no 16th row)
                 int r = rbl + u;
                 r = (r < rv - 1) ? r : rv - 1;           // clamp: unconditional loads
-                if constexpr (EMODE == E_BWD_INPLACE) act[u % W8_RING] = ld4(p.out + (row0 + r) * p.ldo + cn);
+                if constexpr (EMODE == E_BWD_INPLACE) act[u % RING] = ld4(p.out + (row0 + r) * p.ldo + cn);
                 else {
                     const int jj = __builtin_amdgcn_ds_bpermute(u << 2, jv);
-                    act[u % W8_RING] = ld4(p.pq + (long)jj * p.ldpq + p.H + cn);
+                    act[u % RING] = ld4(p.pq + (long)jj * p.ldpq + p.H + cn);
                 }
             }
         };
@@ -393,14 +409,27 @@ __global__ __launch_bounds__(512) void gpe_edgegemm_w8_kernel(RgParams p, int st
             amax_t = 0.f;
             if constexpr (GATHER_ACT) {
                 const long ptl = (long)tile_e * (4 * NPW) + (e_rv - 1) / KK;
+                if constexpr (NPW > NPE) e_ptl = ptl;
 #pragma unroll
-                for (int q = 0; q < NPW; ++q) pve[q] = ld4(p.pq + ((e_pt + q < ptl ? e_pt + q : ptl) + vz) * p.ldpq + cn);
+                for (int q = 0; q < NPE; ++q) pve[q] = ld4(p.pq + (prow(e_pt + q < ptl ? e_pt + q : ptl) + vz) * p.ldpq + cn);
             }
         };
         auto epi_row = [&](int u, float4 z) {
             if (u >= RW) return;                         // (compile time)
+            if constexpr (GATHER_ACT && NPW > NPE) {
+                // first row of point q >= 1: its P row was requested one point earlier; request the next point's into the entry the
+                // finished point has freed (unconditional, clamped — and pinned where it is first needed: see w8_pin4)
+                if (u % KK == 0 && u / KK >= 1) {
+                    const int q = u / KK;
+                    w8_pin4(pve[q % NPE]);
+                    if (q + 1 < NPW) {
+                        const long pg = e_pt + q + 1;
+                        pve[(q + 1) % NPE] = ld4(p.pq + (prow(pg < e_ptl ? pg : e_ptl) + vz) * p.ldpq + cn);
+                    }
+                }
+            }
             w8_pin4(z);
-            if constexpr (!FWD) w8_pin4(act[u % W8_RING]);
+            if constexpr (!FWD) w8_pin4(act[u % RING]);
             if (!epi_on) return;
             const int r = rbl + u;                       // row inside the tile: wave-uniform -> the descriptor's scalar offset
             if constexpr (KK != 16) {
@@ -437,9 +466,9 @@ __global__ __launch_bounds__(512) void gpe_edgegemm_w8_kernel(RgParams p, int st
                     }
                 }
             } else {
-                float4 av = act[u % W8_RING];
+                float4 av = act[u % RING];
                 if constexpr (GATHER_ACT) {
-                    const float4 pv = pve[u / KK];
+                    const float4 pv = pve[(u / KK) % NPE];
                     av.x = fmaxf(av.x + pv.x, 0.f); av.y = fmaxf(av.y + pv.y, 0.f);
                     av.z = fmaxf(av.z + pv.z, 0.f); av.w = fmaxf(av.w + pv.w, 0.f);
                 }
@@ -562,12 +591,14 @@ __global__ __launch_bounds__(512) void gpe_edgegemm_w8_kernel(RgParams p, int st
                             begin_epi(tile_e, do_epi);
                             if constexpr (GATHER_ACT) { jgv_cur = jgv_e; jgv_e = load_jgv(tile); }
                         }
-                        // stored activations: rows 8..15 of the tile being finished one ring turn ahead of their use; rows 0..7 of
-                        // the tile being MULTIPLIED (finished in the next iteration) as soon as their ring entry is free
-                        if (q >= EP0) epi_row(q - EP0, zq);
-                        // (each request reuses the ring entry the row finished just above has freed)
-                        if (q >= EP0 && q < EP0 + 8) issue_act_load(q - EP0 + 8, tile_e, jgv_cur);
-                        if (q >= EP0 + 8) issue_act_load(q - EP0 - 8, tile, jgv_e);
+                        if (q >= EP0 && q - EP0 < RW) {
+                            epi_row(q - EP0, zq);
+                            // the ring entry this row has freed takes the next row that maps to it: row u + RING of the tile being
+                            // finished — or, after the entry's last row, row u % RING of the tile being MULTIPLIED (finished in the next
+                            // iteration: its first RING rows arrive a whole MFMA block ahead)
+                            if (q - EP0 + RING < RW) issue_act_load(q - EP0 + RING, tile_e, jgv_cur);
+                            else issue_act_load((q - EP0) % RING, tile, jgv_e);
+                        }
                         if (q + 1 >= EP0 && q + 1 < NSLOT) {         // C row of the NEXT slot's epilogue (LDS prefetch)
                             const int rr = rbl + ((q + 1 - EP0 < RW) ? q + 1 - EP0 : RW - 1);
                             zq = ld4(&Cs[rr * LDC + cn]);
@@ -668,11 +699,11 @@ __global__ __launch_bounds__(512) void gpe_edgegemm_w8_kernel(RgParams p, int st
                 W8_REFRESH_SCALARS()
                 begin_epi(prev >= 0 ? prev : 0, prev >= 0);
                 jgv_cur = jgv_e;
-                // rows 0..7 were requested in the last iteration; rows 8..15 as the ring frees
+                // the first RING rows were requested in the last iteration; the others as the ring frees
 #pragma unroll
                 for (int u = 0; u < RW; ++u) {
                     epi_row(u, ld4(&Cs[(rbl + u) * LDC + cn]));
-                    if (u < 8) issue_act_load(u + 8, prev >= 0 ? prev : 0, jgv_cur);
+                    if (u + RING < RW) issue_act_load(u + RING, prev >= 0 ? prev : 0, jgv_cur);
                 }
             }
             if (p.amax_out && !GATHER_ACT) {
