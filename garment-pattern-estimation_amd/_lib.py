@@ -80,7 +80,7 @@ def set_math(mode):
 
 
 def set_f16x3_min_rows(rows):
-    """Size gate of the f16x3 mode: edge launches with fewer rows run the exact fp32 kernels (default 65536; 0 = always use the
+    """Size gate of the f16x3 mode: edge launches with fewer rows run the exact fp32 kernels (default 32768; 0 = always use the
     fp16 pipe, which is what the parity tests of small fixtures set).  Returns the previous value."""
     prev = lib().gpe_f16x3_min_rows_set(int(rows))
     if prev < 0:

@@ -105,7 +105,7 @@ int gpe_h3_pq_passes(unsigned* out, float* part, const float* pq, long rows, int
 int gpe_h3_absmax(unsigned* out, const float* x, long rows, int cols, long ld, hipStream_t s);
 // rows below which the f16x3 kernels are not used (their scale passes cost more than they save at small E); part of the
 // arithmetic mode: gpe_f16x3_min_rows_set (gpe_rowgemm.hip)
-#define GPE_H3_MIN_ROWS_DEFAULT 65536
+#define GPE_H3_MIN_ROWS_DEFAULT 32768
 long gpe_h3_min_rows();
 // power of two that brings a tensor whose largest magnitude has the bit pattern `amax` into [2^14, 2^15), and its inverse.
 // The exponent is clamped to +-100 (tensors below 2^-86 lose relative precision gracefully), zero / non-finite -> 1.

@@ -65,6 +65,19 @@ struct RdParams {
 #ifndef RD_B3_DBG
 #define RD_B3_DBG 0
 #endif
+//   RD_B3_PRIO       s_setprio of the producer waves (the fp32 producer/consumer kernel runs them at 3)
+//   RD_B3_LEFT_CONS  1 = the left-over tiles (odd row / column of the 13 x 13 / 10 x 13 tile grid) are multiplied by the CONSUMER waves
+//                    (parked three quarters of the time) instead of the producers (the critical path of an iteration)
+// Measured in one session (us per launch at cfg 2 inside the training step, gathered 13 x 13 / dense 10 x 13; profiles/r05_b_redgemm_probe.md):
+//   round 4's kernel 381 / 369 (378 / 368) | producers at priority 3: 363 / 361 | at priority 1: 359 / 359 | left-overs on the consumers:
+//   444 / 403 (13 x 13 spills 15 registers; the 10 x 13 instance, which does not, is slower as well) | both: 478 / 406.
+// -> producers at priority 1; the left-overs stay with the producers: whatever either wave of a SIMD issues adds to the tile time.
+#ifndef RD_B3_PRIO
+#define RD_B3_PRIO 1
+#endif
+#ifndef RD_B3_LEFT_CONS
+#define RD_B3_LEFT_CONS 0
+#endif
 
 __device__ __forceinline__ float4 rd_ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 
@@ -647,6 +660,20 @@ __global__ __launch_bounds__(512, 2) void gpe_redgemm_b3_kernel(RdParams p)
     const int j = lane & 15, g = lane >> 4;
     float* dst = p.part + (size_t)blockIdx.x * p.MgPad * p.NgPad;
 
+    // this wave's share of the left-over tiles (producers and consumers are numbered 0..3 alike): list index t = w4, w4+4, ...  ->  (m, n)
+    int offU[PMAX > 0 ? PMAX : 1], offV[PMAX > 0 ? PMAX : 1];
+    int my_count = 0;
+#pragma unroll
+    for (int s_ = 0; s_ < PMAX; ++s_) {
+        const int t = w4 + 4 * s_;
+        int m = 0, n = 0;
+        if (t < LEFT) {
+            ++my_count;
+            if ((MT & 1) && t < NT) { m = MT - 1; n = t; }
+            else { const int t2 = t - (MT & 1) * NT; m = t2; n = NT - 1; }
+        }
+        offU[s_] = 16 * m; offV[s_] = 16 * n;
+    }
     if (wave < 4) {
         // ================================ consumers ================================
         const int mt0 = (w4 & 1) * MB, nt0 = (w4 >> 1) * NB;
@@ -655,6 +682,9 @@ __global__ __launch_bounds__(512, 2) void gpe_redgemm_b3_kernel(RdParams p)
         for (int q = 0; q < MB; ++q)
 #pragma unroll
             for (int n = 0; n < NB; ++n) acc[q][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        f32x4 accL[(RD_B3_LEFT_CONS && PMAX > 0) ? PMAX : 1];
+#pragma unroll
+        for (int s_ = 0; s_ < ((RD_B3_LEFT_CONS && PMAX > 0) ? PMAX : 1); ++s_) accL[s_] = (f32x4){0.f, 0.f, 0.f, 0.f};
         __syncthreads();                           // prologue: tile 0 staged
         int buf = 0;
         GpeTileSeq sq = gpe_tile_seq(p.pin_tpc, p.rev, p.pin_clouds, p.num_tiles);
@@ -679,8 +709,32 @@ __global__ __launch_bounds__(512, 2) void gpe_redgemm_b3_kernel(RdParams p)
 #pragma unroll
                 for (int n = 0; n < NB; ++n) acc[q][n] = rd_mfma32_p<F16>(ah, bh[n], acc[q][n]);
             }
+            if constexpr (RD_B3_LEFT_CONS && PMAX > 0) {
+#pragma unroll
+                for (int s_ = 0; s_ < PMAX; ++s_) {
+                    if (s_ < my_count) {
+                        const uint4 ah = *reinterpret_cast<const uint4*>(ub + LU::slot(0, g, offU[s_] + j));
+                        const uint4 al = *reinterpret_cast<const uint4*>(ub + LU::slot(1, g, offU[s_] + j));
+                        const uint4 bh2 = *reinterpret_cast<const uint4*>(vb + LV::slot(0, g, offV[s_] + j));
+                        const uint4 bl2 = *reinterpret_cast<const uint4*>(vb + LV::slot(1, g, offV[s_] + j));
+                        f32x4 a3 = rd_mfma32_p<F16>(al, bh2, accL[s_]);
+                        a3 = rd_mfma32_p<F16>(ah, bl2, a3);
+                        accL[s_] = rd_mfma32_p<F16>(ah, bh2, a3);
+                    }
+                }
+            }
             __syncthreads();
             buf ^= 1;
+        }
+        if constexpr (RD_B3_LEFT_CONS && PMAX > 0) {
+#pragma unroll
+            for (int s_ = 0; s_ < PMAX; ++s_) {
+                if (s_ < my_count) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        dst[(size_t)(offU[s_] + 4 * g + r) * p.NgPad + offV[s_] + j] = accL[s_][r] * invU * invV;
+                }
+            }
         }
 #pragma unroll
         for (int q = 0; q < MB; ++q)
@@ -692,6 +746,7 @@ __global__ __launch_bounds__(512, 2) void gpe_redgemm_b3_kernel(RdParams p)
         __syncthreads();                           // tail: producers' column sums in LDS
     } else {
         // ================================ producers ================================
+        if (RD_B3_PRIO) __builtin_amdgcn_s_setprio(RD_B3_PRIO);
         const int cq = lane << 2;
         const bool u_on = cq < p.Mg, v_on = cq < p.Ng;
         const int cu = u_on ? cq : 0, cv = v_on ? cq : 0;
@@ -699,20 +754,6 @@ __global__ __launch_bounds__(512, 2) void gpe_redgemm_b3_kernel(RdParams p)
         if (p.v_shift && v_on) {
 #pragma unroll
             for (int t = 0; t < 4; ++t) if (cq + t < p.Ng) sh[t] = p.v_shift[cq + t];
-        }
-        // my left-over tiles: list index t = w4, w4+4, ...  ->  (m, n)
-        int offU[PMAX > 0 ? PMAX : 1], offV[PMAX > 0 ? PMAX : 1];
-        int my_count = 0;
-#pragma unroll
-        for (int s_ = 0; s_ < PMAX; ++s_) {
-            const int t = w4 + 4 * s_;
-            int m = 0, n = 0;
-            if (t < LEFT) {
-                ++my_count;
-                if ((MT & 1) && t < NT) { m = MT - 1; n = t; }
-                else { const int t2 = t - (MT & 1) * NT; m = t2; n = NT - 1; }
-            }
-            offU[s_] = 16 * m; offV[s_] = 16 * n;
         }
         f32x4 accP[PMAX > 0 ? PMAX : 1];
 #pragma unroll
@@ -910,7 +951,7 @@ __global__ __launch_bounds__(512, 2) void gpe_redgemm_b3_kernel(RdParams p)
                 if (!(RD_B3_DBG & 2)) { fetchU(next < p.num_tiles ? next : tile); fetchV(next < p.num_tiles ? next : tile); }
                 if (VMODE == V_GATHER) jgv = load_jgv(next2 < p.num_tiles ? next2 : tile);
             }
-            if (PMAX > 0 && !(RD_B3_DBG & 8)) {
+            if (PMAX > 0 && !RD_B3_LEFT_CONS && !(RD_B3_DBG & 8)) {
                 const char* ub = Ub + buf * LU::BYTES;
                 const char* vb = Vb + buf * LV::BYTES;
 #pragma unroll
@@ -930,12 +971,14 @@ __global__ __launch_bounds__(512, 2) void gpe_redgemm_b3_kernel(RdParams p)
             __syncthreads();
             buf ^= 1;
         }
+        if constexpr (!RD_B3_LEFT_CONS) {
 #pragma unroll
-        for (int s_ = 0; s_ < PMAX; ++s_) {
-            if (s_ < my_count) {
+            for (int s_ = 0; s_ < PMAX; ++s_) {
+                if (s_ < my_count) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    dst[(size_t)(offU[s_] + 4 * g + r) * p.NgPad + offV[s_] + j] = accP[s_][r] * invU * invV;
+                    for (int r = 0; r < 4; ++r)
+                        dst[(size_t)(offU[s_] + 4 * g + r) * p.NgPad + offV[s_] + j] = accP[s_][r] * invU * invV;
+                }
             }
         }
         double* red = reinterpret_cast<double*>(smem_b3);       // [4][UC]

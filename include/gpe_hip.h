@@ -72,7 +72,7 @@ int gpe_debug_set(int flags);
  * are fp32 (fp64 for reductions) in every mode. */
 int gpe_math_set(int mode);
 int gpe_math_get(void);
-/* f16x3 size gate (part of the arithmetic mode): edge launches with fewer rows use the exact fp32 kernels.  Default 65536;
+/* f16x3 size gate (part of the arithmetic mode): edge launches with fewer rows use the exact fp32 kernels.  Default 32768 (round 5: with the two-waves-per-SIMD kernels BASELINE cfg 1 — 40 960 edges — is faster on the fp16 pipe: kernel time 3.56 -> 3.48 ms per step; it was 65536 before);
  * the setter returns the previous value (tests set 0 to force the fp16-pipe kernels on small fixtures). */
 long gpe_f16x3_min_rows(void);
 long gpe_f16x3_min_rows_set(long rows);

@@ -27,7 +27,7 @@ def math_mode(request):
     library default afterwards."""
     import gpe_amd
     prev = gpe_amd.set_math(request.param)
-    # the f16x3 size gate (launches under 65536 rows run the exact kernels) is lifted: the fixtures are small and the point of
+    # the f16x3 size gate (launches under 32768 rows run the exact kernels) is lifted: the fixtures are small and the point of
     # the parametrisation is to run the fp16-pipe kernels
     gate = gpe_amd.set_f16x3_min_rows(0)
     yield request.param

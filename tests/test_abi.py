@@ -53,7 +53,7 @@ def test_host_only_queries():
     assert l.gpe_knn_ws_bytes(32, 2048, 150, 16) >= 32 * 2048 * (32 * 8 + 4)
     # the f16x3 size gate is part of the arithmetic mode: settable, restorable
     gate = l.gpe_f16x3_min_rows()
-    assert gate == 65536 and l.gpe_f16x3_min_rows_set(0) == gate and l.gpe_f16x3_min_rows() == 0
+    assert gate == 32768 and l.gpe_f16x3_min_rows_set(0) == gate and l.gpe_f16x3_min_rows() == 0
     assert l.gpe_f16x3_min_rows_set(gate) == 0 and l.gpe_f16x3_min_rows_set(-1) == -22
     assert l.gpe_packed_size(200, 200) == 208 * 208
     assert l.gpe_packed_size(7, 3) == 16 * 16
