@@ -26,7 +26,7 @@ rm -rf $OUT/prof_kt $OUT/prof_fetch $OUT/prof_write          # keep the merge-ba
 cd $ROOT
 if [ -z "$SKIP_BENCH" ]; then
   cp $OUT/${TAG}_hbm_traffic.json $ROOT/profiles/${TAG}_hbm_traffic.json      # on the box: what bench.py will quote
-  timeout 600 python bench.py > $OUT/${TAG}_bench.log 2>&1
+  timeout 900 python bench.py --call-shapes $OUT/${TAG}_call_shapes.txt > $OUT/${TAG}_bench.log 2>&1
   grep '^{' $OUT/${TAG}_bench.log | tail -1 > $OUT/${TAG}_bench.json
 fi
 head -c 600 $OUT/${TAG}_bench.json; echo; head -12 $OUT/${TAG}_kernel_trace.md; head -c 400 $OUT/${TAG}_hbm_traffic.json
