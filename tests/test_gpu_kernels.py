@@ -1673,9 +1673,11 @@ def test_rccl_world1_gradient_exchange(gpe, golden_dir, tmp_path):
         ddp.finish_gradient_sync()
         torch.cuda.synchronize()
         assert torch.equal(l0, l1)
+        assert ddp._avg_op                 # RCCL averages inside the collective (ReduceOp.AVG): no pre-division launch
         for (n, p), (_, q) in zip(model.named_parameters(), plain.named_parameters()):
-            # "world 2" average of a 1-rank sum = grad / 2
-            assert torch.allclose(p.grad, q.grad / 2, rtol=1e-6, atol=1e-12), n
+            # the collective averages over the REAL group (1 rank): the gradients come back unchanged.  (Until round 4 the wrapper
+            # divided by `ddp.world` itself and summed: this check then saw grad / 2.)
+            assert torch.allclose(p.grad, q.grad, rtol=1e-6, atol=1e-12), n
         # what bench.py prints for N > 1: the exchange on its own over RCCL (async all-reduce of every bucket on a scratch
         # arena, barrier, synchronisation) and the exposed part measured around the waits of finish_gradient_sync
         ex = ddp.measure_exchange(iters=3)
