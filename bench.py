@@ -301,21 +301,40 @@ def cpu_baseline(args, data_config, nn_cfg):
             times.append(time.perf_counter() - t0)
         return sum(times[1:]) / len(times[1:])
 
+    def timed_once(B, N, k):
+        cfg = copy.deepcopy(nn_cfg)
+        cfg['k_neighbors'] = k
+        torch.manual_seed(0)
+        model = O.GarmentFullPattern3D(data_config, copy.deepcopy(cfg), copy.deepcopy(cfg['loss'])).train()
+        feats, gt = O.synthetic_batch(B, N, data_config, seed=0)
+        t0 = time.perf_counter()
+        O.train_step(model, feats, {k_: v.clone() for k_, v in gt.items()}, epoch=0, seed=0)
+        return time.perf_counter() - t0
+
     # Thread count: torch's intra-op pool does not scale to a 256-thread host on this op mix, so the baseline picks its
     # thread count by MEASUREMENT inside this run, AT THE BENCHMARKED BATCH (round 4 probed a B=2 sample, which favours few
     # threads): one timed step (after one warm-up at the first setting) at 16 / 64 / nproc threads, then >= 3 timed steps at the
-    # fastest.  --cpu-threads overrides.
+    # fastest.  --cpu-threads overrides.  The scan is bounded (below).
     nproc = os.cpu_count() or 1
     probe = {}
     cpu_batch = args.cpu_batch if args.cpu_batch > 0 else min(args.batch, 32)
     if args.cpu_threads > 0:
         ncores = args.cpu_threads
     else:
-        for nt in sorted({min(n, nproc) for n in (16, 64, nproc)}):
+        # candidates in increasing order, ONE timed step each (one warm-up before the first); the scan stops as soon as a setting is
+        # slower than the best so far — on the 256-thread EPYC 9575F a step takes 10 s at 16 threads, 12 s at 64 and FIVE MINUTES at
+        # 256 (measured, r05_z): probing nproc blindly would cost this line ten minutes
+        best = None
+        for i, nt in enumerate(sorted({min(n, nproc) for n in (16, 64, min(nproc, 128))})):
             torch.set_num_threads(nt)
-            probe[str(nt)] = round(timed(cpu_batch, args.points, args.k, 1), 3)
+            t = timed(cpu_batch, args.points, args.k, 1) if i == 0 else timed_once(cpu_batch, args.points, args.k)
+            probe[str(nt)] = round(t, 3)
+            if best is not None and t > best:
+                break
+            best = t
         ncores = int(min(probe, key=probe.get))
-        probe['note'] = 's/step at B=%d, N=%d, k=%d (1 warm-up + 1 timed per setting), measured in this run' % (cpu_batch, args.points, args.k)
+        probe['note'] = ('s/step at B=%d, N=%d, k=%d (one timed step per setting, one warm-up before the first; the scan stops at the '
+                         'first setting slower than its predecessor), measured in this run' % (cpu_batch, args.points, args.k))
     torch.set_num_threads(ncores)
     t2 = timed(cpu_batch, args.points, args.k, max(args.cpu_steps, 3))
     t1 = timed(8, 1024, 5, max(args.cpu_steps, 5))          # BASELINE cfg 1: the reference's own CPU-runnable case
