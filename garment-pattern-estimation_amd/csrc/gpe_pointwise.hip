@@ -305,6 +305,9 @@ extern "C" int gpe_fold_bias(const float* w, int ldw, int N, int K, const float*
 //   wave-uniform (shuffle-broadcast) row bases and all k loads in flight before the first use.
 // ---------------------------------------------------------------------------------------------------------
 #define GS_BLOCKS 512
+#ifndef GS_KU
+#define GS_KU 8               // neighbour rows in flight per wave
+#endif
 template <int KU>
 __global__ __launch_bounds__(256) void gpe_gather_stats_kernel(const float* __restrict__ pq, int ldpq, int H,
                                                                const int32_t* __restrict__ jg, int k,
@@ -323,6 +326,9 @@ __global__ __launch_bounds__(256) void gpe_gather_stats_kernel(const float* __re
         const int myidx = (lane < k) ? jg[i * k + lane] : 0;
         float4 p4 = make_float4(0.f, 0.f, 0.f, 0.f);
         if (active) p4 = pw_ld4(pq + i * ldpq + c);
+        // a point's k messages are summed in fp32 (k <= 64 terms: 1e-7 relative, the same partial sums the fused edge kernels keep per
+        // tile), the points in fp64: the fp64 conversions and adds per ELEMENT (round 1 - 4) were this pass's whole run time
+        float s32[4] = {0.f, 0.f, 0.f, 0.f}, q32[4] = {0.f, 0.f, 0.f, 0.f};
         for (int s0 = 0; s0 < k; s0 += KU) {
             float4 nb[KU];
 #pragma unroll
@@ -338,13 +344,15 @@ __global__ __launch_bounds__(256) void gpe_gather_stats_kernel(const float* __re
                 if (s0 + u < k) {
                     const float a0 = fmaxf(p4.x + nb[u].x, 0.f), a1 = fmaxf(p4.y + nb[u].y, 0.f);
                     const float a2 = fmaxf(p4.z + nb[u].z, 0.f), a3 = fmaxf(p4.w + nb[u].w, 0.f);
-                    s[0] += a0; q[0] += (double)a0 * a0;
-                    s[1] += a1; q[1] += (double)a1 * a1;
-                    s[2] += a2; q[2] += (double)a2 * a2;
-                    s[3] += a3; q[3] += (double)a3 * a3;
+                    s32[0] += a0; q32[0] = __builtin_fmaf(a0, a0, q32[0]);
+                    s32[1] += a1; q32[1] = __builtin_fmaf(a1, a1, q32[1]);
+                    s32[2] += a2; q32[2] = __builtin_fmaf(a2, a2, q32[2]);
+                    s32[3] += a3; q32[3] = __builtin_fmaf(a3, a3, q32[3]);
                 }
             }
         }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { s[t] += (double)s32[t]; q[t] += (double)q32[t]; }
     }
 #pragma unroll
     for (int t = 0; t < 4; ++t) { red[wave][0][c + t] = s[t]; red[wave][1][c + t] = q[t]; }
@@ -363,7 +371,7 @@ extern "C" int gpe_edge_gather_stats(const float* pq, int ldpq, int H, const int
     if (!pq || !jg || !part || B <= 0 || N <= 0 || k <= 0 || k > 64 || H <= 0 || H > 256 || (H & 3) || (ldpq & 3) ||
         ldpq < 2 * H)
         return GPE_EINVAL;
-    hipLaunchKernelGGL(gpe_gather_stats_kernel<8>, dim3(GS_BLOCKS), dim3(256), 0, (hipStream_t)stream, pq, ldpq, H,
+    hipLaunchKernelGGL(gpe_gather_stats_kernel<GS_KU>, dim3(GS_BLOCKS), dim3(256), 0, (hipStream_t)stream, pq, ldpq, H,
                        jg, k, B, N, gpe_pin_clouds(B) ? 1 : 0, part);
     GPE_CHECK_LAUNCH();
     return GPE_OK;
