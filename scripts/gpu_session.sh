@@ -10,6 +10,7 @@
 #   collect TAG                   scripts/collect_profiles.sh: kernel trace + both PMC passes + the default bench line
 #   sq    TAG                     SQ wave-state counters of one EdgeConv layer at the cfg-2 shape -> TAG_sq_wave_states.md
 #   configs TAG                   the other configurations' bench lines (cfg 1, cfg 4, cfg 5 share, att k = 5, epoch 40)
+#   batch TAG 'b1 b2 ..'          bench lines at other per-GPU batches                     -> TAG_batch_scaling.md
 #   bench TAG [bench args]        one bench line                                            -> TAG_bench.json
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 cd $ROOT
@@ -85,6 +86,16 @@ while [ $# -gt 0 ]; do
       run cfg5_share --points 8192 --batch 64 --steps 10 --warmup 2
       run att_k5 --model att --points 2000 --batch 30 --k 5 --steps 100
       run epoch40 --epoch 40 --steps 50 --no-fast-math-line ;;
+    batch)      # batch TAG 'b1 b2 ..': garments per GPU at N = 2048, k = 16 (the recommendation in scripts/run_scale.sh) -> TAG_batch_scaling.md
+      TAG=$1; BS=$2; shift 2
+      { echo "| batch per GPU | garments/s | ms/step | ms per garment |"; echo "|---|---|---|---|"; } > $OUT/${TAG}_batch_scaling.md
+      for Bv in $BS; do
+        timeout 300 python bench.py --batch $Bv --steps 30 --warmup 4 --no-cpu-baseline --no-fast-math-line --no-kernel-timing > $OUT/${TAG}_batch.log 2>&1
+        grep '^{' $OUT/${TAG}_batch.log | tail -1 | python -c "
+import json,sys
+d=json.loads(sys.stdin.read()); b=$Bv
+print('| %d | %.1f | %.2f | %.3f |' % (b, d['value'], d['ms_per_step'], d['ms_per_step']/b))" | tee -a $OUT/${TAG}_batch_scaling.md
+      done ;;
     bench)
       TAG=$1; shift
       ARGS=""; while [ $# -gt 0 ] && [ "$1" != "--" ]; do ARGS="$ARGS $1"; shift; done
