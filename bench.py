@@ -182,7 +182,7 @@ _TRAFFIC_KERNELS = {
     'gpe_edge_gather_stats': r'gpe_gather_stats_kernel',
     'gpe_edge_dz3': r'gpe_dz3_kernel',
     'gpe_knn:filter': r'gpe_knn_mfma_kernel|gpe_knn_h3_kernel|gpe_knn_planes_kernel|gpe_knn_rerank_kernel|gpe_knn_norms_kernel|gpe_knn_cmax_kernel',
-    'gpe_knn:exact': r'gpe_knn_kernel',
+    'gpe_knn:exact': r'gpe_knn_kernel|gpe_knn3_sort_kernel|gpe_knn3_query_kernel',
     'gpe_edge_pull_dq': r'gpe_pull_dq_kernel',
 }
 

@@ -365,10 +365,18 @@ static void knn_launch(long nblocks, size_t lds, hipStream_t s, int probe, const
                            tiles, pin, 0, nsplit, part);
 }
 
+// C == 3 on a spatially sorted cloud with tile pruning (gpe_knn3.hip): 1 launched, 0 not on its menu
+int gpe_knn3_try(const float* x, int B, int N, int ldx, int k, int32_t* idx, int32_t* idx_glob, void* ws, long ws_bytes,
+                 hipStream_t s);
+
 // all-exact path: every distance by the defined chain (C < 16, k > 48, or GPE_KNN_EXACT=1)
 static int knn_exact(const float* x, int B, int N, int C, int ldx, int k, int32_t* idx, int32_t* idx_glob, void* ws,
                      long ws_bytes, void* stream)
 {
+    if (C == 3) {
+        const int rc = gpe_knn3_try(x, B, N, ldx, k, idx, idx_glob, ws, ws_bytes, (hipStream_t)stream);
+        if (rc != 0) return rc < 0 ? rc : GPE_OK;
+    }
     const size_t lds = ((size_t)2 * KNN_TQ * KNN_LD + 4 * 16 * KNN_LDD) * sizeof(float) + 4 * 64 * sizeof(unsigned long long);
     static const int probe = getenv("GPE_KNN_PROBE") ? atoi(getenv("GPE_KNN_PROBE")) : 0;
     const int tiles = gpe_cdiv(N, KNN_TQ);

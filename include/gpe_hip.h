@@ -87,8 +87,11 @@ int gpe_knn(const float* x, int B, int N, int C, int ldx, int k, int32_t* idx, i
             void* stream);
 /* idx_glob (may be NULL) [B][N][k] = b*N + idx: the GLOBAL row of each neighbour, which is what the gather kernels
  * below take as `jg` (B*N*k must be < 2^31).  ws: gpe_knn_ws_bytes(B, N, C, k) bytes, 16-B aligned (squared norms, per-cloud
- * maxima, candidate lists of the matrix-pipe filter / of a split candidate range); NULL or too small: the all-exact kernel
- * without candidate split runs (same result, slower). */
+ * maxima, candidate lists of the matrix-pipe filter / of a split candidate range; for C = 3 the spatially sorted copy of the
+ * clouds and its tile boxes); NULL or too small: the all-exact all-pairs kernel without candidate split runs (same result, slower).
+ * Paths (all produce the identical, defined result): C = 3 and 128 <= N <= 8192 — the cloud sorted along a Morton curve and
+ * scanned tile by tile with an exact box bound that prunes tiles (gpe_knn3.hip; GPE_KNN_SORTED=0 disables); 16 <= C <= 256 and
+ * k <= 48 — fp16-pipe filter + exact recheck; otherwise the all-pairs VALU kernel. */
 
 /* reverse adjacency of the kNN graph (needed by the gather's backward = scatter-add into x_j rows):
  * rev_off [B][N+1] int32 (local offsets), rev_edge [B][N*k] int32 = local edge ids (i*k+s) sorted ascending

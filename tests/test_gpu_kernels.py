@@ -71,6 +71,49 @@ def test_knn_bit_exact(gpe, B, N, C, k):
     assert bad == 0, '%d / %d queries differ' % (bad, B * N)
 
 
+# xyz clouds (C = 3) of 128 .. 8192 points take the sorted-cloud kernel with tile pruning (gpe_knn3.hip): every shape of data that
+# stresses the pruning bound or the (distance, index) order — exact ties and duplicated points, a constant axis (zero-width grid),
+# all points identical, tight clusters far from the origin, a ragged last tile, k up to 64 and k close to N
+K3_CASES = [(2, 128, 5), (3, 300, 16), (1, 1000, 20), (1, 4096, 20), (1, 8192, 16), (2, 200, 64), (1, 130, 64), (4, 577, 9)]
+
+
+@pytest.mark.parametrize('B,N,k', K3_CASES)
+@pytest.mark.parametrize('data', ['gauss', 'lattice', 'planar', 'clusters', 'same', 'line', 'surface'])
+def test_knn_xyz_sorted_cloud_bit_exact(gpe, B, N, k, data):
+    from oracle import ref_path as O
+    if N >= 4096 and data not in ('gauss', 'lattice', 'surface'):
+        pytest.skip('large clouds: three data kinds are enough')
+    g = torch.Generator().manual_seed(B * 31 + N + k)
+    if data == 'gauss':
+        x = torch.randn(B * N, 3, generator=g)
+    elif data == 'lattice':
+        x = torch.randint(0, 4, (B * N, 3), generator=g).float()
+    elif data == 'planar':
+        x = torch.randn(B * N, 3, generator=g)
+        x[:, 2] = 0.5
+    elif data == 'clusters':
+        x = (torch.randn(8, 3, generator=g) * 20)[torch.randint(0, 8, (B * N,), generator=g)] + 1e-2 * torch.randn(B * N, 3, generator=g)
+    elif data == 'same':
+        x = torch.full((B * N, 3), 0.3)
+    elif data == 'line':
+        x = torch.zeros(B * N, 3)
+        x[:, 0] = torch.randn(B * N, generator=g)
+    else:                                                   # a thin sheet wrapped around a body: what a garment scan looks like
+        u = torch.rand(B * N, generator=g) * 6.2831853
+        v = torch.rand(B * N, generator=g) * 1.5
+        x = torch.stack([0.3 * torch.cos(u) * (1 + 0.2 * torch.sin(3 * v)), v, 0.2 * torch.sin(u)], 1)
+        x = x + 0.003 * torch.randn(B * N, 3, generator=g)
+    ref = O.knn_local(x.contiguous(), B, k).to(torch.int32).view(B, N, k)
+    got = gpe.ops.knn(x.cuda(), B, N, k).cpu()
+    bad = (got != ref).any(-1).sum().item()
+    assert bad == 0, '%d / %d queries differ' % (bad, B * N)
+    # padded rows (ldx = 4) through the same path
+    buf = torch.zeros(B * N, 4)
+    buf[:, :3] = x
+    got = gpe.ops.knn(buf.cuda()[:, :3], B, N, k).cpu()
+    assert torch.equal(got, ref)
+
+
 # C -> fp16-pipe filter instance (blocks of 32 channels, NB = ceil(C / 32)): <2> 32, 33, 64; <5> 100 (two full steps), 150;
 # <8> 200 (seven blocks: an odd last step), 256; C = 300 > 256 keeps the exact-product fp32 filter
 MF_CASES = [(2, 300, 150, 152, 16), (1, 1000, 64, 64, 20), (3, 97, 32, 32, 5), (2, 513, 256, 256, 64), (1, 2048, 33, 36, 16),
@@ -111,7 +154,7 @@ sys.path.insert(0, %r)
 import gpe_amd
 from oracle import ref_path as O
 g = torch.Generator().manual_seed(5)
-for (B, N, C, ld, k) in [(8, 256, 150, 152, 16), (9, 200, 33, 36, 5), (8, 130, 64, 64, 20)]:
+for (B, N, C, ld, k) in [(8, 256, 150, 152, 16), (9, 200, 33, 36, 5), (8, 130, 64, 64, 20), (8, 300, 3, 3, 16)]:
     for kind in ('gauss', 'clusters', 'lattice'):
         if kind == 'gauss':
             x = torch.randn(B * N, C, generator=g)
@@ -128,12 +171,13 @@ print('alt path ok')
 
 
 @pytest.mark.parametrize('env', [{'GPE_KNN_EXACT': '1'}, {'GPE_KNN_SPLIT': '2'}, {'GPE_KNN_EXACT': '1', 'GPE_KNN_SPLIT': '2'},
-                                 {'GPE_KNN_F32FILTER': '1'}, {'GPE_KNN_F32FILTER': '1', 'GPE_KNN_SPLIT': '2'}])
+                                 {'GPE_KNN_F32FILTER': '1'}, {'GPE_KNN_F32FILTER': '1', 'GPE_KNN_SPLIT': '2'},
+                                 {'GPE_KNN_SORTED': '0'}, {'GPE_KNN_SORTED': '0', 'GPE_KNN_SPLIT': '2'}])
 def test_knn_alternative_paths(gpe, env, tmp_path):
     """The paths the dispatcher no longer takes by default on wide rows — the all-exact kernel's float4 / float2 staging
     (C >= 16 goes through a matrix-pipe filter), the exact-product fp32 filter (16 <= C <= 256 now runs the fp16-pipe filter)
-    and the candidate split with its list merge (forced: B >= 8 pins clouds to XCDs, which is what enables pieces) — stay
-    bit-exact.  The overrides are read once per process, hence the subprocess."""
+    and the candidate split with its list merge (forced: B >= 8 pins clouds to XCDs, which is what enables pieces), the all-pairs
+    kernel on an xyz cloud (GPE_KNN_SORTED=0: 128 .. 8192 points otherwise take the sorted-cloud kernel) — stay bit-exact.  The overrides are read once per process, hence the subprocess."""
     import os, subprocess, sys
     script = tmp_path / 'w.py'
     script.write_text(_KNN_ALT_WORKER % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
