@@ -6,7 +6,7 @@
 # own, all buckets back to back) and exchange.exposed_ms_per_step (what backward did not hide), so the table can be checked
 # against RCCL having really connected N ranks.  No such curve has been measured yet.
 # BATCH (env, default 32 = BASELINE's per-GPU share) sets the garments per GPU.  A data-parallel job that may choose its global batch
-# should give each GPU 128 - 256 garments: measured on one MI355X (profiles/r05_z_batch_scaling.md) 3193 / 3542 / 3668 / 3820
+# should give each GPU 128 - 256 garments: measured on one MI355X (profiles/r05_z_batch_scaling.md) 3236 / 3574 / 3770 / 3873
 # garments/s per GPU at 32 / 64 / 128 / 256 — the ~2 ms of latency-bound launches per step are constant, the edge kernels linear —
 # and the gradient exchange stays 11 MB per step whatever the batch (RCCL ReduceOp.AVG on in-place arena slices).
 STEPS=${1:-20}
