@@ -60,6 +60,9 @@ def lib():
         env = os.environ.get('GPE_MATH')
         if env:
             set_math(env)
+        dbg = os.environ.get('GPE_DEBUG_SET')       # measurement switches of include/gpe_hip.h gpe_debug_set (A/B runs of bench.py)
+        if dbg:
+            l.gpe_debug_set(int(dbg, 0))
     return _lib
 
 

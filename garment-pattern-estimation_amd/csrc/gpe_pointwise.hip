@@ -5,7 +5,7 @@
 #include "gpe_common.h"
 #include <math.h>
 
-extern "C" int gpe_abi_version(void) { return 4; }
+extern "C" int gpe_abi_version(void) { return 5; }
 
 int gpe_num_cus()
 {

@@ -17,6 +17,20 @@
 #include <stdlib.h>
 
 extern "C" int gpe_math_get(void);
+extern "C" long gpe_packed_size(int N, int K);
+
+// gpe_rnn_persist.hip: the whole stack as ONE persistent launch (LSTM, <= 256 units, one workgroup per CU); 1 = launched,
+// 0 = not eligible, < 0 = error
+long gpe_rnn_persist_ws_bytes(int gates, int L, int T, int Bn, int H, int bwd);
+int gpe_rnn_persist_fwd(int L, int T, int Bn, int H, const float* xproj0, long xp0_sb, long xp0_st, const void* const* whh,
+                        const void* const* wih, const void* const* bias, float* hs, long hs_sl, long hs_sb, long hs_st, float* cs,
+                        long cs_sl, long cs_st, float* saved, long sv_sl, long sv_st, bool h3, const void* const* whh_amax,
+                        const void* const* wih_amax, void* ws, long ws_bytes, hipStream_t s);
+int gpe_rnn_persist_bwd(int L, int T, int Bn, int H, const float* dtop, long dt_sb, long dt_st, const float* d_hN,
+                        const float* d_cN, const void* const* whh_t, const void* const* wih_t, int KP, const float* cs, long cs_sl,
+                        long cs_st, const float* saved, long sv_sl, long sv_st, float* dgx, long dg_sl, long dg_sb, long dg_st,
+                        float* carry, bool h3, const void* const* whh_amax, const void* const* wih_amax, void* ws, long ws_bytes,
+                        hipStream_t s);
 
 #define WV_MAXCELL 4
 
@@ -484,7 +498,7 @@ extern "C" int gpe_rnn_seq_fwd(int gates, int L, int T, int Bn, int H, const flo
                                const void* const* whh, const void* const* wih, const void* const* bias,
                                const void* const* bhn, float* hs, long hs_sl, long hs_sb, long hs_st, float* cs, long cs_sl, long cs_st,
                                float* saved, long sv_sl, long sv_st, const void* const* whh_pl, const void* const* wih_pl,
-                               const void* const* whh_amax, const void* const* wih_amax, void* stream)
+                               const void* const* whh_amax, const void* const* wih_amax, void* ws, long ws_bytes, void* stream)
 {
     if ((gates != 3 && gates != 4) || L <= 0 || T <= 0 || Bn <= 0 || H <= 0 || !xproj0 || !whh || !hs || !saved ||
         (L > 1 && (!wih || !bias)) || (gates == 4 && !cs) || (gates == 3 && !bhn) || (hs_sb & 3) || (hs_st & 3))
@@ -496,6 +510,13 @@ extern "C" int gpe_rnn_seq_fwd(int gates, int L, int T, int Bn, int H, const flo
     bool h3 = !dbg_f32 && gpe_math_get() == 4 && whh_pl && whh_amax && (L == 1 || (wih_pl && wih_amax));
     for (int l = 0; h3 && l < L; ++l)
         if (!whh_pl[l] || !whh_amax[l] || (l > 0 && (!wih_pl[l] || !wih_amax[l]))) h3 = false;
+    if (G == 4) {
+        // one persistent launch for the whole stack when it fits the chip (gpe_rnn_persist.hip)
+        const int rc = gpe_rnn_persist_fwd(L, T, Bn, H, xproj0, xp0_sb, xp0_st, h3 ? whh_pl : whh, h3 ? wih_pl : wih, bias, hs, hs_sl,
+                                           hs_sb, hs_st, cs, cs_sl, cs_st, saved, sv_sl, sv_st, h3, whh_amax, wih_amax, ws, ws_bytes,
+                                           (hipStream_t)stream);
+        if (rc != 0) return rc < 0 ? rc : GPE_OK;
+    }
     for (int d = 0; d <= T + L - 2; ++d) {
         const int l_lo = (d - (T - 1) > 0) ? d - (T - 1) : 0;
         const int l_hi = (d < L - 1) ? d : L - 1;
@@ -677,11 +698,20 @@ __global__ void gpe_rnn_wave_cell_bwd_kernel(WvBwdParams p)
     }
 }
 
-extern "C" long gpe_rnn_seq_bwd_ws(int gates, int L, int Bn, int H)
+extern "C" long gpe_rnn_seq_fwd_ws(int gates, int L, int T, int Bn, int H)
 {
+    if ((gates != 3 && gates != 4) || L <= 0 || T <= 0 || Bn <= 0 || H <= 0) return GPE_EINVAL;
+    return gpe_rnn_persist_ws_bytes(gates, L, T, Bn, H, 0);
+}
+
+extern "C" long gpe_rnn_seq_bwd_ws(int gates, int L, int T, int Bn, int H)
+{
+    if ((gates != 3 && gates != 4) || L <= 0 || T <= 0 || Bn <= 0 || H <= 0) return GPE_EINVAL;
     const int nz = gpe_cdiv(gates * H, 128);              // sized for the narrow slab (the wide one needs half)
     const int ncell = L < WV_MAXCELL ? L : WV_MAXCELL;
-    return (long)ncell * 2 * nz * Bn * H;
+    const long diag = (long)ncell * 2 * nz * Bn * H;
+    const long pers = gpe_rnn_persist_ws_bytes(gates, L, T, Bn, H, 1) / 4;     // arrival counters of the persistent kernel
+    return diag > pers ? diag : pers;
 }
 
 // dgx / dgh: [L][Bn][T][G*H] (for LSTM pass the same buffer twice); carry: [2][L][Bn][H] scratch;
@@ -692,12 +722,25 @@ extern "C" int gpe_rnn_seq_bwd(int gates, int L, int T, int Bn, int H, const flo
                                const float* d_hN, const float* d_cN, const void* const* whh_t, const void* const* wih_t,
                                const float* hs, long hs_sl, long hs_sb, long hs_st, const float* cs, long cs_sl, long cs_st,
                                const float* saved, long sv_sl, long sv_st, float* dgx, float* dgh, long dg_sl, long dg_sb,
-                               long dg_st, float* part, float* carry, void* stream)
+                               long dg_st, float* part, float* carry, const void* const* whh_tpl, const void* const* wih_tpl,
+                               const void* const* whh_amax, const void* const* wih_amax, void* stream)
 {
     if ((gates != 3 && gates != 4) || L <= 0 || T <= 0 || Bn <= 0 || H <= 0 || !whh_t || !hs || !saved || !dgx || !dgh ||
         !part || !carry || (L > 1 && !wih_t) || (gates == 4 && !cs) || (dg_sb & 3) || (dg_st & 3))
         return GPE_EINVAL;
     const int G = gates, K = G * H;
+    if (G == 4) {
+        // one persistent launch for the whole stack when it fits the chip (gpe_rnn_persist.hip); f16x3: the transposed plane packs
+        // (gpe_pack_multi kind 10) and amax words of every weight
+        bool h3 = gpe_math_get() == 4 && whh_tpl && whh_amax && (L == 1 || (wih_tpl && wih_amax));
+        for (int l = 0; h3 && l < L; ++l)
+            if (!whh_tpl[l] || !whh_amax[l] || (l > 0 && (!wih_tpl[l] || !wih_amax[l]))) h3 = false;
+        const int KP = h3 ? gpe_round_up(K, 32) : (int)(gpe_packed_size(H, K) / gpe_round_up(H, 16));
+        const int rc = gpe_rnn_persist_bwd(L, T, Bn, H, dtop, dt_sb, dt_st, d_hN, d_cN, h3 ? whh_tpl : whh_t, h3 ? wih_tpl : wih_t, KP,
+                                           cs, cs_sl, cs_st, saved, sv_sl, sv_st, dgx, dg_sl, dg_sb, dg_st, carry, h3, whh_amax, wih_amax,
+                                           part, gpe_rnn_persist_ws_bytes(4, L, T, Bn, H, 1), (hipStream_t)stream);
+        if (rc != 0) return rc < 0 ? rc : GPE_OK;
+    }
     const int KS = wv_ks();
     // big batches: four slabs per workgroup (a 3-cell panel diagonal: 2304 single-slab workgroups in 4.5 rounds -> 480 in one,
     // a quarter of the partial images; measured 804 / 717 / 621 / 689 us per backward at 1 / 2 / 4 / 8 slabs); a single row

@@ -212,6 +212,7 @@ size_t gpe_edge_pseudo_bytes(long npts, int k, int Cmax);   // gpe_edgegemm_sr.h
 
 static int g_gpe_dbg = 0;
 extern "C" int gpe_debug_set(int flags) { g_gpe_dbg = flags; return 0; }
+extern "C" int gpe_debug_get(void) { return g_gpe_dbg; }
 static int g_gpe_math = 0;
 extern "C" int gpe_edge_lazy_dz3_ok(int B, int N, int k, int F, int Cprev);
 extern "C" int gpe_math_get(void) { return g_gpe_math; }

@@ -168,6 +168,9 @@ class PackPlan:
         fp16 planes + the amax word they are normalised by (a kind-9 job of the plan's FIRST launch)."""
         self._add(w, K_GATES, G * H, w.shape[1], aux=H)
         self._add(w, K_GATES_H3, G * H, w.shape[1], aux=H)
+        if G == 4:
+            # the persistent backward launch (csrc/gpe_rnn_persist.hip) reads W^T through the fp16 pipe
+            self._add(w, K_TRANS_H3, w.shape[1], G * H)
 
     def add_edge_first(self, w1, b1):
         H, C2 = w1.shape
@@ -968,6 +971,9 @@ def edge_conv_general(x, B, N, k, training, eps, momentum, nb, aggr, tensors):
 # -------------------------------------------------------------------------------------------------
 # recurrent stacks (LSTM / GRU)
 # -------------------------------------------------------------------------------------------------
+RNN_WS_HOOK = None         # measurement aid (scripts/rnn_trace.py): called with ('fwd' | 'bwd', workspace tensor) of every recurrence
+
+
 class RNNStackFn(torch.autograd.Function):
     """torch.nn.LSTM / torch.nn.GRU (batch_first, n_layers, no dropout) as used by the reference's decoders / encoder
     (nn/net_blocks.py:336-497): returns (top-layer outputs [Bn, T, H] as a view of the h history, h_T [L, Bn, H],
@@ -1033,11 +1039,15 @@ class RNNStackFn(torch.autograd.Function):
         # overflow to inf; rnn_stack decides)
         h3 = bool(h0_ok) and all(t is not None for t in pl_hh + am_hh + pl_ih[1:] + am_ih[1:])
         keep = (whh, wih, biases, pl_hh, am_hh, pl_ih, am_ih)   # operands stay referenced until the launches are queued
+        ws_n = L.query('gpe_rnn_seq_fwd_ws', G, Lr, T, Bn, Hh)    # arrival counters of the persistent launch (0: diagonal launches)
+        ws = torch.empty(ws_n, device=dev, dtype=torch.uint8) if ws_n > 0 else None
+        if RNN_WS_HOOK is not None:
+            RNN_WS_HOOK('fwd', ws)
         L.call('gpe_rnn_seq_fwd', G, Lr, T, Bn, Hh, xproj, xp_sb, xp_st, _ptr_array(whh), _ptr_array(wih),
                _ptr_array(biases), None if lstm else _ptr_array(bhns), hs, hs.stride(0), hs.stride(1), hs.stride(2),
                cs, cs.stride(0) if lstm else 0, cs.stride(1) if lstm else 0, saved, saved.stride(0), saved.stride(1),
                _ptr_array(pl_hh) if h3 else None, _ptr_array(pl_ih) if h3 else None,
-               _ptr_array(am_hh) if h3 else None, _ptr_array(am_ih) if h3 else None)
+               _ptr_array(am_hh) if h3 else None, _ptr_array(am_ih) if h3 else None, ws, max(ws_n, 0))
         del keep
         hN = cN = None
         if want_state:
@@ -1065,7 +1075,9 @@ class RNNStackFn(torch.autograd.Function):
         GHp = round_up(GH, 4)
         dgx = torch.empty(Lr, Bn, T, GHp, device=dev, dtype=F32)
         dgh = dgx if lstm else torch.empty(Lr, Bn, T, GHp, device=dev, dtype=F32)
-        part = torch.empty(L.query('gpe_rnn_seq_bwd_ws', G, Lr, Bn, Hh), device=dev, dtype=F32)
+        part = torch.empty(L.query('gpe_rnn_seq_bwd_ws', G, Lr, T, Bn, Hh), device=dev, dtype=F32)
+        if RNN_WS_HOOK is not None:
+            RNN_WS_HOOK('bwd', part)
         carry = torch.empty(2, Lr, Bn, Hh, device=dev, dtype=F32)
         whh_t = [pack_weight(params[4 * l + 1], transpose=True) for l in range(Lr)]
         wih_t = [None] + [pack_weight(params[4 * l], transpose=True) for l in range(1, Lr)]
@@ -1073,10 +1085,22 @@ class RNNStackFn(torch.autograd.Function):
             g_top = g_top.contiguous()
         ghN = g_hN.contiguous() if g_hN is not None else None
         gcN = g_cN.contiguous() if (lstm and g_cN is not None) else None
+        # f16x3: transposed fp16 plane packs + amax words for the persistent backward launch (absent -> exact fp32 there)
+        tp_hh, ta_hh, tp_ih, ta_ih = [], [], [None], [None]
+        if lstm:
+            for l in range(Lr):
+                a, b = planned_planes(params[4 * l + 1], K_TRANS_H3)
+                tp_hh.append(a); ta_hh.append(b)
+                if l > 0:
+                    a, b = planned_planes(params[4 * l], K_TRANS_H3)
+                    tp_ih.append(a); ta_ih.append(b)
+        h3b = lstm and all(t is not None for t in tp_hh + ta_hh + tp_ih[1:] + ta_ih[1:])
         L.call('gpe_rnn_seq_bwd', G, Lr, T, Bn, Hh, g_top, g_top.stride(0) if g_top is not None else 0,
                g_top.stride(1) if g_top is not None else 0, ghN, gcN, _ptr_array(whh_t), _ptr_array(wih_t),
                hs, hs.stride(0), hs.stride(1), hs.stride(2), cs, cs.stride(0) if lstm else 0, cs.stride(1) if lstm else 0,
-               saved, saved.stride(0), saved.stride(1), dgx, dgh, dgx.stride(0), dgx.stride(1), dgx.stride(2), part, carry)
+               saved, saved.stride(0), saved.stride(1), dgx, dgh, dgx.stride(0), dgx.stride(1), dgx.stride(2), part, carry,
+               _ptr_array(tp_hh) if h3b else None, _ptr_array(tp_ih) if h3b else None,
+               _ptr_array(ta_hh) if h3b else None, _ptr_array(ta_ih) if h3b else None)
         grads = [None] * (4 * Lr)
         d_x = None
         d_h0 = torch.empty(Lr, Bn, Hh, device=dev, dtype=F32) if want_h0 else None

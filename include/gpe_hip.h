@@ -39,6 +39,7 @@ int gpe_abi_version(void);
 /* profiling aid: ablation switches for the fused edge kernels (0 = production behaviour; results are WRONG otherwise, except
  * bit 512, which only makes gpe_edge_lazy_dz3_ok answer 0 — the eager in-place dz3 pass, same results to rounding) */
 int gpe_debug_set(int flags);
+int gpe_debug_get(void);
 /* arithmetic of the fused per-edge GEMMs (gpe_edge_mlp_fwd / gpe_edge_mlp_bwd / gpe_edge_redgemm):
  *   0 = "f32"    exact fp32 matrix instruction (v_mfma_f32_16x16x4_f32)
  *   1 = "bf16x3" split-bf16: every fp32 operand x = hi + lo (two bf16), a*b ~= ah*bh + ah*bl + al*bh on the bf16 matrix
@@ -315,7 +316,14 @@ int gpe_rnn_seq_fwd(int gates, int L, int T, int Bn, int H, const float* xproj0,
                     const void* const* whh, const void* const* wih, const void* const* bias, const void* const* bhn,
                     float* hs, long hs_sl, long hs_sb, long hs_st, float* cs, long cs_sl, long cs_st, float* saved,
                     long sv_sl, long sv_st, const void* const* whh_pl, const void* const* wih_pl,
-                    const void* const* whh_amax, const void* const* wih_amax, void* stream);
+                    const void* const* whh_amax, const void* const* wih_amax, void* ws, long ws_bytes, void* stream);
+/* ws: gpe_rnn_seq_fwd_ws bytes of scratch (4-byte aligned; may be NULL when the query answers 0).  An LSTM stack of <= 256
+ * units whose 16-row tiles fit the chip (layers x ceil(H/16) x row tiles <= compute units: the pattern decoder, 32 rows x 2
+ * layers) then runs as ONE persistent launch (gpe_rnn_persist.hip): every workgroup keeps its weight slices in LDS for all T
+ * steps and cells hand their state rows on through arrival counters in `ws` (zeroed in-call) instead of kernel boundaries.
+ * Same arithmetic per product as the diagonal launches (K is split over four waves instead of two: results agree to fp32
+ * rounding, not bit for bit). */
+long gpe_rnn_seq_fwd_ws(int gates, int L, int T, int Bn, int H);
 /* whh_pl / wih_pl / whh_amax / wih_amax (host arrays of L device pointers, or NULL; entry 0 of the wih arrays unused): the fp16
  * plane packs (gpe_pack_multi kind 8) of W_hh_l / W_ih_l and their amax words (kind 9).  With all of them present and the f16x3
  * arithmetic selected (gpe_math_set(4)) the gate products run on the fp16 pipe: the state rows enter scaled by 2^12 and split in
@@ -327,12 +335,17 @@ int gpe_rnn_seq_fwd(int gates, int L, int T, int Bn, int H, const float* xproj0,
  * + l*dg_sl + b*dg_sb + t*dg_st (pitches % 4 == 0): pre-activation gradients on the input side / recurrent side (LSTM: pass
  * the same buffer twice).  part: workspace of gpe_rnn_seq_bwd_ws floats; carry: [2][L][Bn][H] scratch — on return
  * carry[0][l] holds dc_0 (LSTM) / the z-gated part of dh_0 (GRU) of layer l. */
-long gpe_rnn_seq_bwd_ws(int gates, int L, int Bn, int H);
+long gpe_rnn_seq_bwd_ws(int gates, int L, int T, int Bn, int H);
 int gpe_rnn_seq_bwd(int gates, int L, int T, int Bn, int H, const float* dtop, long dt_sb, long dt_st, const float* d_hN,
                     const float* d_cN, const void* const* whh_t, const void* const* wih_t, const float* hs, long hs_sl,
                     long hs_sb, long hs_st, const float* cs, long cs_sl, long cs_st, const float* saved, long sv_sl,
                     long sv_st, float* dgx, float* dgh, long dg_sl, long dg_sb, long dg_st, float* part, float* carry,
-                    void* stream);
+                    const void* const* whh_tpl, const void* const* wih_tpl, const void* const* whh_amax,
+                    const void* const* wih_amax, void* stream);
+/* whh_tpl / wih_tpl / whh_amax / wih_amax (host arrays of L device pointers, or NULL; entry 0 of the wih arrays unused): the
+ * TRANSPOSED fp16 plane packs (gpe_pack_multi kind 10) of W_hh_l / W_ih_l and their amax words — used by the persistent
+ * backward launch (same eligibility as the forward's) in f16x3 mode: the dG rows are normalised per wave by the largest
+ * magnitude the wave loaded, three fp16 MFMAs per product, fp32 accumulate.  Absent: exact fp32. */
 
 /* ---- attention variant (GarmentSegmentPattern3D, nn/nets.py:187-299) ------------------------------------------ */
 /* sparsemax.Sparsemax(dim=1) over rows of width W <= 32 (nn/nets.py:225): forward and backward */

