@@ -124,34 +124,48 @@ __device__ __forceinline__ ps_u32x4 ps_mask4(ps_u32x4 v, int k0, int K)
     return v;
 }
 
-// One K segment of a 16-row tile: A = rows [arow][K] behind `rs` (sc1 loads, row pitch `pitch` floats), B = the workgroup's weight
-// slice in LDS with NT 16-column tiles.  This wave multiplies its share of the K steps into acc.  sA: power of two applied to A
-// before the fp16 split (H3); DYN: take it from the largest magnitude this wave loaded instead and return its inverse.
-//   H3 slice layout  [plane][KP / 8][16 NT columns][8 halves]   step = 32 k
-//   fp32 slice layout [KP / 4][16 NT columns][4 floats]          step = 16 k
+// One K segment of a 16-row tile, in two phases so that the loads of two segments can be in flight together:
+//   ps_load: A = rows [arow][K] behind `rs` (sc1 loads, row pitch `pitch` floats) -> this wave's share of the K steps, in registers;
+//   ps_mma : B = the workgroup's weight slice in LDS with NT 16-column tiles; multiplies the loaded steps into acc.
+// sA: power of two applied to A before the fp16 split (H3); DYN: take it from the largest magnitude this wave loaded instead and
+// return its inverse.
+//   H3 slice layout  [plane][KP / 8][16 NT columns][8 halves]   step = 32 k, two quads per lane
+//   fp32 slice layout [KP / 4][16 NT columns][4 floats]          step = 16 k, one quad per lane
+template <bool H3, int MAXS>
+struct PsA { ps_u32x4 v[H3 ? 2 * MAXS : MAXS]; };
+
+template <bool H3, int MAXS>
+__device__ __forceinline__ void ps_load(PsA<H3, MAXS>& A, __amdgpu_buffer_rsrc_t rs, int arow, long pitch, int K, int s_lo, int nsteps)
+{
+    const int g = (threadIdx.x & 63) >> 4;
+    const int rowoff = (int)(arow * pitch) * 4;
+#pragma unroll
+    for (int i = 0; i < MAXS; ++i) {
+        const int s = (s_lo + i < nsteps) ? s_lo + i : nsteps - 1;
+        if constexpr (H3) {
+            const int k0 = 32 * s + 8 * g;
+            A.v[2 * i] = ps_mask4(__builtin_amdgcn_raw_buffer_load_b128(rs, rowoff + k0 * 4, 0, 16), k0, K);
+            A.v[2 * i + 1] = ps_mask4(__builtin_amdgcn_raw_buffer_load_b128(rs, rowoff + k0 * 4 + 16, 0, 16), k0 + 4, K);
+        } else {
+            const int k0 = 16 * s + 4 * g;
+            A.v[i] = ps_mask4(__builtin_amdgcn_raw_buffer_load_b128(rs, rowoff + k0 * 4, 0, 16), k0, K);
+        }
+    }
+}
+
 template <bool H3, int NT, int MAXS, bool DYN>
-__device__ __forceinline__ float ps_segment(__amdgpu_buffer_rsrc_t rs, int arow, long pitch, int K, int KP, const char* W,
-                                            int s_lo, int s_hi, int nsteps, float sA, f32x4 (&acc)[NT])
+__device__ __forceinline__ float ps_mma(const PsA<H3, MAXS>& A, int KP, const char* W, int s_lo, int s_hi, float sA, f32x4 (&acc)[NT])
 {
     const int lane = threadIdx.x & 63;
     const int j = lane & 15, g = lane >> 4;
-    const int rowoff = (int)(arow * pitch) * 4;
     float inv = 1.f;
     if constexpr (H3) {
-        ps_u32x4 v[2 * MAXS];
-#pragma unroll
-        for (int i = 0; i < MAXS; ++i) {
-            const int s = (s_lo + i < nsteps) ? s_lo + i : nsteps - 1;
-            const int k0 = 32 * s + 8 * g;
-            v[2 * i] = ps_mask4(__builtin_amdgcn_raw_buffer_load_b128(rs, rowoff + k0 * 4, 0, 16), k0, K);
-            v[2 * i + 1] = ps_mask4(__builtin_amdgcn_raw_buffer_load_b128(rs, rowoff + k0 * 4 + 16, 0, 16), k0 + 4, K);
-        }
         if constexpr (DYN) {
             unsigned m = 0u;
 #pragma unroll
             for (int i = 0; i < 2 * MAXS; ++i)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { const unsigned a = v[i][e] & 0x7fffffffu; m = m > a ? m : a; }
+                for (int e = 0; e < 4; ++e) { const unsigned a = A.v[i][e] & 0x7fffffffu; m = m > a ? m : a; }
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) { const unsigned t = (unsigned)__shfl_xor((int)m, o); m = m > t ? m : t; }
             gpe_h3_scale_of(m, sA, inv);
@@ -162,7 +176,7 @@ __device__ __forceinline__ float ps_segment(__amdgpu_buffer_rsrc_t rs, int arow,
             const int s = s_lo + i;
             if (s < s_hi) {
                 ps_u32x4 ah, al;
-                const ps_u32x4 a0 = v[2 * i], a1 = v[2 * i + 1];
+                const ps_u32x4 a0 = A.v[2 * i], a1 = A.v[2 * i + 1];
                 { unsigned h, l; ps_split2(__uint_as_float(a0[0]), __uint_as_float(a0[1]), sA, h, l); ah[0] = h; al[0] = l; }
                 { unsigned h, l; ps_split2(__uint_as_float(a0[2]), __uint_as_float(a0[3]), sA, h, l); ah[1] = h; al[1] = l; }
                 { unsigned h, l; ps_split2(__uint_as_float(a1[0]), __uint_as_float(a1[1]), sA, h, l); ah[2] = h; al[2] = l; }
@@ -179,13 +193,6 @@ __device__ __forceinline__ float ps_segment(__amdgpu_buffer_rsrc_t rs, int arow,
             }
         }
     } else {
-        ps_u32x4 v[MAXS];
-#pragma unroll
-        for (int i = 0; i < MAXS; ++i) {
-            const int s = (s_lo + i < nsteps) ? s_lo + i : nsteps - 1;
-            const int k0 = 16 * s + 4 * g;
-            v[i] = ps_mask4(__builtin_amdgcn_raw_buffer_load_b128(rs, rowoff + k0 * 4, 0, 16), k0, K);
-        }
 #pragma unroll
         for (int i = 0; i < MAXS; ++i) {
             const int s = s_lo + i;
@@ -199,7 +206,7 @@ __device__ __forceinline__ float ps_segment(__amdgpu_buffer_rsrc_t rs, int arow,
 #pragma unroll
                     for (int n = 0; n < NT; ++n) {
                         const float bv = (t == 0) ? b4[n].x : (t == 1) ? b4[n].y : (t == 2) ? b4[n].z : b4[n].w;
-                        acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(v[i][t]), bv, acc[n], 0, 0, 0);
+                        acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(A.v[i][t]), bv, acc[n], 0, 0, 0);
                     }
             }
         }
@@ -284,21 +291,20 @@ __global__ __launch_bounds__(256) void gpe_rnn_persist_fwd_kernel(PsFwdParams p)
             f32x4 accH[4], accX[4];
 #pragma unroll
             for (int n = 0; n < 4; ++n) { accH[n] = (f32x4){0.f, 0.f, 0.f, 0.f}; accX[n] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
-            if (l > 0) {                             // h_{l-1,t} (slot t+1) x W_ih_l: the layer below runs ahead
-                ps_wait(p.flags + ((long)(l - 1) * T + t) * p.NRT + rt, need);
-                PS_STAMP(1);
-                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-                    p.hs + (l - 1) * p.hs_sl + (long)(t + 1) * p.hs_st, 0, nrec, 0x00020000);
-                ps_segment<H3, 4, MAXS, false>(rs, arow, p.hs_sb, H, KP, W1, s_lo, s_hi, nsteps, PS_SA, accX);
-                PS_STAMP(2);
-            }
-            if (t > 0) ps_wait(p.flags + ((long)l * T + t - 1) * p.NRT + rt, need);
+            // both flags first, then the loads of both segments back to back (one latency instead of two), then the products
+            PsA<H3, MAXS> A1, A0;
+            if (l > 0) ps_wait(p.flags + ((long)(l - 1) * T + t) * p.NRT + rt, need);   // h_{l-1,t}: the layer below runs ahead
+            PS_STAMP(1);
+            if (t > 0) ps_wait(p.flags + ((long)l * T + t - 1) * p.NRT + rt, need);     // h_{l,t-1}
             PS_STAMP(3);
-            {                                        // h_{l,t-1} (slot t) x W_hh_l
-                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-                    p.hs + l * p.hs_sl + (long)t * p.hs_st, 0, nrec, 0x00020000);
-                ps_segment<H3, 4, MAXS, false>(rs, arow, p.hs_sb, H, KP, W0, s_lo, s_hi, nsteps, PS_SA, accH);
-            }
+            if (l > 0)                               // h_{l-1,t} (slot t+1) x W_ih_l
+                ps_load<H3, MAXS>(A1, __builtin_amdgcn_make_buffer_rsrc(p.hs + (l - 1) * p.hs_sl + (long)(t + 1) * p.hs_st, 0, nrec, 0x00020000),
+                                  arow, p.hs_sb, H, s_lo, nsteps);
+            ps_load<H3, MAXS>(A0, __builtin_amdgcn_make_buffer_rsrc(p.hs + l * p.hs_sl + (long)t * p.hs_st, 0, nrec, 0x00020000),
+                              arow, p.hs_sb, H, s_lo, nsteps);                           // h_{l,t-1} (slot t) x W_hh_l
+            if (l > 0) ps_mma<H3, 4, MAXS, false>(A1, KP, W1, s_lo, s_hi, PS_SA, accX);
+            PS_STAMP(2);
+            ps_mma<H3, 4, MAXS, false>(A0, KP, W0, s_lo, s_hi, PS_SA, accH);
 #pragma unroll
             for (int n = 0; n < 4; ++n)
 #pragma unroll
@@ -395,23 +401,28 @@ __global__ __launch_bounds__(256) void gpe_rnn_persist_bwd_kernel(PsBwdParams p)
             PS_STAMP(0);
             const int arow = (16 * rt + j < Bn) ? 16 * rt + j : Bn - 1;
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-            if (up) {                                // dG_{l+1,t} x W_ih_{l+1}: the layer above runs ahead
-                ps_wait(p.flags + ((long)(l + 1) * T + t) * p.NRT + rt, need);
-                PS_STAMP(1);
-                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-                    p.dgx + (l + 1) * p.dg_sl + (long)t * p.dg_st, 0, nrec, 0x00020000);
+            // both flags first, then the loads of both segments back to back (one latency instead of two), then the products
+            PsA<H3, MAXS> A1, A0;
+            const bool rec = t < T - 1;
+            if (up) ps_wait(p.flags + ((long)(l + 1) * T + t) * p.NRT + rt, need);       // dG_{l+1,t}: the layer above runs ahead
+            PS_STAMP(1);
+            if (rec) ps_wait(p.flags + ((long)l * T + t + 1) * p.NRT + rt, need);        // dG_{l,t+1}
+            PS_STAMP(3);
+            if (up)                                  // dG_{l+1,t} x W_ih_{l+1}
+                ps_load<H3, MAXS>(A1, __builtin_amdgcn_make_buffer_rsrc(p.dgx + (l + 1) * p.dg_sl + (long)t * p.dg_st, 0, nrec, 0x00020000),
+                                  arow, p.dg_sb, K4, s_lo, nsteps);
+            if (rec)                                 // dG_{l,t+1} x W_hh_l
+                ps_load<H3, MAXS>(A0, __builtin_amdgcn_make_buffer_rsrc(p.dgx + l * p.dg_sl + (long)(t + 1) * p.dg_st, 0, nrec, 0x00020000),
+                                  arow, p.dg_sb, K4, s_lo, nsteps);
+            if (up) {
                 f32x4 a1[1] = {{0.f, 0.f, 0.f, 0.f}};
-                const float ia = ps_segment<H3, 1, MAXS, true>(rs, arow, p.dg_sb, K4, KP, W1, s_lo, s_hi, nsteps, 1.f, a1);
+                const float ia = ps_mma<H3, 1, MAXS, true>(A1, KP, W1, s_lo, s_hi, 1.f, a1);
                 acc = a1[0] * (ia * invw1);
-                PS_STAMP(2);
             }
-            if (t < T - 1) {                         // dG_{l,t+1} x W_hh_l
-                ps_wait(p.flags + ((long)l * T + t + 1) * p.NRT + rt, need);
-                PS_STAMP(3);
-                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-                    p.dgx + l * p.dg_sl + (long)(t + 1) * p.dg_st, 0, nrec, 0x00020000);
+            PS_STAMP(2);
+            if (rec) {
                 f32x4 a0[1] = {{0.f, 0.f, 0.f, 0.f}};
-                const float ia = ps_segment<H3, 1, MAXS, true>(rs, arow, p.dg_sb, K4, KP, W0, s_lo, s_hi, nsteps, 1.f, a0);
+                const float ia = ps_mma<H3, 1, MAXS, true>(A0, KP, W0, s_lo, s_hi, 1.f, a0);
                 acc += a0[0] * (ia * invw0);
             }
 #pragma unroll

@@ -47,6 +47,6 @@ for kind in ('fwd', 'bwd'):
             v = s[:, inner, b] - s[:, inner, a]
             ok = (s[:, inner, a] > 0) & (s[:, inner, b] > 0)
             return np.median(v[ok]) if ok.any() else float('nan')
-        print('   start->seg1 polled %.2f | seg1 loads+mfma %.2f | (seg1 done|start)->seg0 polled %.2f | seg0 loads+mfma+partials %.2f | '
-              'barrier+epilogue+stores issued %.2f | drain %.2f | barrier+atomic %.2f'
-              % (d(0, 1), d(1, 2), (s[:, inner, 3] - np.maximum(s[:, inner, 2], s[:, inner, 0])).mean(), d(3, 4), d(4, 5), d(5, 6), d(6, 7)))
+        print('   start->flag 1 seen %.2f | ->flag 0 seen %.2f | loads of both segments + products of segment 1 %.2f | products of segment 0 + '
+              'partials %.2f | barrier+epilogue+stores issued %.2f | drain %.2f | barrier+atomic %.2f'
+              % (d(0, 1), d(1, 3), d(3, 2), d(2, 4), d(4, 5), d(5, 6), d(6, 7)))
