@@ -18,6 +18,10 @@
 #include "gpe_common.h"
 #include <stdlib.h>
 
+long gpe_gemm_x6_red_ws(int Mg, int Ng);                                                 // gpe_gemm_x6.hip
+int gpe_gemm_x6_redgemm(const GpeRows& u, const GpeRows& v, const float* v_shift, long rows, int Mg, int Ng, float* part, bool want_cs,
+                        int* nsplit, int* MgPad, int* NgPad, double** part_cs, hipStream_t s);
+extern "C" int gpe_debug_get(void);
 static int g_rd_math = 0;            // 0: exact fp32 MFMA, 1: bf16x3, 2: f16x3 where the operand scales are known (gpe_math_set)
 void gpe_redgemm_set_math(int m) { g_rd_math = m; }
 
@@ -1386,7 +1390,9 @@ extern "C" long gpe_redgemm_ws(int Mg, int Ng)
     const long mr = gpe_round_up(Mg, 4);
     const long thin = Ng <= 4 ? (long)RDT_GX * mr * 4 + 2L * RDT_GX * mr + 8 : 0;      // gpe_redgemm_thin_kernel
     const long m2 = big > deep ? big : deep;
-    return m2 > thin ? m2 : thin;
+    const long m3 = m2 > thin ? m2 : thin;
+    const long x6 = gpe_gemm_x6_red_ws(Mg, Ng);
+    return m3 > x6 ? m3 : x6;
 }
 
 template <int MH, int NH, int VMODE>
@@ -1475,6 +1481,22 @@ static int rd_run(RdParams& p, int vmode, float* G, int ldG, float* colsum, floa
                            p.Ng, p.MgPad, p.NgPad, G, ldG, colsum, accumulate);
         GPE_CHECK_LAUNCH();
         return GPE_OK;
+    }
+    // f16x3 mode: row-rich dense products off the edge kernels' menu (the decoders' weight gradients, 10304 rows x 1000 x 250; the
+    // [P|Q] projection's, 65536 x 400 x 150) on the bf16 pipe, three-term splits (gpe_gemm_x6.hip): same partial image, same finish
+    if (vmode == V_DENSE && g_rd_math == 2 && !p.lz_g && !(gpe_debug_get() & 16384) &&
+        !(gpe_cdiv(p.Ng, 16) == 13 && (gpe_cdiv(p.Mg, 16) == 13 || gpe_cdiv(p.Mg, 16) == 10) && gy == 1 && p.amax_u && p.amax_v)) {
+        int ns = 0, mp = 0, np = 0;
+        double* pcs = nullptr;
+        const int rc = gpe_gemm_x6_redgemm(p.u, p.v, p.v_shift, p.rows, p.Mg, p.Ng, part, colsum != nullptr, &ns, &mp, &np, &pcs, s);
+        if (rc < 0) return rc;
+        if (rc == 1) {
+            const long fin_x = gpe_cdiv((long)p.Mg * p.Ng, RD_FIN_E) + (colsum ? gpe_cdiv(p.Mg, RD_FIN_E) : 0);
+            hipLaunchKernelGGL(gpe_redgemm_finish, dim3(fin_x), dim3(RD_FIN_E * RD_FIN_Q), 0, s, part, pcs, ns, p.Mg, p.Ng, mp, np, G, ldG,
+                               colsum, accumulate);
+            GPE_CHECK_LAUNCH();
+            return GPE_OK;
+        }
     }
     const long in_max = (p.u.inner > p.v.inner ? p.u.inner : p.v.inner) > 1 ? (p.u.inner > p.v.inner ? p.u.inner : p.v.inner) : 1;
     static const int dbg_deep = getenv("GPE_RD_DEEP") ? atoi(getenv("GPE_RD_DEEP")) : -1;   // measurement override: 0 = never the deep kernel

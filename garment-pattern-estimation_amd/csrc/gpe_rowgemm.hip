@@ -210,6 +210,9 @@ void gpe_edgegemm_set_math(int m);
 void gpe_redgemm_set_math(int m);
 size_t gpe_edge_pseudo_bytes(long npts, int k, int Cmax);   // gpe_edgegemm_sr.hip
 
+int gpe_gemm_x6_linear(const GpeRows& a, const float* wp, int Npad, int Kq, const float* bias, const GpeRows& addend, float* y,
+                       long y_so, long y_si, int y_inner, long M, int N, int K, int act, hipStream_t s);      // gpe_gemm_x6.hip
+extern "C" long gpe_packed_size(int N, int K);
 static int g_gpe_dbg = 0;
 extern "C" int gpe_debug_set(int flags) { g_gpe_dbg = flags; return 0; }
 extern "C" int gpe_debug_get(void) { return g_gpe_dbg; }
@@ -335,6 +338,13 @@ extern "C" int gpe_linear(const float* a, long a_so, long a_si, int a_inner, con
     p.wp = wp; p.Npad = gpe_round_up(N, 16); p.bias = bias;
     p.addend = GpeRows{addend, ad_so, ad_si, ad_inner};
     p.y = y; p.y_so = y_so; p.y_si = y_si; p.y_inner = y_inner; p.act = act;
+    // f16x3 mode: the big dense products (the layer-2 [P|Q] projection and its input gradient, 65536 rows x 400 x 150) on the bf16
+    // pipe, three-term splits, six MFMAs per product (gpe_gemm_x6.hip); gpe_debug_set(16384) keeps the exact kernels (A/B runs)
+    if (g_gpe_math == 4 && !(g_gpe_dbg & 16384)) {
+        const int rc = gpe_gemm_x6_linear(p.a, wp, p.Npad, (int)(gpe_packed_size(N, K) / p.Npad / 4), bias, p.addend, y, y_so, y_si, y_inner, M, N, K,
+                                          act, (hipStream_t)stream);
+        if (rc != 0) return rc < 0 ? rc : GPE_OK;
+    }
     if (K <= RG_SMALLK && !(N & 3) && M >= 4096 && rg_rows_aligned16(y, y_so, y_si, y_inner) &&
         (!addend || rg_rows_aligned16(addend, ad_so, ad_si, ad_inner))) {
         long gx = gpe_cdiv(M, 4 * 8);                      // >= 8 rows per wave

@@ -374,6 +374,71 @@ def test_redgemm_two_level_rows(gpe):
     assert relerr(cs, dg.double().cpu().reshape(-1, GH).sum(0)) < 3e-6
 
 
+def test_dense_gemms_on_the_bf16_pipe(gpe):
+    """csrc/gpe_gemm_x6.hip (round 6): in f16x3 mode the row-rich dense products of gpe_linear / gpe_redgemm run on the bf16 pipe with
+    three-term splits (six MFMAs per product, no scales).  Same bars as the exact kernels against fp64 — ragged M / N / K, bias +
+    addend + ReLU, 16-byte and scalar output rows, two-level rows, centring shift, accumulate — and gpe_debug_set(16384) (the exact
+    kernels) must give other bits: the new path really ran."""
+    from gpe_amd import _lib as Lb
+    ops = gpe.ops
+    g = torch.Generator().manual_seed(11)
+    prev = gpe.set_math('f16x3')
+    try:
+        # ---- NT: Y = act(A W^T + b + addend) ----
+        for (M, N, K, act, addend, ldy) in [(65536, 400, 150, 0, False, 400), (65536, 150, 400, 0, False, 150), (5003, 250, 1000, 1, True, 252),
+                                            (20000, 72, 100, 0, False, 72), (10304, 1000, 250, 0, True, 1000)]:
+            ap = torch.randn(M, (K + 3) // 4 * 4, generator=g)              # rows padded to 16 bytes (what the package's tensors are)
+            a = ap[:, :K]
+            w = torch.randn(N, K, generator=g) / K ** 0.5
+            b = torch.randn(N, generator=g)
+            ad = torch.randn(M, N, generator=g) if addend else None
+            ad_c = ad.cuda() if addend else None
+            ref = a.double() @ w.double().t() + b.double() + (ad.double() if addend else 0)
+            if act:
+                ref = torch.relu(ref)
+            ac, wp, bc = ap.cuda()[:, :K], ops.pack_weight(w.cuda()), b.cuda()
+            outs = []
+            for dbg in (0, 16384):
+                Lb.query('gpe_debug_set', dbg)
+                y = torch.zeros(M, ldy, device='cuda')
+                ops.linear_raw((ac, ac.stride(0), 0, 0), wp, bc, M, N, K, (y, ldy, 0, 0), act, (ad_c, N, 0, 0) if addend else None)
+                assert relerr(y[:, :N], ref) < 2e-6, (M, N, K, dbg)
+                assert float(y[:, N:].abs().max()) == 0.0 if ldy > N else True
+                outs.append(y)
+            assert not torch.equal(outs[0], outs[1]), (M, N, K)
+        # ---- TN: G = U^T (V - shift), colsum ----
+        for (rows, Mg, Ng, shift, two_level) in [(10304, 1000, 250, False, True), (65536, 400, 150, True, False), (736, 1000, 250, False, True),
+                                                 (20000, 77, 130, True, False), (65536, 150, 200, False, False)]:
+            if two_level:
+                T = 14 if rows % 14 == 0 else 23
+                Bn = rows // T
+                ub = torch.randn(Bn, T, Mg, generator=g).cuda()
+                vb = torch.randn(Bn, T + 1, (Ng + 3) // 4 * 4, generator=g).cuda()
+                ud, vd = ops._rows3d(ub), ops._rows3d(vb[:, :T, :Ng])
+                u, v = ub.reshape(rows, Mg).double().cpu(), vb[:, :T, :Ng].reshape(rows, Ng).double().cpu()
+            else:
+                uc = torch.randn(rows, (Mg + 3) // 4 * 4, generator=g).cuda()
+                vc = (torch.randn(rows, (Ng + 3) // 4 * 4, generator=g) + 3.0).cuda()
+                ud, vd = (uc[:, :Mg], uc.stride(0), 0, 0), (vc[:, :Ng], vc.stride(0), 0, 0)
+                u, v = uc[:, :Mg].double().cpu(), vc[:, :Ng].double().cpu()
+            sh = v.mean(0).float().cuda() if shift else None
+            ref = u.t() @ (v - (sh.double().cpu() if shift else 0))
+            outs = []
+            for dbg in (0, 16384):
+                Lb.query('gpe_debug_set', dbg)
+                G, cs = ops.redgemm_raw(ud, vd, rows, Mg, Ng, v_shift=sh)
+                assert relerr(G, ref) < 3e-6, (rows, Mg, Ng, dbg)
+                assert relerr(cs, u.sum(0)) < 3e-6
+                outs.append(G)
+            assert not torch.equal(outs[0], outs[1]), (rows, Mg, Ng)
+            Lb.query('gpe_debug_set', 0)
+            G2, cs2 = ops.redgemm_raw(ud, vd, rows, Mg, Ng, v_shift=sh, accumulate_into=(outs[0].clone(), cs.clone()))
+            assert relerr(G2, 2 * ref) < 3e-6 and relerr(cs2, 2 * u.sum(0)) < 3e-6
+    finally:
+        Lb.query('gpe_debug_set', 0)
+        gpe.set_math(prev)
+
+
 # --------------------------------------------------------------------------------------------------
 def _oracle_conv(C, H, Fo, k, seed):
     from oracle import ref_path as O
