@@ -12,21 +12,21 @@
 // on the fly while they are staged (the weights of gpe_linear arrive as the plain fp32 pack), so the kernels take the same
 // arguments as the exact ones and are selected by the arithmetic mode alone (gpe_math_set(4): the parity-grade fast mode).
 //
-// A workgroup computes a 128 x 128 output block, K in steps of 32.  TN (many steps per block): one 512-thread workgroup per CU, TWO
-// ROLES (one wave of each per SIMD) —
+// A workgroup computes a 128 x 128 output block, K in steps of 32.  TN (many steps per block): one 768-thread workgroup per CU, TWO
+// ROLES (one multiplying and two staging waves per SIMD) —
 //   waves 0-3  multiply: 2 x 2 waves, each 64 x 64 = 4 x 4 MFMA tiles, 96 MFMAs per step from the LDS image of the step;
-//   waves 4-7  stage   : global loads three steps ahead of the MFMAs (three register sets: the loads of a step have two whole steps
-//              to arrive), three-term split (~500 VALU per step: it issues under the partner wave's MFMAs instead of behind the
-//              wave's own), LDS writes into the other of two buffers; one barrier per step.
+//   waves 4-11 stage   : global loads three steps ahead of the MFMAs (three register sets: the loads of a step have two whole steps
+//              to arrive), three-term split (~5.5 VALU per value, 4 cycles each: it issues under the partner wave's MFMAs instead
+//              of behind the wave's own), LDS writes into the other of two buffers; one barrier per step.
 //   (A first version did both jobs in every wave: MFMA pipe 0.26 - 0.31 busy, issue-stalled 0.33 - 0.41 — the splits sat between
 //   the MFMA blocks; profiles/r06_b_dense_gemms.md.)
 // LDS image of one operand of one step: [3 planes][128 rows][4 slots of 8 bf16], slot' = kgroup ^ (row & 8 ? 2 : 0): ds_read_b128 is
 // serviced in the lane groups {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, ... (MI355X_MICROARCH.md, LDS) — with lane (j, g) reading
 // row 16 t + j, k group g, the XOR puts the 16 lanes of every group on 16 different four-bank slots.
 //   NT stager: thread -> (row, k quad): one float4 along k of each operand per 256 pieces, 8-byte LDS writes (conflict-free).
-//   TN stager: the reduction index is the SLOW index of both operands.  Thread -> (8 consecutive rows, column quad): eight float4
-//              loads (256-byte runs along the columns), transposed in registers — column c of the eight rows = the 8 k-values of one
-//              MFMA fragment lane — split, one 16-byte LDS write per column and plane (2-way).  Stager waves 0, 1 stage U, 2, 3 V.
+//   TN stager: the reduction index is the SLOW index of both operands.  Thread -> (4 consecutive rows, column quad): four float4
+//              loads (128-byte runs along the columns), transposed in registers — column c of the four rows = half of the 8 k-values
+//              of one MFMA fragment lane — split, one 8-byte LDS write per column and plane.  Staging waves 4-7 take U, 8-11 V.
 // TN splits the rows over gridDim.x workgroups per output block; partial blocks go to the caller's `part` image
 // [split][MgPad][NgPad] (+ fp64 column sums) and gpe_redgemm_finish adds them in fp64 (gpe_redgemm.hip: same image as the exact path).
 #include "gpe_edgegemm_split_kernel.h"
@@ -39,6 +39,7 @@
 #define GX_LDS (2 * GX_BUF)           // two steps; the epilogue's C image 128 x 132 x 4 = 67584 bytes (+ 4 KB of column sums) fits
 
 typedef SplitBf16x3 GXS;
+extern "C" int gpe_debug_get(void);
 
 __device__ __forceinline__ int gx_slot(int row, int kg) { return kg ^ ((row >> 2) & 2); }
 
@@ -219,15 +220,21 @@ struct GxRedParams {
     long rows, rows_per_split;
     int Mg, Ng, MgPad, NgPad;
     float* part; double* part_cs;
+    unsigned long long* trace;              // measurement aid (scripts/gemm_trace.py): [2 roles][steps][4] stamps of workgroup 0, else NULL
 };
+#define GX_STAMP(role_, s_, i_)                                                                              \
+    do {                                                                                                     \
+        if (p.trace && blockIdx.x + blockIdx.y + blockIdx.z == 0 && (tid & 255) == 0 && (s_) < 64)             \
+            p.trace[((role_) * 64 + (s_)) * 4 + (i_)] = wall_clock64();                                      \
+    } while (0)
 
-struct GxTnRegs { float4 r[8]; };
+struct GxTnRegs { float4 r[4]; };
 
-__global__ __launch_bounds__(512) void gpe_gemm_x6_tn_kernel(GxRedParams p)
+__global__ __launch_bounds__(768) void gpe_gemm_x6_tn_kernel(GxRedParams p)
 {
     extern __shared__ __align__(16) char gx_smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int role = wave >> 2;
+    const int role = wave >= 4;                         // waves 0-3 multiply, waves 4-11 stage
     const int j = lane & 15, g = lane >> 4, wm = (wave >> 1) & 1, wn = wave & 1;
     const int split = blockIdx.x;
     const int m0 = blockIdx.y * GX_B, n0 = blockIdx.z * GX_B;
@@ -239,14 +246,16 @@ __global__ __launch_bounds__(512) void gpe_gemm_x6_tn_kernel(GxRedParams p)
     for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    double* red = reinterpret_cast<double*>(gx_smem + GX_B * GX_LDC * 4);          // [4 rg][128] column sums, behind the C image
+    double* red = reinterpret_cast<double*>(gx_smem + GX_B * GX_LDC * 4);          // [8 rq][128] column sums, behind the C image
 
     if (role == 1) {
-        // ---- stager: waves 4, 5 -> U (columns m0 ..), waves 6, 7 -> V (columns n0 ..); thread -> (row group rg of 8 rows, column
-        // quad mq), rg fastest: a 16-byte LDS write instruction then meets 2 rows x 4 slots per 8-lane group (2-way) ----
-        const bool isv = wave >= 6;
-        const int t7 = tid & 127;
-        const int rg = t7 & 3, mq = t7 >> 2;
+        // ---- stager: waves 4-7 -> U (columns m0 ..), waves 8-11 -> V (columns n0 ..); thread -> (row quad rq of the step's 32 rows,
+        // column quad mq): four float4 loads, 16 values to split (the step timeline of the first role-split version — four staging
+        // waves, eight rows per thread — showed the multiplying waves waiting 45 % of every step for the stagers' ~800 VALU:
+        // profiles/r06_b_dense_gemms.md) ----
+        const bool isv = wave >= 8;
+        const int t8 = (tid - 256) & 255;
+        const int rq = t8 & 7, mq = t8 >> 3;
         const GpeRows op = isv ? p.v : p.u;
         const int width = isv ? p.Ng : p.Mg;
         const int c0 = (isv ? n0 : m0) + 4 * mq;           // first of this thread's four columns
@@ -266,12 +275,12 @@ __global__ __launch_bounds__(512) void gpe_gemm_x6_tn_kernel(GxRedParams p)
         const long r_last = r_end > r_begin ? r_end - 1 : r_begin;
         auto load = [&](GxTnRegs& R, int s) {
             if (s >= nsteps) s = nsteps - 1;
-            const long rbase = r_begin + 32L * s + 8 * rg;
+            const long rbase = r_begin + 32L * s + 4 * rq;
             const unsigned rb0 = (unsigned)(rbase < r_last ? rbase : r_last);
             unsigned o = rb0 / inner_eff, i = rb0 - o * inner_eff;
             const unsigned left = (unsigned)r_last - rb0;  // rows that may still advance
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
+            for (int q = 0; q < 4; ++q) {
                 R.r[q] = ld4(op.base + (long)o * op.stride_outer + (long)i * si_eff + cc);
                 const unsigned i2 = i + ((unsigned)q < left ? 1u : 0u);
                 const bool wrap = i2 == inner_eff;
@@ -281,11 +290,11 @@ __global__ __launch_bounds__(512) void gpe_gemm_x6_tn_kernel(GxRedParams p)
         };
         auto commit = [&](GxTnRegs& R, int s) {
             char* Ob = gx_smem + (s & 1) * GX_BUF + (isv ? GX_OP : 0);
-            const long rbase = r_begin + 32L * s + 8 * rg;
-            float v[8][4];
+            const long rbase = r_begin + 32L * s + 4 * rq;
+            float v[4][4];
             float s4[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
+            for (int q = 0; q < 4; ++q) {
                 const bool ok = rbase + q < r_end;
                 const float x[4] = {R.r[q].x, R.r[q].y, R.r[q].z, R.r[q].w};
 #pragma unroll
@@ -299,17 +308,12 @@ __global__ __launch_bounds__(512) void gpe_gemm_x6_tn_kernel(GxRedParams p)
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const int row = 4 * mq + c;                // LDS row = output column inside the block
-                unsigned k01[3], k23[3], k45[3], k67[3];
+                unsigned k01[3], k23[3];
                 GXS::split2(v[0][c], v[1][c], k01);
                 GXS::split2(v[2][c], v[3][c], k23);
-                GXS::split2(v[4][c], v[5][c], k45);
-                GXS::split2(v[6][c], v[7][c], k67);
-                char* dst = Ob + row * 64 + 16 * gx_slot(row, rg);
+                char* dst = Ob + row * 64 + 16 * gx_slot(row, rq >> 1) + 8 * (rq & 1);   // k = 4 rq .. 4 rq + 3: half a slot
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl) {
-                    const x6_u32x4 w = {k01[pl], k23[pl], k45[pl], k67[pl]};
-                    *reinterpret_cast<x6_u32x4*>(dst + pl * GX_PLANE) = w;
-                }
+                for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<uint2*>(dst + pl * GX_PLANE) = make_uint2(k01[pl], k23[pl]);
             }
         };
         GxTnRegs R0, R1, R2;
@@ -319,40 +323,58 @@ __global__ __launch_bounds__(512) void gpe_gemm_x6_tn_kernel(GxRedParams p)
         }
         __syncthreads();
         for (int s = 0; s < nsteps; s += 3) {
+            GX_STAMP(1, s, 0);
             if (s + 1 < nsteps) commit(R1, s + 1);
+            GX_STAMP(1, s, 1);
             load(R0, s + 3);
+            GX_STAMP(1, s, 2);
             __syncthreads();
+            GX_STAMP(1, s, 3);
             if (s + 1 >= nsteps) break;
+            GX_STAMP(1, s + 1, 0);
             if (s + 2 < nsteps) commit(R2, s + 2);
+            GX_STAMP(1, s + 1, 1);
             load(R1, s + 4);
+            GX_STAMP(1, s + 1, 2);
             __syncthreads();
+            GX_STAMP(1, s + 1, 3);
             if (s + 2 >= nsteps) break;
+            GX_STAMP(1, s + 2, 0);
             if (s + 3 < nsteps) commit(R0, s + 3);
+            GX_STAMP(1, s + 2, 1);
             load(R2, s + 5);
+            GX_STAMP(1, s + 2, 2);
             __syncthreads();
+            GX_STAMP(1, s + 2, 3);
         }
         // (the staging buffers are dead: every multiplying wave is past its last fragment read — the loop's last barrier)
         if (do_cs)
-            for (int c = 0; c < 4; ++c) red[rg * GX_B + 4 * mq + c] = cs[c];
+            for (int c = 0; c < 4; ++c) red[rq * GX_B + 4 * mq + c] = cs[c];
     } else {
         __syncthreads();
         for (int s = 0; s < nsteps; ++s) {
             const char* Ab = gx_smem + (s & 1) * GX_BUF;
+            GX_STAMP(0, s, 0);
             gx_compute(Ab, Ab + GX_OP, wm, wn, j, g, acc);
+            GX_STAMP(0, s, 1);
             __syncthreads();
+            GX_STAMP(0, s, 3);
         }
         gx_stage_c(reinterpret_cast<float*>(gx_smem), wm, wn, j, g, acc);
     }
     __syncthreads();
     const float* Cs = reinterpret_cast<const float*>(gx_smem);
     float* dst = p.part + (size_t)split * p.MgPad * p.NgPad;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int r = (tid >> 5) + 16 * i, cq = (tid & 31) << 2;
+    for (int e = tid; e < GX_B * 32; e += 768) {
+        const int r = e >> 5, cq = (e & 31) << 2;
         st4(dst + (size_t)(m0 + r) * p.NgPad + n0 + cq, ld4(&Cs[r * GX_LDC + cq]));
     }
-    if (p.part_cs && blockIdx.z == 0 && tid < GX_B)
-        p.part_cs[(size_t)split * p.MgPad + m0 + tid] = (red[tid] + red[GX_B + tid]) + (red[2 * GX_B + tid] + red[3 * GX_B + tid]);
+    if (p.part_cs && blockIdx.z == 0 && tid < GX_B) {
+        double t = 0.0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) t += red[q * GX_B + tid];
+        p.part_cs[(size_t)split * p.MgPad + m0 + tid] = t;
+    }
 }
 
 // =====================================================================================================================
@@ -387,9 +409,10 @@ int gpe_gemm_x6_linear(const GpeRows& a, const float* wp, int Npad, int Kq, cons
 long gpe_gemm_x6_red_ws(int Mg, int Ng)
 {
     const long MgPad = gpe_round_up(Mg, GX_B), NgPad = gpe_round_up(Ng, GX_B);
-    return 32L * MgPad * NgPad + 2L * 32 * MgPad + 8;
+    return 32L * MgPad * NgPad + 2L * 32 * MgPad + 8 + 1024;      // (+ 4 KB: the step timeline of gpe_debug_set(32768))
 }
 
+long gpe_gemm_x6_red_ws(int Mg, int Ng);
 // 1 = partial blocks written (the caller runs gpe_redgemm_finish over *nsplit partials of MgPad x NgPad), 0 = not on the menu
 int gpe_gemm_x6_redgemm(const GpeRows& u, const GpeRows& v, const float* v_shift, long rows, int Mg, int Ng, float* part, bool want_cs,
                         int* nsplit, int* MgPad, int* NgPad, double** part_cs, hipStream_t s)
@@ -410,8 +433,12 @@ int gpe_gemm_x6_redgemm(const GpeRows& u, const GpeRows& v, const float* v_shift
     size_t off = (size_t)S * p.MgPad * p.NgPad;
     off = (off + 1) & ~(size_t)1;
     p.part_cs = want_cs ? reinterpret_cast<double*>(part + off) : nullptr;
+    if (gpe_debug_get() & 32768) {
+        p.trace = reinterpret_cast<unsigned long long*>(part + gpe_gemm_x6_red_ws(Mg, Ng) - 1024);
+        if (hipMemsetAsync(p.trace, 0, 4096, s) != hipSuccess) return GPE_ELAUNCH;
+    }
     GPE_ENSURE_MAX_LDS(gpe_gemm_x6_tn_kernel);
-    hipLaunchKernelGGL(gpe_gemm_x6_tn_kernel, dim3(S, mb, nb), dim3(512), GX_LDS, s, p);
+    hipLaunchKernelGGL(gpe_gemm_x6_tn_kernel, dim3(S, mb, nb), dim3(768), GX_LDS, s, p);
     GPE_CHECK_LAUNCH();
     *nsplit = S; *MgPad = p.MgPad; *NgPad = p.NgPad; *part_cs = p.part_cs;
     return 1;
