@@ -15,11 +15,12 @@ exact-fp32-MFMA step is measured in the same run and reported as `exact_f32` and
 
 Rank 0 prints ONE JSON line.  `value` = garments processed by all ranks / max-over-ranks wall time of exactly K
 steps (barrier + synchronize on both sides).  Extra objects:
-  roofline      — the dominant kernel family of the step, priced as SURVEY.md 8(d) prescribes against the roofs it actually sits
-                  under: t_roof = max(HBM bytes / 8 TB/s, EXECUTED matrix-pipe FLOPs / peak of the instruction it runs)
-                  (f16x3: 3 fp16 MFMA FLOPs per algorithmic one vs 2.5 PF; exact: 1 vs 157.3 TF), frac = t_roof / launch
-                  duration (HIP events on the launch stream), `bound` = the larger of the two.  HBM bytes = the counter traffic
-                  of the committed PMC pass of THESE kernel sources, else the algorithmic bytes.
+  roofline      — the dominant kernel of the step, priced as SURVEY.md 8(d) prescribes: t_roof = max(ALGORITHMIC HBM bytes / 8 TB/s,
+                  EXECUTED matrix-pipe FLOPs / peak of the instruction it runs) (f16x3: 3 fp16 MFMA FLOPs per algorithmic one vs
+                  2.5 PF; exact: 1 vs 157.3 TF), frac = t_roof / launch duration (HIP events on the launch stream; rocprofv3's
+                  average of the same kernel beside it), `achieved` = algorithmic bytes / duration, `bound` = the larger roof.
+                  `traffic` = counter bytes of the committed PMC pass of THESE kernel sources, `hbm_util` = traffic / duration / peak,
+                  `refetch` = traffic / algorithmic bytes (re-fetched bytes are waste, not achievement).
   roofline_per_kernel — the same for every kernel family of the step, and `roofline_step`: whole-step HBM and pipe fractions;
   roofline_gather — the EdgeConv neighbourhood gather: bytes_gather = N*k*(C*s+4) + N*C*s + N*F*s
                   per garment and layer, for (a) the kernel that carries the layer-2 gather (the fused gather->GEMM
@@ -242,6 +243,26 @@ def pmc_traffic(family, launches_per_step=None):
     return per_step / n, src
 
 
+def rocprof_avg_ms(family):
+    """rocprofv3 --kernel-trace average duration (ms) of the main device kernel of `family`, from the newest
+    profiles/*_kernel_avg.json (profiles/summarize_rocpd.py) of THIS tree's kernel sources; (None, why) otherwise."""
+    import glob
+    import re
+    if not _PMC_APPLIES[0] or family not in _TRAFFIC_KERNELS:
+        return None, _PMC_APPLIES[1]
+    files = sorted(glob.glob(os.path.join(REPO, 'profiles', '*_kernel_avg.json')))
+    if not files:
+        return None, 'no profiles/*_kernel_avg.json'
+    doc = json.load(open(files[-1]))
+    if doc.get('csrc_sha') != csrc_sha():
+        return None, 'refused: profiles/%s is a trace of csrc %s, this tree is %s' % (os.path.basename(files[-1]), doc.get('csrc_sha'), csrc_sha())
+    hits = [v for k, v in doc['kernels'].items() if re.search(_TRAFFIC_KERNELS[family], k)]
+    if not hits:
+        return None, None
+    best = max(hits, key=lambda v: v['total_us'])
+    return best['avg_us'] * 1e-3, 'profiles/' + os.path.basename(files[-1])
+
+
 def pmc_step_bytes():
     """counter HBM bytes of one whole training step (every kernel of the PMC pass), or None"""
     doc, src, _ = _pmc_doc()
@@ -376,15 +397,20 @@ def roofline_tables(rec, nsteps, args, step_s, f16_rows):
         f16 = (edge and on_f16) or key == 'gpe_knn:filter' or (entry == 'gpe_rnn_seq_fwd' and args.math == 'f16x3')
         pipe_peak = PEAK_F16_TFLOPS if f16 else PEAK_F32_TFLOPS
         exec_fl = (3.0 if f16 else 1.0) * fl / n_l
+        # frac = t_roof / t with t_roof from the ALGORITHMIC bytes (what the launch has to move once) and the matrix-pipe
+        # FLOPs it executes; the counter traffic of the committed PMC pass is reported beside it (hbm_util = counter bytes / t / peak,
+        # refetch = counter bytes / algorithmic bytes): re-fetched bytes are waste, not achievement
         traffic, tsrc = pmc_traffic(key, n_l / nsteps)
-        hbm = traffic if traffic else by / n_l
-        t_hbm, t_pipe = hbm / (PEAK_HBM_GBS * 1e9), exec_fl / (pipe_peak * 1e12)
+        alg = by / n_l
+        t_hbm, t_pipe = alg / (PEAK_HBM_GBS * 1e9), exec_fl / (pipe_peak * 1e12)
         bound = 'hbm' if t_hbm >= t_pipe else 'mfma'
         per_kernel[key] = {
             'launches_per_step': n_l / nsteps, 'avg_launch_ms': ms / n_l, 'ms_per_step': ms / nsteps,
             'bound': bound, 'frac': max(t_hbm, t_pipe) / t,
-            'hbm_bytes_per_launch': hbm, 'hbm_bytes_source': tsrc if traffic else 'algorithmic (no PMC pass of these sources)',
-            'algorithmic_bytes_per_launch': by / n_l, 'hbm_GBs': hbm / t / 1e9, 'hbm_frac': t_hbm / t,
+            'algorithmic_bytes_per_launch': alg, 'hbm_GBs': alg / t / 1e9, 'hbm_frac': t_hbm / t,
+            'traffic': traffic, 'traffic_source': tsrc if traffic else 'none (no PMC pass of these sources / this workload)',
+            'hbm_util': (traffic / t / (PEAK_HBM_GBS * 1e9)) if traffic else None,
+            'refetch': (traffic / alg) if (traffic and alg) else None,
             'flops_per_launch': fl / n_l, 'pipe': ('v_mfma_f32_16x16x32_f16 x3 per product' if f16 else 'v_mfma_f32_16x16x4_f32') if fl else None,
             'pipe_TFLOPs': exec_fl / t / 1e12 if fl else None, 'pipe_peak': pipe_peak if fl else None,
             'pipe_frac': t_pipe / t if fl else None}
@@ -402,14 +428,17 @@ def roofline_tables(rec, nsteps, args, step_s, f16_rows):
         roof = {'kernel': dom, 'bound': 'hbm', 'achieved': pk['hbm_GBs'], 'peak': PEAK_HBM_GBS, 'unit': 'GB/s'}
     else:
         roof = {'kernel': dom, 'bound': 'mfma', 'achieved': pk['pipe_TFLOPs'], 'peak': pk['pipe_peak'], 'unit': 'TFLOP/s'}
-    traffic, tsrc = pmc_traffic(dom, pk['launches_per_step'])
-    roof.update(frac=pk['frac'], traffic=traffic, traffic_unit='HBM bytes/launch', traffic_source=tsrc,
+    rp_ms, rp_src = rocprof_avg_ms(dom)
+    roof.update(frac=pk['frac'], traffic=pk['traffic'], traffic_unit='HBM bytes/launch (PMC counters)', traffic_source=pk['traffic_source'],
+                hbm_util=pk['hbm_util'], refetch=pk['refetch'],
                 launches_per_step=pk['launches_per_step'], avg_launch_ms=pk['avg_launch_ms'],
+                rocprof_avg_launch_ms=rp_ms, rocprof_source=rp_src,
                 flops_per_launch=pk['flops_per_launch'], algorithmic_bytes_per_launch=pk['algorithmic_bytes_per_launch'],
                 hbm_frac=pk['hbm_frac'], pipe=pk['pipe'], pipe_frac=pk['pipe_frac'],
-                rule='frac = max(HBM bytes / 8 TB/s, executed matrix-pipe FLOPs / pipe peak) / launch duration (SURVEY.md 8d); '
-                     'HBM bytes = PMC counter traffic of these kernel sources when committed, else algorithmic bytes; the dominant '
-                     'KERNEL = the single-kernel entry with the most time per step',
+                rule='SURVEY.md 8(d): frac = max(ALGORITHMIC bytes / 8 TB/s, executed matrix-pipe FLOPs / pipe peak) / launch duration '
+                     '(HIP events on the launch stream; rocprof_avg_launch_ms = rocprofv3\'s average of the same kernel from the committed '
+                     'trace of these sources); `achieved` = algorithmic bytes / duration; hbm_util prices the PMC counter bytes instead, '
+                     'refetch = counter / algorithmic bytes; the dominant KERNEL = the single-kernel entry with the most time per step',
                 largest_sequence=(None if first == dom else
                                   {'entry': first, 'ms_per_step': per_kernel[first]['ms_per_step'],
                                    'launches_per_call': 'a sequence of dependent device kernels behind one C-ABI call',
@@ -424,6 +453,7 @@ def roofline_tables(rec, nsteps, args, step_s, f16_rows):
     roof_step = {'ms_per_step': step_s * 1e3, 'hbm_bytes_per_step': sb, 'hbm_bytes_source': ssrc,
                  'hbm_frac': sb / step_s / (PEAK_HBM_GBS * 1e9) if sb else None,
                  'algorithmic_bytes_per_step': alg_b, 'algorithmic_hbm_frac': alg_b / step_s / (PEAK_HBM_GBS * 1e9),
+                 'refetch': (sb / alg_b) if (sb and alg_b) else None,
                  'pipe_time_ms': {'fp16 MFMA (x3)': t_f16 * 1e3, 'fp32 MFMA': t_f32 * 1e3},
                  'pipe_frac': (t_f16 + t_f32) / step_s}
     return roof, per_kernel, roof_step
@@ -639,8 +669,9 @@ def main():
                        'math_mode': args.math,
                        'storage': 'fp32 tensors in HBM' + ('; the aggregated block\'s activation a3 in fp16 (lazy dz3, k = 16 above the '
                                                             'size gate)' if args.math == 'f16x3' and args.k == 16 else ''),
-                       'exact_f32': ({'value': fast['f32']['value'], 'ms_per_step': fast['f32']['ms_per_step']}
-                                     if fast and fast.get('f32') else None),
+                       # (flat scalars: the driver's parsed record drops nested objects inside `config`)
+                       'exact_f32_value': fast['f32']['value'] if fast and fast.get('f32') else None,
+                       'exact_f32_ms': fast['f32']['ms_per_step'] if fast and fast.get('f32') else None,
                        'loss_epoch': args.epoch,
                        'step': 'fwd + ComposedPatternLoss + bwd' + (' + RCCL grad all-reduce' if world > 1 else '')
                                + (' + Adam (torch)' if args.torch_adam else ' + fused Adam (flat arena)'),

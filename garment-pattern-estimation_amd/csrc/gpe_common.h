@@ -16,6 +16,31 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// do the byte ranges [p, p + n) and [q, q + m) meet?  (NULL never overlaps.)  The edge entry points refuse an output that overlaps
+// one of their inputs: several kernels write rows through a buffer descriptor and read through plain pointers, which the compiler
+// treats as disjoint memory — aliased, the stores lose their order against the loads (gpe_edgegemm_w8_kernel.h, W8_BUFSTORE)
+static inline bool gpe_overlap(const void* p, size_t n, const void* q, size_t m)
+{
+    if (!p || !q || !n || !m) return false;
+    const uintptr_t a = (uintptr_t)p, b = (uintptr_t)q;
+    return a < b + m && b < a + n;
+}
+
+// Measurement switches of the library (A/B runs inside one GPU session: scripts/gpu_session.sh ab): environment variables that are
+// ONLY consulted when GPE_DEBUG=1 is set — a production process cannot be steered off the product path by a stray variable.
+//   GPE_W8 GPE_REV GPE_LAZY_DZ3 GPE_H3_LEFT          edge kernels        GPE_RD_DEEP GPE_RD_NOPC        reduce-GEMM paths
+//   GPE_KNN_PROBE _PIN _VEC _SPLIT _EXACT _F32FILTER GPE_KNN_SORTED      kNN      GPE_WV_KS GPE_WV_BJ GPE_RNN_F32   recurrences
+static inline const char* gpe_dbg_env_str(const char* name)
+{
+    static const int on = getenv("GPE_DEBUG") ? atoi(getenv("GPE_DEBUG")) : 0;
+    return on ? getenv(name) : nullptr;
+}
+static inline int gpe_dbg_env(const char* name, int dflt)
+{
+    const char* e = gpe_dbg_env_str(name);
+    return e ? atoi(e) : dflt;
+}
+
 static inline int gpe_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 static inline int gpe_round_up(int a, int b) { return (a + b - 1) / b * b; }
 
@@ -179,7 +204,7 @@ struct GpeTileSeq { int t, c, step, tpc, rev, nt; };
 // GPE_REV=0 keeps every kernel walking up (A/B measurements).
 static inline int gpe_walk_rev(int down)
 {
-    static const int off = getenv("GPE_REV") ? atoi(getenv("GPE_REV")) == 0 : 0;
+    static const int off = gpe_dbg_env("GPE_REV", 1) == 0;
     return off ? 0 : down;
 }
 // rev != 0 walks the same sequence from the far end: pinned — XCD x takes its clouds in the order x + 8 (ncl - 1), ..., x + 8, x

@@ -893,7 +893,7 @@ static int x6_left_scheme(int amode, int emode)
     static int tab[4] = {-1, 0, 0, 0};
     if (tab[0] < 0) {
         const int def[4] = {X6_LEFT_F2, X6_LEFT_F3, X6_LEFT_B3, X6_LEFT_B2};
-        const char* e = getenv("GPE_H3_LEFT");
+        const char* e = gpe_dbg_env_str("GPE_H3_LEFT");
         for (int i = 3; i >= 0; --i) {
             int v = def[i];
             if (e && strlen(e) == 4 && (e[i] == '0' || e[i] == '2')) v = e[i] - '0';

@@ -28,7 +28,7 @@ static int w8_enabled(int kind)
 {
     static int tab[4] = {-1, 0, 0, 0};
     if (tab[0] < 0) {
-        const char* e = getenv("GPE_W8");
+        const char* e = gpe_dbg_env_str("GPE_W8");
         for (int i = 3; i >= 0; --i) {
             int v = 1;
             if (e && strlen(e) == 4) v = e[i] != '0';

@@ -63,6 +63,8 @@ __global__ __launch_bounds__(512) void gpe_edgegemm_w8_kernel(RgParams p, int st
     static_assert(NT == 13 || (NT == 10 && KCH == 13), "shapes of the shipped edge MLPs");
     static_assert(KCH == 13 || KCH == 10, "K = 200 / 150");
     static_assert(!LAZY || (AMODE == A_DENSE && EMODE == E_BWD_INPLACE), "lazy dz3: in-place backward");
+    static_assert(EMODE != E_BWD_INPLACE || (W8_BUFSTORE & 4) == 0, "the in-place backward loads the rows it overwrites through plain "
+                  "pointers: its stores must be plain too (buffer and global accesses are disjoint memory to the compiler)");
     constexpr bool FWD = EMODE == E_EDGE_FWD;
     constexpr bool TRACK = FWD && AGGT != 0;
     constexpr bool OUTH = FWD && AGGT == 2;              // activation rows stored as _Float16 (RgParams::out_half)
@@ -371,12 +373,14 @@ __global__ __launch_bounds__(512) void gpe_edgegemm_w8_kernel(RgParams p, int st
             *reinterpret_cast<uint2*>(row + PLANE) = make_uint2(q0[1], q1[1]);
         };
         // the finisher of this wave's point has folded the partials that lie in the rows about to be re-staged (flag = number of
-        // folded tiles).  Bounded spin: a lost flag would cost wrong numbers in a test, never a hung GPU.
+        // folded tiles).  Bounded spin; a flag that never comes (it cannot, short of a scheduling fault: the finisher sets it right
+        // after the tile's second barrier, which this wave has passed too) TRAPS — committing over partials that were not folded
+        // would be silent corruption
         auto wait_folded = [&](int want) {
             int spins = 0;
-            while (__hip_atomic_load(&flag_sh[pt], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < want && spins < (1 << 16)) {
+            while (__hip_atomic_load(&flag_sh[pt], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < want) {
                 __builtin_amdgcn_s_sleep(1);
-                ++spins;
+                if (++spins > (1 << 22)) __builtin_trap();
             }
         };
 

@@ -378,16 +378,16 @@ static int knn_exact(const float* x, int B, int N, int C, int ldx, int k, int32_
         if (rc != 0) return rc < 0 ? rc : GPE_OK;
     }
     const size_t lds = ((size_t)2 * KNN_TQ * KNN_LD + 4 * 16 * KNN_LDD) * sizeof(float) + 4 * 64 * sizeof(unsigned long long);
-    static const int probe = getenv("GPE_KNN_PROBE") ? atoi(getenv("GPE_KNN_PROBE")) : 0;
+    static const int probe = gpe_dbg_env("GPE_KNN_PROBE", 0);
     const int tiles = gpe_cdiv(N, KNN_TQ);
-    static const int dbg_pin = getenv("GPE_KNN_PIN") ? atoi(getenv("GPE_KNN_PIN")) : -1;      // measurement overrides
-    static const int dbg_vec = getenv("GPE_KNN_VEC") ? atoi(getenv("GPE_KNN_VEC")) : 0;
+    static const int dbg_pin = gpe_dbg_env("GPE_KNN_PIN", -1);      // measurement overrides
+    static const int dbg_vec = gpe_dbg_env("GPE_KNN_VEC", 0);
     const int pin = (dbg_pin >= 0) ? (dbg_pin && B >= GPE_NXCD) : (gpe_pin_clouds(B) ? 1 : 0);
     // Candidate split.  With every workgroup resident (4 per CU) an XCD works on 128 items at a time = 128 / (tiles * nsplit)
     // clouds, whose tables (N x ldx floats each) are streamed once per item: they must fit the XCD's 4 MiB L2 together or the
     // cyclic stream evicts every line before its next use (measured at cfg 2, layer 2: 4 x 1.25 MB -> 396-475 MB fetched for
     // 39 MB; 3 tables -> 36 MB).  nsplit pieces per query tile put nsplit x fewer clouds in flight.
-    static const int dbg_split = getenv("GPE_KNN_SPLIT") ? atoi(getenv("GPE_KNN_SPLIT")) : 0;
+    static const int dbg_split = gpe_dbg_env("GPE_KNN_SPLIT", 0);
     int nsplit = 1;
     if (pin) {
         const double table = (double)N * ldx * sizeof(float), l2_budget = 3.2 * 1024 * 1024;
@@ -1229,15 +1229,15 @@ extern "C" int gpe_knn(const float* x, int B, int N, int C, int ldx, int k, int3
 {
     if (!x || !idx || B < 0 || N <= 0 || C <= 0 || ldx < C || k <= 0 || k > 64 || k > N || (long)B * N * k >= (1L << 31)) return GPE_EINVAL;
     if (B == 0) return GPE_OK;
-    static const int force_exact = getenv("GPE_KNN_EXACT") ? atoi(getenv("GPE_KNN_EXACT")) : 0;
+    static const int force_exact = gpe_dbg_env("GPE_KNN_EXACT", 0);
     if (C < KNN_MF_MINC || k > 48 || force_exact) return knn_exact(x, B, N, C, ldx, k, idx, idx_glob, ws, ws_bytes, stream);
     // ---- matrix-pipe filter + exact recheck ----
     const int K2 = knn_k2(k, N);
     const int tiles = gpe_cdiv(N, KNN_TQ);
-    static const int dbg_pin = getenv("GPE_KNN_PIN") ? atoi(getenv("GPE_KNN_PIN")) : -1;
-    static const int dbg_vec = getenv("GPE_KNN_VEC") ? atoi(getenv("GPE_KNN_VEC")) : 0;
-    static const int dbg_split = getenv("GPE_KNN_SPLIT") ? atoi(getenv("GPE_KNN_SPLIT")) : 0;
-    static const int mprobe = getenv("GPE_KNN_PROBE") ? atoi(getenv("GPE_KNN_PROBE")) : 0;   // timing aid (wrong results)
+    static const int dbg_pin = gpe_dbg_env("GPE_KNN_PIN", -1);
+    static const int dbg_vec = gpe_dbg_env("GPE_KNN_VEC", 0);
+    static const int dbg_split = gpe_dbg_env("GPE_KNN_SPLIT", 0);
+    static const int mprobe = gpe_dbg_env("GPE_KNN_PROBE", 0);   // timing aid (wrong results)
     const int pin = (dbg_pin >= 0) ? (dbg_pin && B >= GPE_NXCD) : (gpe_pin_clouds(B) ? 1 : 0);
     // No candidate split here.  knn_exact cuts the candidate range in pieces so that the tables in flight fit an L2; for this
     // path every piece would pay its own first-tile ranking and its own list build-up (selection work x 1.7 at two pieces) plus
@@ -1251,7 +1251,7 @@ extern "C" int gpe_knn(const float* x, int B, int N, int C, int ldx, int k, int3
     const size_t norm_bytes = (nq * sizeof(float) + 255) & ~(size_t)255;
     const size_t cmax_bytes = ((size_t)B * sizeof(int) + 255) & ~(size_t)255;
     // the fp16-pipe filter (default for C <= 256; GPE_KNN_F32FILTER=1 keeps the exact-product filter for A/B measurements)
-    static const int f32filter = getenv("GPE_KNN_F32FILTER") ? atoi(getenv("GPE_KNN_F32FILTER")) : 0;
+    static const int f32filter = gpe_dbg_env("GPE_KNN_F32FILTER", 0);
     const int CP = (C + 31) & ~31;
     const size_t pl_bytes = (nq * 2 * (size_t)CP * sizeof(_Float16) + 255) & ~(size_t)255;
     bool h3 = !f32filter && C <= KNN_H3_MAXC;

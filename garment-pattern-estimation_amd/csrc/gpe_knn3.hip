@@ -7,7 +7,7 @@
 //   1. gpe_knn3_sort_kernel   (one workgroup per cloud) orders the cloud's points along a 16 x 16 x 16 Morton curve of their
 //                             bounding box (LDS counting sort) and writes them as float4 (x, y, z, original index) plus the
 //                             bounding box of every run of 64 sorted points (a "tile").
-//   2. gpe_knn3_query_kernel  one wave = K3_QW = 8 consecutive sorted points (spatial neighbours).  It sorts the cloud's tiles by a lower
+//   2. gpe_knn3_query_kernel  one wave = K3_QW = 4 consecutive sorted points (spatial neighbours).  It sorts the cloud's tiles by a lower
 //                             bound of their distance to the box of its queries, scans them in that order — lane = candidate,
 //                             the queries' coordinates wave-uniform, no LDS staging and no workgroup barrier — and stops at the
 //                             first tile whose bound exceeds the LARGEST k-th distance among its queries: neither that tile nor any
@@ -221,6 +221,7 @@ __device__ __forceinline__ void k3_select(unsigned long long key, int lane, int 
 #ifndef K3_QW
 #define K3_QW 4
 #endif
+static_assert(64 % K3_QW == 0 && K3_QW <= 16, "a wave's queries must lie in ONE tile of 64 sorted points (the pruning argument), in registers");
 __global__ __launch_bounds__(256) void gpe_knn3_query_kernel(const float4* __restrict__ xs, const float* __restrict__ tb, int N, int k,
                                                              int tiles, int wgs, int32_t* __restrict__ idx, int32_t* __restrict__ idx_glob)
 {
@@ -342,7 +343,7 @@ __global__ __launch_bounds__(256) void gpe_knn3_query_kernel(const float4* __res
 int gpe_knn3_try(const float* x, int B, int N, int ldx, int k, int32_t* idx, int32_t* idx_glob, void* ws, long ws_bytes,
                  hipStream_t s)
 {
-    static const int off = getenv("GPE_KNN_SORTED") ? atoi(getenv("GPE_KNN_SORTED")) == 0 : 0;
+    static const int off = gpe_dbg_env("GPE_KNN_SORTED", 1) == 0;
     if (off || N < K3_MINN || N > K3_MAXN || k > 64 || k > N) return 0;
     const int tiles = gpe_cdiv(N, 64);
     const size_t xs_bytes = (size_t)B * N * sizeof(float4), tb_bytes = (size_t)B * tiles * 8 * sizeof(float);

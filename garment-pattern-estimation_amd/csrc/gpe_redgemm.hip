@@ -1499,7 +1499,7 @@ static int rd_run(RdParams& p, int vmode, float* G, int ldG, float* colsum, floa
         }
     }
     const long in_max = (p.u.inner > p.v.inner ? p.u.inner : p.v.inner) > 1 ? (p.u.inner > p.v.inner ? p.u.inner : p.v.inner) : 1;
-    static const int dbg_deep = getenv("GPE_RD_DEEP") ? atoi(getenv("GPE_RD_DEEP")) : -1;   // measurement override: 0 = never the deep kernel
+    static const int dbg_deep = gpe_dbg_env("GPE_RD_DEEP", -1);   // measurement override: 0 = never the deep kernel
     // the edge weight-gradient shapes (<= 208 x 208 outputs, plain 16-B rows, >= 4 row tiles per workgroup) stay on the
     // producer/consumer kernels below at every size: measured (profiles/r04_h_rd_paths.md, dense V, 150 x 200) 48 / 64 / 106 / 206 us
     // against the deep kernel's 70 / 107 / 204 / 403 us at E = 41 k / 66 k / 131 k / 262 k rows (f16x3: 46 / 53 / 70 / 127 us); the deep
@@ -1533,7 +1533,7 @@ static int rd_run(RdParams& p, int vmode, float* G, int ldG, float* colsum, floa
     dim3 grid(gx, gy);
     int rc = GPE_EINVAL;
     const int mt_all = gpe_cdiv(p.Mg, 16), nt_all = gpe_cdiv(p.Ng, 16);
-    static const int dbg_nopc = getenv("GPE_RD_NOPC") ? atoi(getenv("GPE_RD_NOPC")) : 0;     // measurement override
+    static const int dbg_nopc = gpe_dbg_env("GPE_RD_NOPC", 0);     // measurement override
     const bool pc_ok = !dbg_nopc && gy == 1 && nt_all == 13 && (mt_all == 13 || mt_all == 10) && rd_rows_vec(p.u, p.Mg) &&
                        (vmode == V_GATHER || rd_rows_vec(p.v, p.Ng)) && p.num_tiles >= 4 * gx &&
                        (vmode != V_GATHER || (p.k > 1 && p.rows * p.k < (1L << 32)));   // umulhi row / k (kmagic)

@@ -462,7 +462,7 @@ static int wv_ks()
 {
     static int ks = 0;
     if (!ks) {
-        const char* e = getenv("GPE_WV_KS");
+        const char* e = gpe_dbg_env_str("GPE_WV_KS");
         const int v = e ? atoi(e) : 0;
         ks = (v == 256) ? 256 : 128;
     }
@@ -506,7 +506,7 @@ extern "C" int gpe_rnn_seq_fwd(int gates, int L, int T, int Bn, int H, const flo
     const int G = gates;
     // f16x3: the gate products on the fp16 pipe when the arithmetic mode asks for it and the caller supplies the plane packs and
     // amax words of every weight (gpe_pack_multi kinds 9 + 8); else the exact fp32 instruction
-    static const int dbg_f32 = getenv("GPE_RNN_F32") ? atoi(getenv("GPE_RNN_F32")) : 0;        // A/B measurements: keep the exact kernels
+    static const int dbg_f32 = gpe_dbg_env("GPE_RNN_F32", 0);        // A/B measurements: keep the exact kernels
     bool h3 = !dbg_f32 && gpe_math_get() == 4 && whh_pl && whh_amax && (L == 1 || (wih_pl && wih_amax));
     for (int l = 0; h3 && l < L; ++l)
         if (!whh_pl[l] || !whh_amax[l] || (l > 0 && (!wih_pl[l] || !wih_amax[l]))) h3 = false;
@@ -745,7 +745,7 @@ extern "C" int gpe_rnn_seq_bwd(int gates, int L, int T, int Bn, int H, const flo
     // big batches: four slabs per workgroup (a 3-cell panel diagonal: 2304 single-slab workgroups in 4.5 rounds -> 480 in one,
     // a quarter of the partial images; measured 804 / 717 / 621 / 689 us per backward at 1 / 2 / 4 / 8 slabs); a single row
     // tile (the pattern decoders) stays at one slab per workgroup — it is a latency chain, not a throughput problem
-    static const int dbg_bj = getenv("GPE_WV_BJ") ? atoi(getenv("GPE_WV_BJ")) : 0;             // measurement override
+    static const int dbg_bj = gpe_dbg_env("GPE_WV_BJ", 0);             // measurement override
     int jslabs = (Bn > 3 * RG_BM) ? (gpe_cdiv(K, KS) < 4 ? gpe_cdiv(K, KS) : 4) : 1;
     if (dbg_bj > 0 && Bn > 3 * RG_BM) jslabs = dbg_bj < gpe_cdiv(K, KS) ? dbg_bj : gpe_cdiv(K, KS);
     const int nz = gpe_cdiv(gpe_cdiv(K, KS), jslabs);

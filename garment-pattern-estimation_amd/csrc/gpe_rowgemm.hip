@@ -386,7 +386,7 @@ extern "C" int gpe_linear(const float* a, long a_so, long a_si, int a_inner, con
 // size gate.  Host only.
 extern "C" int gpe_edge_lazy_dz3_ok(int B, int N, int k, int F, int Cprev)
 {
-    static const int dbg_off = getenv("GPE_LAZY_DZ3") ? atoi(getenv("GPE_LAZY_DZ3")) == 0 : 0;   // A/B measurements
+    static const int dbg_off = gpe_dbg_env("GPE_LAZY_DZ3", 1) == 0;   // A/B measurements
     if (dbg_off || (g_gpe_dbg & 512) || g_gpe_math != 4 || k != 16 || B <= 0 || N <= 0) return 0;    // gpe_debug_set(512): eager dz3
     if (F <= 96 || F > 208 || Cprev <= 96 || Cprev > 208 || (Cprev & 3)) return 0;
     if (gpe_cdiv(Cprev, 16) != 13 || (gpe_cdiv(F, 16) != 10 && gpe_cdiv(F, 16) != 13)) return 0;   // the fp16 reduce-GEMM's instantiated shapes
@@ -439,6 +439,13 @@ extern "C" int gpe_edge_mlp_fwd(int a_mode, const float* pq, int ldpq, const int
     if (a_mode == 0 && (!pq || !jg || (ldpq & 3) || (Cin & 3) || Cin > RG_KSLAB)) return GPE_EINVAL;
     if (a_mode == 1 && (!a_in || lda < Cin)) return GPE_EINVAL;
     if (agg && (!mx || !mn || !amx || !amn || ldagg < Cout)) return GPE_EINVAL;
+    {
+        // the activation rows must not alias an input or a per-point output (gpe_common.h gpe_overlap)
+        const size_t E_ = (size_t)B * N * k, P_ = (size_t)B * N, ob = E_ * ldo * (out_half ? 2 : 4);
+        if (gpe_overlap(out, ob, a_mode == 1 ? a_in : nullptr, E_ * lda * 4) || gpe_overlap(out, ob, a_mode == 0 ? pq : nullptr, P_ * ldpq * 4) ||
+            gpe_overlap(out, ob, agg ? mx : nullptr, P_ * ldagg * 4) || gpe_overlap(out, ob, agg ? mn : nullptr, P_ * ldagg * 4))
+            return GPE_EINVAL;
+    }
     // one column block up to 256 outputs; wider layers (dense MLPs of the attention / MLP-decoder variants) run as
     // several 208-column blocks (grid.y), each with its own slice of the statistics / epilogue
     const int NT = (Cout > 256) ? 13 : rg_pick_nt_single(Cout);
@@ -483,6 +490,13 @@ extern "C" int gpe_edge_mlp_bwd(const float* a, int lda, int act_mode, const flo
         (ldo & 3) || ldo < Cout || lda < Cin)
         return GPE_EINVAL;
     if (act_mode == 1 && (!pq || !jg || !dP || (ldpq & 3) || (Cout & 3) || Cout > 256)) return GPE_EINVAL;
+    {
+        // dz_out is read (the stored activation) and overwritten in place by design; it must not alias `a`, the [P|Q] table or dP
+        const size_t E_ = (size_t)B * N * k, P_ = (size_t)B * N, ob = E_ * ldo * 4;
+        if (gpe_overlap(dz_out, ob, a, E_ * lda * (lz_g ? 2 : 4)) || gpe_overlap(dz_out, ob, act_mode == 1 ? pq : nullptr, P_ * ldpq * 4) ||
+            gpe_overlap(dz_out, ob, act_mode == 1 ? dP : nullptr, P_ * lddp * 4))
+            return GPE_EINVAL;
+    }
     const int NT = (Cout > 256) ? 13 : rg_pick_nt_single(Cout);       // wide dense layers: several column blocks
     if (NT < 0) return GPE_EINVAL;
     const int ny = gpe_cdiv(Cout, 16 * NT);

@@ -107,10 +107,9 @@ _JOB = np.dtype([('w', '<u8'), ('w2', '<u8'), ('out', '<u8'), ('total', '<i8'), 
 assert _JOB.itemsize == 64
 
 
-# PackPlan.refresh on a side stream under the layer-1 kNN search: built in round 5 and MEASURED SLOWER (cfg 2, one session, twice each:
-# 10.19 / 10.17 ms per step without, 10.34 / 10.34 with — the stream fork / join costs more than the 0.09 ms of pack launches it hides).
-# Off; GPE_PACK_ASYNC=1 turns it on for A/B runs.
-PACK_ASYNC = os.environ.get('GPE_PACK_ASYNC', '0') == '1'
+# (PackPlan.refresh on a side stream under the layer-1 kNN search was built in round 5 and MEASURED SLOWER — cfg 2, one session, twice
+# each: 10.19 / 10.17 ms per step without, 10.34 / 10.34 with: the stream fork / join costs more than the 0.09 ms of pack launches it
+# hides — and removed in round 6: profiles/r05_c_reverted_experiments.md.)
 
 
 def bump_weights_epoch():
@@ -146,8 +145,6 @@ class PackPlan:
         self.frozen = False
         self.h3_current = False
         self._stream = None
-        self._side = None
-        self._ready = None
         self._keys_box = box = []              # shared with the finalizer: the keys this plan currently owns in _PACKS
         me = weakref.ref(self)
         # pop only entries that are still THIS plan's: a newer plan over the same parameters may have re-registered the keys
@@ -282,29 +279,8 @@ class PackPlan:
             else:
                 L.call('gpe_pack_multi', self.table_noh3, self.n_noh3, self.blocks_noh3)
 
-        if PACK_ASYNC and self.specs[0][0].is_cuda:
-            # The pack launches (two or three small grids, ~0.09 ms per step at cfg 2) run on a side stream: the first thing a model
-            # forward does after this call is the layer-1 kNN search, which reads no pack — the first consumer of a pack makes its
-            # stream wait for `_ready` (see _planned).  The side stream first waits for everything queued so far (the optimizer's
-            # update of the parameters, last step's readers of the old packs).
-            main = self._stream
-            if self._side is None or self._side.device != main.device:
-                self._side = torch.cuda.Stream(device=main.device)
-            self._side.wait_stream(main)
-            with torch.cuda.stream(self._side):
-                launches()
-                self._ready = torch.cuda.Event()
-                self._ready.record(self._side)
-        else:
-            launches()
-            self._ready = None
+        launches()
         self.vers, self.epoch = vers, WEIGHTS_EPOCH
-
-    def _await(self):
-        """Called by the accessors of this plan's packs: the consumer's stream waits for an in-flight refresh (once)."""
-        if self._ready is not None:
-            torch.cuda.current_stream().wait_event(self._ready)
-            self._ready = None
 
 
 def _planned(t, kind, t2=None):
@@ -318,7 +294,6 @@ def _planned(t, kind, t2=None):
         return None
     if plan.vers[i] != t._version + (t2._version if t2 is not None else 0):
         return None
-    plan._await()
     return out
 
 
@@ -614,7 +589,7 @@ segment_mean.pool_mode, segment_max.pool_mode, segment_add.pool_mode = 0, 1, 2
 # -------------------------------------------------------------------------------------------------
 # EdgeConv layer
 # -------------------------------------------------------------------------------------------------
-_HALF_ACT_GUARD = os.environ.get('GPE_HALF_ACT_GUARD', 'fallback')
+_HALF_ACT_GUARD = 'fallback'
 
 
 def set_half_act_guard(mode):
@@ -634,6 +609,10 @@ def set_half_act_guard(mode):
         raise ValueError("half-activation guard mode must be 'fallback', 'strict' or 'off'")
     prev, _HALF_ACT_GUARD = _HALF_ACT_GUARD, mode
     return prev
+
+
+if os.environ.get('GPE_HALF_ACT_GUARD'):                 # (validated: a typo raises instead of silently meaning 'fallback')
+    set_half_act_guard(os.environ['GPE_HALF_ACT_GUARD'])
 
 
 class HalfActGuard:
@@ -686,6 +665,12 @@ class HalfActGuard:
                 self._trip(v)
                 return False
             return True
+        if self._pending is not None:
+            # an earlier step's read has not been consumed: look at it now if it has landed, and otherwise KEEP it — the oldest unread
+            # word is the one that says when the limit was first reached (a newer read must not overwrite it: ADVICE r5)
+            self.allow()
+            if self._pending is not None:
+                return True
         host = torch.empty(1, dtype=torch.int32, pin_memory=True)
         host.copy_(word, non_blocking=True)
         ev = torch.cuda.Event()

@@ -19,6 +19,21 @@ for r in rows:
     print('| %s | %.1f | %.0f | %.1f | %.1f | %.1f | %.1f | %s | %s | %s |' % (
         name, r[1] / steps, r[2], r[3], r[4], r[5], 100 * r[2] / tot, r[6], r[7], r[8]))
 
+# ---- machine-readable averages (bench.py quotes the dominant kernel's next to its HIP-event duration): --json <file> ------------
+if '--json' in sys.argv:
+    import hashlib
+    import json
+    import os
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'garment-pattern-estimation_amd', 'csrc')
+    h = hashlib.sha1()
+    for f in sorted(os.listdir(d)):
+        if f.endswith(('.hip', '.h')):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), 'rb').read())
+    out = {'csrc_sha': h.hexdigest()[:16], 'steps': steps, 'source': 'rocprofv3 --kernel-trace (rocpd), per kernel over the whole trace',
+           'kernels': {re.sub(r'\(.*', '', r[0]).replace('void ', ''): {'launches': r[1], 'total_us': r[2], 'avg_us': r[3]} for r in rows}}
+    json.dump(out, open(sys.argv[sys.argv.index('--json') + 1], 'w'), indent=1)
+
 # ---- idle gaps between consecutive kernels (where the GPU waits for the host) ------------------------------------
 if len(sys.argv) > 3 and sys.argv[3] == 'gaps':
     ks = db.execute('select name, start, end from kernels order by start').fetchall()

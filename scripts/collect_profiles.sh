@@ -15,7 +15,7 @@ rm -rf $OUT/prof_kt $OUT/prof_fetch $OUT/prof_write
 timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/prof_kt -- python $ROOT/bench.py --steps $STEPS --warmup 3 \
     --no-cpu-baseline --no-kernel-timing --no-fast-math-line > $OUT/${TAG}_kt.log 2>&1
 DB=$(find $OUT/prof_kt -name '*.db' | head -1)
-python $ROOT/profiles/summarize_rocpd.py $DB $((STEPS + 3)) > $OUT/${TAG}_kernel_trace.md
+python $ROOT/profiles/summarize_rocpd.py $DB $((STEPS + 3)) --json $OUT/${TAG}_kernel_avg.json > $OUT/${TAG}_kernel_trace.md
 for C in FETCH_SIZE WRITE_SIZE; do
   D=$OUT/prof_$(echo $C | tr A-Z a-z | sed s/_size//)
   timeout 600 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $D -- python $ROOT/bench.py --steps 2 --warmup 1 \
@@ -26,6 +26,7 @@ rm -rf $OUT/prof_kt $OUT/prof_fetch $OUT/prof_write          # keep the merge-ba
 cd $ROOT
 if [ -z "$SKIP_BENCH" ]; then
   cp $OUT/${TAG}_hbm_traffic.json $ROOT/profiles/${TAG}_hbm_traffic.json      # on the box: what bench.py will quote
+  cp $OUT/${TAG}_kernel_avg.json $ROOT/profiles/${TAG}_kernel_avg.json
   timeout 900 python bench.py --call-shapes $OUT/${TAG}_call_shapes.txt > $OUT/${TAG}_bench.log 2>&1
   grep '^{' $OUT/${TAG}_bench.log | tail -1 > $OUT/${TAG}_bench.json
 fi

@@ -54,14 +54,14 @@ while [ $# -gt 0 ]; do
       # (-rP: the captured output of passing tests — the ReLU / max-winner decision counts of tests/relu_align.py and the measured
       # gradient errors are printed there; the summary keeps those lines, the full log stays in gpurun_out/)
       timeout 1700 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider -rPs > $OUT/${TAG}_gpu_tests_full.txt 2>&1
-      ( grep -E "ReLU decisions|worst parameter-gradient|full size:|edgeconv .* err|^SKIPPED|^FAILED|^ERROR| passed| failed" $OUT/${TAG}_gpu_tests_full.txt | sort -u | head -400 ) > $OUT/${TAG}_gpu_tests.txt
+      ( grep -E "ReLU decisions|binding output bar|the 1e-4 bar alone|un-aligned|self-difference|worst parameter-gradient|full size:|edgeconv .* err|^SKIPPED|^FAILED|^ERROR| passed| failed" $OUT/${TAG}_gpu_tests_full.txt | sort -u | head -400 ) > $OUT/${TAG}_gpu_tests.txt
       tail -3 $OUT/${TAG}_gpu_tests_full.txt; grep -E "^(FAILED|ERROR)" $OUT/${TAG}_gpu_tests_full.txt | head -20 ;;
     ab)
       TAG=$1; VAR=$2; VALS=$3; shift 3
       ARGS=""; while [ $# -gt 0 ] && [ "$1" != "--" ]; do ARGS="$ARGS $1"; shift; done
       : > $OUT/${TAG}_ab_$VAR.txt
       for rep in $(seq ${REPS:-2}); do for V in $VALS; do
-        env $VAR=$V timeout 300 python bench.py --steps 60 --warmup 5 --no-cpu-baseline --no-fast-math-line $ARGS > $OUT/${TAG}_ab.log 2>&1
+        env GPE_DEBUG=1 $VAR=$V timeout 300 python bench.py --steps 60 --warmup 5 --no-cpu-baseline --no-fast-math-line $ARGS > $OUT/${TAG}_ab.log 2>&1
         grep '^{' $OUT/${TAG}_ab.log | tail -1 > $OUT/${TAG}_ab.json
         if [ ! -s $OUT/${TAG}_ab.json ]; then echo "$VAR=$V FAILED"; tail -5 $OUT/${TAG}_ab.log; fi
         line $OUT/${TAG}_ab.json "$VAR=$V" | tee -a $OUT/${TAG}_ab_$VAR.txt

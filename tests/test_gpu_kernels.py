@@ -181,7 +181,7 @@ def test_knn_alternative_paths(gpe, env, tmp_path):
     import os, subprocess, sys
     script = tmp_path / 'w.py'
     script.write_text(_KNN_ALT_WORKER % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    r = subprocess.run([sys.executable, str(script)], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+    r = subprocess.run([sys.executable, str(script)], env=dict(os.environ, GPE_DEBUG='1', **env), capture_output=True, text=True, timeout=600)   # (the switches are only read under GPE_DEBUG=1)
     assert r.returncode == 0 and 'alt path ok' in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 

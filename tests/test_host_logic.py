@@ -236,7 +236,7 @@ def test_bench_quotes_counter_traffic_only_for_what_it_measured(monkeypatch):
     assert b32 - b16 == E * 150 * 2
 
 
-def test_bench_dominant_kernel_is_a_single_kernel_entry():
+def test_bench_dominant_kernel_is_a_single_kernel_entry(monkeypatch):
     """bench.py's top-level `roofline` prices the dominant KERNEL (rocprof's average duration of that kernel must
     agree): sequences of dependent launches behind one C-ABI call (the recurrences: 40 / 80 launches) are priced in
     roofline_per_kernel and only NAMED in roofline.largest_sequence when they outweigh it; the w8 kernels' counter traffic is found
@@ -246,6 +246,13 @@ def test_bench_dominant_kernel_is_a_single_kernel_entry():
     spec = importlib.util.spec_from_file_location('bench_mod3', os.path.join(os.path.dirname(os.path.dirname(__file__)), 'bench.py'))
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
+    if bench._pmc_doc()[0] is None:
+        # kernel sources edited since the last committed PMC pass (refused, see the test above): exercise the logic on that file with
+        # this tree's hash stamped in
+        import glob
+        import json
+        real = json.load
+        monkeypatch.setattr(bench.json, 'load', lambda f: dict(real(f), csrc_sha=bench.csrc_sha()))
 
     class Ev:                                                  # stands in for a HIP event pair: elapsed_time in ms
         def __init__(self, ms):
@@ -268,7 +275,13 @@ def test_bench_dominant_kernel_is_a_single_kernel_entry():
     assert roof['kernel'] == 'gpe_edge_mlp_bwd:gather'          # ... the dominant KERNEL is the gathered backward
     assert roof['largest_sequence']['entry'] == 'gpe_rnn_seq_bwd'
     assert roof['bound'] == 'hbm' and roof['traffic_source'].startswith('profiles/') and 1.8e9 < roof['traffic'] < 2.3e9
-    assert abs(roof['frac'] - roof['traffic'] / 0.42e-3 / 8e12) < 1e-6
+    # frac prices the ALGORITHMIC bytes (dz2 in + dz1 out + the [P|Q] table + the indices), the counter traffic is
+    # reported beside it as hbm_util / refetch
+    alg = 32 * 2048 * 16 * (200 * 4 + 200 * 4 + 4) + 32 * 2048 * 2 * 200 * 4
+    assert abs(roof['algorithmic_bytes_per_launch'] - alg) < 1 and abs(roof['frac'] - alg / 0.42e-3 / 8e12) < 1e-6
+    assert abs(roof['achieved'] - alg / 0.42e-3 / 1e9) < 1e-3
+    assert abs(roof['hbm_util'] - roof['traffic'] / 0.42e-3 / 8e12) < 1e-6 and abs(roof['refetch'] - roof['traffic'] / alg) < 1e-9
+    assert 'rocprof_avg_launch_ms' in roof
     for fam in ('gpe_edge_mlp_fwd:gather', 'gpe_edge_mlp_fwd:dense', 'gpe_edge_mlp_bwd:inplace', 'gpe_edge_mlp_bwd:gather'):
         assert bench.pmc_traffic(fam, 2.0)[0] is not None, fam
 
