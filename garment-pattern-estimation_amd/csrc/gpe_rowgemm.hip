@@ -491,9 +491,12 @@ extern "C" int gpe_edge_mlp_bwd(const float* a, int lda, int act_mode, const flo
         return GPE_EINVAL;
     if (act_mode == 1 && (!pq || !jg || !dP || (ldpq & 3) || (Cout & 3) || Cout > 256)) return GPE_EINVAL;
     {
-        // dz_out is read (the stored activation) and overwritten in place by design; it must not alias `a`, the [P|Q] table or dP
+        // dz_out is read (the stored activation) and overwritten in place by design.  It may also BE `a` (the gathered backward run
+        // in place over dz_1's rows, same pitch: a tile's rows are staged two tiles before they are finished, by the same workgroup,
+        // with the tile barriers in between); any other overlap with `a`, and any with the [P|Q] table or dP, is refused
         const size_t E_ = (size_t)B * N * k, P_ = (size_t)B * N, ob = E_ * ldo * 4;
-        if (gpe_overlap(dz_out, ob, a, E_ * lda * (lz_g ? 2 : 4)) || gpe_overlap(dz_out, ob, act_mode == 1 ? pq : nullptr, P_ * ldpq * 4) ||
+        const bool in_place = act_mode == 1 && !lz_g && (const void*)a == (const void*)dz_out && lda == ldo;
+        if ((!in_place && gpe_overlap(dz_out, ob, a, E_ * lda * (lz_g ? 2 : 4))) || gpe_overlap(dz_out, ob, act_mode == 1 ? pq : nullptr, P_ * ldpq * 4) ||
             gpe_overlap(dz_out, ob, act_mode == 1 ? dP : nullptr, P_ * lddp * 4))
             return GPE_EINVAL;
     }

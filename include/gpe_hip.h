@@ -237,7 +237,10 @@ int gpe_edge_redgemm(const float* u, int ldu, int v_mode, const float* v, int ld
  * (A dense [E][lda]; coef_out [4][Cout] = {s,c1,k2,mean} of the BatchNorm being crossed; Wp = packed TRANSPOSE of the
  * unfolded Linear).
  * act_mode 0: act = dz_out's previous contents (in place over the stored activation);
- * act_mode 1: act = relu(P_i+Q_j) gathered, and dP[i] = sum_s dz[(i,s)] is also written (ld lddp). */
+ * act_mode 1: act = relu(P_i+Q_j) gathered, and dP[i] = sum_s dz[(i,s)] is also written (ld lddp).
+ * Aliasing: act_mode 1 may run IN PLACE (dz_out == a, ldo == lda); any other overlap of dz_out with a, pq or dP — and, in
+ * gpe_edge_mlp_fwd, of out with a_in, pq, mx or mn — is refused with -22 (several kernels store rows through a buffer descriptor
+ * and load through plain pointers: aliased, the stores would lose their order against the loads). */
 int gpe_edge_mlp_bwd(const float* a, int lda, int act_mode, const float* pq, int ldpq, const int32_t* jg,
                      int B, int N, int k, int Cin, int Cout, const float* wp, const float* coef_out,
                      float* dz_out, int ldo, float* dP, int lddp, const uint32_t* amax_a, uint32_t* amax_out, void* ws,
