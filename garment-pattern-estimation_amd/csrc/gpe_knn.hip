@@ -366,16 +366,27 @@ static void knn_launch(long nblocks, size_t lds, hipStream_t s, int probe, const
 }
 
 // C == 3 on a spatially sorted cloud with tile pruning (gpe_knn3.hip): 1 launched, 0 not on its menu
-int gpe_knn3_try(const float* x, int B, int N, int ldx, int k, int32_t* idx, int32_t* idx_glob, void* ws, long ws_bytes,
+int gpe_knn3_try(const float* x, int B, int N, int ldx, int k, int32_t* idx, int32_t* idx_glob, int32_t* order_out, void* ws, long ws_bytes,
                  hipStream_t s);
 
 // all-exact path: every distance by the defined chain (C < 16, k > 48, or GPE_KNN_EXACT=1)
+__global__ void gpe_knn_identity_order_kernel(int* __restrict__ order, long nq, int N)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nq) order[i] = (int)(i % N);
+}
+
 static int knn_exact(const float* x, int B, int N, int C, int ldx, int k, int32_t* idx, int32_t* idx_glob, void* ws,
-                     long ws_bytes, void* stream)
+                     long ws_bytes, void* stream, int32_t* order_out = nullptr)
 {
     if (C == 3) {
-        const int rc = gpe_knn3_try(x, B, N, ldx, k, idx, idx_glob, ws, ws_bytes, (hipStream_t)stream);
+        const int rc = gpe_knn3_try(x, B, N, ldx, k, idx, idx_glob, order_out, ws, ws_bytes, (hipStream_t)stream);
         if (rc != 0) return rc < 0 ? rc : GPE_OK;
+    }
+    if (order_out) {                                   // no curve order on this path: the identity is a valid (locality-free) answer
+        hipLaunchKernelGGL(gpe_knn_identity_order_kernel, dim3((unsigned)gpe_cdiv((long)B * N, 256)), dim3(256), 0, (hipStream_t)stream,
+                           order_out, (long)B * N, N);
+        GPE_CHECK_LAUNCH();
     }
     const size_t lds = ((size_t)2 * KNN_TQ * KNN_LD + 4 * 16 * KNN_LDD) * sizeof(float) + 4 * 64 * sizeof(unsigned long long);
     static const int probe = gpe_dbg_env("GPE_KNN_PROBE", 0);
@@ -793,13 +804,22 @@ typedef unsigned knn_u32x4 __attribute__((ext_vector_type(4)));
 
 // planes of the feature table: pl[row] = [h plane: CP halves | l plane: CP halves] (CP = C rounded up to 32, zero pad),
 // isc[row] = 2^-sh.  Wave = KNN_NORM_ROWS rows; pass 1 the rows' largest magnitudes, pass 2 the split (the rows come from L2).
+// `order` (may be NULL): plane row r of a cloud holds point order[r] of that cloud — the filter then works in the caller's locality
+// order throughout (queries and candidates) and translates back when it writes its lists.
 __global__ __launch_bounds__(256) void gpe_knn_planes_kernel(const float* __restrict__ x, long rows, int C, int ldx, int CP,
-                                                             _Float16* __restrict__ pl, float* __restrict__ isc)
+                                                             _Float16* __restrict__ pl, float* __restrict__ isc,
+                                                             const int* __restrict__ order, int N)
 {
     const int lane = threadIdx.x & 63;
     const long r0 = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * KNN_NORM_ROWS;
     if (r0 >= rows) return;
     const long last = rows - 1;
+    long src[KNN_NORM_ROWS];                              // source row of plane row r0 + u
+#pragma unroll
+    for (int u = 0; u < KNN_NORM_ROWS; ++u) {
+        const long r = (r0 + u < last) ? r0 + u : last;
+        src[u] = order ? (r / N) * N + order[r] : r;
+    }
     float m[KNN_NORM_ROWS];
 #pragma unroll
     for (int u = 0; u < KNN_NORM_ROWS; ++u) m[u] = 0.f;
@@ -808,7 +828,7 @@ __global__ __launch_bounds__(256) void gpe_knn_planes_kernel(const float* __rest
         const int cc = (c < C) ? c : 0;
         float v[KNN_NORM_ROWS];
 #pragma unroll
-        for (int u = 0; u < KNN_NORM_ROWS; ++u) v[u] = x[((r0 + u < last) ? r0 + u : last) * ldx + cc];
+        for (int u = 0; u < KNN_NORM_ROWS; ++u) v[u] = x[src[u] * ldx + cc];
 #pragma unroll
         for (int u = 0; u < KNN_NORM_ROWS; ++u) m[u] = (c < C) ? fmaxf(m[u], fabsf(v[u])) : m[u];
     }
@@ -829,7 +849,7 @@ __global__ __launch_bounds__(256) void gpe_knn_planes_kernel(const float* __rest
         const int cc = (c < C) ? c : 0;
         float v[KNN_NORM_ROWS];
 #pragma unroll
-        for (int u = 0; u < KNN_NORM_ROWS; ++u) v[u] = x[((r0 + u < last) ? r0 + u : last) * ldx + cc];
+        for (int u = 0; u < KNN_NORM_ROWS; ++u) v[u] = x[src[u] * ldx + cc];
 #pragma unroll
         for (int u = 0; u < KNN_NORM_ROWS; ++u) {
             if (r0 + u <= last) {
@@ -848,8 +868,12 @@ template <int NBMAX>
 __global__ __launch_bounds__(256, 2) void gpe_knn_h3_kernel(const _Float16* __restrict__ pl, const float* __restrict__ isc, int N,
                                                             int CP, int kk, int K2, const float* __restrict__ norms,
                                                             const int* __restrict__ cmax, float ce, int B, int tiles, int pin,
-                                                            int nsplit, unsigned long long* __restrict__ part, int probe)
+                                                            int nsplit, unsigned long long* __restrict__ part, int probe,
+                                                            const int* __restrict__ ord)
 {
+    // ord (may be NULL): the planes are in the caller's locality order (plane row r = point ord[r] of the cloud); norms / lists are in
+    // point numbering.  The scan then starts one tile before the queries' own tile (see tile_c0 below).
+    const int rot = ord != nullptr;
     extern __shared__ __align__(16) float smem[];
     constexpr int PLANE_B = KNN_TC * KNN_H3_PITCH;
     constexpr int BUF_B = 2 * PLANE_B;
@@ -882,6 +906,8 @@ __global__ __launch_bounds__(256, 2) void gpe_knn_h3_kernel(const _Float16* __re
     const _Float16* cloud = pl + (size_t)b * N * 2 * CP;
     const float* cnorm = norms + (size_t)b * N;
     const float* cisc = isc + (size_t)b * N;
+    const int* cord = ord ? ord + (size_t)b * N : nullptr;
+    auto pt = [&](int r) -> int { return cord ? cord[r] : r; };      // plane row -> point
     float* const dW = dS + wave * 16 * KNN_LDD;
     unsigned long long* const mW = mS + wave * 64;
 
@@ -893,13 +919,13 @@ __global__ __launch_bounds__(256, 2) void gpe_knn_h3_kernel(const _Float16* __re
 
     const int j = lane & 15, g = lane >> 4;
     const int myq = (q0 + 16 * wave + j < N) ? q0 + 16 * wave + j : N - 1;
-    const float nq = cnorm[myq];
+    const float nq = cnorm[pt(myq)];
     const float fq = -2.f * cisc[myq];                    // exact (a power of two)
     const float cm = __int_as_float(cmax[b]);
     float m2e_of;
     {
         const int qi = (q0 + 16 * wave + (lane & 15) < N) ? q0 + 16 * wave + (lane & 15) : N - 1;
-        m2e_of = 2.02f * ce * (cnorm[qi] + cm);
+        m2e_of = 2.02f * ce * (cnorm[pt(qi)] + cm);
     }
     // ---- the wave's 16 queries: resident B fragments (lane (j, g): query j, halves 32 blk + 8 g .. + 7 of both planes) ----
     const int NB = CP >> 5;
@@ -918,7 +944,18 @@ __global__ __launch_bounds__(256, 2) void gpe_knn_h3_kernel(const _Float16* __re
     knn_u32x4 pre[4];
     float pre_n = 0.f, pre_s = 0.f;
     int pre_first = 0, pre_tp = 0;
-    int pf_c0 = c_first, pf_ci = 0, pf_tp = 0;
+    // visit order of the candidate tiles of this piece: rotated so that the scan STARTS one tile before the queries' own tile (rot:
+    // the rows are in a locality order, e.g. the Morton order of the points — the first three tiles then hold most of the true
+    // neighbours and the insertion bound is tight for the rest of the scan); rot = 0: ascending from the piece's first tile
+    const int ntile_p = (c_stop - c_first + KNN_TC - 1) / KNN_TC;
+    int v_start = 0;
+    if (rot && ntile_p > 0) {
+        v_start = qt - 1 - c_first / KNN_TC;
+        v_start = v_start < 0 ? 0 : (v_start >= ntile_p ? ntile_p - 1 : v_start);
+    }
+    auto tile_c0 = [&](int v) -> int { int t = v_start + v; t = t >= ntile_p ? t - ntile_p : t; return c_first + t * KNN_TC; };
+    int pf_v = 0;
+    int pf_c0 = tile_c0(0), pf_ci = 0, pf_tp = 0;
     auto prefetch = [&]() {
         const int ch0 = pf_ci * KNN_H3_CCH;
         const int nv = ((CP - ch0) >> 3) < 8 ? ((CP - ch0) >> 3) : 8;     // valid 16-byte pieces per plane row of this chunk
@@ -934,10 +971,10 @@ __global__ __launch_bounds__(256, 2) void gpe_knn_h3_kernel(const _Float16* __re
         pre_tp = pf_tp;
         if (pre_first && tid < KNN_TC) {
             const int pr = (pf_c0 + tid < N) ? pf_c0 + tid : N - 1;
-            pre_n = cnorm[pr];
+            pre_n = cnorm[pt(pr)];
             pre_s = cisc[pr];
         }
-        if (++pf_ci == nchunk) { pf_ci = 0; pf_c0 += KNN_TC; pf_tp ^= 1; }
+        if (++pf_ci == nchunk) { pf_ci = 0; ++pf_v; pf_c0 = tile_c0(pf_v < ntile_p ? pf_v : 0); pf_tp ^= 1; }
     };
     auto commit = [&](int buf) {
 #pragma unroll
@@ -958,7 +995,8 @@ __global__ __launch_bounds__(256, 2) void gpe_knn_h3_kernel(const _Float16* __re
     __syncthreads();
 
     int step = 0, buf = 0, tp = 0;
-    for (int c0 = c_first; c0 < c_stop; c0 += KNN_TC, tp ^= 1) {
+    for (int v = 0; v < ntile; ++v, tp ^= 1) {
+        const int c0 = tile_c0(v);
         f32x4 acc[4];
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -1013,11 +1051,11 @@ __global__ __launch_bounds__(256, 2) void gpe_knn_h3_kernel(const _Float16* __re
                     dmin = fminf(fminf(dmin, fminf(d.x, d.y)), fminf(d.z, d.w));
                 }
                 unsigned qm = 0xffffu;
-                if (c0 != c_first) {
+                if (v != 0) {
                     const unsigned long long hm = __ballot(dmin < thrq);
                     qm = (unsigned)((hm | (hm >> 16) | (hm >> 32) | (hm >> 48)) & 0xffffull);
                 }
-                if ((probe & 1) && c0 > c_first) qm = 0;
+                if ((probe & 1) && v > 0) qm = 0;
                 if (qm != 0) {
                     asm volatile("" ::: "memory");
 #pragma unroll
@@ -1030,7 +1068,7 @@ __global__ __launch_bounds__(256, 2) void gpe_knn_h3_kernel(const _Float16* __re
                         const float d = dW[i * KNN_LDD + lane];
                         float ldv = ld_[i];
                         int liv = li_[i];
-                        const float t = knn_select_mf(c0 == c_first, d, lane, cand, K2, kk, knn_readlane_f(m2e_of, i),
+                        const float t = knn_select_mf(v == 0, d, lane, cand, K2, kk, knn_readlane_f(m2e_of, i),
                                                       knn_readlane_f(thrq, i), mW, ldv, liv);
                         ld_[i] = ldv; li_[i] = liv;
                         thrq = ((lane & 15) == i) ? t : thrq;
@@ -1043,12 +1081,15 @@ __global__ __launch_bounds__(256, 2) void gpe_knn_h3_kernel(const _Float16* __re
             ++step;
         }
     }
+    // lists out, in POINT numbering (the rerank reads rows and norms by point): query plane row -> point, candidate rows -> points
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
         const int q = q0 + 16 * wave + i;
-        if (q < N && lane < K2)
-            part[(((size_t)b * N + q) * nsplit + piece) * K2 + lane] =
-                ((unsigned long long)(unsigned)__float_as_int(ld_[i]) << 32) | (unsigned)li_[i];
+        if (q < N && lane < K2) {
+            const int li = (li_[i] >= 0) ? pt(li_[i]) : li_[i];
+            part[(((size_t)b * N + pt(q)) * nsplit + piece) * K2 + lane] =
+                ((unsigned long long)(unsigned)__float_as_int(ld_[i]) << 32) | (unsigned)li;
+        }
     }
 }
 
@@ -1224,13 +1265,18 @@ extern "C" long gpe_knn_ws_bytes(int B, int N, int C, int k)
     return (long)(lists + norm_bytes + ((size_t)B * sizeof(int) + 255 & ~(size_t)255) + plane_bytes + 256);
 }
 
-extern "C" int gpe_knn(const float* x, int B, int N, int C, int ldx, int k, int32_t* idx, int32_t* idx_glob, void* ws,
-                       long ws_bytes, void* stream)
+extern "C" int gpe_knn(const float* x, int B, int N, int C, int ldx, int k, int32_t* idx, int32_t* idx_glob, const int32_t* order_in,
+                       int32_t* order_out, void* ws, long ws_bytes, void* stream)
 {
     if (!x || !idx || B < 0 || N <= 0 || C <= 0 || ldx < C || k <= 0 || k > 64 || k > N || (long)B * N * k >= (1L << 31)) return GPE_EINVAL;
     if (B == 0) return GPE_OK;
     static const int force_exact = gpe_dbg_env("GPE_KNN_EXACT", 0);
-    if (C < KNN_MF_MINC || k > 48 || force_exact) return knn_exact(x, B, N, C, ldx, k, idx, idx_glob, ws, ws_bytes, stream);
+    if (C < KNN_MF_MINC || k > 48 || force_exact) return knn_exact(x, B, N, C, ldx, k, idx, idx_glob, ws, ws_bytes, stream, order_out);
+    if (order_out) {                                   // (only the xyz search produces an order; a filter-path caller gets the identity)
+        hipLaunchKernelGGL(gpe_knn_identity_order_kernel, dim3((unsigned)gpe_cdiv((long)B * N, 256)), dim3(256), 0, (hipStream_t)stream,
+                           order_out, (long)B * N, N);
+        GPE_CHECK_LAUNCH();
+    }
     // ---- matrix-pipe filter + exact recheck ----
     const int K2 = knn_k2(k, N);
     const int tiles = gpe_cdiv(N, KNN_TQ);
@@ -1285,20 +1331,22 @@ extern "C" int gpe_knn(const float* x, int B, int N, int C, int ldx, int k, int3
     if (dbg_vec > 0 && dbg_vec < vec) vec = dbg_vec;
     if (h3) {
         hipLaunchKernelGGL(gpe_knn_planes_kernel, dim3((unsigned)gpe_cdiv((long)nq, 4 * KNN_NORM_ROWS)), dim3(256), 0, s, x, (long)nq, C,
-                           ldx, CP, planes, iscale);
+                           ldx, CP, planes, iscale, gpe_dbg_env("GPE_KNN_NOORDER", 0) ? nullptr : order_in, N);
         GPE_CHECK_LAUNCH();
         const size_t lds3 = (size_t)2 * 2 * KNN_TC * KNN_H3_PITCH + (size_t)4 * 16 * KNN_LDD * sizeof(float) +
                             4 * 64 * sizeof(unsigned long long) + 4 * KNN_TC * sizeof(float);
         const int NB = CP >> 5;
+        static const int no_order = gpe_dbg_env("GPE_KNN_NOORDER", 0);     // A/B: ignore the caller's order (planes built above with it: keep both off)
+        const int32_t* rot = no_order ? nullptr : order_in;
         if (NB <= 2)
             hipLaunchKernelGGL((gpe_knn_h3_kernel<2>), dim3((unsigned)nblocks), dim3(256), lds3, s, planes, iscale, N, CP, k, K2, norms,
-                               cmax, ce, B, tiles, pin, nsplit, part, mprobe);
+                               cmax, ce, B, tiles, pin, nsplit, part, mprobe, rot);
         else if (NB <= 5)
             hipLaunchKernelGGL((gpe_knn_h3_kernel<5>), dim3((unsigned)nblocks), dim3(256), lds3, s, planes, iscale, N, CP, k, K2, norms,
-                               cmax, ce, B, tiles, pin, nsplit, part, mprobe);
+                               cmax, ce, B, tiles, pin, nsplit, part, mprobe, rot);
         else
             hipLaunchKernelGGL((gpe_knn_h3_kernel<8>), dim3((unsigned)nblocks), dim3(256), lds3, s, planes, iscale, N, CP, k, K2, norms,
-                               cmax, ce, B, tiles, pin, nsplit, part, mprobe);
+                               cmax, ce, B, tiles, pin, nsplit, part, mprobe, rot);
     } else if (vec == 4)
         hipLaunchKernelGGL((gpe_knn_mfma_kernel<4>), dim3((unsigned)nblocks), dim3(256), lds, s, x, N, C, ldx, k, K2, norms, cmax, ce,
                            B, tiles, pin, nsplit, part, mprobe);

@@ -80,7 +80,7 @@ __device__ __forceinline__ unsigned k3_code(float px, float py, float pz, const 
 }
 
 // xs [B][N] float4 (x, y, z, bits of the original index), tb [B][tiles][8] = {lo x, lo y, lo z, -, hi x, hi y, hi z, -}
-__global__ __launch_bounds__(1024) void gpe_knn3_sort_kernel(const float* __restrict__ x, int N, int ldx, float4* __restrict__ xs,
+__global__ __launch_bounds__(1024) void gpe_knn3_sort_kernel(const float* __restrict__ x, int N, int ldx, int* __restrict__ order_out, float4* __restrict__ xs,
                                                              float* __restrict__ tb, int tiles)
 {
     extern __shared__ __align__(16) float k3_smem[];
@@ -153,6 +153,10 @@ __global__ __launch_bounds__(1024) void gpe_knn3_sort_kernel(const float* __rest
     __syncthreads();
     float4* out = xs + (size_t)b * N;
     for (int i = tid; i < N; i += 1024) out[i] = sp[i];
+    // the curve order itself, for the caller (gpe_knn order_out): sorted position -> original index.  The layer-2 search of an
+    // EdgeConv stack takes it as a LOCALITY order of its rows (gpe_knn.hip: rotated tile visits)
+    if (order_out)
+        for (int i = tid; i < N; i += 1024) order_out[(size_t)b * N + i] = __float_as_int(sp[i].w);
     for (int t = wave; t < tiles; t += 16) {
         const int i = 64 * t + lane;
         const float4 p = sp[i < N ? i : N - 1];                  // (N - 1 lies in the last tile: the clamp adds no foreign point)
@@ -340,8 +344,8 @@ __global__ __launch_bounds__(256) void gpe_knn3_query_kernel(const float4* __res
 
 // 1 = launched, 0 = not on this path's menu (the caller runs the all-pairs kernel), < 0 error.  ws: >= B*N*16 + B*tiles*32 bytes.
 // GPE_KNN_SORTED=0 keeps the all-pairs kernel (A/B measurements, tests of the old path).
-int gpe_knn3_try(const float* x, int B, int N, int ldx, int k, int32_t* idx, int32_t* idx_glob, void* ws, long ws_bytes,
-                 hipStream_t s)
+int gpe_knn3_try(const float* x, int B, int N, int ldx, int k, int32_t* idx, int32_t* idx_glob, int32_t* order_out, void* ws,
+                 long ws_bytes, hipStream_t s)
 {
     static const int off = gpe_dbg_env("GPE_KNN_SORTED", 1) == 0;
     if (off || N < K3_MINN || N > K3_MAXN || k > 64 || k > N) return 0;
@@ -353,7 +357,7 @@ int gpe_knn3_try(const float* x, int B, int N, int ldx, int k, int32_t* idx, int
     float* tb = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + xs_bytes);
     const size_t lds = (size_t)N * sizeof(float4) + K3_CELLS * sizeof(unsigned) + 96 * sizeof(float) + 16 * sizeof(unsigned);
     GPE_ENSURE_MAX_LDS(gpe_knn3_sort_kernel);
-    hipLaunchKernelGGL(gpe_knn3_sort_kernel, dim3(B), dim3(1024), lds, s, x, N, ldx, xs, tb, tiles);
+    hipLaunchKernelGGL(gpe_knn3_sort_kernel, dim3(B), dim3(1024), lds, s, x, N, ldx, order_out, xs, tb, tiles);
     GPE_CHECK_LAUNCH();
     const int wgs = gpe_cdiv(N, 4 * K3_QW);
     hipLaunchKernelGGL(gpe_knn3_query_kernel, dim3((unsigned)((long)B * wgs)), dim3(256), 0, s, xs, tb, N, k, tiles, wgs, idx, idx_glob);

@@ -31,6 +31,7 @@ class DynamicEdgeConv(nn.Module):
         self.k = k
         self.aggr = aggr
         self.last_knn = None
+        self.last_order = None                               # the locality order the last graph search worked in (int32 [B, N])
         self.half_act_guard = ops.HalfActGuard()             # f16x3: watches the fp16-stored activation (ops.set_half_act_guard)
 
     def register_packs(self, plan):
@@ -39,7 +40,8 @@ class DynamicEdgeConv(nn.Module):
         for b in blocks[1:]:
             plan.add_linear(b[0].weight, fwd=False, bwd=True)     # forward packs carry the folded BatchNorm scale
 
-    def forward(self, x, n_clouds, n_points):
+    def forward(self, x, n_clouds, n_points, order=None):
+        """order: the previous EdgeConv layer's `last_order` (a speed hint for this layer's graph search; results do not depend on it)"""
         nb = len(self.nn)
         blocks = [self.nn[i] for i in range(nb)]
         lin = [b[0] for b in blocks]
@@ -54,9 +56,10 @@ class DynamicEdgeConv(nn.Module):
         if H0 % 4 or H0 > 256:
             # a first-block width the fused P|Q kernels do not take: the general (explicit-message) formulation
             out, idx = ops.edge_conv_general(x, n_clouds, n_points, self.k, self.training, eps, mom, nb, self.aggr, args)
+            self.last_order = None
         else:
-            out, idx = ops.EdgeConvFn.apply(x, n_clouds, n_points, self.k, self.training, eps, mom, nb, self.aggr,
-                                            self.half_act_guard, *args)
+            out, idx, self.last_order = ops.EdgeConvFn.apply(x, n_clouds, n_points, self.k, self.training, eps, mom, nb, self.aggr,
+                                                             self.half_act_guard, order, *args)
         self.last_knn = idx
         return out
 
@@ -113,8 +116,10 @@ class EdgeConvFeatures(nn.Module):
         # batch vector of the reference (nn/net_blocks.py:165-167); the kernels only need (B, N)
         batch = torch.arange(B, device=positions.device).repeat_interleave(N)
         out = pos_flat
+        order = None                                         # layer l + 1 searches its graph in layer l's locality order
         for conv in self.conv_layers:
-            out = conv(out, B, N)
+            out = conv(out, B, N, order=order)
+            order = conv.last_order
         if self.config['skip_connections']:
             out = torch.cat([out, pos_flat], dim=-1)
         if global_pool:

@@ -430,16 +430,24 @@ def redgemm_raw(u_desc, v_desc, rows, Mg, Ng, want_colsum=True, accumulate_into=
     return G, cs
 
 
-def knn(x, B, N, k, want_global=False):
+def knn(x, B, N, k, want_global=False, order=None, want_order=False):
     """x: [B*N, C] rows (ld = x.stride(0)).  -> int32 [B, N, k] local neighbour indices (and, optionally, the same
     graph as global row numbers b*N + idx, the form the gather kernels consume).
-    Replaces torch_cluster.knn under DynamicEdgeConv (nn/net_blocks.py:127-135)."""
+    Replaces torch_cluster.knn under DynamicEdgeConv (nn/net_blocks.py:127-135,174).
+    order (int32 [B, N], optional): a locality order of the points, a speed hint for the wide-feature search (include/gpe_hip.h
+    gpe_knn); want_order: also return the order this search worked in (the xyz search's Morton-curve order; else the identity)."""
     _dev_check(x)
     idx = torch.empty(B, N, k, device=x.device, dtype=torch.int32)
     jg = torch.empty(B, N, k, device=x.device, dtype=torch.int32) if want_global else None
+    oo = torch.empty(B, N, device=x.device, dtype=torch.int32) if want_order else None
+    if order is not None:
+        assert order.dtype == torch.int32 and order.shape == (B, N) and order.is_contiguous() and order.device == x.device
     nws = L.query('gpe_knn_ws_bytes', B, N, x.shape[1], k)
-    L.call('gpe_knn', x, B, N, x.shape[1], x.stride(0), k, idx, jg, _workspace(nws, x.device), nws)
-    return (idx, jg) if want_global else idx
+    L.call('gpe_knn', x, B, N, x.shape[1], x.stride(0), k, idx, jg, order, oo, _workspace(nws, x.device), nws)
+    out = (idx, jg) if want_global else (idx,)
+    if want_order:
+        out = out + (oo,)
+    return out if len(out) > 1 else out[0]
 
 
 def knn_reverse(idx):
@@ -690,7 +698,9 @@ class EdgeConvFn(torch.autograd.Function):
     nb = EConv_hidden_depth + 1 >= 2; the shipped configs use nb = 3, aggr = 'max'."""
 
     @staticmethod
-    def forward(ctx, x, B, N, k, training, eps, momentum, nb, aggr, guard, *tensors):
+    def forward(ctx, x, B, N, k, training, eps, momentum, nb, aggr, guard, order, *tensors):
+        # order (int32 [B, N] or None): a locality order of the points — the previous layer's curve order — handed to the graph
+        # search as a speed hint (include/gpe_hip.h gpe_knn); third output: the order this layer's search worked in
         _dev_check(x)
         dev = x.device
         BN, C = x.shape
@@ -705,7 +715,7 @@ class EdgeConvFn(torch.autograd.Function):
                              '(got %d): use ops.edge_conv_general' % H0)
         E = BN * k
         nblk = L.query('gpe_stats_blocks')
-        idx, jg = knn(x, B, N, k, want_global=True)
+        idx, jg, order_out = knn(x, B, N, k, want_global=True, order=order, want_order=True)
         wpq_p, _, bpq = edge_first_operands(Ws[0], params[1])
         PQ = torch.empty(BN, 2 * H0, device=dev, dtype=F32)
         linear_raw(_rows2d(x), wpq_p, bpq, BN, 2 * H0, C, _rows2d(PQ))
@@ -781,11 +791,11 @@ class EdgeConvFn(torch.autograd.Function):
         ctx.words = words
         ctx.save_for_backward(x, idx, jg, PQ, *params, *acts[1:], *stats,
                               *([mx, mn, amx, amn] if aggr == 'max' else [abar]))
-        ctx.mark_non_differentiable(idx)
-        return out, idx
+        ctx.mark_non_differentiable(idx, order_out)
+        return out, idx, order_out
 
     @staticmethod
-    def backward(ctx, g_out, _g_idx):
+    def backward(ctx, g_out, _g_idx, _g_order=None):
         if ctx.done:
             raise RuntimeError('EdgeConvFn.backward ran twice on the same graph: the stored activations are overwritten '
                                'in place by the first pass (retain_graph is not supported)')
@@ -905,7 +915,7 @@ class EdgeConvFn(torch.autograd.Function):
             _, wpq_t, _ = edge_first_operands(W1, b1)
             gx = torch.empty(BN, C, device=dev, dtype=F32)
             linear_raw(_rows2d(dPQ), wpq_t, None, BN, C, 2 * H0, _rows2d(gx))
-        return (gx, None, None, None, None, None, None, None, None, None, *grads, *([None] * (3 * nb)))
+        return (gx, None, None, None, None, None, None, None, None, None, None, *grads, *([None] * (3 * nb)))
 
 
 class EdgeInputsFn(torch.autograd.Function):

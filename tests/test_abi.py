@@ -66,7 +66,7 @@ def test_host_only_queries():
 def test_bad_arguments_are_rejected_without_a_gpu():
     l = _lib.lib()
     # NULL pointers / bad dims must come back as -EINVAL before any launch is attempted
-    assert l.gpe_knn(None, 1, 8, 3, 3, 4, None, None, None, 0, None) == -22
+    assert l.gpe_knn(None, 1, 8, 3, 3, 4, None, None, None, None, None, 0, None) == -22
     assert l.gpe_linear(None, 0, 0, 0, None, None, None, 0, 0, 0, None, 0, 0, 0, 4, 4, 4, 0, None) == -22
     assert l.gpe_edge_gather_stats(None, 0, 0, None, 1, 1, 1, None, None) == -22
     assert l.gpe_edge_pq_amax(None, 0, 0, 0, None, None, 0, None) == -22

@@ -215,6 +215,43 @@ def test_knn_candidate_split_full_size(gpe):
     assert (srt[..., 1:] != srt[..., :-1]).all()
 
 
+@pytest.mark.parametrize('B,N,C,k,kind', [(32, 2048, 150, 16, 'random'), (32, 2048, 150, 16, 'curve'), (3, 700, 150, 16, 'reverse'),
+                                          (9, 1000, 40, 20, 'random'), (2, 192, 64, 9, 'lattice')])
+def test_knn_with_a_locality_order_is_still_exact(gpe, B, N, C, k, kind):
+    """gpe_knn's order_in (round 6) is a SPEED hint of the wide-feature search: plane rows laid out in the caller's order, every query
+    tile's scan started one tile before its own tile.  The answer must not depend on it: bit-exact against the C oracle and equal to
+    the un-hinted search for a random permutation, for the curve order of an xyz search over correlated positions (features =
+    smooth function of position + noise: the case the hint is for), for the reversed identity, and on a lattice with massive ties
+    (the rerank's exact per-query fallback)."""
+    from oracle import ref_path as O
+    g = torch.Generator().manual_seed(B * 1000 + N)
+    pos = torch.randn(B * N, 3, generator=g)
+    if kind == 'lattice':
+        x = torch.randint(0, 3, (B * N, C), generator=g).float()
+    elif kind == 'curve':
+        proj = torch.randn(3, C, generator=g)
+        x = torch.tanh(pos @ proj) + 0.05 * torch.randn(B * N, C, generator=g)
+    else:
+        x = torch.randn(B * N, C, generator=g)
+    buf = torch.zeros(B * N, (C + 3) // 4 * 4)
+    buf[:, :C] = x
+    xd = buf.cuda()[:, :C]
+    if kind == 'curve':
+        _, order = gpe.ops.knn(pos.cuda(), B, N, 8, want_order=True)        # the Morton-curve order of the xyz search
+        assert torch.equal(order.long().sort(1).values.cpu(), torch.arange(N).expand(B, N))
+    elif kind == 'reverse':
+        order = torch.arange(N - 1, -1, -1, dtype=torch.int32).expand(B, N).contiguous().cuda()
+    else:
+        order = torch.stack([torch.randperm(N, generator=g) for _ in range(B)]).to(torch.int32).cuda()
+    plain = gpe.ops.knn(xd, B, N, k)
+    hinted, echo = gpe.ops.knn(xd, B, N, k, order=order, want_order=True)
+    assert torch.equal(plain, hinted)
+    assert torch.equal(echo.cpu(), torch.arange(N, dtype=torch.int32).expand(B, N))      # a filter-path search reports the identity
+    for b in sorted({0, B // 2, B - 1}):
+        ref = O.knn_local(x[b * N:(b + 1) * N].contiguous(), 1, k).to(torch.int32).view(N, k)
+        assert torch.equal(hinted[b].cpu(), ref), b
+
+
 def test_knn_strided_rows(gpe):
     from oracle import ref_path as O
     g = torch.Generator().manual_seed(11)
