@@ -73,6 +73,8 @@ def parse():
     ap.add_argument('--edge-dbg', type=int, default=int(os.environ.get('GPE_EDGE_DBG', '0')), help='measurement aid: gpe_debug_set flags for the edge kernels (0 = product path)')
     ap.add_argument('--f16x3-min-rows', type=int, default=-1, help='measurement aid: override the f16x3 size gate (gpe_f16x3_min_rows_set); -1 = library default')
     ap.add_argument('--torch-adam', action='store_true', help='torch.optim.Adam instead of the fused arena optimizer')
+    ap.add_argument('--reserve-cus', type=int, default=-1, help='compute units left out of every persistent launch (room for RCCL under the '
+                    'edge kernels); -1 = the package default: 16 when N > 1, else 0')
     return ap.parse_args()
 
 
@@ -494,7 +496,7 @@ def main():
         # slices of it, Adam (+ zero_grad) is one launch (nn/trainer.py:162-185: Adam, lr 0.002)
         arena = optim.FlatArena(model)
         opt = optim.FusedAdam(arena, lr=2e-3)
-    wrapped = parallel.DistributedHotPath(model, device_ids=[dev], arena=arena)
+    wrapped = parallel.DistributedHotPath(model, device_ids=[dev], arena=arena, reserve_cus=None if args.reserve_cus < 0 else args.reserve_cus)
     feats, gt = synthetic(args.batch, args.points, data_config, seed=1000 + rank, device=dev)
 
     def step(i):
@@ -646,6 +648,7 @@ def main():
     if world > 1:
         exchange = wrapped.measure_exchange(iters=10)      # every rank participates; rank 0 reports
         exchange['exposed_ms_per_step'] = wrapped.exposed_ms()
+        exchange['reserved_cus'] = wrapped.reserved_cus
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -672,7 +675,7 @@ def main():
                        # (flat scalars: the driver's parsed record drops nested objects inside `config`)
                        'exact_f32_value': fast['f32']['value'] if fast and fast.get('f32') else None,
                        'exact_f32_ms': fast['f32']['ms_per_step'] if fast and fast.get('f32') else None,
-                       'loss_epoch': args.epoch,
+                       'loss_epoch': args.epoch, 'reserved_cus': wrapped.reserved_cus,
                        'step': 'fwd + ComposedPatternLoss + bwd' + (' + RCCL grad all-reduce' if world > 1 else '')
                                + (' + Adam (torch)' if args.torch_adam else ' + fused Adam (flat arena)'),
                        'final_loss': final_loss},

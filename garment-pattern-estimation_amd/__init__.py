@@ -9,6 +9,6 @@ layout of the reference's nn/nets.py and nn/net_blocks.py, so `getattr(nets, con
 The directory name contains '-', so import it with importlib or through the `gpe_amd` alias module at the
 repository root:  `import gpe_amd; from gpe_amd import nets`."""
 from . import _lib, ops, net_blocks, nets, metrics, optim, parallel, staging, configs  # noqa: F401
-from ._lib import set_math, get_math, set_f16x3_min_rows  # noqa: F401
+from ._lib import set_math, get_math, set_f16x3_min_rows, set_reserved_cus  # noqa: F401
 
-__all__ = ['_lib', 'ops', 'net_blocks', 'nets', 'metrics', 'optim', 'parallel', 'staging', 'configs', 'set_math', 'get_math', 'set_f16x3_min_rows']
+__all__ = ['_lib', 'ops', 'net_blocks', 'nets', 'metrics', 'optim', 'parallel', 'staging', 'configs', 'set_math', 'get_math', 'set_f16x3_min_rows', 'set_reserved_cus']

@@ -91,6 +91,15 @@ def set_f16x3_min_rows(rows):
     return prev
 
 
+def set_reserved_cus(n):
+    """Leave `n` compute units out of every persistent launch (include/gpe_hip.h gpe_reserve_cus_set): room for RCCL's kernels while
+    the fused edge kernels run.  Returns the previous reservation."""
+    prev = lib().gpe_reserve_cus_set(int(n))
+    if prev < 0:
+        raise ValueError('reserved CUs must lie in 0 .. 192')
+    return prev
+
+
 def get_math():
     return {v: k for k, v in MATH_MODES.items()}[lib().gpe_math_get()]
 

@@ -7,18 +7,28 @@
 
 extern "C" int gpe_abi_version(void) { return 5; }
 
+// compute units the persistent kernels may fill: the device's count minus the caller's reservation (gpe_reserve_cus_set)
+static int g_reserved_cus = 0;
+extern "C" int gpe_reserve_cus_set(int n)
+{
+    if (n < 0 || n > 192) return GPE_EINVAL;
+    const int prev = g_reserved_cus;
+    g_reserved_cus = n;
+    return prev;
+}
 int gpe_num_cus()
 {
     static int cus[64] = {0};
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    if (hipGetDevice(&dev) != hipSuccess) return 256 - g_reserved_cus;
     int& c = cus[dev & 63];
     if (!c) {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, dev) == hipSuccess) c = prop.multiProcessorCount;
         if (c <= 0) c = 256;
     }
-    return c;
+    const int left = c - g_reserved_cus;
+    return left > 8 ? left : 8;
 }
 
 __device__ __forceinline__ float4 pw_ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }

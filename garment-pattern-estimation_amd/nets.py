@@ -52,56 +52,50 @@ class BaseModule(nn.Module):
         return self
 
 
+# ---- GarmentFullPattern3D: what the reference's constructor fixes (nn/nets.py:49-130), as tables ------------------------------------
+# attribute <- data_config key (nn/nets.py:53-57)
+_DATA_FIELDS = (('panel_elem_len', 'element_size'), ('max_panel_len', 'max_panel_len'), ('max_pattern_size', 'max_pattern_len'),
+                ('rotation_size', 'rotation_size'), ('translation_size', 'translation_size'))
+# NN defaults (nn/nets.py:60-73); a *_hidden_size the caller left out falls back to the matching *_encoding_size IN THE CALLER'S DICT
+# (nn/nets.py:75-78: configs saved before the hidden sizes existed)
+_NN_DEFAULTS = {'panel_encoding_size': 250, 'panel_hidden_size': 250, 'panel_n_layers': 3,
+                'pattern_encoding_size': 250, 'pattern_hidden_size': 250, 'pattern_n_layers': 2,
+                'dropout': 0, 'lstm_init': 'kaiming_normal_', 'feature_extractor': 'EdgeConvFeatures',
+                'panel_decoder': 'LSTMDecoderModule', 'pattern_decoder': 'LSTMDecoderModule', 'stitch_tag_dim': 3}
+_HIDDEN_FALLBACK = (('panel_hidden_size', 'panel_encoding_size'), ('pattern_hidden_size', 'pattern_encoding_size'))
+# loss defaults (nn/nets.py:83-92)
+_LOSS_DEFAULTS = {'loss_components': ['shape', 'loop', 'rotation', 'translation'],
+                  'quality_components': ['shape', 'discrete', 'rotation', 'translation'],
+                  'loop_loss_weight': 1., 'stitch_tags_margin': 0.3, 'epoch_with_stitches': 40,
+                  'stitch_supervised_weight': 0.1, 'stitch_hardnet_version': False, 'panel_origin_invariant_loss': True}
+
+
 class GarmentFullPattern3D(BaseModule):
     """nn/nets.py:41-184: EdgeConv encoder -> pattern LSTM -> panel LSTM + placement Linear."""
 
     def __init__(self, data_config, config={}, in_loss_config={}):
         super().__init__()
-        self.panel_elem_len = data_config['element_size']
-        self.max_panel_len = data_config['max_panel_len']
-        self.max_pattern_size = data_config['max_pattern_len']
-        self.rotation_size = data_config['rotation_size']
-        self.translation_size = data_config['translation_size']
-        self.config.update({
-            'panel_encoding_size': 250, 'panel_hidden_size': 250, 'panel_n_layers': 3,
-            'pattern_encoding_size': 250, 'pattern_hidden_size': 250, 'pattern_n_layers': 2,
-            'dropout': 0, 'lstm_init': 'kaiming_normal_', 'feature_extractor': 'EdgeConvFeatures',
-            'panel_decoder': 'LSTMDecoderModule', 'pattern_decoder': 'LSTMDecoderModule',
-            'stitch_tag_dim': 3})
-        # back-compat mutation of the CALLER's dict, as the reference does (nn/nets.py:75-78)
-        if 'panel_hidden_size' not in config:
-            config['panel_hidden_size'] = config['panel_encoding_size']
-        if 'pattern_hidden_size' not in config:
-            config['pattern_hidden_size'] = config['pattern_encoding_size']
+        for attr, key in _DATA_FIELDS:
+            setattr(self, attr, data_config[key])
+        for hidden, enc in _HIDDEN_FALLBACK:                 # mutates the caller's dict (and raises KeyError when neither key is
+            if hidden not in config:                         # given), like the reference
+                config[hidden] = config[enc]
+        self.config.update(_NN_DEFAULTS)
         self.config.update(config)
-        self.config['loss'] = {
-            'loss_components': ['shape', 'loop', 'rotation', 'translation'],
-            'quality_components': ['shape', 'discrete', 'rotation', 'translation'],
-            'loop_loss_weight': 1., 'stitch_tags_margin': 0.3, 'epoch_with_stitches': 40,
-            'stitch_supervised_weight': 0.1, 'stitch_hardnet_version': False,
-            'panel_origin_invariant_loss': True}
-        self.config['loss'].update(in_loss_config)
-        self.loss = ComposedPatternLoss(data_config, self.config['loss'])
-        self.config['loss'] = self.loss.config
-
-        feature_extractor_module = getattr(blocks, self.config['feature_extractor'])
-        self.feature_extractor = feature_extractor_module(self.config['pattern_encoding_size'], self.config)
-        if hasattr(self.feature_extractor, 'config'):
-            self.config.update(self.feature_extractor.config)
-        panel_decoder_module = getattr(blocks, self.config['panel_decoder'])
-        self.panel_decoder = panel_decoder_module(
-            encoding_size=self.config['panel_encoding_size'], hidden_size=self.config['panel_hidden_size'],
-            out_elem_size=self.panel_elem_len + self.config['stitch_tag_dim'] + 1,
-            n_layers=self.config['panel_n_layers'], out_len=self.max_panel_len,
-            dropout=self.config['dropout'], custom_init=self.config['lstm_init'])
-        pattern_decoder_module = getattr(blocks, self.config['pattern_decoder'])
-        self.pattern_decoder = pattern_decoder_module(
-            encoding_size=self.config['pattern_encoding_size'], hidden_size=self.config['pattern_hidden_size'],
-            out_elem_size=self.config['panel_encoding_size'], n_layers=self.config['pattern_n_layers'],
-            out_len=self.max_pattern_size, dropout=self.config['dropout'],
-            custom_init=self.config['lstm_init'])
-        self.placement_decoder = nn.Linear(self.config['panel_encoding_size'],
-                                           self.rotation_size + self.translation_size)
+        self.loss = ComposedPatternLoss(data_config, {**{k: (list(v) if isinstance(v, list) else v) for k, v in _LOSS_DEFAULTS.items()},
+                                                      **in_loss_config})
+        self.config['loss'] = self.loss.config               # the loss object owns the merged dict from here on
+        cfg = self.config
+        self.feature_extractor = getattr(blocks, cfg['feature_extractor'])(cfg['pattern_encoding_size'], cfg)
+        cfg.update(getattr(self.feature_extractor, 'config', {}))
+        # one row per sequence decoder: name, class key, output width, sequence length (`out_len` is swallowed by **kwargs in the
+        # recurrent decoders and used by MLPDecoder: nn/net_blocks.py:273-298,365)
+        for name, out_width, out_len in (('panel', self.panel_elem_len + cfg['stitch_tag_dim'] + 1, self.max_panel_len),
+                                         ('pattern', cfg['panel_encoding_size'], self.max_pattern_size)):
+            setattr(self, name + '_decoder', getattr(blocks, cfg[name + '_decoder'])(
+                encoding_size=cfg[name + '_encoding_size'], hidden_size=cfg[name + '_hidden_size'], out_elem_size=out_width,
+                n_layers=cfg[name + '_n_layers'], out_len=out_len, dropout=cfg['dropout'], custom_init=cfg['lstm_init']))
+        self.placement_decoder = nn.Linear(cfg['panel_encoding_size'], self.rotation_size + self.translation_size)
 
     def forward_encode(self, positions_batch):
         return self.feature_extractor(positions_batch)[0]
@@ -110,20 +104,19 @@ class GarmentFullPattern3D(BaseModule):
         panel_encodings = self.pattern_decoder(garment_encodings, self.max_pattern_size)
         return panel_encodings.contiguous().view(-1, panel_encodings.shape[-1])
 
+    def _as_pattern(self, flat, last_dims):
+        """[B * panels, ...] rows of a decoder -> [B, panels, *last_dims, -1] (views of ONE tensor per decoder, as in the reference)"""
+        return flat.contiguous().view(-1, self.max_pattern_size, *last_dims, flat.shape[-1])
+
     def forward_panel_decode(self, flat_panel_encodings, batch_size):
-        flat_panels = self.panel_decoder(flat_panel_encodings, self.max_panel_len)
-        flat_placement = ops.linear(flat_panel_encodings, self.placement_decoder.weight,
-                                    self.placement_decoder.bias)
-        flat_rotations = flat_placement[:, :self.rotation_size]
-        flat_translations = flat_placement[:, self.rotation_size:]
-        panel_predictions = flat_panels.contiguous().view(batch_size, self.max_pattern_size, self.max_panel_len, -1)
-        stitch_tags = panel_predictions[:, :, :, self.panel_elem_len:-1]
-        free_edge_class = panel_predictions[:, :, :, -1]
-        outlines = panel_predictions[:, :, :, :self.panel_elem_len]
-        rotations = flat_rotations.contiguous().view(batch_size, self.max_pattern_size, -1)
-        translations = flat_translations.contiguous().view(batch_size, self.max_pattern_size, -1)
-        return {'outlines': outlines, 'rotations': rotations, 'translations': translations,
-                'stitch_tags': stitch_tags, 'free_edges_mask': free_edge_class}
+        """nn/nets.py:143-169: per panel the edge sequence [edges][outline | stitch tag | free-edge logit] and the placement
+        [rotation | translation]; the output dict slices those two tensors."""
+        edges = self._as_pattern(self.panel_decoder(flat_panel_encodings, self.max_panel_len), (self.max_panel_len,))
+        place = self._as_pattern(ops.linear(flat_panel_encodings, self.placement_decoder.weight, self.placement_decoder.bias), ())
+        assert edges.shape[0] == batch_size
+        e, r = self.panel_elem_len, self.rotation_size
+        return {'outlines': edges[..., :e], 'rotations': place[..., :r], 'translations': place[..., r:],
+                'stitch_tags': edges[..., e:-1], 'free_edges_mask': edges[..., -1]}
 
     def forward_decode(self, garment_encodings):
         flat_panel_encodings = self.forward_pattern_decode(garment_encodings)

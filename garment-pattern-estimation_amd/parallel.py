@@ -25,7 +25,10 @@ class DistributedHotPath(nn.Module):
     a bucket has its gradient, the bucket's slice leaves for the all-reduce.  The arena gradient buffer must be zero when
     a backward pass starts (FusedAdam.step clears it; otherwise call `arena.zero_grad()`)."""
 
-    def __init__(self, module, device_ids=None, bucket_bytes=8 << 20, process_group=None, arena=None):
+    def __init__(self, module, device_ids=None, bucket_bytes=8 << 20, process_group=None, arena=None, reserve_cus=None):
+        """reserve_cus: compute units left out of every persistent launch of this process while the model trains (room for the
+        collective's kernels under the fused edge kernels: include/gpe_hip.h gpe_reserve_cus_set).  None = 16 when the world has
+        more than one rank (two CUs per XCD: measured cost at N = 1, cfg 2: profiles/r06_z_reserved_cus.md), else 0."""
         super().__init__()
         self.module = module
         self.device_ids = list(device_ids) if device_ids is not None else []
@@ -54,6 +57,12 @@ class DistributedHotPath(nn.Module):
                 p.register_post_accumulate_grad_hook(lambda _p, i=i: self._on_hook(_p, i))
         self._exposed = []
         self._reset()
+        if reserve_cus is None:
+            reserve_cus = 16 if self.world > 1 else 0
+        self.reserved_cus = int(reserve_cus)
+        if torch.cuda.is_available():
+            from . import _lib
+            _lib.set_reserved_cus(self.reserved_cus)
 
     def forward(self, *args, **kwargs):
         return self.module(*args, **kwargs)

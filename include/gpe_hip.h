@@ -40,6 +40,13 @@ int gpe_abi_version(void);
  * bit 512, which only makes gpe_edge_lazy_dz3_ok answer 0 — the eager in-place dz3 pass, same results to rounding) */
 int gpe_debug_set(int flags);
 int gpe_debug_get(void);
+/* Multi-GPU: leave n compute units (0 .. 192; use a multiple of 8 = whole CUs per XCD, which keeps the cloud -> XCD pinning on) out
+ * of every persistent launch.  The fused edge kernels, the reduce-GEMMs and the persistent LSTM size their grids to "one workgroup
+ * per CU" and hold 100 - 160 KB of LDS each for the whole launch: with nothing reserved, a collective's kernel queued on another
+ * stream (RCCL's all-reduce of a gradient bucket, launched from inside backward: garment-pattern-estimation_amd/parallel.py) only
+ * gets onto the chip when one of them retires — the "overlap" degenerates into waiting at kernel boundaries.  Process-global like the
+ * arithmetic mode; returns the previous reservation, -22 for a bad n. */
+int gpe_reserve_cus_set(int n);
 /* arithmetic of the fused per-edge GEMMs (gpe_edge_mlp_fwd / gpe_edge_mlp_bwd / gpe_edge_redgemm):
  *   0 = "f32"    exact fp32 matrix instruction (v_mfma_f32_16x16x4_f32)
  *   1 = "bf16x3" split-bf16: every fp32 operand x = hi + lo (two bf16), a*b ~= ah*bh + ah*bl + al*bh on the bf16 matrix

@@ -20,7 +20,7 @@ def test_header_declares_expected_surface():
     for name, (res, args) in sigs.items():
         if name in ('gpe_abi_version', 'gpe_packed_size', 'gpe_packed_gates_size', 'gpe_redgemm_ws',
                     'gpe_stats_blocks', 'gpe_point_sums_blocks', 'gpe_debug_set', 'gpe_math_set', 'gpe_math_get',
-                    'gpe_attn_pool_ws', 'gpe_packed_ngates_size', 'gpe_rnn_seq_bwd_ws', 'gpe_rnn_seq_fwd_ws', 'gpe_debug_get', 'gpe_f16x3_min_rows',
+                    'gpe_attn_pool_ws', 'gpe_packed_ngates_size', 'gpe_rnn_seq_bwd_ws', 'gpe_rnn_seq_fwd_ws', 'gpe_debug_get', 'gpe_reserve_cus_set', 'gpe_f16x3_min_rows',
                     'gpe_f16x3_min_rows_set', 'gpe_edge_ws_bytes', 'gpe_knn_ws_bytes', 'gpe_packed_planes_size', 'gpe_edge_lazy_dz3_ok'):
             continue
         assert res == 'i' and args[-1] == 'p', name
@@ -61,6 +61,15 @@ def test_host_only_queries():
     assert l.gpe_stats_blocks() > 0 and l.gpe_point_sums_blocks() > 0
     assert l.gpe_redgemm_ws(200, 200) > 200 * 200
     assert l.gpe_redgemm_ws(1000, 250) > 1000 * 250
+
+
+def test_cu_reservation_is_host_only():
+    """gpe_reserve_cus_set (round 6): compute units left out of every persistent launch for a concurrent collective; host-only state."""
+    l = _lib.lib()
+    assert l.gpe_reserve_cus_set(16) == 0 and l.gpe_reserve_cus_set(0) == 16
+    assert l.gpe_reserve_cus_set(-1) == -22 and l.gpe_reserve_cus_set(500) == -22
+    import gpe_amd
+    assert gpe_amd.set_reserved_cus(8) == 0 and gpe_amd.set_reserved_cus(0) == 8
 
 
 def test_bad_arguments_are_rejected_without_a_gpu():
