@@ -417,7 +417,9 @@ long gpe_gemm_x6_red_ws(int Mg, int Ng);
 int gpe_gemm_x6_redgemm(const GpeRows& u, const GpeRows& v, const float* v_shift, long rows, int Mg, int Ng, float* part, bool want_cs,
                         int* nsplit, int* MgPad, int* NgPad, double** part_cs, hipStream_t s)
 {
-    if (rows < 512 || rows >= (1L << 31) || Mg < 48 || Ng < 48 || 2.0 * rows * Mg * Ng < 2.5e8) return 0;
+    // also the row-poor products (32 .. 736 rows: the exact kernels run those on ONE workgroup per column block — 39 - 53 us for
+    // 2 - 90 MFLOP): here they are a handful of 128 x 128 blocks of one to six steps
+    if (rows < 32 || rows >= (1L << 31) || Mg < 48 || Ng < 48 || 2.0 * rows * Mg * Ng < 2.0e6) return 0;
     if (!gx_rows16(u, Mg) || !gx_rows16(v, Ng)) return 0;
     const int mb = gpe_cdiv(Mg, GX_B), nb = gpe_cdiv(Ng, GX_B);
     int S = gpe_num_cus() / (mb * nb);

@@ -17,6 +17,7 @@
 #include <stdlib.h>
 
 extern "C" int gpe_math_get(void);
+extern "C" int gpe_debug_get(void);
 extern "C" long gpe_packed_size(int N, int K);
 
 // gpe_rnn_persist.hip: the whole stack as ONE persistent launch (LSTM, <= 256 units, one workgroup per CU); 1 = launched,
@@ -580,17 +581,39 @@ struct WvBwdCell {
     int nseg_mask;                                 // bit s: segment s present
 };
 // nz = K-slab GROUPS of the launch (partials per segment); a workgroup multiplies `jslabs` consecutive slabs of its group
-struct WvBwdParams { int Bn, H, K, Kpad_n, nz, jslabs, ncell; WvBwdCell cell[WV_MAXCELL]; };
+// fuse (LSTM): the workgroup that completes an output block — the last of the block's split-K partials to arrive, by a counter per
+// (cell, row tile, column block) at cnt — runs the pointwise cell backward of that block itself (no second launch per diagonal);
+// Hp = row pitch of the partial images (H rounded up to 4: 16-byte write-through stores)
+struct WvBwdParams { int Bn, H, K, Kpad_n, nz, jslabs, ncell, fuse, Hp; unsigned* cnt; WvBwdCell cell[WV_MAXCELL]; };
 
 // grid (row tiles, cdiv(H, 64), ncell * 2 * nz): block z -> (cell, segment, K slab)
 // (The same products on the fp16 pipe were built and measured in round 4 — dG rows scaled by a per-cell amax word that the
 // pointwise kernel filled by atomicMax, transposed plane packs — and dropped: gpe_rnn_seq_bwd 1.00 -> 1.09 ms per step at cfg 2,
 // the atomics + the word memset + the split of 16 short slabs per workgroup cost more than the MFMAs they replace;
 // profiles/r04_e_recurrences.md.)
+// pointwise LSTM cell backward of one element (shared by the stand-alone kernel and the fused epilogue)
+__device__ __forceinline__ void wv_lstm_cell_bwd(const WvBwdCell& c, int H, long b, int u, long e, float dh)
+{
+    const float* sv = c.saved + b * 4 * H;
+    float* gx = c.dgx + b * c.dg_stride;
+    const float ig = sv[u], fg = sv[H + u], gg = sv[2 * H + u], og = sv[3 * H + u];
+    const float tc = tanhf(c.c[e]);
+    float dc = dh * og * (1.f - tc * tc);
+    if (c.carry_in) dc += c.carry_in[e];
+    gx[u] = dc * gg * ig * (1.f - ig);
+    gx[H + u] = dc * c.c_prev[e] * fg * (1.f - fg);
+    gx[2 * H + u] = dc * ig * (1.f - gg * gg);
+    gx[3 * H + u] = dh * tc * og * (1.f - og);
+    c.carry_out[e] = dc * fg;
+}
+
+typedef unsigned wv_st4 __attribute__((ext_vector_type(4)));
+
 template <int KS>
 __global__ __launch_bounds__(256) void gpe_rnn_wave_splitk_kernel(WvBwdParams p)
 {
     extern __shared__ __align__(16) float smem[];
+    __shared__ unsigned last_sh;
     constexpr int NT = 4;
     const int lda = KS + 4;
     constexpr int ldc = 16 * NT + 4;
@@ -601,59 +624,125 @@ __global__ __launch_bounds__(256) void gpe_rnn_wave_splitk_kernel(WvBwdParams p)
     const int ci = zz / (2 * p.nz), rem = zz - ci * 2 * p.nz;
     const int seg = rem / p.nz, z = rem - seg * p.nz;
     const WvBwdCell& c = p.cell[ci];
-    if (!((c.nseg_mask >> seg) & 1)) return;
+    const int nsegs = (c.nseg_mask & 1) + ((c.nseg_mask >> 1) & 1);
+    const bool present = (c.nseg_mask >> seg) & 1;
+    // fused: a cell without any product (the top layer's last step) is finished by the workgroups of (segment 0, slab group 0)
+    if (!present && !(p.fuse && nsegs == 0 && seg == 0 && z == 0)) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 15, g = lane >> 4;
     const int row0 = blockIdx.x * RG_BM;
     const int rv = (p.Bn - row0 < RG_BM) ? (p.Bn - row0) : RG_BM;
     const int n0 = blockIdx.y * (16 * NT);
-    f32x4 acc[NT];
+    const int ncols = (p.H - n0 < 16 * NT) ? (p.H - n0) : 16 * NT;
+    const int Hp = p.fuse ? p.Hp : p.H;
+    if (present) {
+        f32x4 acc[NT];
 #pragma unroll
-    for (int n = 0; n < NT; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const bool split = rv <= 32;
-    // this workgroup's slabs ks = (z * jslabs + i) * KS, i < jslabs, while ks < K: the next slab's loads stay in flight
-    // under the current slab's MFMAs (same pipeline as the forward)
-    {
-        const int ks0 = z * p.jslabs * KS;
-        int njobs = (p.K - ks0 + KS - 1) / KS;
-        if (njobs > p.jslabs) njobs = p.jslabs;
-        WvRegs<NT, KS> R;
-        auto job_fetch = [&](int i) {
-            const int ks = ks0 + i * KS;
-            wv_fetch<NT, KS>(R, c.a[seg] + ks, c.as[seg], c.w[seg] + (long)(ks >> 4) * 4 * p.Kpad_n * 4, p.K - ks, p.Kpad_n, row0, rv,
-                             n0, 0);
-        };
-        job_fetch(0);
-        for (int i = 0; i < njobs; ++i) {
-            const int ks = ks0 + i * KS;
-            const int kslab = (p.K - ks < KS) ? (p.K - ks) : KS;
-            __syncthreads();
-            wv_commit<NT, KS>(R, p.K - ks, p.Kpad_n, rv, n0, 0, As, Ws, lda);
-            __syncthreads();
-            job_fetch(i + 1 < njobs ? i + 1 : i);
-            wv_mma<NT>(As, Ws, lda, (kslab + 15) & ~15, acc, split);
+        for (int n = 0; n < NT; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const bool split = rv <= 32;
+        // this workgroup's slabs ks = (z * jslabs + i) * KS, i < jslabs, while ks < K: the next slab's loads stay in flight
+        // under the current slab's MFMAs (same pipeline as the forward)
+        {
+            const int ks0 = z * p.jslabs * KS;
+            int njobs = (p.K - ks0 + KS - 1) / KS;
+            if (njobs > p.jslabs) njobs = p.jslabs;
+            WvRegs<NT, KS> R;
+            auto job_fetch = [&](int i) {
+                const int ks = ks0 + i * KS;
+                wv_fetch<NT, KS>(R, c.a[seg] + ks, c.as[seg], c.w[seg] + (long)(ks >> 4) * 4 * p.Kpad_n * 4, p.K - ks, p.Kpad_n, row0, rv,
+                                 n0, 0);
+            };
+            job_fetch(0);
+            for (int i = 0; i < njobs; ++i) {
+                const int ks = ks0 + i * KS;
+                const int kslab = (p.K - ks < KS) ? (p.K - ks) : KS;
+                __syncthreads();
+                wv_commit<NT, KS>(R, p.K - ks, p.Kpad_n, rv, n0, 0, As, Ws, lda);
+                __syncthreads();
+                job_fetch(i + 1 < njobs ? i + 1 : i);
+                wv_mma<NT>(As, Ws, lda, (kslab + 15) & ~15, acc, split);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Cs[(16 * wave + 4 * g + r) * ldc + 16 * n + j] = acc[n][r];
+        __syncthreads();
+        const int cq = lane << 2;
+        float* dst0 = c.part + ((long)(seg * p.nz + z) * p.Bn) * Hp;
+        if (p.fuse) {
+            // write-through (sc1) 16-byte stores: the block's last arriver reads them inside this launch.  Hp is a multiple of 4, so
+            // a quad that starts inside the row may run into its pad columns
+            if (cq < ((ncols + 3) & ~3)) {
+                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(dst0, 0, (unsigned)((long)p.Bn * Hp * 4), 0x00020000);
+                for (int r = wave; r < rv; r += 4) {
+                    float4 v = ld4(&Cs[r * ldc + cq]);
+                    if (split) {
+                        const float4 v2 = ld4(&Cs[(r + 32) * ldc + cq]);
+                        v.x += v2.x; v.y += v2.y; v.z += v2.z; v.w += v2.w;
+                    }
+                    const wv_st4 o = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
+                    __builtin_amdgcn_raw_buffer_store_b128(o, rs, (int)(((long)(row0 + r) * Hp + n0 + cq) * 4), 0, 16);
+                }
+            }
+        } else if (cq < ncols) {
+            for (int r = wave; r < rv; r += 4) {
+                float4 v = ld4(&Cs[r * ldc + cq]);
+                if (split) {
+                    const float4 v2 = ld4(&Cs[(r + 32) * ldc + cq]);
+                    v.x += v2.x; v.y += v2.y; v.z += v2.z; v.w += v2.w;
+                }
+                float* dst = dst0 + (long)(row0 + r) * p.H + n0 + cq;
+                const float o[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int t = 0; t < 4; ++t) if (cq + t < ncols) dst[t] = o[t];
+            }
         }
     }
-    __syncthreads();
+    if (!p.fuse) return;
+    // ---- fused cell backward: count this workgroup in; the block's last arriver owns the pointwise pass (MI355X_MICROARCH.md
+    // "splitk-seam": sc1 partial stores, every storing wave drains, ONE relaxed agent-scope ticket, sc1 partial loads) ----
+    const int nparts = nsegs * p.nz;
+    if (nparts > 1) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0)
+            last_sh = __hip_atomic_fetch_add(p.cnt + ((long)ci * gridDim.x + blockIdx.x) * gridDim.y + blockIdx.y, 1u, __ATOMIC_RELAXED,
+                                             __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if (last_sh != (unsigned)(nparts - 1)) return;
+    } else if (nparts == 1) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(c.part, 0, (unsigned)((long)2 * p.nz * p.Bn * Hp * 4), 0x00020000);
+    // 64 rows x 16 column quads; a thread: row tid / 16 + 16 it, quad tid % 16
+    const int q4 = (tid & 15) << 2;
+    if (q4 < ncols) {
 #pragma unroll
-    for (int n = 0; n < NT; ++n)
+        for (int it = 0; it < RG_BM / 16; ++it) {
+            const int r = (tid >> 4) + 16 * it;
+            if (r >= rv) break;
+            const long b = row0 + r;
+            float dh4[4] = {0.f, 0.f, 0.f, 0.f};
+            for (int s = 0; s < 2; ++s)
+                if ((c.nseg_mask >> s) & 1)
+                    for (int zq = 0; zq < p.nz; ++zq) {
+                        const wv_st4 v = __builtin_amdgcn_raw_buffer_load_b128(rp, (int)((((long)(s * p.nz + zq) * p.Bn + b) * Hp + n0 + q4) * 4), 0, 16);
+                        dh4[0] += __uint_as_float(v[0]); dh4[1] += __uint_as_float(v[1]);
+                        dh4[2] += __uint_as_float(v[2]); dh4[3] += __uint_as_float(v[3]);
+                    }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) Cs[(16 * wave + 4 * g + r) * ldc + 16 * n + j] = acc[n][r];
-    __syncthreads();
-    const int ncols = (p.H - n0 < 16 * NT) ? (p.H - n0) : 16 * NT;
-    const int cq = lane << 2;
-    if (cq < ncols) {
-        float* dst0 = c.part + ((long)(seg * p.nz + z) * p.Bn) * p.H;
-        for (int r = wave; r < rv; r += 4) {
-            float4 v = ld4(&Cs[r * ldc + cq]);
-            if (split) {
-                const float4 v2 = ld4(&Cs[(r + 32) * ldc + cq]);
-                v.x += v2.x; v.y += v2.y; v.z += v2.z; v.w += v2.w;
+            for (int t = 0; t < 4; ++t) {
+                const int u = n0 + q4 + t;
+                if (u >= p.H) break;
+                const long e = b * p.H + u;
+                float dh = dh4[t];
+                if (c.dh_out) dh += c.dh_out[b * c.dho_stride + u];
+                if (c.dh_extra) dh += c.dh_extra[e];
+                wv_lstm_cell_bwd(c, p.H, b, u, e, dh);
             }
-            float* dst = dst0 + (long)(row0 + r) * p.H + n0 + cq;
-            const float o[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-            for (int t = 0; t < 4; ++t) if (cq + t < ncols) dst[t] = o[t];
         }
     }
 }
@@ -675,15 +764,7 @@ __global__ void gpe_rnn_wave_cell_bwd_kernel(WvBwdParams p)
     const float* sv = c.saved + b * 4 * H;
     float* gx = c.dgx + b * c.dg_stride;
     if (G == 4) {
-        const float ig = sv[u], fg = sv[H + u], gg = sv[2 * H + u], og = sv[3 * H + u];
-        const float tc = tanhf(c.c[e]);
-        float dc = dh * og * (1.f - tc * tc);
-        if (c.carry_in) dc += c.carry_in[e];
-        gx[u] = dc * gg * ig * (1.f - ig);
-        gx[H + u] = dc * c.c_prev[e] * fg * (1.f - fg);
-        gx[2 * H + u] = dc * ig * (1.f - gg * gg);
-        gx[3 * H + u] = dh * tc * og * (1.f - og);
-        c.carry_out[e] = dc * fg;
+        wv_lstm_cell_bwd(c, H, b, u, e, dh);
     } else {
         if (c.carry_in) dh += c.carry_in[e];
         const float rg = sv[u], zg = sv[H + u], ng = sv[2 * H + u], hn = sv[3 * H + u];
@@ -709,7 +790,9 @@ extern "C" long gpe_rnn_seq_bwd_ws(int gates, int L, int T, int Bn, int H)
     if ((gates != 3 && gates != 4) || L <= 0 || T <= 0 || Bn <= 0 || H <= 0) return GPE_EINVAL;
     const int nz = gpe_cdiv(gates * H, 128);              // sized for the narrow slab (the wide one needs half)
     const int ncell = L < WV_MAXCELL ? L : WV_MAXCELL;
-    const long diag = (long)ncell * 2 * nz * Bn * H;
+    // partial images (row pitch H rounded up to 4: the fused kernel stores them in 16-byte pieces) + one arrival counter per
+    // (diagonal, cell, row tile, column block) of the fused split-K + cell-backward launches
+    const long diag = (long)ncell * 2 * nz * Bn * gpe_round_up(H, 4) + (long)(T + L) * WV_MAXCELL * gpe_cdiv(Bn, RG_BM) * gpe_cdiv(H, 64) + 64;
     const long pers = gpe_rnn_persist_ws_bytes(gates, L, T, Bn, H, 1) / 4;     // arrival counters of the persistent kernel
     return diag > pers ? diag : pers;
 }
@@ -751,20 +834,37 @@ extern "C" int gpe_rnn_seq_bwd(int gates, int L, int T, int Bn, int H, const flo
     const int nz = gpe_cdiv(gpe_cdiv(K, KS), jslabs);
     const long BH = (long)Bn * H;
     hipStream_t s = (hipStream_t)stream;
+    // LSTM, gpe_debug_set(65536): the pointwise cell backward runs in the split-K launch itself (the last partial of an output block
+    // to arrive does it): one launch per diagonal instead of two.  Built, bit-compatible (same tests), and
+    // MEASURED SLOWER — cfg 2, one session, twice each: gpe_rnn_seq_bwd 0.838 ms with two launches, 1.115 / 1.117 ms fused (step
+    // 9.15 -> 9.46 / 9.50 ms): the block's last arriver runs drain + ticket + write-through partial reads + a latency-bound
+    // 64 x 64 pointwise pass on ONE workgroup per block at the tail of every diagonal, which costs more than the 9 us memory-parallel
+    // launch it replaces.  Off by default.
+    const int fuse = (G == 4) && L <= WV_MAXCELL && (gpe_debug_get() & 65536);
+    const int Hp = fuse ? gpe_round_up(H, 4) : H;
+    const long BHp = (long)Bn * Hp;
+    const int gxr = gpe_cdiv(Bn, RG_BM), gyc = gpe_cdiv(H, 64);
+    const int ncell_max = L < WV_MAXCELL ? L : WV_MAXCELL;
+    unsigned* cnt_base = reinterpret_cast<unsigned*>(part + (((long)ncell_max * 2 * nz * BHp + 15) & ~15L));
+    const long cnt_per_launch = (long)WV_MAXCELL * gxr * gyc;
+    int launch_no = 0;
+    if (fuse && hipMemsetAsync(cnt_base, 0, (size_t)(T + L) * cnt_per_launch * sizeof(unsigned), s) != hipSuccess) return GPE_ELAUNCH;
     const size_t lds = ((size_t)RG_BM * (KS + 4) + (size_t)KS * 64) * sizeof(float);
-    if (KS == 256) GPE_ENSURE_MAX_LDS((gpe_rnn_wave_splitk_kernel<256>));
-    else GPE_ENSURE_MAX_LDS((gpe_rnn_wave_splitk_kernel<128>));
+    if (KS == 256) GPE_ENSURE_MAX_LDS_N((gpe_rnn_wave_splitk_kernel<256>), 160 * 1024 - 64);     // (4 bytes of static __shared__ beside the dynamic image)
+    else GPE_ENSURE_MAX_LDS_N((gpe_rnn_wave_splitk_kernel<128>), 160 * 1024 - 64);
     for (int d = T + L - 2; d >= 0; --d) {
         const int l_lo = (d - (T - 1) > 0) ? d - (T - 1) : 0;
         const int l_hi = (d < L - 1) ? d : L - 1;
         for (int l0 = l_lo; l0 <= l_hi; l0 += WV_MAXCELL) {
             WvBwdParams p = {};
             p.Bn = Bn; p.H = H; p.K = K; p.Kpad_n = gpe_round_up(H, 16); p.nz = nz; p.jslabs = jslabs;
+            p.fuse = fuse; p.Hp = Hp; p.cnt = cnt_base + (long)launch_no * cnt_per_launch;
+            ++launch_no;
             int n = 0, any_seg = 0;
             for (int l = l0; l <= l_hi && n < WV_MAXCELL; ++l, ++n) {
                 const int t = d - l;
                 WvBwdCell& c = p.cell[n];
-                c.part = part + (long)n * 2 * nz * BH;
+                c.part = part + (long)n * 2 * nz * BHp;
                 if (t < T - 1) {                 // recurrent path: dGh_{l,t+1} . W_hh_l
                     c.a[0] = dgh + l * dg_sl + (long)(t + 1) * dg_st; c.as[0] = dg_sb; c.w[0] = (const float*)whh_t[l];
                     c.nseg_mask |= 1;
@@ -793,12 +893,13 @@ extern "C" int gpe_rnn_seq_bwd(int gates, int L, int T, int Bn, int H, const flo
                 c.dg_stride = dg_sb;
             }
             p.ncell = n;
-            if (any_seg) {
+            if (any_seg || fuse) {
                 const dim3 grid(gpe_cdiv(Bn, RG_BM), gpe_cdiv(H, 64), n * 2 * nz);
                 if (KS == 256) hipLaunchKernelGGL(gpe_rnn_wave_splitk_kernel<256>, grid, dim3(256), lds, s, p);
                 else hipLaunchKernelGGL(gpe_rnn_wave_splitk_kernel<128>, grid, dim3(256), lds, s, p);
                 GPE_CHECK_LAUNCH();
             }
+            if (fuse) continue;
             if (G == 4)
                 hipLaunchKernelGGL((gpe_rnn_wave_cell_bwd_kernel<4>), dim3(gpe_cdiv(BH, 256), n), dim3(256), 0, s, p);
             else

@@ -733,6 +733,36 @@ def test_persistent_lstm_stack_matches_the_diagonal_launches(gpe, Bn, In, Hh, T,
             gpe.set_math(prev)
 
 
+def test_fused_cell_backward_matches_the_two_launch_diagonals(gpe):
+    """gpe_debug_set(65536): the LSTM cell backward inside the split-K launch (last-arriver ticket per output block).  Measured slower
+    than the two launches and off by default (csrc/gpe_rnn_wave.hip); kept correct: same gradients as the default path to rounding."""
+    from gpe_amd import ops, net_blocks
+    from gpe_amd import _lib as Lb
+    Bn, In, Hh, T, L = 736, 250, 250, 14, 3
+    torch.manual_seed(5)
+    rnn = torch.nn.LSTM(In, Hh, L, batch_first=True).cuda()
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(Bn, In, generator=g).cuda()
+    h0 = (torch.randn(L, Bn, Hh, generator=g) * 0.3).cuda()
+    c0 = (torch.randn(L, Bn, Hh, generator=g) * 0.3).cuda()
+    wgt = torch.randn(Bn, T, Hh, generator=g).cuda()
+    params = net_blocks._rnn_params(rnn, L)
+    outs = []
+    try:
+        for dbg in (0, 65536):
+            Lb.query('gpe_debug_set', dbg)
+            for p in rnn.parameters():
+                p.grad = None
+            xd = x.clone().requires_grad_()
+            top, hN, cN = ops.rnn_stack(xd, h0, c0, T, L, 'lstm', params, want_state=True)
+            ((top * wgt).sum() + hN.sum() * 0.5 + cN.sum() * 0.25).backward()
+            outs.append([xd.grad.clone()] + [p.grad.clone() for p in rnn.parameters()])
+    finally:
+        Lb.query('gpe_debug_set', 0)
+    for a, b in zip(*outs):
+        assert relerr(a, b) < 2e-6
+
+
 def test_rnn_large_start_state_takes_the_exact_kernels(gpe):
     """ops.rnn_stack in f16x3 mode with a caller-supplied start state of magnitude >= 16: the fp16-pipe kernels scale the
     state rows by 2^12 and would overflow — rnn_stack reads the largest |h0| and runs the exact fp32 kernels for that call; results
