@@ -54,7 +54,7 @@ while [ $# -gt 0 ]; do
       # (-rP: the captured output of passing tests — the ReLU / max-winner decision counts of tests/relu_align.py and the measured
       # gradient errors are printed there; the summary keeps those lines, the full log stays in gpurun_out/)
       timeout 1700 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider -rPs > $OUT/${TAG}_gpu_tests_full.txt 2>&1
-      ( grep -E "ReLU decisions|binding output bar|the 1e-4 bar alone|un-aligned|self-difference|worst parameter-gradient|full size:|edgeconv .* err|^SKIPPED|^FAILED|^ERROR| passed| failed" $OUT/${TAG}_gpu_tests_full.txt | sort -u | head -400 ) > $OUT/${TAG}_gpu_tests.txt
+      ( grep -E "ReLU decisions|binding output bar|the 1e-4 bar alone|un-aligned|self-difference|worst parameter-gradient|full size:|edgeconv .* err|^SKIPPED|^FAILED|^ERROR| passed| failed" $OUT/${TAG}_gpu_tests_full.txt | sort -u | head -900 ) > $OUT/${TAG}_gpu_tests.txt
       tail -3 $OUT/${TAG}_gpu_tests_full.txt; grep -E "^(FAILED|ERROR)" $OUT/${TAG}_gpu_tests_full.txt | head -20 ;;
     ab)
       TAG=$1; VAR=$2; VALS=$3; shift 3
