@@ -33,6 +33,13 @@ int gpe_rnn_persist_bwd(int L, int T, int Bn, int H, const float* dtop, long dt_
                         float* carry, bool h3, const void* const* whh_amax, const void* const* wih_amax, void* ws, long ws_bytes,
                         hipStream_t s);
 
+// gpe_rnn_persist_mt.hip: the same for stacks with several row tiles per workgroup (f16x3 only; waves own row tiles)
+long gpe_rnn_pm_ws_bytes(int gates, int L, int T, int Bn, int H, int bwd);
+int gpe_rnn_pm_fwd(int L, int T, int Bn, int H, const float* xproj0, long xp0_sb, long xp0_st, const void* const* whh,
+                   const void* const* wih, const void* const* bias, float* hs, long hs_sl, long hs_sb, long hs_st, float* cs,
+                   long cs_sl, long cs_st, float* saved, long sv_sl, long sv_st, const void* const* whh_amax,
+                   const void* const* wih_amax, void* ws, long ws_bytes, hipStream_t s);
+
 #define WV_MAXCELL 4
 
 struct WvFwdCell {
@@ -517,6 +524,11 @@ extern "C" int gpe_rnn_seq_fwd(int gates, int L, int T, int Bn, int H, const flo
                                            hs_sb, hs_st, cs, cs_sl, cs_st, saved, sv_sl, sv_st, h3, whh_amax, wih_amax, ws, ws_bytes,
                                            (hipStream_t)stream);
         if (rc != 0) return rc < 0 ? rc : GPE_OK;
+        if (h3) {
+            const int rc2 = gpe_rnn_pm_fwd(L, T, Bn, H, xproj0, xp0_sb, xp0_st, whh_pl, wih_pl, bias, hs, hs_sl, hs_sb, hs_st, cs, cs_sl,
+                                           cs_st, saved, sv_sl, sv_st, whh_amax, wih_amax, ws, ws_bytes, (hipStream_t)stream);
+            if (rc2 != 0) return rc2 < 0 ? rc2 : GPE_OK;
+        }
     }
     for (int d = 0; d <= T + L - 2; ++d) {
         const int l_lo = (d - (T - 1) > 0) ? d - (T - 1) : 0;
@@ -782,7 +794,8 @@ __global__ void gpe_rnn_wave_cell_bwd_kernel(WvBwdParams p)
 extern "C" long gpe_rnn_seq_fwd_ws(int gates, int L, int T, int Bn, int H)
 {
     if ((gates != 3 && gates != 4) || L <= 0 || T <= 0 || Bn <= 0 || H <= 0) return GPE_EINVAL;
-    return gpe_rnn_persist_ws_bytes(gates, L, T, Bn, H, 0);
+    const long a = gpe_rnn_persist_ws_bytes(gates, L, T, Bn, H, 0), b = gpe_rnn_pm_ws_bytes(gates, L, T, Bn, H, 0);
+    return a > b ? a : b;
 }
 
 extern "C" long gpe_rnn_seq_bwd_ws(int gates, int L, int T, int Bn, int H)
