@@ -53,7 +53,7 @@ struct PmFwdParams {
     unsigned long long* trace;               // measurement aid (gpe_debug_set 8192): [grid][4 waves][T * PM_MAXQ][8] stamps of lane 0, else NULL
 };
 #ifndef PM_NW
-#define PM_NW 8                   // waves per workgroup (two per SIMD: one wave's cell update and waits under the other's products)
+#define PM_NW 4                   // waves per workgroup (8 = two per SIMD was measured: no faster — what the two waves of a SIMD issue adds up)
 #endif
 #define PM_MAXQ (16 / PM_NW)      // row tiles a wave may own (PM_NW * PM_MAXQ = 16 tiles per workgroup)
 // timing probes of a measurement build (wrong numbers): 1 no payload loads after the first item, 2 no plain stores, 4 no products,
@@ -140,23 +140,36 @@ struct PmFwdItem {
 };
 
 // products of k-steps [s_lo, s_hi) of one K segment: A = weight fragments from the LDS slice ([plane][KP / 8][64 columns][8 halves]),
-// B = the loaded planes
+// B = the loaded planes.  The eight fragments of a k-step are read one k-step ahead of their twelve MFMAs (hipcc left alone reads
+// two fragments, waits, multiplies: the LDS latency of every pair was exposed), and consecutive MFMAs go to different accumulators.
 __device__ __forceinline__ void pm_mma(const pm_u32x4 (&bh)[PM_MAXS], const pm_u32x4 (&bl)[PM_MAXS], const char* W, int KP, int s_lo,
                                        int s_hi, int j, int g, f32x4 (&acc)[4])
 {
     const int plane_b = KP * 128;                                   // (KP / 8) groups x 64 columns x 16 bytes
+    const char* w0 = W + (g * 64 + j) * 16;
+    pm_u32x4 wh[2][4], wl[2][4];
+    auto fetch = [&](int s, int buf) {
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            wh[buf][n] = *reinterpret_cast<const pm_u32x4*>(w0 + s * 4096 + 256 * n);
+            wl[buf][n] = *reinterpret_cast<const pm_u32x4*>(w0 + s * 4096 + 256 * n + plane_b);
+        }
+    };
+    if (s_lo < s_hi) fetch(s_lo, 0);
 #pragma unroll
     for (int s = 0; s < PM_MAXS; ++s) {
         if (s >= s_lo && s < s_hi) {
-            const char* wb = W + ((4 * s + g) * 64 + j) * 16;
+            const int buf = (s - s_lo) & 1;
+            if (s + 1 < s_hi) fetch(s + 1, buf ^ 1);
 #pragma unroll
-            for (int n = 0; n < 4; ++n) {
-                const pm_u32x4 wh = *reinterpret_cast<const pm_u32x4*>(wb + 256 * n);
-                const pm_u32x4 wl = *reinterpret_cast<const pm_u32x4*>(wb + 256 * n + plane_b);
-                acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(pm_f16x8, wl), __builtin_bit_cast(pm_f16x8, bh[s]), acc[n], 0, 0, 0);
-                acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(pm_f16x8, wh), __builtin_bit_cast(pm_f16x8, bl[s]), acc[n], 0, 0, 0);
-                acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(pm_f16x8, wh), __builtin_bit_cast(pm_f16x8, bh[s]), acc[n], 0, 0, 0);
-            }
+            for (int n = 0; n < 4; ++n)
+                acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(pm_f16x8, wl[buf][n]), __builtin_bit_cast(pm_f16x8, bh[s]), acc[n], 0, 0, 0);
+#pragma unroll
+            for (int n = 0; n < 4; ++n)
+                acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(pm_f16x8, wh[buf][n]), __builtin_bit_cast(pm_f16x8, bl[s]), acc[n], 0, 0, 0);
+#pragma unroll
+            for (int n = 0; n < 4; ++n)
+                acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(pm_f16x8, wh[buf][n]), __builtin_bit_cast(pm_f16x8, bh[s]), acc[n], 0, 0, 0);
         }
     }
 }

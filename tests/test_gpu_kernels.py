@@ -695,7 +695,8 @@ def test_persistent_lstm_stack_matches_the_diagonal_launches(gpe, Bn, In, Hh, T,
     params = net_blocks._rnn_params(rnn, L)
     plan = ops.PackPlan()
     net_blocks._register_rnn_packs(plan, rnn, L, Hh, G)
-    assert Lb.query('gpe_rnn_seq_fwd_ws', G, L, T, Bn, Hh) == 0 or dbg == 0          # multi-tile stacks need the switch
+    # (dbg != 0: stacks with more row tiles than the chip has room for — the K-split kernels take them only under the switch; in
+    # f16x3 mode their FORWARD runs in gpe_rnn_persist_mt.hip whatever the switch says: test_multi_tile_persistent_lstm_forward)
     noise = torch.randn(1 << 22, device='cuda')
     side = torch.cuda.Stream()
 
@@ -731,6 +732,65 @@ def test_persistent_lstm_stack_matches_the_diagonal_launches(gpe, Bn, In, Hh, T,
         finally:
             Lb.query('gpe_debug_set', 0)
             gpe.set_math(prev)
+
+
+@pytest.mark.parametrize('Bn,In,Hh,T,L,seq,reserve', [(736, 250, 250, 14, 3, False, 0), (730, 250, 250, 6, 3, False, 16), (900, 40, 96, 5, 2, True, 0),
+                                                      (1500, 32, 64, 4, 1, False, 0), (2100, 64, 32, 7, 4, True, 0)])
+def test_multi_tile_persistent_lstm_forward(gpe, Bn, In, Hh, T, L, seq, reserve):
+    """csrc/gpe_rnn_persist_mt.hip (round 6): the forward of an LSTM stack whose 16-row tiles outnumber the chip (the 736-row panel
+    decoder) as ONE persistent launch in f16x3 mode — waves own row tiles, state rows published already split into their fp16 terms,
+    one 128-byte line per arrival counter.  (a) Same numbers as the diagonal launches (gpe_debug_set(131072) keeps them) to fp32
+    rounding: outputs, final states and — through the saved gates / cell states the backward reads — every gradient; (b) race-free:
+    repeated runs, alone and beside a second stream's load, are bit-identical; (c) ragged row counts, sequence inputs (a different
+    addend per step), one to four layers, and with CUs held back for a collective."""
+    from gpe_amd import ops, net_blocks
+    from gpe_amd import _lib as Lb
+    torch.manual_seed(Bn + T)
+    rnn = torch.nn.LSTM(In, Hh, L, batch_first=True).cuda()
+    g = torch.Generator().manual_seed(3)
+    x = (torch.randn(Bn, T, In, generator=g) if seq else torch.randn(Bn, In, generator=g)).cuda()
+    h0 = (torch.randn(L, Bn, Hh, generator=g) * 0.3).cuda()
+    c0 = (torch.randn(L, Bn, Hh, generator=g) * 0.3).cuda()
+    wgt = torch.randn(Bn, T, Hh, generator=g).cuda()
+    params = net_blocks._rnn_params(rnn, L)
+    plan = ops.PackPlan()
+    net_blocks._register_rnn_packs(plan, rnn, L, Hh, 4)
+    noise = torch.randn(1 << 22, device='cuda')
+    side = torch.cuda.Stream()
+
+    def run():
+        for p in rnn.parameters():
+            p.grad = None
+        xd = x.clone().requires_grad_()
+        top, hN, cN = ops.rnn_stack(xd, h0, c0, T, L, 'lstm', params, want_state=True, h0_bounded=True)
+        ((top * wgt).sum() + hN.sum() * 0.5 + cN.sum() * 0.25).backward()
+        return [top.detach().clone(), hN.clone(), cN.clone(), xd.grad.clone()] + [p.grad.clone() for p in rnn.parameters()]
+
+    prev = gpe.set_math('f16x3')
+    try:
+        plan.refresh()
+        Lb.query('gpe_reserve_cus_set', reserve)
+        Lb.query('gpe_debug_set', 131072)
+        ref = run()
+        Lb.query('gpe_debug_set', 0)
+        assert Lb.query('gpe_rnn_seq_fwd_ws', 4, L, T, Bn, Hh) > (1 << 20)                # the state planes: this kernel IS eligible
+        first = run()
+        for a, b in zip(first, ref):
+            assert relerr(a, b) < 2e-5
+        assert not torch.equal(first[0], ref[0])                                       # ... and it was another kernel
+        for rep in range(6):
+            if rep % 2:
+                with torch.cuda.stream(side):
+                    for _ in range(8):
+                        noise.mul_(1.0001)
+            again = run()
+            for a, b in zip(again, first):
+                assert torch.equal(a, b), rep
+        torch.cuda.synchronize()
+    finally:
+        Lb.query('gpe_debug_set', 0)
+        Lb.query('gpe_reserve_cus_set', 0)
+        gpe.set_math(prev)
 
 
 def test_fused_cell_backward_matches_the_two_launch_diagonals(gpe):
