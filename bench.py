@@ -71,6 +71,9 @@ def parse():
     ap.add_argument('--no-fast-math-line', action='store_true', help='skip the extra mixed / bf16x3 measurements')
     ap.add_argument('--call-shapes', default=None, metavar='FILE', help='write per-(entry, int args) launch counts and mean durations')
     ap.add_argument('--edge-dbg', type=int, default=int(os.environ.get('GPE_EDGE_DBG', '0')), help='measurement aid: gpe_debug_set flags for the edge kernels (0 = product path)')
+    ap.add_argument('--graph', action='store_true',
+                    help='the timed steps replay ONE captured hipGraph of the step (gpe_amd/graph.py StepGraph: same launches, no Python '
+                         'between them); single GPU only.  The per-kernel timing afterwards runs eager steps')
     ap.add_argument('--f16x3-min-rows', type=int, default=-1, help='measurement aid: override the f16x3 size gate (gpe_f16x3_min_rows_set); -1 = library default')
     ap.add_argument('--torch-adam', action='store_true', help='torch.optim.Adam instead of the fused arena optimizer')
     ap.add_argument('--reserve-cus', type=int, default=-1, help='compute units left out of every persistent launch (room for RCCL under the '
@@ -510,12 +513,24 @@ def main():
             arena.zero_grad()
         return loss
 
+    eager_step = step
+    sg = None
+    if args.graph:
+        if world > 1:
+            raise SystemExit('--graph: single GPU only')
+        from gpe_amd import graph as gpe_graph
+        sg = gpe_graph.StepGraph(lambda f, g: model.loss(wrapped(f, log_step=0, epoch=args.epoch), g, epoch=args.epoch)[0], opt, warmup=2)
+
+        def step(i):
+            torch.manual_seed(i * 131 + rank)
+            return sg.step(feats, gt)
+
     def barrier():
         if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
+    for i in range(max(args.warmup, 4) if args.graph else args.warmup):      # (graph: two eager steps, the capture, one replay)
         step(i)
     barrier()
     t0 = time.perf_counter()
@@ -538,7 +553,7 @@ def main():
         if rank == 0:
             _lib.TIMING = []
         for i in range(nsteps):
-            step(args.warmup + args.steps + i)
+            eager_step(args.warmup + args.steps + i)
         barrier()
         rec, _lib.TIMING = _lib.TIMING, None
     if rank == 0 and rec is not None:
@@ -628,11 +643,11 @@ def main():
             gpe_amd.set_math(mode)
             n_f = max(3, min(args.steps, 10))
             for i in range(2):
-                step(10_000 + i)
+                eager_step(10_000 + i)
             barrier()
             t1 = time.perf_counter()
             for i in range(n_f):
-                step(10_002 + i)
+                eager_step(10_002 + i)
             barrier()
             dt = time.perf_counter() - t1
             if world > 1:
@@ -676,6 +691,7 @@ def main():
                        'exact_f32_value': fast['f32']['value'] if fast and fast.get('f32') else None,
                        'exact_f32_ms': fast['f32']['ms_per_step'] if fast and fast.get('f32') else None,
                        'loss_epoch': args.epoch, 'reserved_cus': wrapped.reserved_cus,
+                       'launch': ('one captured hipGraph per step (StepGraph: %d capture(s), %d replays)' % (sg.captures, sg.replays)) if sg else 'eager (one Python call per launch)',
                        'step': 'fwd + ComposedPatternLoss + bwd' + (' + RCCL grad all-reduce' if world > 1 else '')
                                + (' + Adam (torch)' if args.torch_adam else ' + fused Adam (flat arena)'),
                        'final_loss': final_loss},

@@ -5,7 +5,7 @@
 #include "gpe_common.h"
 #include <math.h>
 
-extern "C" int gpe_abi_version(void) { return 5; }
+extern "C" int gpe_abi_version(void) { return 6; }
 
 // compute units the persistent kernels may fill: the device's count minus the caller's reservation (gpe_reserve_cus_set)
 static int g_reserved_cus = 0;

@@ -735,10 +735,12 @@ extern "C" int gpe_edge_sum_k(const float* a, int lda, long npts, int k, int F, 
 __global__ __launch_bounds__(256) void gpe_adam_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                                                        float* __restrict__ v, long n, float lr_over_bc1, float b1,
                                                        float b2, float eps, float wd, float rsqrt_bc2, float gscale,
-                                                       int zero_grad)
+                                                       int zero_grad, const float* __restrict__ hyper)
 {
     const long i4 = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (i4 >= n) return;
+    // gpe_adam_step_dev: the two step-dependent scalars come from device memory (a captured launch is replayed with new values)
+    if (hyper) { lr_over_bc1 = hyper[0]; rsqrt_bc2 = hyper[1]; }
     if (i4 + 3 < n) {
         float4 pv = *reinterpret_cast<float4*>(p + i4), gv = *reinterpret_cast<float4*>(g + i4);
         float4 mv = *reinterpret_cast<float4*>(m + i4), vv = *reinterpret_cast<float4*>(v + i4);
@@ -774,8 +776,31 @@ extern "C" int gpe_adam_step(float* p, float* g, float* m, float* v, long n, flo
     const float lr_over_bc1 = (float)((double)lr / bc1);
     const float rsqrt_bc2 = (float)(1.0 / sqrt(bc2));
     hipLaunchKernelGGL(gpe_adam_kernel, dim3(gpe_cdiv(gpe_cdiv(n, 4), 256)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n,
-                       lr_over_bc1, beta1, beta2, eps, weight_decay, rsqrt_bc2, gscale, zero_grad);
+                       lr_over_bc1, beta1, beta2, eps, weight_decay, rsqrt_bc2, gscale, zero_grad, (const float*)nullptr);
     GPE_CHECK_LAUNCH();
+    return GPE_OK;
+}
+
+// the same step with its two step-dependent scalars read from DEVICE memory: hyper[0] = lr / (1 - beta1^step),
+// hyper[1] = 1 / sqrt(1 - beta2^step) (gpe_adam_hyper computes them on the host).  For steps replayed from a captured hipGraph,
+// where kernel arguments are frozen (gpe_amd/graph.py).
+extern "C" int gpe_adam_step_dev(float* p, float* g, float* m, float* v, long n, const float* hyper, float beta1, float beta2,
+                                 float eps, float weight_decay, float gscale, int zero_grad, void* stream)
+{
+    if (!p || !g || !m || !v || !hyper || n <= 0 || (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) || (((uintptr_t)hyper) & 3))
+        return GPE_EINVAL;
+    hipLaunchKernelGGL(gpe_adam_kernel, dim3(gpe_cdiv(gpe_cdiv(n, 4), 256)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n,
+                       0.f, beta1, beta2, eps, weight_decay, 1.f, gscale, zero_grad, hyper);
+    GPE_CHECK_LAUNCH();
+    return GPE_OK;
+}
+
+extern "C" int gpe_adam_hyper(float lr, float beta1, float beta2, long step, float* out_host)
+{
+    if (!out_host || step <= 0) return GPE_EINVAL;
+    const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+    out_host[0] = (float)((double)lr / bc1);
+    out_host[1] = (float)(1.0 / sqrt(bc2));
     return GPE_OK;
 }
 

@@ -255,6 +255,9 @@ def _init_tenzor(*shape, device='cpu', init_type=''):
         t = torch.empty(shape)
         nn.init.kaiming_normal_(t)
         return t.to(device)
+    if ops.HOST_DRAWN is not None:
+        # a step driven by graph.StepGraph: a static device buffer, refilled from the same generator in front of every replay
+        return ops.HOST_DRAWN.get(tuple(shape), nn.init.kaiming_normal_)
     up = _StateUploader.get(device)
     buf, ev = up.staging(tuple(shape))
     nn.init.kaiming_normal_(buf)                             # same generator, same element order as torch.empty(shape)

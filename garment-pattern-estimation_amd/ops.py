@@ -598,6 +598,10 @@ segment_mean.pool_mode, segment_max.pool_mode, segment_add.pool_mode = 0, 1, 2
 # EdgeConv layer
 # -------------------------------------------------------------------------------------------------
 _HALF_ACT_GUARD = 'fallback'
+# graph.StepGraph: CAPTURE is the StepGraph whose hipGraph capture is in progress (host reads are impossible then), HOST_DRAWN the
+# provider of host-drawn device tensors (start states, dropout masks) while a StepGraph drives the step — else None
+CAPTURE = None
+HOST_DRAWN = None
 
 
 def set_half_act_guard(mode):
@@ -653,6 +657,8 @@ class HalfActGuard:
         """May the coming forward store the activation in fp16?  Polls the previous step's word without blocking."""
         if _HALF_ACT_GUARD == 'off':
             return True
+        if CAPTURE is not None:                          # no polling inside a capture: the decision as it stands
+            return not self.disabled
         if self._pending is not None and self._pending[1].query():
             v = self._value(self._pending[0])
             self._pending = None
@@ -665,6 +671,9 @@ class HalfActGuard:
         """After the forward launch that filled `word` (int32[1], the activation's amax bits).  'strict': returns False when the
         launch must be repeated with fp32 storage."""
         if _HALF_ACT_GUARD == 'off':
+            return True
+        if CAPTURE is not None:                          # the StepGraph reads this word after every replay
+            CAPTURE.guards.append((self, word))
             return True
         if _HALF_ACT_GUARD == 'strict':
             v = self._value(word.cpu())
@@ -1164,6 +1173,10 @@ def _dropout_mask(T, Bn, H, p, device):
     is [T, Bn, H] (ATen RNN.cpp apply_layer_stack -> dropout -> empty_like(input).bernoulli_(1 - p).div_(1 - p)).  Drawn on the
     CPU generator in that shape — the stream the reference's CPU run consumes, like the random start states — and handed over
     batch-major."""
+    if HOST_DRAWN is not None:
+        def fill(pin):
+            pin.copy_(torch.empty(T, Bn, H).bernoulli_(1 - p).div_(1 - p).transpose(0, 1))
+        return HOST_DRAWN.get((Bn, T, H), fill)
     noise = torch.empty(T, Bn, H).bernoulli_(1 - p).div_(1 - p)
     return noise.transpose(0, 1).contiguous().to(device, non_blocking=True)
 

@@ -178,32 +178,41 @@ class FusedAdam:
         self.steps = [0] * len(self.arena.params)
         self.last_lr = self.lr if schedule is None else schedule.lr(0)
 
-    def step(self, grad_scale=1.0):
+    def _runs(self, live, advance):
+        """Maximal runs of consecutive live arena segments that share one step count -> [(lo, hi, step)].  torch.optim.Adam leaves a
+        parameter alone in a step in which it received no gradient (grad None): no moment decay, no weight decay, no move, no step
+        count.  Same here (normally ONE run = the whole arena; the attention model's unused feature_extractor.lin splits it in
+        two).  advance=False only looks (the step counts a run WOULD take)."""
         a = self.arena
-        lr = self.lr if self.schedule is None else self.schedule.lr(self.t)
-        self.t += 1
-        # torch.optim.Adam leaves a parameter alone in a step in which it received no gradient (grad None): no moment decay,
-        # no weight decay, no move, no step count.  Same here: a launch covers a maximal run of consecutive arena segments that
-        # were touched AND share one step count (normally ONE run = the whole arena; the attention model's unused
-        # feature_extractor.lin splits it in two).  Nothing recorded at all (gradients written by hand into arena.grad) =
-        # everything is live.
-        n = len(a.params)
-        live = a.touched if (a.touched and len(a.touched) < n) else set(range(n))
-        runs, start, cur = [], None, None
-        for i in range(n):
+        runs, start, cur, end = [], None, None, None
+        for i in range(len(a.params)):
             if i in live:
-                self.steps[i] += 1
-                if start is not None and self.steps[i] != cur:
+                st = self.steps[i] + 1
+                if advance:
+                    self.steps[i] = st
+                if start is not None and st != cur:
                     runs.append((start, end, cur))
                     start = None
                 if start is None:
-                    start, cur = a.offsets[i], self.steps[i]
+                    start, cur = a.offsets[i], st
                 end = a.offsets[i] + (a.params[i].numel() + 3) // 4 * 4
             elif start is not None:
                 runs.append((start, end, cur))
                 start = None
         if start is not None:
             runs.append((start, end, cur))
+        return runs
+
+    def _live(self):
+        # nothing recorded at all (gradients written by hand into arena.grad) = everything is live
+        a, n = self.arena, len(self.arena.params)
+        return set(a.touched) if (a.touched and len(a.touched) < n) else set(range(n))
+
+    def step(self, grad_scale=1.0):
+        a = self.arena
+        lr = self.lr if self.schedule is None else self.schedule.lr(self.t)
+        self.t += 1
+        runs = self._runs(self._live(), advance=True)
         for lo, hi, st in runs:
             L.call('gpe_adam_step', a.flat[lo:hi], a.grad[lo:hi], self.m[lo:hi], self.v[lo:hi], hi - lo, float(lr),
                    float(self.betas[0]), float(self.betas[1]), self.eps, self.weight_decay, st, float(grad_scale), 1)
@@ -212,6 +221,34 @@ class FusedAdam:
         self.last_lr = lr
         a.begin_step()
         ops.bump_weights_epoch()       # parameters changed through raw pointers: torch's version counters did not move
+
+    # ---- a step inside a captured hipGraph (graph.StepGraph): kernel arguments are frozen, so the learning rate and the bias
+    # corrections reach the kernel through a two-float device buffer per run, rewritten in front of every replay ----
+    def step_captured(self, ctx, grad_scale=1.0):
+        """Called INSIDE the capture, after backward: queues the launches, advances nothing.  -> the runs' (lo, hi)."""
+        a = self.arena
+        self._cap_live = self._live()
+        runs = self._runs(self._cap_live, advance=False)
+        for r, (lo, hi, _) in enumerate(runs):
+            L.call('gpe_adam_step_dev', a.flat[lo:hi], a.grad[lo:hi], self.m[lo:hi], self.v[lo:hi], hi - lo, ctx.hyper_slot(r)[0],
+                   float(self.betas[0]), float(self.betas[1]), self.eps, self.weight_decay, float(grad_scale), 1)
+        if len(runs) != 1 or runs[0][:2] != (0, a.numel):
+            a.grad.zero_()
+        a.begin_step()
+        return [(lo, hi) for lo, hi, _ in runs]
+
+    def advance_captured(self, ctx, layout):
+        """Called in front of every replay: the host side of step() — schedule, step counts — and the scalars of each run."""
+        lr = self.lr if self.schedule is None else self.schedule.lr(self.t)
+        self.t += 1
+        runs = self._runs(self._cap_live, advance=True)
+        if [(lo, hi) for lo, hi, _ in runs] != layout:
+            raise RuntimeError('FusedAdam: the runs of the captured step no longer match the step counts (parameters that took '
+                               'different numbers of steps since the capture): capture again')
+        for r, (_, _, st) in enumerate(runs):
+            ctx.write_hyper(r, lr, self.betas[0], self.betas[1], st)
+        self.last_lr = lr
+        ops.bump_weights_epoch()
 
     def zero_grad(self, set_to_none=False):
         """Gradients are cleared inside step(); this only exists for trainer loops that call it unconditionally."""

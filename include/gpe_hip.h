@@ -501,6 +501,12 @@ int gpe_panel_shift(const float* feat, int D, const int32_t* lead, const int32_t
  * the gradient is read as g*gscale; zero_grad != 0 clears g afterwards.  The OneCycleLR value is passed in as lr. */
 int gpe_adam_step(float* p, float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
                   float weight_decay, long step, float gscale, int zero_grad, void* stream);
+/* the same step with the two step-dependent scalars read from DEVICE memory — hyper[0] = lr / (1 - beta1^step),
+ * hyper[1] = 1 / sqrt(1 - beta2^step), as gpe_adam_hyper writes them into a HOST pair — for a step that is replayed from a
+ * captured hipGraph, whose kernel arguments are frozen (gpe_amd/graph.py; nn/trainer.py:162-185 runs Adam under OneCycleLR) */
+int gpe_adam_step_dev(float* p, float* g, float* m, float* v, long n, const float* hyper, float beta1, float beta2, float eps,
+                      float weight_decay, float gscale, int zero_grad, void* stream);
+int gpe_adam_hyper(float lr, float beta1, float beta2, long step, float* out_host);
 /* out = (x - shift) / scale per column; shift_host / scale_host are HOST arrays of C <= 8 floats */
 int gpe_standardize(const float* x, long rows, int C, const float* shift_host, const float* scale_host, float* out,
                     void* stream);

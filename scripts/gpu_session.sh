@@ -81,7 +81,9 @@ while [ $# -gt 0 ]; do
       TAG=$1; shift
       run() { N=$1; shift; timeout 400 python bench.py --no-cpu-baseline "$@" > $OUT/${TAG}_$N.log 2>&1
               grep '^{' $OUT/${TAG}_$N.log | tail -1 > $OUT/${TAG}_${N}_bench.json; line $OUT/${TAG}_${N}_bench.json $N; }
-      run cfg1 --points 1024 --batch 8 --k 5 --steps 100
+      run cfg1 --points 1024 --batch 8 --k 5 --steps 100 --graph          # host-bound shape: the step replayed from one hipGraph
+      run cfg1_eager --points 1024 --batch 8 --k 5 --steps 100
+      run cfg1_f32 --points 1024 --batch 8 --k 5 --steps 100 --graph --math f32 --no-fast-math-line
       run cfg4 --model att --points 4096 --k 20 --steps 30
       run cfg5_share --points 8192 --batch 64 --steps 10 --warmup 2
       run att_k5 --model att --points 2000 --batch 30 --k 5 --steps 100
