@@ -120,20 +120,108 @@ __device__ __forceinline__ float gpe_pack_elem(const GpePackJob& jb, int n, int 
 
 typedef _Float16 pk_f16x8 __attribute__((ext_vector_type(8)));
 
-__global__ __launch_bounds__(256) void gpe_pack_multi_kernel(const GpePackJob* __restrict__ jobs, int njobs)
+// blocks a job occupies in a gpe_pack_multi launch (ops.PackPlan builds first_block from it).  Row-major sources (kinds 0, 2, 8:
+// the reduction index k is the fast index of the weight) go through 64 x 64 tiles: rows are read in whole 256-byte pieces and turned
+// in LDS — read column by column (round 2 - 5) every load instruction touched 64 cache lines for 64 floats.  Kind 9: 4096 elements
+// per block (a quarter of the same-word atomics).  Everything else: 1024 outputs per block.
+#define GPE_PACK_TILE 64
+static long gpe_pack_blocks(int kind, long total, int Npad, int K)
+{
+    if (kind == 0 || kind == 2) return (long)gpe_cdiv(Npad, GPE_PACK_TILE) * gpe_cdiv(total / Npad, GPE_PACK_TILE);
+    if (kind == 8) return (long)gpe_cdiv(Npad, GPE_PACK_TILE) * gpe_cdiv(gpe_round_up(K, 32), GPE_PACK_TILE);
+    if (kind == 9) return gpe_cdiv(total, 4096);
+    return gpe_cdiv(total, 1024);
+}
+extern "C" long gpe_pack_job_blocks(int kind, long total, int Npad, int K)
+{
+    if (kind < 0 || kind > 10 || total <= 0 || ((kind == 0 || kind == 2 || kind == 8) && Npad <= 0)) return GPE_EINVAL;
+    return gpe_pack_blocks(kind, total, Npad, K);
+}
+
+
+// kinds 0 / 2 / 8: one 64-column x 64-k tile of the output per block
+__device__ __forceinline__ void gpe_pack_tile(const GpePackJob& jb, long tb)
+{
+    __shared__ float tile[GPE_PACK_TILE][GPE_PACK_TILE + 2];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int ntn = (jb.Npad + GPE_PACK_TILE - 1) / GPE_PACK_TILE;
+    const int tk = (int)(tb / ntn), tn = (int)(tb - (long)tk * ntn);
+    const int n0 = tn * GPE_PACK_TILE, k0 = tk * GPE_PACK_TILE;
+    const bool pair = ((jb.ldw & 1) == 0) && ((((uintptr_t)jb.w) & 7) == 0);       // rows start on 8-byte boundaries
+    const int H = jb.aux, G = (jb.kind == 0) ? 1 : jb.N / H;
+    // phase 1: a wave reads its 16 columns' source rows two at a time, 256 bytes of each
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        const int c = wave * 16 + s * 2 + (lane >> 5), kk = 2 * (lane & 31);
+        const int n = n0 + c, k = k0 + kk;
+        long row = -1;
+        if (jb.kind == 0) row = (n < jb.N) ? n : -1;
+        else {
+            const int b = n / (16 * G), gate = (n >> 4) % G, u = (b << 4) + (n & 15);
+            row = (n < jb.Npad && u < H) ? (long)gate * H + u : -1;
+        }
+        float2 v = make_float2(0.f, 0.f);
+        if (row >= 0) {
+            const float* src = jb.w + row * jb.ldw + k;
+            if (pair && k + 1 < jb.K) v = *reinterpret_cast<const float2*>(src);
+            else {
+                if (k < jb.K) v.x = src[0];
+                if (k + 1 < jb.K) v.y = src[1];
+            }
+        }
+        *reinterpret_cast<float2*>(&tile[c][kk]) = v;
+    }
+    __syncthreads();
+    // phase 2: outputs in their own order (consecutive threads = consecutive columns)
+    if (jb.kind != 8) {
+        const int Kpad = (int)(jb.total / jb.Npad);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int q = tid + 256 * i, kq = q >> 6, c = q & 63;
+            if (n0 + c < jb.Npad && k0 + 4 * kq < Kpad)
+                *reinterpret_cast<float4*>(jb.out + ((long)((k0 >> 2) + kq) * jb.Npad + n0 + c) * 4) =
+                    make_float4(tile[c][4 * kq], tile[c][4 * kq + 1], tile[c][4 * kq + 2], tile[c][4 * kq + 3]);
+        }
+        return;
+    }
+    const int KP = (jb.K + 31) & ~31, KG = KP >> 3;
+    float sc, inv;
+    gpe_h3_scale_of(*reinterpret_cast<const unsigned*>(jb.w2), sc, inv);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int q = tid + 256 * i, plane = q >> 9, r = q & 511, kg = r >> 6, c = r & 63;
+        if (n0 + c < jb.Npad && k0 + 8 * kg < KP) {
+            pk_f16x8 o;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const float xs = tile[c][8 * kg + t] * sc;
+                const _Float16 h = (_Float16)xs;
+                o[t] = plane ? (_Float16)(xs - (float)h) : h;
+            }
+            *reinterpret_cast<pk_f16x8*>(reinterpret_cast<char*>(jb.out) + ((long)(plane * KG + (k0 >> 3) + kg) * jb.Npad + n0 + c) * 16) = o;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void gpe_pack_multi_kernel(const GpePackJob* __restrict__ jobs, int njobs, int tiled)
 {
     // wave-uniform job lookup: jobs are sorted by first_block
     int ji = 0;
     for (int q = 1; q < njobs; ++q) ji = ((long)blockIdx.x >= jobs[q].first_block) ? q : ji;
     const GpePackJob jb = jobs[ji];
-    const long e = (((long)blockIdx.x - jb.first_block) * 256 + threadIdx.x) * 4;
+    if (tiled && (jb.kind == 0 || jb.kind == 2 || jb.kind == 8)) {
+        gpe_pack_tile(jb, (long)blockIdx.x - jb.first_block);
+        return;
+    }
     if (jb.kind == 9) {
         // largest |w| of a [N][K] matrix (row pitch ldw) -> atomicMax into the uint32 word at jb.out (zeroed by the caller):
-        // phase 1 of the fp16-plane packs below, which normalise a weight by a power of two taken from it
-        __shared__ unsigned red[4];
+        // phase 1 of the fp16-plane packs below, which normalise a weight by a power of two taken from it.  4096 elements per block
+        __shared__ unsigned red9[4];
+        const long e9 = ((long)blockIdx.x - jb.first_block) * 4096 + threadIdx.x;
         unsigned m = 0u;
-        for (int t = 0; t < 4; ++t) {
-            const long i = e + t;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const long i = e9 + 256 * t;
             if (i < jb.total) {
                 const long n = i / jb.K;
                 const unsigned a = __float_as_uint(jb.w[n * jb.ldw + (i - n * jb.K)]) & 0x7fffffffu;
@@ -145,15 +233,16 @@ __global__ __launch_bounds__(256) void gpe_pack_multi_kernel(const GpePackJob* _
             const unsigned t = (unsigned)__shfl_xor((int)m, o);
             m = m > t ? m : t;
         }
-        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+        if ((threadIdx.x & 63) == 0) red9[threadIdx.x >> 6] = m;
         __syncthreads();
         if (threadIdx.x == 0) {
-            const unsigned a = red[0] > red[1] ? red[0] : red[1], b = red[2] > red[3] ? red[2] : red[3];
+            const unsigned a = red9[0] > red9[1] ? red9[0] : red9[1], b = red9[2] > red9[3] ? red9[2] : red9[3];
             const unsigned r = a > b ? a : b;
             if (r) atomicMax(reinterpret_cast<unsigned*>(jb.out), r);
         }
         return;
     }
+    const long e = (((long)blockIdx.x - jb.first_block) * 256 + threadIdx.x) * 4;
     if (e >= jb.total) return;
     if (jb.kind == 8 || jb.kind == 10) {
         // two-term fp16 planes of a weight in the B-fragment order of v_mfma_f32_16x16x32_f16: out = [plane h | plane l], a plane =
@@ -213,7 +302,7 @@ extern "C" int gpe_pack_multi(const void* jobs_dev, int njobs, long total_blocks
 {
     if (!jobs_dev || njobs <= 0 || total_blocks <= 0 || total_blocks >= (1L << 31)) return GPE_EINVAL;
     hipLaunchKernelGGL(gpe_pack_multi_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream,
-                       reinterpret_cast<const GpePackJob*>(jobs_dev), njobs);
+                       reinterpret_cast<const GpePackJob*>(jobs_dev), njobs, 1);
     GPE_CHECK_LAUNCH();
     return GPE_OK;
 }

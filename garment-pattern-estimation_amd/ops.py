@@ -198,14 +198,19 @@ class PackPlan:
         # f16x3 plane packs are normalised by their tensor's largest magnitude: one amax word per planes job, filled by a kind-9
         # job of an EARLIER launch (self.pre_table) into self.words (zeroed before every refresh)
         h3 = [i for i, sp in enumerate(self.specs) if sp[2] in (K_GATES_H3, K_TRANS_H3)]
-        self.words = torch.zeros(max(len(h3), 1), device=dev, dtype=torch.int32)
-        pre = np.zeros(len(h3), dtype=_JOB)
+        # ... one word and one amax job per MATRIX (its gate-interleaved and its transposed planes share them)
+        mats = []
+        for i in h3:
+            if all(self.specs[i][0] is not self.specs[j][0] for j in mats):
+                mats.append(i)
+        self.words = torch.zeros(max(len(mats), 1), device=dev, dtype=torch.int32)
+        pre = np.zeros(len(mats), dtype=_JOB)
         pblk = 0
-        for wi, i in enumerate(h3):
+        for wi, i in enumerate(mats):
             p = self.specs[i][0]
             n_el = p.numel()
             pre[wi] = (p.data_ptr(), 0, self.words[wi:wi + 1].data_ptr(), n_el, pblk, p.stride(0), p.shape[0], p.shape[1], K_AMAX, 0, 0)
-            pblk += (n_el + 1023) // 1024
+            pblk += L.query('gpe_pack_job_blocks', K_AMAX, n_el, 0, 0)
         self.pre_blocks = pblk
         self.pre_table = torch.from_numpy(pre.view(np.uint8).copy()).to(dev) if h3 else None
         self.word_of = {}
@@ -219,7 +224,8 @@ class PackPlan:
             elif kind in (K_GATES_H3, K_TRANS_H3):
                 npad = 16 * (N // aux) * ((aux + 15) // 16) if kind == K_GATES_H3 else round_up(N, 16)
                 total = L.query('gpe_packed_planes_size', npad, K)
-                word = self.words[h3.index(i):h3.index(i) + 1]
+                wi = [j for j, m_ in enumerate(mats) if self.specs[m_][0] is p][0]
+                word = self.words[wi:wi + 1]
                 w2 = word.data_ptr()
                 self.word_of[(p.data_ptr(), kind)] = word
             else:
@@ -229,7 +235,7 @@ class PackPlan:
             self.outs.append(out)
             tab[i] = (p.data_ptr(), w2, out.data_ptr(), total, blk,
                       p.stride(0) if p.dim() == 2 else 0, N, K, kind, npad, aux)
-            blk += (total + 1023) // 1024            # gpe_pack_multi_kernel: 256 threads x one output quad
+            blk += L.query('gpe_pack_job_blocks', kind, total, npad, K)
             key = (p.data_ptr(), kind)
             _PACKS[key] = (self._me, out, i)
             self.keys.append(key)
@@ -243,7 +249,7 @@ class PackPlan:
         blk2 = 0
         for j in range(len(keep)):
             tab2[j]['first_block'] = blk2
-            blk2 += (int(tab2[j]['total']) + 1023) // 1024
+            blk2 += L.query('gpe_pack_job_blocks', int(tab2[j]['kind']), int(tab2[j]['total']), int(tab2[j]['Npad']), int(tab2[j]['K']))
         self.table_noh3 = torch.from_numpy(tab2.view(np.uint8).copy()).to(dev) if h3 else self.table
         self.blocks_noh3, self.n_noh3 = (blk2, len(keep)) if h3 else (blk, len(self.specs))
         self.home = self._home()

@@ -124,7 +124,9 @@ int gpe_pack_weight(const float* w, int ldw, int N, int K, int transpose, const 
                     float* wp, void* stream);
 /* every weight-derived operand of a model refreshed by ONE launch (after an optimizer step): `jobs_dev` is a device array
  * of njobs 64-byte records {const float* w, w2; float* out; long total, first_block; int ldw, N, K, kind, Npad, aux}
- * sorted by first_block (1024 outputs per 256-thread block: one float4 per thread; ABI version 3 — version 2 had 256).  kind 0 plain pack, 1 transposed pack, 2 gate-interleaved pack (aux = H),
+ * sorted by first_block; a job occupies gpe_pack_job_blocks(kind, total, Npad, K) 256-thread blocks (ABI version 6: row-major sources —
+ * kinds 0, 2, 8 — are packed in 64 x 64 tiles, kind 9 reads 4096 elements per block, everything else writes 1024 outputs per block;
+ * versions 3 - 5: 1024 outputs per block throughout).  kind 0 plain pack, 1 transposed pack, 2 gate-interleaved pack (aux = H),
  * 3 pack of [W1a-W1b ; W1b] from W1 [H][2C] (gpe_w1_split + pack; aux = H), 4 its transpose, 5 out = w + w2 (N floats),
  * 6 out = [w[0:aux] | 0] (N floats), 7 out = w + [w2[0:aux] | 0] (N floats; GRU input-side bias b_ih + [b_hr | b_hz | 0]).
  * f16x3 operands of the recurrences (ABI version 4): kind 9 = largest |w| of the [N][K] matrix, atomicMax into the uint32 word at
@@ -134,6 +136,7 @@ int gpe_pack_weight(const float* w, int ldw, int N, int K, int transpose, const 
  * (total = 2 * (KP/8) * Npad * 4; gpe_packed_planes_size).  A kind-9 job must run in an EARLIER launch than the planes that
  * read its word. */
 long gpe_packed_planes_size(int Npad, int K);        /* floats (4-byte units) of a kind-8 / kind-10 output */
+long gpe_pack_job_blocks(int kind, long total, int Npad, int K);
 int gpe_pack_multi(const void* jobs_dev, int njobs, long total_blocks, void* stream);
 /* folded bias: out[n] = bias[n] + sum_k w[n][k]*t[k]   (t = beta - mean*s of the previous BatchNorm) */
 int gpe_fold_bias(const float* w, int ldw, int N, int K, const float* bias, const float* t, float* out,

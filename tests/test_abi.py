@@ -21,7 +21,8 @@ def test_header_declares_expected_surface():
         if name in ('gpe_abi_version', 'gpe_packed_size', 'gpe_packed_gates_size', 'gpe_redgemm_ws',
                     'gpe_stats_blocks', 'gpe_point_sums_blocks', 'gpe_debug_set', 'gpe_math_set', 'gpe_math_get',
                     'gpe_attn_pool_ws', 'gpe_packed_ngates_size', 'gpe_rnn_seq_bwd_ws', 'gpe_rnn_seq_fwd_ws', 'gpe_debug_get', 'gpe_reserve_cus_set', 'gpe_f16x3_min_rows',
-                    'gpe_f16x3_min_rows_set', 'gpe_edge_ws_bytes', 'gpe_knn_ws_bytes', 'gpe_packed_planes_size', 'gpe_edge_lazy_dz3_ok'):
+                    'gpe_f16x3_min_rows_set', 'gpe_edge_ws_bytes', 'gpe_knn_ws_bytes', 'gpe_packed_planes_size', 'gpe_edge_lazy_dz3_ok',
+                    'gpe_pack_job_blocks', 'gpe_adam_hyper'):
             continue
         assert res == 'i' and args[-1] == 'p', name
 

@@ -68,8 +68,9 @@ def test_every_fixture_config_constructs_with_reference_layout(tag, golden_dir):
 
 
 def test_pack_plan_job_table():
-    """the 64-byte job records gpe_pack_multi reads (include/gpe_hip.h): one 256-thread block per 1024 outputs (ABI 3),
-    jobs sorted by first_block, every output buffer sized to its job"""
+    """the 64-byte job records gpe_pack_multi reads (include/gpe_hip.h): gpe_pack_job_blocks(kind, ..) 256-thread blocks per job (ABI 6:
+    64 x 64 tiles for the row-major sources, 1024 outputs per block otherwise), jobs sorted by first_block, every output buffer sized
+    to its job; one amax word per MATRIX, shared by its two plane packs"""
     import numpy as np
     ops = gpe_amd.ops
     dc = configs.data_config()
@@ -88,8 +89,20 @@ def test_pack_plan_job_table():
         assert int(job['total']) == out.numel() and int(job['out']) == out.data_ptr()
         if int(job['kind']) < 5:
             assert int(job['total']) % 4 == 0                 # whole float4 quads
-        blk += (int(job['total']) + 1023) // 1024
+        kind, total, npad, K = int(job['kind']), int(job['total']), int(job['Npad']), int(job['K'])
+        nb = gpe_amd._lib.query('gpe_pack_job_blocks', kind, total, npad, K)
+        if kind in (0, 2):
+            assert nb == -(-npad // 64) * -(-(total // npad) // 64)
+        elif kind == 8:
+            assert nb == -(-npad // 64) * -(-(-(-K // 32) * 32) // 64)
+        else:
+            assert nb == (total + 1023) // 1024
+        blk += nb
     assert plan.blocks == blk
+    pre = plan.pre_table.numpy().view(ops._JOB)
+    assert len(set(int(j['w']) for j in pre)) == len(pre) == plan.words.numel()          # one amax job per matrix
+    planes = [j for j in tab if int(j['kind']) in (8, 10)]
+    assert len(planes) > len(pre) and all(int(j['w2']) in set(int(q['out']) for q in pre) for j in planes)
 
 
 def test_stitch_model_layout(golden_dir):
