@@ -67,3 +67,40 @@ def test_step_graph_replays_the_eager_steps(gpe, mode, model_kind):
     finally:
         gpe.set_f16x3_min_rows(prev_rows)
         gpe.set_math(prev)
+
+
+def test_step_graph_recaptures_when_the_half_activation_guard_trips(gpe):
+    """The fp16 storage of the aggregated EdgeConv activation is watched in graph mode too: the amax words of the captured forward are
+    read after every replay; a layer that outgrows fp16 (here: its last Linear scaled by 1e5 between two replays) warns, switches to
+    fp32 rows, and the next step is captured again."""
+    import warnings
+    from gpe_amd import optim, graph, ops
+    prev = gpe.set_math('f16x3')
+    prev_rows = gpe.set_f16x3_min_rows(0)
+    mode0 = ops.set_half_act_guard('fallback')
+    try:
+        model, feats, gt = _setup(gpe, 'lstm', k=16, batch=8, points=512)
+        convs = [m for m in model.modules() if hasattr(m, 'half_act_guard')]
+        assert convs and gpe._lib.query('gpe_edge_lazy_dz3_ok', 8, 512, 16, 150, 200) == 1
+        opt = optim.FusedAdam(optim.FlatArena(model), lr=1e-4)
+        sg = graph.StepGraph(lambda f, g: model.loss(model(f), g, epoch=0)[0], opt, warmup=1)
+        for i in range(3):
+            torch.manual_seed(i)
+            sg.step(feats, gt)
+        sg.synchronize()
+        assert sg.captures == 1 and sg.replays == 2 and len(sg.guards) == len(convs) and not any(c.half_act_guard.disabled for c in convs)
+        with torch.no_grad():
+            convs[0].nn[2][0].weight.mul_(1e5)
+        with warnings.catch_warnings(record=True) as wl:
+            warnings.simplefilter('always')
+            for i in range(3, 9):
+                torch.manual_seed(i)
+                loss = sg.step(feats, gt)
+                sg.synchronize()                       # (lets the asynchronous read of the words land before the next step looks)
+        assert convs[0].half_act_guard.disabled and convs[0].half_act_guard.last_amax > 65504
+        assert any('fp16 storage' in str(w.message) for w in wl)
+        assert sg.captures == 2 and bool(torch.isfinite(loss))
+    finally:
+        ops.set_half_act_guard(mode0)
+        gpe.set_f16x3_min_rows(prev_rows)
+        gpe.set_math(prev)
