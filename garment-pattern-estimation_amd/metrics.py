@@ -321,7 +321,10 @@ class ComposedPatternLoss:
             if 'loop' in comps:
                 if self.loop_loss.pad_vector is None:
                     raise ValueError('PanelLoopLoss needs data_stats')
-                pad0, pad1 = float(self.loop_loss.pad_vector[0]), float(self.loop_loss.pad_vector[1])
+                pv = self.loop_loss.pad_vector
+                if getattr(self, '_pad_cache', (None,))[0] is not pv:          # (two tensor -> float reads per step otherwise)
+                    self._pad_cache = (pv, float(pv[0]), float(pv[1]))
+                pad0, pad1 = self._pad_cache[1], self._pad_cache[2]
             rot = preds['rotations'] if 'rotation' in comps else None
             tr = preds['translations'] if 'translation' in comps else None
             out = ops.PatternLossFn.apply(

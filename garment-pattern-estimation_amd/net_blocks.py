@@ -107,14 +107,15 @@ class EdgeConvFeatures(nn.Module):
             conv.register_packs(plan)
         plan.add_linear(self.lin.weight)
 
-    def forward(self, positions, global_pool=True):
+    def forward(self, positions, global_pool=True, want_batch=True):
         B, N = positions.size(0), positions.size(1)
         pos_flat = positions.reshape(-1, positions.size(-1))
         if pos_flat.dtype != torch.float32:
             pos_flat = pos_flat.float()
         pos_flat = pos_flat.contiguous()
         # batch vector of the reference (nn/net_blocks.py:165-167); the kernels only need (B, N)
-        batch = torch.arange(B, device=positions.device).repeat_interleave(N)
+        # (want_batch=False: a caller that only takes the pooled encoding — nets.GarmentFullPattern3D — saves the two launches)
+        batch = torch.arange(B, device=positions.device).repeat_interleave(N) if want_batch else None
         out = pos_flat
         order = None                                         # layer l + 1 searches its graph in layer l's locality order
         for conv in self.conv_layers:

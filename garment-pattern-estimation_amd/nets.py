@@ -98,6 +98,8 @@ class GarmentFullPattern3D(BaseModule):
         self.placement_decoder = nn.Linear(cfg['panel_encoding_size'], self.rotation_size + self.translation_size)
 
     def forward_encode(self, positions_batch):
+        if isinstance(self.feature_extractor, blocks.EdgeConvFeatures):
+            return self.feature_extractor(positions_batch, want_batch=False)[0]
         return self.feature_extractor(positions_batch)[0]
 
     def forward_pattern_decode(self, garment_encodings):

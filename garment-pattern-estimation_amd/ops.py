@@ -717,6 +717,7 @@ class EdgeConvFn(torch.autograd.Function):
         # order (int32 [B, N] or None): a locality order of the points — the previous layer's curve order — handed to the graph
         # search as a speed hint (include/gpe_hip.h gpe_knn); third output: the order this layer's search worked in
         _dev_check(x)
+        ctx.set_materialize_grads(False)                   # (no zero tensors for the gradients of idx / order_out)
         dev = x.device
         BN, C = x.shape
         assert BN == B * N
@@ -814,8 +815,10 @@ class EdgeConvFn(torch.autograd.Function):
         if ctx.done:
             raise RuntimeError('EdgeConvFn.backward ran twice on the same graph: the stored activations are overwritten '
                                'in place by the first pass (retain_graph is not supported)')
-        ctx.done = True
         B, N, k, C, nb, aggr, training = ctx.dims
+        if g_out is None:                                  # only the graph / the order were used downstream
+            return (None,) * (11 + 4 * nb + 3 * nb)
+        ctx.done = True
         widths = ctx.widths
         sv = ctx.saved_tensors
         x, idx, jg, PQ = sv[:4]
