@@ -516,8 +516,8 @@ def main():
     eager_step = step
     sg = None
     if args.graph:
-        if world > 1:
-            raise SystemExit('--graph: single GPU only')
+        if world > 1 or args.torch_adam:
+            raise SystemExit('--graph: single GPU and the fused Adam only')
         from gpe_amd import graph as gpe_graph
         sg = gpe_graph.StepGraph(lambda f, g: model.loss(wrapped(f, log_step=0, epoch=args.epoch), g, epoch=args.epoch)[0], opt, warmup=2)
 

@@ -72,6 +72,9 @@ class StepGraph:
         """forward_loss(*inputs) -> scalar loss tensor (forward + loss; backward and optimizer.step() are run here).
         optimizer: optim.FusedAdam.  warmup: eager steps before the capture (>= 1: lazily built state — pack plans, workspaces,
         kernel attributes — must exist before a capture)."""
+        if not (hasattr(optimizer, 'step_captured') and hasattr(optimizer, 'advance_captured')):
+            raise TypeError('StepGraph needs an optimizer whose step-dependent scalars live in device memory (optim.FusedAdam); a '
+                            'torch optimizer bakes them into its kernels\' arguments')
         self.forward_loss = forward_loss
         self.opt = optimizer
         self.warmup = max(int(warmup), 1)
