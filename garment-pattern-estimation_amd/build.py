@@ -17,7 +17,9 @@ EXTRA_FLAGS = {'gpe_edgegemm_sr_dense.hip': ['-mllvm', '-amdgpu-sched-strategy=m
                # whole-step A/B in one session (scripts/ab_bench.sh): edge weight-gradient reduce-GEMMs 3.01 -> 2.94 ms per step
                'gpe_redgemm.hip': ['-mllvm', '-amdgpu-sched-strategy=max-memory-clause'],
                # kNN 1.19 -> 1.16 ms per step
-               'gpe_knn.hip': ['-mllvm', '-amdgpu-sched-strategy=max-ilp'] + (['-DKNN_FT_TIMING'] if os.environ.get('KNN_FT_TIMING') else []),
+               'gpe_knn.hip': ['-mllvm', '-amdgpu-sched-strategy=max-ilp'],
+               # (KNN_FT_TIMING=1: per-section cycle counters instead of the first list of every wave, scripts/knn_ft_sections.py)
+               'gpe_knn_ft.hip': (['-DKNN_FT_TIMING'] if os.environ.get('KNN_FT_TIMING') else []) + os.environ.get('KNN_FT_FLAGS', '').split(),
                # the bf16x6 mode's forward edge kernels 2.94 -> 2.89 ms per step
                'gpe_edgegemm_x6.hip': ['-mllvm', '-amdgpu-sched-strategy=max-memory-clause'],
                # the f16x3 mode's edge kernels: forward 2.50 -> 2.43, backward 2.24 -> 2.05 ms per step (with the slot fences off)
