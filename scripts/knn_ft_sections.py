@@ -28,7 +28,7 @@ part = ws.view(torch.int64)[: B * N * 64].view(B, N, 64).cpu()
 inv = torch.empty(B, N, dtype=torch.long)
 o = order.cpu().long()
 # the lists are stored by POINT; wave w of workgroup qt owns plane rows 128 qt + 16 w .. -> its first query is point order[b][row]
-rows = torch.arange(0, N, 16)
+rows = torch.arange(0, N, int(os.environ.get("ROWS_PER_WAVE", "16")))
 keys = part[torch.arange(B)[:, None], o[:, rows]]          # [B, N/16, 64]
 cyc = (keys[..., :6] >> 32).double()
 names = ['commit+prefetch', 'lds+mfma+dist', 'append+tighten', 'barrier', 'tightens', 'tiles with a hit']
