@@ -1137,24 +1137,18 @@ __device__ __forceinline__ float knn_exact_chain(const float* __restrict__ q, co
     return acc;
 }
 
-__global__ __launch_bounds__(256) void gpe_knn_rerank_kernel(const float* __restrict__ x, long nq_total, int N, int C, int ldx,
-                                                             int k, int K2, int nsplit,
-                                                             const unsigned long long* __restrict__ part,
-                                                             const float* __restrict__ norms, const int* __restrict__ cmax,
-                                                             float ce, int32_t* __restrict__ idx,
-                                                             int32_t* __restrict__ idx_glob, int unsorted)
+// one query, by one wave (mW: 64 keys of LDS scratch of this wave)
+__device__ __forceinline__ void knn_rerank_query(const float* __restrict__ x, long q, int N, int C, int ldx, int k, int K2, int nsplit,
+                                                 const unsigned long long* __restrict__ part, const float* __restrict__ norms,
+                                                 const int* __restrict__ cmax, float ce, int32_t* __restrict__ idx,
+                                                 int32_t* __restrict__ idx_glob, int unsorted, unsigned long long* mW)
 {
     // unsorted (gpe_knn_ft_kernel's output): 64 keys per query in no order, ~0 = empty slot, 64 valid keys = redo this query exactly
-    __shared__ unsigned long long strip[4][64];
     const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const long q = (long)blockIdx.x * 4 + wave;
-    if (q >= nq_total) return;
     const int b = (int)(q / N);
     const float* cloud = x + (size_t)b * N * ldx;
     const float* qrow = x + q * ldx;
     const bool vec4 = (ldx % 4 == 0) && ((uintptr_t)x % 16 == 0);      // every row starts 16-byte aligned
-    unsigned long long* const mW = strip[wave];
     const int nk = unsorted ? 64 : nsplit * K2;                       // <= 64
     // ---- merge the pieces' sorted lists: rank of every key among all of them (keys are distinct: distinct candidates) ----
     unsigned long long key = (lane < nk) ? part[q * nk + lane] : ~0ull;
@@ -1252,6 +1246,106 @@ __global__ __launch_bounds__(256) void gpe_knn_rerank_kernel(const float* __rest
         idx_glob[q * k + lane] = v;
     }
 #endif
+}
+
+__global__ __launch_bounds__(256) void gpe_knn_rerank_kernel(const float* __restrict__ x, long nq_total, int N, int C, int ldx,
+                                                             int k, int K2, int nsplit,
+                                                             const unsigned long long* __restrict__ part,
+                                                             const float* __restrict__ norms, const int* __restrict__ cmax,
+                                                             float ce, int32_t* __restrict__ idx,
+                                                             int32_t* __restrict__ idx_glob, int unsorted)
+{
+    __shared__ unsigned long long strip[4][64];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long q = (long)blockIdx.x * 4 + wave;
+    if (q >= nq_total) return;
+    knn_rerank_query(x, q, N, C, ldx, k, K2, nsplit, part, norms, cmax, ce, idx, idx_glob, unsorted, strip[wave]);
+}
+
+// The recheck behind the threshold scan, TWO queries per wave (lanes 0..31 / 32..63): the scan's last tighten leaves ~18 keys per
+// query, and a wave that walks one query's near-ties keeps ~12 of its 64 lanes busy through the 150-channel exact chains.  A pair
+// whose lists do not both fit 32 lanes (or that must be re-done exactly) goes through knn_rerank_query, one query after the other.
+// Same rules, same arithmetic: T = d~[k-th] + 2E, runs of keys closer than 2E re-ranked by (exact distance, index).
+__global__ __launch_bounds__(256) void gpe_knn_rerank2_kernel(const float* __restrict__ x, long nq_total, int N, int C, int ldx, int k,
+                                                              const unsigned long long* __restrict__ part,
+                                                              const float* __restrict__ norms, const int* __restrict__ cmax,
+                                                              float ce, int32_t* __restrict__ idx, int32_t* __restrict__ idx_glob)
+{
+    __shared__ unsigned long long strip[4][64];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long q0 = ((long)blockIdx.x * 4 + wave) * 2;
+    if (q0 >= nq_total) return;
+    unsigned long long* const mW = strip[wave];
+    const int h = lane >> 5, l = lane & 31;
+    const bool two = q0 + 1 < nq_total;
+    const long q = (h && two) ? q0 + 1 : q0;                         // (an odd last query: the upper half repeats it and writes nothing)
+    // the first 32 slots of both lists, and how many valid keys each list holds (a prefix of its 64 slots)
+    unsigned long long key = part[q * 64 + l];
+    const unsigned long long hi32 = part[q * 64 + 32 + l];
+    const unsigned long long v_lo = __ballot(key != ~0ull), v_hi = __ballot(hi32 != ~0ull);
+    const bool packable = (v_hi == 0ull) && k <= 32;
+    if (!packable) {
+        knn_rerank_query(x, q0, N, C, ldx, k, 64, 1, part, norms, cmax, ce, idx, idx_glob, 1, mW);
+        if (two) knn_rerank_query(x, q0 + 1, N, C, ldx, k, 64, 1, part, norms, cmax, ce, idx, idx_glob, 1, mW);
+        return;
+    }
+    const int nv = __builtin_popcount((unsigned)(v_lo >> (32 * h)));
+    const int nvmax = max(__builtin_popcount((unsigned)v_lo), __builtin_popcount((unsigned)(v_lo >> 32)));
+    const int base = 32 * h;
+    // ---- rank sort of each half's valid prefix ----
+    {
+        int rank = 0;
+        const int klo = (int)(unsigned)key, khi = (int)(unsigned)(key >> 32);
+        for (int s2 = 0; s2 < nvmax; ++s2) {
+            const unsigned long long kn = ((unsigned long long)(unsigned)__shfl(khi, base + s2) << 32) | (unsigned)__shfl(klo, base + s2);
+            rank += (s2 < nv && (kn < key || (kn == key && s2 < l))) ? 1 : 0;
+        }
+        if (l >= nv) rank = l;
+        mW[base + rank] = key;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        key = mW[lane];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    const float da = __int_as_float((int)(key >> 32));               // approximate distance (empty slots: NaN pattern, never compared true)
+    const int id = (int)(unsigned)key;
+    const int b = (int)(q / N);
+    const float* cloud = x + (size_t)b * N * ldx;
+    const float* qrow = x + q * ldx;
+    const bool vec4 = (ldx % 4 == 0) && ((uintptr_t)x % 16 == 0);
+    const float m2e = 2.02f * ce * (norms[q] + __int_as_float(cmax[b]));
+    const float T = __shfl(da, base + k - 1) + m2e;
+    const unsigned long long below = __ballot(l < nv && da <= T);
+    const int m = __builtin_popcount((unsigned)(below >> base));     // a prefix of the half's sorted list
+    const int mmax = max(__builtin_popcount((unsigned)below), __builtin_popcount((unsigned)(below >> 32)));
+    // ---- runs of entries closer than 2E to their neighbour: exact distances, sorted inside the run by (d, index) ----
+    const bool in_s = l < m;
+    const float dnext = __shfl(da, (lane + 1) & 63);
+    const bool near_next = (l + 1 < m) && (dnext - da <= m2e);
+    const unsigned long long nn = __ballot(near_next);
+    const bool near_prev = (l > 0) && ((nn >> (lane - 1)) & 1ull);
+    const bool flagged = in_s && (near_next || near_prev);
+    const unsigned long long fl = __ballot(flagged);
+    int newpos = l;
+    if (fl) {
+        const unsigned long long starts = __ballot(in_s && !near_prev);
+        const unsigned long long le = ((lane == 63) ? ~0ull : ((1ull << (lane + 1)) - 1ull)) & (0xffffffffull << base);
+        const int start = 63 - __builtin_clzll((starts & le) | (1ull << base));      // absolute lane of the run's first entry
+        float dex = da;
+        if (flagged) dex = knn_exact_chain(qrow, cloud + (size_t)id * ldx, C, vec4);
+        int r = 0;
+        for (int s2 = 0; s2 < mmax; ++s2) {
+            const float dj = __shfl(dex, base + s2);
+            const int ij = __shfl(id, base + s2);
+            const int sj = __shfl(start, base + s2);
+            r += (s2 < m && sj == start && (dj < dex || (dj == dex && ij < id))) ? 1 : 0;
+        }
+        if (flagged) newpos = (start - base) + r;
+    }
+    if (in_s && newpos < k && (h == 0 || two)) {
+        idx[q * k + newpos] = id;
+        if (idx_glob) idx_glob[q * k + newpos] = b * N + id;
+    }
 }
 
 // what the filter path keeps per query: the K2 best candidates by the matrix-pipe distance
@@ -1360,8 +1454,13 @@ extern "C" int gpe_knn(const float* x, int B, int N, int C, int ldx, int k, int3
             const long nb = pin ? (long)GPE_NXCD * gpe_cdiv(B, GPE_NXCD) * qtiles : (long)B * qtiles;
             const int rc = gpe_knn_ft_launch(wide ? 1 : 0, nb, s, planes, iscale, N, CP, k, norms, cmax, ce, B, qtiles, pin, part, rot, mprobe);
             if (rc != GPE_OK) return rc;
-            hipLaunchKernelGGL(gpe_knn_rerank_kernel, dim3((unsigned)gpe_cdiv((long)nq, 4)), dim3(256), 0, s, x, (long)nq, N, C, ldx, k, K2,
-                               nsplit, part, norms, cmax, ce, idx, idx_glob, 1);
+            static const int rr2 = gpe_dbg_env("GPE_KNN_RR2", 1);                // A/B: 0 = one query per wave
+            if (rr2)
+                hipLaunchKernelGGL(gpe_knn_rerank2_kernel, dim3((unsigned)gpe_cdiv((long)nq, 8)), dim3(256), 0, s, x, (long)nq, N, C, ldx, k,
+                                   part, norms, cmax, ce, idx, idx_glob);
+            else
+                hipLaunchKernelGGL(gpe_knn_rerank_kernel, dim3((unsigned)gpe_cdiv((long)nq, 4)), dim3(256), 0, s, x, (long)nq, N, C, ldx, k, K2,
+                                   nsplit, part, norms, cmax, ce, idx, idx_glob, 1);
             GPE_CHECK_LAUNCH();
             return GPE_OK;
         }
