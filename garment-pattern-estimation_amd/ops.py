@@ -95,6 +95,72 @@ def _word(words, i):
 
 
 # -------------------------------------------------------------------------------------------------
+# Leaf weight-gradient launches on a side stream
+# -------------------------------------------------------------------------------------------------
+# The weight-gradient reduce-GEMMs of a recurrent stack are LEAVES of the backward pass (nothing downstream reads them before the
+# optimizer), and what follows the panel decoder's backward on the critical path is the pattern decoder's persistent backward
+# launch, which occupies a few CUs for 0.2 ms.  `side_grads(...)` moves the launches issued inside it to one side stream per device
+# (forked behind everything the current stream has queued, joined back by an autograd callback when the backward pass ends), so
+# that the two overlap.  Only when every gradient involved lands in a flat arena (optim.FlatArena: nothing is returned to autograd),
+# outside stream captures, and with world size 1 (parallel.DistributedHotPath switches it off: its buckets leave for the all-reduce
+# as soon as the arena is told a gradient is written).  GPE_DEBUG=1 GPE_SIDE_GRADS=0 keeps everything on one stream (A/B).
+SIDE_GRADS = not (os.environ.get('GPE_DEBUG') == '1' and os.environ.get('GPE_SIDE_GRADS') == '0')
+_SIDE_STREAMS = {}
+_SIDE_JOIN_QUEUED = [False]
+_SIDE_DIRTY = [False]                 # the side stream holds launches the current stream has not waited for
+
+
+def _side_stream():
+    idx = torch.cuda.current_device()
+    st = _SIDE_STREAMS.get(idx)
+    if st is None:
+        st = _SIDE_STREAMS[idx] = torch.cuda.Stream(device=idx)
+    return st
+
+
+def join_side():
+    """The current stream waits for everything on the side stream.  Runs as an autograd callback at the end of every backward pass
+    that used the side stream, and once more in front of every optimizer step (optim.FusedAdam) — the second call is what a pass
+    that died with an exception half-way leaves to."""
+    _SIDE_JOIN_QUEUED[0] = False
+    if _SIDE_DIRTY[0]:
+        _SIDE_DIRTY[0] = False
+        torch.cuda.current_stream().wait_stream(_side_stream())
+
+
+class side_grads:
+    """with side_grads(params, tensors) as on_side: ...  — the launches inside run on the side stream when that is legal (see above);
+    `tensors` = every main-stream tensor the launches read (kept away from the allocator until the side stream has passed them)."""
+
+    def __init__(self, params, tensors):
+        self.on = bool(SIDE_GRADS and params and all(_SINK.get(p.data_ptr()) is not None and _SINK[p.data_ptr()][0]() is not None
+                                                     for p in params) and not torch.cuda.is_current_stream_capturing())
+        self.tensors = tensors
+        self.ctx = None
+
+    def __enter__(self):
+        if not self.on:
+            return False
+        main, side = torch.cuda.current_stream(), _side_stream()
+        side.wait_stream(main)
+        for t in self.tensors:
+            if t is not None:
+                t.record_stream(side)
+        _SIDE_DIRTY[0] = True
+        if not _SIDE_JOIN_QUEUED[0]:
+            _SIDE_JOIN_QUEUED[0] = True
+            torch.autograd.Variable._execution_engine.queue_callback(join_side)
+        self.ctx = torch.cuda.stream(side)
+        self.ctx.__enter__()
+        return True
+
+    def __exit__(self, *exc):
+        if self.ctx is not None:
+            self.ctx.__exit__(*exc)
+        return False
+
+
+# -------------------------------------------------------------------------------------------------
 # PackPlan: weight-derived operands refreshed by one launch
 # -------------------------------------------------------------------------------------------------
 WEIGHTS_EPOCH = 0          # bumped by optimizers that update parameters through raw pointers (optim.FusedAdam)
@@ -523,11 +589,13 @@ class LinearFn(torch.autograd.Function):
             gx = torch.empty(*x.shape, device=x.device, dtype=F32)
             linear_raw(_rows2d(gy), pack_weight(weight, transpose=True), None, M, K, N, (gx, K, 0, 0))
         if ctx.needs_input_grad[1] or bias is not None:
-            gw = _gbuf(weight)
-            gb = _gbuf(bias) if bias is not None else torch.empty(N, device=x.device, dtype=F32)
-            redgemm_raw(_rows2d(gy), xd, M, N, K, out=(gw, gb))
-            gw = _gret(weight, gw)
-            gb = _gret(bias, gb) if bias is not None else None
+            # (a leaf of the backward pass: on the side stream when weight and bias gradients both land in the arena)
+            with side_grads([weight, bias] if bias is not None else [], [gy, x]):
+                gw = _gbuf(weight)
+                gb = _gbuf(bias) if bias is not None else torch.empty(N, device=x.device, dtype=F32)
+                redgemm_raw(_rows2d(gy), xd, M, N, K, out=(gw, gb))
+                gw = _gret(weight, gw)
+                gb = _gret(bias, gb) if bias is not None else None
         return gx, gw, gb
 
 
@@ -1119,37 +1187,44 @@ class RNNStackFn(torch.autograd.Function):
         d_h0 = torch.empty(Lr, Bn, Hh, device=dev, dtype=F32) if want_h0 else None
         d_c0 = carry[0].clone() if want_c0 else None
         nz = (GH + 255) // 256
-        for l in range(Lr):
-            w_ih, w_hh, b_ih, b_hh = params[4 * l: 4 * l + 4]
-            gx_rows, gh_rows = _rows3d(dgx[l][:, :, :GH]), _rows3d(dgh[l][:, :, :GH])
-            d_whh, d_bhh = _gbuf(w_hh), _gbuf(b_hh)
-            redgemm_raw(gh_rows, _rows3d(hs[l][:, :T, :Hh]), Bn * T, GH, Hh, out=(d_whh, d_bhh))
-            d_wih, d_bih = _gbuf(w_ih), _gbuf(b_ih)
-            if l == 0 and not seq:
-                # the same input row feeds every step: sum the gate gradients over T first, then ONE Bn-row product
-                # (T times fewer rows than dG^T x over the repeated input)
-                dGs = torch.empty(Bn, GH, device=dev, dtype=F32)
-                L.call('gpe_reduce_inner', dgx[0], T * GHp, GHp, T, Bn, GH, dGs, GH, 0)
-                redgemm_raw(_rows2d(dGs), _rows2d(x), Bn, GH, In, out=(d_wih, d_bih))
-                if ctx.needs_input_grad[0]:
-                    d_x = torch.empty(Bn, In, device=dev, dtype=F32)
-                    linear_raw(_rows2d(dGs), pack_weight(w_ih, transpose=True), None, Bn, In, GH, _rows2d(d_x))
-            else:
-                Kin = In if l == 0 else Hh
-                src = _rows3d(x) if l == 0 else _rows3d(hs[l - 1][:, 1:, :Hh])
-                redgemm_raw(gx_rows, src, Bn * T, GH, Kin, out=(d_wih, d_bih))
-                if l == 0 and ctx.needs_input_grad[0]:
-                    d_x = torch.empty(Bn, T, In, device=dev, dtype=F32)
-                    linear_raw(gx_rows, pack_weight(w_ih, transpose=True), None, Bn * T, In, GH, (d_x, In, 0, 0))
-            if want_h0:
+        # ---- what the rest of the backward pass waits for: the input gradient and the start-state gradients ----
+        dGs = None
+        gx0 = _rows3d(dgx[0][:, :, :GH])
+        if not seq:
+            # the same input row feeds every step: sum the gate gradients over T first, then ONE Bn-row product
+            # (T times fewer rows than dG^T x over the repeated input)
+            dGs = torch.empty(Bn, GH, device=dev, dtype=F32)
+            L.call('gpe_reduce_inner', dgx[0], T * GHp, GHp, T, Bn, GH, dGs, GH, 0)
+            if ctx.needs_input_grad[0]:
+                d_x = torch.empty(Bn, In, device=dev, dtype=F32)
+                linear_raw(_rows2d(dGs), pack_weight(params[0], transpose=True), None, Bn, In, GH, _rows2d(d_x))
+        elif ctx.needs_input_grad[0]:
+            d_x = torch.empty(Bn, T, In, device=dev, dtype=F32)
+            linear_raw(gx0, pack_weight(params[0], transpose=True), None, Bn * T, In, GH, (d_x, In, 0, 0))
+        if want_h0:
+            for l in range(Lr):
                 # dh_0 = dG_{l,0} . W_hh (+ the z-gated direct path of a GRU)
                 rec = torch.empty(nz, Bn, Hh, device=dev, dtype=F32)
                 L.call('gpe_linear_splitk', dgh[l][:, 0], T * GHp, whh_t[l], rec, Bn, Hh, GH)
                 L.call('gpe_reduce_inner', rec, Hh, Bn * Hh, nz, Bn, Hh, d_h0[l], Hh, 0)
                 if not lstm:
                     L.call('gpe_add', d_h0[l], carry[0][l], d_h0[l], Bn * Hh)
-            grads[4 * l: 4 * l + 4] = [_gret(w_ih, d_wih), _gret(w_hh, d_whh), _gret(b_ih, d_bih),
-                                       _gret(b_hh, d_bhh)]
+        # ---- the weight gradients: leaves of the backward pass (on the side stream when every one of them lands in the arena) ----
+        with side_grads(list(params), [dgx, dgh, hs, x, dGs]):
+            for l in range(Lr):
+                w_ih, w_hh, b_ih, b_hh = params[4 * l: 4 * l + 4]
+                gx_rows, gh_rows = _rows3d(dgx[l][:, :, :GH]), _rows3d(dgh[l][:, :, :GH])
+                d_whh, d_bhh = _gbuf(w_hh), _gbuf(b_hh)
+                redgemm_raw(gh_rows, _rows3d(hs[l][:, :T, :Hh]), Bn * T, GH, Hh, out=(d_whh, d_bhh))
+                d_wih, d_bih = _gbuf(w_ih), _gbuf(b_ih)
+                if l == 0 and not seq:
+                    redgemm_raw(_rows2d(dGs), _rows2d(x), Bn, GH, In, out=(d_wih, d_bih))
+                else:
+                    Kin = In if l == 0 else Hh
+                    src = _rows3d(x) if l == 0 else _rows3d(hs[l - 1][:, 1:, :Hh])
+                    redgemm_raw(gx_rows, src, Bn * T, GH, Kin, out=(d_wih, d_bih))
+                grads[4 * l: 4 * l + 4] = [_gret(w_ih, d_wih), _gret(w_hh, d_whh), _gret(b_ih, d_bih),
+                                           _gret(b_hh, d_bhh)]
         return (d_x, d_h0, d_c0, None, None, None, None, None, *grads)
 
 

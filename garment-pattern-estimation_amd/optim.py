@@ -210,6 +210,7 @@ class FusedAdam:
 
     def step(self, grad_scale=1.0):
         a = self.arena
+        ops.join_side()                # weight gradients written on the side stream (ops.side_grads)
         lr = self.lr if self.schedule is None else self.schedule.lr(self.t)
         self.t += 1
         runs = self._runs(self._live(), advance=True)
@@ -227,6 +228,7 @@ class FusedAdam:
     def step_captured(self, ctx, grad_scale=1.0):
         """Called INSIDE the capture, after backward: queues the launches, advances nothing.  -> the runs' (lo, hi)."""
         a = self.arena
+        ops.join_side()
         self._cap_live = self._live()
         runs = self._runs(self._cap_live, advance=False)
         for r, (lo, hi, _) in enumerate(runs):

@@ -55,6 +55,9 @@ class DistributedHotPath(nn.Module):
             a.listeners.append(self._on_written)
             for i, p in enumerate(a.params):
                 p.register_post_accumulate_grad_hook(lambda _p, i=i: self._on_hook(_p, i))
+            # a bucket leaves as soon as the arena is told its last gradient is written: every gradient launch stays on the one stream
+            from . import ops
+            ops.SIDE_GRADS = False
         self._exposed = []
         self._reset()
         if reserve_cus is None:
