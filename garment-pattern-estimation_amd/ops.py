@@ -102,9 +102,13 @@ def _word(words, i):
 # launch, which occupies a few CUs for 0.2 ms.  `side_grads(...)` moves the launches issued inside it to one side stream per device
 # (forked behind everything the current stream has queued, joined back by an autograd callback when the backward pass ends), so
 # that the two overlap.  Only when every gradient involved lands in a flat arena (optim.FlatArena: nothing is returned to autograd),
-# outside stream captures, and with world size 1 (parallel.DistributedHotPath switches it off: its buckets leave for the all-reduce
+# outside stream captures (measured: no gain inside a captured step), and with world size 1 (parallel.DistributedHotPath switches it off: its buckets leave for the all-reduce
 # as soon as the arena is told a gradient is written).  GPE_DEBUG=1 GPE_SIDE_GRADS=0 keeps everything on one stream (A/B).
+# Only for steps the GPU bounds: the fork / join / record_stream bookkeeping costs the host ~0.3 ms per step, which a host-bound shape
+# (BASELINE cfg 1 with eager launches: 3.6 -> 4.0 ms) cannot hide.  The proxy is the size of the step's last EdgeConv graph (edges).
 SIDE_GRADS = not (os.environ.get('GPE_DEBUG') == '1' and os.environ.get('GPE_SIDE_GRADS') == '0')
+SIDE_MIN_EDGES = 1 << 17
+_LAST_EDGES = [0]
 _SIDE_STREAMS = {}
 _SIDE_JOIN_QUEUED = [False]
 _SIDE_DIRTY = [False]                 # the side stream holds launches the current stream has not waited for
@@ -133,7 +137,7 @@ class side_grads:
     `tensors` = every main-stream tensor the launches read (kept away from the allocator until the side stream has passed them)."""
 
     def __init__(self, params, tensors):
-        self.on = bool(SIDE_GRADS and params and all(_SINK.get(p.data_ptr()) is not None and _SINK[p.data_ptr()][0]() is not None
+        self.on = bool(SIDE_GRADS and _LAST_EDGES[0] >= SIDE_MIN_EDGES and params and all(_SINK.get(p.data_ptr()) is not None and _SINK[p.data_ptr()][0]() is not None
                                                      for p in params) and not torch.cuda.is_current_stream_capturing())
         self.tensors = tensors
         self.ctx = None
@@ -798,6 +802,7 @@ class EdgeConvFn(torch.autograd.Function):
             raise ValueError('EdgeConvFn (the fused P|Q path) needs a first-block width that is a multiple of 4 and <= 256 '
                              '(got %d): use ops.edge_conv_general' % H0)
         E = BN * k
+        _LAST_EDGES[0] = E                                 # (what side_grads takes for the size of the step)
         nblk = L.query('gpe_stats_blocks')
         idx, jg, order_out = knn(x, B, N, k, want_global=True, order=order, want_order=True)
         wpq_p, _, bpq = edge_first_operands(Ws[0], params[1])
