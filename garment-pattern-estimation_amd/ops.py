@@ -108,6 +108,7 @@ def _word(words, i):
 # (BASELINE cfg 1 with eager launches: 3.6 -> 4.0 ms) cannot hide.  The proxy is the size of the step's last EdgeConv graph (edges).
 SIDE_GRADS = not (os.environ.get('GPE_DEBUG') == '1' and os.environ.get('GPE_SIDE_GRADS') == '0')
 SIDE_MIN_EDGES = 1 << 17
+SIDE_PQ = not (os.environ.get('GPE_DEBUG') == '1' and os.environ.get('GPE_SIDE_PQ') == '0')     # the forward fork of EdgeConvFn (A/B)
 _LAST_EDGES = [0]
 _SIDE_STREAMS = {}
 _SIDE_JOIN_QUEUED = [False]
@@ -804,10 +805,33 @@ class EdgeConvFn(torch.autograd.Function):
         E = BN * k
         _LAST_EDGES[0] = E                                 # (what side_grads takes for the size of the step)
         nblk = L.query('gpe_stats_blocks')
-        idx, jg, order_out = knn(x, B, N, k, want_global=True, order=order, want_order=True)
         wpq_p, _, bpq = edge_first_operands(Ws[0], params[1])
-        PQ = torch.empty(BN, 2 * H0, device=dev, dtype=F32)
-        linear_raw(_rows2d(x), wpq_p, bpq, BN, 2 * H0, C, _rows2d(PQ))
+        ews, ews_n = edge_workspace(B, N, k, max(round_up(widths[-1], 4), 2 * H0), dev)
+        words = f16x3_words(2 * nb + 1, E, dev)           # (+ 1: max |s g| of the layer-output gradient, lazy dz3)
+        # The [P|Q] projection (and its f16x3 bound) needs the layer input only — not the graph: on a GPU-bound step it runs on the
+        # side stream beside the graph search, whose kernels leave most of the chip's issue slots empty
+        fork = bool(SIDE_GRADS and SIDE_PQ and E >= SIDE_MIN_EDGES and not torch.cuda.is_current_stream_capturing())
+        if fork:
+            main, side = torch.cuda.current_stream(), _side_stream()
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                PQ = torch.empty(BN, 2 * H0, device=dev, dtype=F32)
+                linear_raw(_rows2d(x), wpq_p, bpq, BN, 2 * H0, C, _rows2d(PQ))
+                if words is not None:
+                    sws, sws_n = edge_workspace(B, N, k, max(round_up(widths[-1], 4), 2 * H0), dev)      # (the side stream's own workspace)
+                    L.call('gpe_edge_pq_amax', PQ, 2 * H0, H0, BN, _word(words, 0), sws, sws_n)
+            x.record_stream(side)
+            if words is not None:
+                words.record_stream(side)
+            idx, jg, order_out = knn(x, B, N, k, want_global=True, order=order, want_order=True)
+            main.wait_stream(side)
+            PQ.record_stream(main)
+        else:
+            idx, jg, order_out = knn(x, B, N, k, want_global=True, order=order, want_order=True)
+            PQ = torch.empty(BN, 2 * H0, device=dev, dtype=F32)
+            linear_raw(_rows2d(x), wpq_p, bpq, BN, 2 * H0, C, _rows2d(PQ))
+            if words is not None:
+                L.call('gpe_edge_pq_amax', PQ, 2 * H0, H0, BN, _word(words, 0), ews, ews_n)
 
         def stats_of(part, l):
             g, be = params[4 * l + 2], params[4 * l + 3]
@@ -818,10 +842,6 @@ class EdgeConvFn(torch.autograd.Function):
 
         # caller-owned state of the edge calls: one workspace, and in f16x3 mode the amax words of this layer's tensors —
         # [0] the bound of relu(P_i + Q_j), [l] activation a_l, [nb + l] dz_l (backward)
-        ews, ews_n = edge_workspace(B, N, k, max(round_up(widths[-1], 4), 2 * H0), dev)
-        words = f16x3_words(2 * nb + 1, E, dev)           # (+ 1: max |s g| of the layer-output gradient, lazy dz3)
-        if words is not None:
-            L.call('gpe_edge_pq_amax', PQ, 2 * H0, H0, BN, _word(words, 0), ews, ews_n)
         part = torch.empty(nblk, 2, H0, device=dev, dtype=torch.float64) if training else None
         if training:
             L.call('gpe_edge_gather_stats', PQ, 2 * H0, H0, jg, B, N, k, part)
@@ -910,6 +930,15 @@ class EdgeConvFn(torch.autograd.Function):
         grads = [None] * (4 * nb)
         words = ctx.words                  # f16x3 amax words of this layer (None in the other modes): see forward
         ews, ews_n = edge_workspace(B, N, k, max(ldF, 2 * H0), dev)
+        # the transposed graph of the gather backward needs the forward's graph only: on a GPU-bound step it is built on the side stream
+        # now and finds its CUs in the gaps between the edge kernels (main waits for it in front of gpe_edge_pull_dq)
+        rev = None
+        if SIDE_GRADS and SIDE_PQ and E >= SIDE_MIN_EDGES and not torch.cuda.is_current_stream_capturing():
+            main, side = torch.cuda.current_stream(), _side_stream()
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                rev = knn_reverse(idx)
+            idx.record_stream(side)
 
         # ---- last block: BatchNorm applied after the aggregation -----------------------------------------
         psb = L.query('gpe_point_sums_blocks')
@@ -992,7 +1021,12 @@ class EdgeConvFn(torch.autograd.Function):
                 dz = prev
 
         # ---- block 0: gather backward = deterministic pull through the transposed graph -----------------
-        rev_off, rev_edge = knn_reverse(idx)
+        if rev is not None:
+            torch.cuda.current_stream().wait_stream(_side_stream())
+            rev_off, rev_edge = rev
+            rev_off.record_stream(torch.cuda.current_stream()); rev_edge.record_stream(torch.cuda.current_stream())
+        else:
+            rev_off, rev_edge = knn_reverse(idx)
         L.call('gpe_edge_pull_dq', dz, dz.stride(0), rev_off, rev_edge, B, N, k, H0, dPQ[:, H0:], 2 * H0)
         dWpq, dbpq = redgemm_raw(_rows2d(dPQ), _rows2d(x), BN, 2 * H0, C, want_colsum=True)
         W1, b1 = Ws[0], params[1]
