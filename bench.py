@@ -472,7 +472,7 @@ def main():
         _PMC_APPLIES[0] = False
         _PMC_APPLIES[1] = 'not quoted: the committed PMC passes measure the default workload, this run changes ' + ', '.join('--' + k for k in off)
     import gpe_amd
-    from gpe_amd import _lib, configs, nets, parallel
+    from gpe_amd import _lib, configs, nets, ops, parallel
     if args.edge_dbg:
         _lib.query('gpe_debug_set', args.edge_dbg)
     if args.f16x3_min_rows >= 0:
@@ -552,9 +552,13 @@ def main():
         nsteps = min(args.steps, 5)
         if rank == 0:
             _lib.TIMING = []
+        # (one stream for these steps: a launch that shares the chip with a side-stream launch — ops.side_grads — would be charged
+        # the other's time; `value` above is measured with the side stream at work, this pass prices every kernel on its own)
+        side_was, ops.SIDE_GRADS = ops.SIDE_GRADS, False
         for i in range(nsteps):
             eager_step(args.warmup + args.steps + i)
         barrier()
+        ops.SIDE_GRADS = side_was
         rec, _lib.TIMING = _lib.TIMING, None
     if rank == 0 and rec is not None:
         agg = {}
@@ -692,6 +696,7 @@ def main():
                        'exact_f32_ms': fast['f32']['ms_per_step'] if fast and fast.get('f32') else None,
                        'loss_epoch': args.epoch, 'reserved_cus': wrapped.reserved_cus,
                        'launch': ('one captured hipGraph per step (StepGraph: %d capture(s), %d replays)' % (sg.captures, sg.replays)) if sg else 'eager (one Python call per launch)',
+                       'side_stream': bool(ops.SIDE_GRADS and not sg and ops._LAST_EDGES[0] >= ops.SIDE_MIN_EDGES and world == 1),
                        'step': 'fwd + ComposedPatternLoss + bwd' + (' + RCCL grad all-reduce' if world > 1 else '')
                                + (' + Adam (torch)' if args.torch_adam else ' + fused Adam (flat arena)'),
                        'final_loss': final_loss},
