@@ -696,7 +696,7 @@ def main():
                        'exact_f32_ms': fast['f32']['ms_per_step'] if fast and fast.get('f32') else None,
                        'loss_epoch': args.epoch, 'reserved_cus': wrapped.reserved_cus,
                        'launch': ('one captured hipGraph per step (StepGraph: %d capture(s), %d replays)' % (sg.captures, sg.replays)) if sg else 'eager (one Python call per launch)',
-                       'side_stream': bool(ops.SIDE_GRADS and not sg and ops._LAST_EDGES[0] >= ops.SIDE_MIN_EDGES and world == 1),
+                       'side_stream': bool(ops.SIDE_GRADS and not sg and ops._LAST_EDGES[0] >= ops.SIDE_MIN_EDGES),
                        'step': 'fwd + ComposedPatternLoss + bwd' + (' + RCCL grad all-reduce' if world > 1 else '')
                                + (' + Adam (torch)' if args.torch_adam else ' + fused Adam (flat arena)'),
                        'final_loss': final_loss},

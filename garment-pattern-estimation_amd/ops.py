@@ -102,8 +102,9 @@ def _word(words, i):
 # launch, which occupies a few CUs for 0.2 ms.  `side_grads(...)` moves the launches issued inside it to one side stream per device
 # (forked behind everything the current stream has queued, joined back by an autograd callback when the backward pass ends), so
 # that the two overlap.  Only when every gradient involved lands in a flat arena (optim.FlatArena: nothing is returned to autograd),
-# outside stream captures (measured: no gain inside a captured step), and with world size 1 (parallel.DistributedHotPath switches it off: its buckets leave for the all-reduce
-# as soon as the arena is told a gradient is written).  GPE_DEBUG=1 GPE_SIDE_GRADS=0 keeps everything on one stream (A/B).
+# and outside stream captures (measured: no gain inside a captured step).  With more than one rank a gradient bucket leaves for the
+# all-reduce when the arena is told its last gradient is written = queued: parallel.DistributedHotPath joins the side stream in front
+# of a collective issued from the main stream.  GPE_DEBUG=1 GPE_SIDE_GRADS=0 keeps everything on one stream (A/B).
 # Only for steps the GPU bounds: the fork / join / record_stream bookkeeping costs the host ~0.3 ms per step, which a host-bound shape
 # (BASELINE cfg 1 with eager launches: 3.6 -> 4.0 ms) cannot hide.  The proxy is the size of the step's last EdgeConv graph (edges).
 SIDE_GRADS = not (os.environ.get('GPE_DEBUG') == '1' and os.environ.get('GPE_SIDE_GRADS') == '0')

@@ -55,9 +55,6 @@ class DistributedHotPath(nn.Module):
             a.listeners.append(self._on_written)
             for i, p in enumerate(a.params):
                 p.register_post_accumulate_grad_hook(lambda _p, i=i: self._on_hook(_p, i))
-            # a bucket leaves as soon as the arena is told its last gradient is written: every gradient launch stays on the one stream
-            from . import ops
-            ops.SIDE_GRADS = False
         self._exposed = []
         self._reset()
         if reserve_cus is None:
@@ -117,6 +114,14 @@ class DistributedHotPath(nn.Module):
         self._launched.add(bi)
         _, _, lo, hi = self._buckets[bi]
         flat = self.arena.grad[lo:hi]
+        if flat.is_cuda:
+            # "written" means "queued": on the stream of the launch that told the arena.  The collective's stream waits for the CURRENT
+            # stream only, and gradients of this bucket may sit on the other one (ops.side_grads runs the leaf weight-gradient launches
+            # on a side stream): inside a side block the side stream is behind everything the main stream had queued at the fork —
+            # which is every gradient written so far — and on the main stream the side stream is joined here.
+            from . import ops
+            if ops._SIDE_DIRTY[0] and torch.cuda.current_stream() != ops._side_stream():
+                torch.cuda.current_stream().wait_stream(ops._side_stream())
         if self._avg_op:
             # RCCL averages inside the collective: no extra elementwise launch per bucket and step
             self._inflight.append(dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=self.group, async_op=True))

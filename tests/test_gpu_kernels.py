@@ -2148,6 +2148,9 @@ def test_two_rank_exchange_on_shared_gpu(gpe, golden_dir, tmp_path):
         plain = build(); run(plain, plain)
         local_g = {n: (p.grad.clone() if p.grad is not None else None) for n, p in plain.named_parameters()}
         model = build()
+        from gpe_amd import ops
+        ops.SIDE_MIN_EDGES = 0                           # the leaf weight-gradient launches on the side stream (ops.side_grads) although the
+        assert ops.SIDE_GRADS                            # fixture is small: buckets must still leave with complete gradients
         ddp = parallel.DistributedHotPath(model, device_ids=[torch.device('cuda', 0)], bucket_bytes=16 << 10)
         assert len(ddp._buckets) > 2
         # N > 1: two CUs per XCD are kept out of the persistent launches by default (room for the collective's kernels)
@@ -2159,6 +2162,7 @@ def test_two_rank_exchange_on_shared_gpu(gpe, golden_dir, tmp_path):
         ex = ddp.exposed_ms()
         assert ex is not None and ex >= 0.0               # the un-hidden part of the exchange is measured and reported (bench.py N > 1 lines)
         assert 0 < early < len(ddp._buckets)             # some buckets left during backward, the None-grad one at the end
+        assert ops._SIDE_STREAMS                          # (the side stream was used)
         for n, p in model.named_parameters():
             g = local_g[n]
             if g is None:
