@@ -134,6 +134,29 @@ def join_side():
         torch.cuda.current_stream().wait_stream(_side_stream())
 
 
+# Work that only a LATER phase of the step needs and that has its inputs early — the transposed graphs of the gather backward need
+# the forward's graphs only — waits in _IDLE_JOBS for a stretch of the step that leaves the chip idle: the first recurrent stack of the
+# forward (the pattern decoder's persistent launch sits on the CUs of one XCD) launches it on the side stream (run_idle_jobs).
+_IDLE_JOBS = []
+
+
+def run_idle_jobs():
+    if not _IDLE_JOBS:
+        return
+    if torch.cuda.is_current_stream_capturing():
+        del _IDLE_JOBS[:]
+        return
+    main, side = torch.cuda.current_stream(), _side_stream()
+    side.wait_stream(main)
+    _SIDE_DIRTY[0] = True
+    with torch.cuda.stream(side):
+        for job in _IDLE_JOBS:
+            job['rev'] = knn_reverse(job['idx'])
+            job['idx'].record_stream(side)
+            job['event'] = side.record_event()
+    del _IDLE_JOBS[:]
+
+
 class side_grads:
     """with side_grads(params, tensors) as on_side: ...  — the launches inside run on the side stream when that is legal (see above);
     `tensors` = every main-stream tensor the launches read (kept away from the allocator until the side stream has passed them)."""
@@ -899,6 +922,12 @@ class EdgeConvFn(torch.autograd.Function):
         ctx.widths = widths
         ctx.done = False
         ctx.words = words
+        ctx.rev_job = None
+        if fork and training:
+            if order is None:
+                del _IDLE_JOBS[:]                            # (a new forward pass: whatever an abandoned one left behind is dropped)
+            ctx.rev_job = {'idx': idx, 'rev': None, 'event': None}
+            _IDLE_JOBS.append(ctx.rev_job)
         ctx.save_for_backward(x, idx, jg, PQ, *params, *acts[1:], *stats,
                               *([mx, mn, amx, amn] if aggr == 'max' else [abar]))
         ctx.mark_non_differentiable(idx, order_out)
@@ -933,8 +962,13 @@ class EdgeConvFn(torch.autograd.Function):
         ews, ews_n = edge_workspace(B, N, k, max(ldF, 2 * H0), dev)
         # the transposed graph of the gather backward needs the forward's graph only: on a GPU-bound step it is built on the side stream
         # now and finds its CUs in the gaps between the edge kernels (main waits for it in front of gpe_edge_pull_dq)
-        rev = None
-        if SIDE_GRADS and SIDE_PQ and E >= SIDE_MIN_EDGES and not torch.cuda.is_current_stream_capturing():
+        rev, rev_event = None, None
+        job = getattr(ctx, 'rev_job', None)
+        if job is not None and job['rev'] is not None:
+            rev, rev_event = job['rev'], job['event']       # built during the forward's idle stretch (run_idle_jobs)
+        elif SIDE_GRADS and SIDE_PQ and E >= SIDE_MIN_EDGES and not torch.cuda.is_current_stream_capturing():
+            if job is not None and job in _IDLE_JOBS:
+                _IDLE_JOBS.remove(job)
             main, side = torch.cuda.current_stream(), _side_stream()
             side.wait_stream(main)
             with torch.cuda.stream(side):
@@ -1023,7 +1057,10 @@ class EdgeConvFn(torch.autograd.Function):
 
         # ---- block 0: gather backward = deterministic pull through the transposed graph -----------------
         if rev is not None:
-            torch.cuda.current_stream().wait_stream(_side_stream())
+            if rev_event is not None:
+                torch.cuda.current_stream().wait_event(rev_event)
+            else:
+                torch.cuda.current_stream().wait_stream(_side_stream())
             rev_off, rev_edge = rev
             rev_off.record_stream(torch.cuda.current_stream()); rev_edge.record_stream(torch.cuda.current_stream())
         else:
@@ -1111,6 +1148,7 @@ class RNNStackFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, h0, c0, T, n_layers, kind, want_state, h0_ok, *params):
+        run_idle_jobs()                                    # (the chip is about to idle: ops._IDLE_JOBS)
         _dev_check(x)
         ctx.set_materialize_grads(False)
         dev = x.device
