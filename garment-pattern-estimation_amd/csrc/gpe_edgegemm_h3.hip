@@ -183,7 +183,10 @@ int gpe_edgegemm_h3_try(const RgParams& p_in, int amode, int emode, int stats_nb
     const bool tracks = emode == E_EDGE_FWD || emode == E_BWD_INPLACE;
     const bool reuse = (p.dbg & 128) != 0;                // profiling only: keep the scales of the previous launch (no passes)
     const long wn = (long)16 * KCH * p.Npad;              // the packed weight: 4 KCH k-quads x Npad columns x 4 (gpe_packed_size)
-    if (!reuse) {
+    // (w_ready: the caller's gpe_pack_fold launch left the weight's amax in slots[1], cleared slots[0] and the output word; only
+    // honoured when no pass of this call accumulates into slots[0] afterwards — i.e. the A operand's word is the caller's)
+    const bool w_ready = p_in.w_ready && p.user_amax_a;
+    if (!reuse && !w_ready) {
         hipLaunchKernelGGL(gpe_h3_wmax_kernel, dim3(1), dim3(1024), 0, s, p.wp, wn, slots, tracks ? p.user_amax_out : nullptr);
         GPE_CHECK_LAUNCH();
     }

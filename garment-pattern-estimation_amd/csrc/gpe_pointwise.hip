@@ -5,7 +5,7 @@
 #include "gpe_common.h"
 #include <math.h>
 
-extern "C" int gpe_abi_version(void) { return 6; }
+extern "C" int gpe_abi_version(void) { return 7; }
 
 // compute units the persistent kernels may fill: the device's count minus the caller's reservation (gpe_reserve_cus_set)
 static int g_reserved_cus = 0;
@@ -364,6 +364,107 @@ extern "C" int gpe_pack_weight_gates(const float* w, int ldw, int H, int K, floa
     const long total = (long)Npad * gpe_round_up(K, 16);
     hipLaunchKernelGGL(gpe_pack_gates_kernel, dim3(gpe_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, w, ldw, H,
                        K, wp, Npad, total);
+    GPE_CHECK_LAUNCH();
+    return GPE_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// What a forward block of the edge MLP needs from the BatchNorm in front of it, in ONE launch (round 6; three before: gpe_pack_weight
+// with col_scale = s -> gpe_fold_bias(t) -> the packed weight's amax pass of the f16x3 edge launch): PF_BLOCKS workgroups share
+// W' = W diag(s) in the edge kernels' order and b' = b + W t; with the caller's edge workspace every workgroup leaves the largest
+// magnitude of its share in a partial slot, takes a ticket behind a release fence, and the LAST one folds the partials into the
+// f16x3 weight slot and clears the A-operand slot and the caller's output word (what the edge launch's own pass would have done).
+// No workgroup waits for another.  Same arithmetic, same summation orders as the separate kernels: bit-identical results.
+// ---------------------------------------------------------------------------------------------------------
+#define PF_BLOCKS 64
+#define PF_WAVES 16
+__global__ __launch_bounds__(64 * PF_WAVES) void gpe_pack_fold_kernel(const float* __restrict__ w, int ldw, int N, int K,
+                                                                      const float* __restrict__ col_scale, const float* __restrict__ t,
+                                                                      const float* __restrict__ bias, float* __restrict__ wp, int Npad,
+                                                                      long total, float* __restrict__ bias_out, unsigned* slots,
+                                                                      unsigned* clear_word, unsigned* ticket)
+{
+    __shared__ double fred[PF_WAVES][64];
+    __shared__ unsigned mred[PF_WAVES];
+    __shared__ unsigned last_sh;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // ---- W' = W diag(s), the element order of gpe_pack_kernel; its largest magnitude on the way ----
+    unsigned m = 0u;
+    for (long e = (long)blockIdx.x * (64 * PF_WAVES) + threadIdx.x; e < total; e += (long)gridDim.x * (64 * PF_WAVES)) {
+        const int tq = (int)(e & 3);
+        const long r = e >> 2;
+        const int n = (int)(r % Npad);
+        const long kq = r / Npad;
+        const int k = (int)(kq * 4 + tq);
+        float v = 0.f;
+        if (n < N && k < K) v = w[(size_t)n * ldw + k] * col_scale[k];
+        wp[e] = v;
+        const unsigned a = __float_as_uint(v) & 0x7fffffffu;
+        m = m > a ? m : a;
+    }
+    // ---- b' = b + W t: one wave per row, lanes stride over k, fixed-order sum of the 64 partials (gpe_fold_bias_kernel) ----
+    for (int n0 = blockIdx.x * PF_WAVES; n0 < N; n0 += gridDim.x * PF_WAVES) {
+        const int n = n0 + wave;
+        double fs = 0.0;
+        if (n < N)
+            for (int k = lane; k < K; k += 64) fs += (double)w[(size_t)n * ldw + k] * (double)t[k];
+        fred[wave][lane] = fs;
+        __syncthreads();
+        if (lane == 0 && n < N) {
+            double acc = bias ? (double)bias[n] : 0.0;
+            for (int l = 0; l < 64; ++l) acc += fred[wave][l];
+            bias_out[n] = (float)acc;
+        }
+        __syncthreads();
+    }
+    if (!slots) return;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned u = (unsigned)__shfl_xor((int)m, o);
+        m = m > u ? m : u;
+    }
+    if (lane == 0) mred[wave] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < PF_WAVES; ++i) m = m > mred[i] ? m : mred[i];
+        __hip_atomic_store(slots + 2 + blockIdx.x, m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __threadfence();                                     // release: the partial before the ticket
+        last_sh = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!last_sh) return;
+    __threadfence();                                         // acquire: every workgroup's partial
+    unsigned mm = 0u;
+    if (threadIdx.x < gridDim.x) mm = __hip_atomic_load(slots + 2 + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (wave == 0) {                                         // (gridDim.x <= 64)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const unsigned u = (unsigned)__shfl_xor((int)mm, o);
+            mm = mm > u ? mm : u;
+        }
+        if (lane == 0) {
+            slots[1] = mm;
+            slots[0] = 0u;
+            if (clear_word) clear_word[0] = 0u;
+            __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+extern "C" int gpe_pack_fold(const float* w, int ldw, int N, int K, const float* col_scale, const float* t, const float* bias,
+                             float* wp, float* bias_out, void* ws, long ws_bytes, uint32_t* clear_word, uint32_t* ticket, void* stream)
+{
+    if (!w || !col_scale || !t || !wp || !bias_out || N <= 0 || K <= 0 || ldw < K) return GPE_EINVAL;
+    unsigned* slots = nullptr;
+    if (ws) {
+        const GpeEdgeWs e = gpe_edge_ws(ws, ws_bytes);
+        if (!e.h3 || !ticket) return GPE_EINVAL;
+        slots = e.h3;
+    }
+    const int Npad = gpe_round_up(N, 16);
+    const long total = (long)Npad * gpe_pack_kpad(K);
+    hipLaunchKernelGGL(gpe_pack_fold_kernel, dim3(PF_BLOCKS), dim3(64 * PF_WAVES), 0, (hipStream_t)stream, w, ldw, N, K, col_scale, t, bias,
+                       wp, Npad, total, bias_out, slots, clear_word, ticket);
     GPE_CHECK_LAUNCH();
     return GPE_OK;
 }

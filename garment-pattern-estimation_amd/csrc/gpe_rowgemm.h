@@ -57,6 +57,7 @@ struct RgParams {
     // fp16 storage of the aggregated block's activation (row g): out_half = the forward stores `out` as _Float16 rows
     // (ldo in halves); the lazy consumers always read their A operand that way (a.stride_outer in halves)
     int out_half;
+    int w_ready;                          // f16x3: ws.h3[1] already holds the packed weight's amax and the clears are done (gpe_pack_fold)
     // host side only: what the CALLER passed (include/gpe_hip.h: amax_a / amax_out / ws of the edge entry points)
     const unsigned* user_amax_a;    // amax word of the A operand (gather: of relu(P_i + Q_j)); NULL = measure in-call
     unsigned* user_amax_out;        // receives the largest magnitude written to `out`; NULL = not wanted

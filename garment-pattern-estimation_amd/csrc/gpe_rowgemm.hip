@@ -434,6 +434,8 @@ extern "C" int gpe_edge_mlp_fwd(int a_mode, const float* pq, int ldpq, const int
         return GPE_EINVAL;
     // out_half: `out` is a _Float16 [E][ldo] tensor (the aggregated block's activation when its backward will form dz3 lazily):
     // only the dense f16x3 forward of a max-aggregated block above the size gate stores it (gpe_edge_lazy_dz3_ok)
+    const int w_ready = (out_half >> 1) & 1;           // bit 1: the packed weight's f16x3 scale is in the workspace (gpe_pack_fold)
+    out_half &= 1;
     if (out_half && (a_mode != 1 || !agg || !gpe_edge_lazy_dz3_ok(B, N, k, Cout, Cin))) return GPE_EINVAL;
     // the gather producer builds one <= 256-wide K slab; dense rows stream any K in 256-wide slabs
     if (a_mode == 0 && (!pq || !jg || (ldpq & 3) || (Cin & 3) || Cin > RG_KSLAB)) return GPE_EINVAL;
@@ -463,6 +465,7 @@ extern "C" int gpe_edge_mlp_fwd(int a_mode, const float* pq, int ldpq, const int
     p.dbg = g_gpe_dbg; p.pin_clouds = B;
     p.user_amax_a = amax_a; p.user_amax_out = amax_out; p.ws = gpe_edge_ws(ws, ws_bytes);
     p.out_half = out_half;
+    p.w_ready = w_ready;
     p.rev = gpe_walk_rev(a_mode == 1);                 // F2 walks up, F3 down (gpe_common.h)
     int tracked = 0;
     p.tracked = &tracked;

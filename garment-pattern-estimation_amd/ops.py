@@ -94,6 +94,31 @@ def _word(words, i):
     return None if words is None else words[i:i + 1]
 
 
+_TICKETS = {}
+
+
+def _ticket(device):
+    """the last-arriver ticket of gpe_pack_fold: one zeroed uint32 per (device, stream), left zero by every launch."""
+    dev = torch.device(device)
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    key = (idx, torch.cuda.current_stream(idx).cuda_stream)
+    t = _TICKETS.get(key)
+    if t is None:
+        t = _TICKETS[key] = torch.zeros(1, device=torch.device('cuda', idx), dtype=torch.int32)
+    return t
+
+
+def pack_fold(W, bias, stats, ews, ews_n, clear_word):
+    """-> (packed W diag(s), b + W t) of the BatchNorm fold in one launch; ews given (f16x3): the packed weight's amax lands in the
+    edge workspace and the coming gpe_edge_mlp_fwd is told so (bit 1 of its out_half)."""
+    N, K = W.shape
+    wp = torch.empty(L.query('gpe_packed_size', N, K), device=W.device, dtype=F32)
+    bf = torch.empty(N, device=W.device, dtype=F32)
+    L.call('gpe_pack_fold', W, W.stride(0), N, K, stats[2], stats[3], bias, wp, bf, ews, ews_n if ews is not None else 0, clear_word,
+           _ticket(W.device) if ews is not None else None)
+    return wp, bf
+
+
 # -------------------------------------------------------------------------------------------------
 # Leaf weight-gradient launches on a side stream
 # -------------------------------------------------------------------------------------------------
@@ -888,16 +913,17 @@ class EdgeConvFn(torch.autograd.Function):
                 mn = torch.empty(BN, ldo, device=dev, dtype=F32)
                 amx = torch.empty(BN, ldo, device=dev, dtype=torch.uint8)
                 amn = torch.empty(BN, ldo, device=dev, dtype=torch.uint8)
-            wp = pack_weight(Ws[l], col_scale=stats[l - 1][2])
-            bf = fold_bias(Ws[l], params[4 * l + 1], stats[l - 1][3])
             w_out = _word(words, l)                        # (the last activation's word feeds the bound of a lazily formed dz)
+            # the BatchNorm fold of this block's Linear: pack + folded bias (+ the packed weight's f16x3 amax) in one launch
+            wp, bf = pack_fold(Ws[l], params[4 * l + 1], stats[l - 1], ews if words is not None else None, ews_n, w_out)
+            wr = 2 if words is not None else 0             # bit 1 of out_half: the weight's scale is in the workspace
             if l == 1:
                 L.call('gpe_edge_mlp_fwd', 0, PQ, 2 * H0, jg, None, 0, B, N, k, Cin, Cout, wp, bf, a, ldo, part,
-                       agg, mx, mn, amx, amn, ldo, _word(words, 0), w_out, ews, ews_n, 0)
+                       agg, mx, mn, amx, amn, ldo, _word(words, 0), w_out, ews, ews_n, wr)
             else:
                 prev = acts[l - 1]
                 L.call('gpe_edge_mlp_fwd', 1, None, 0, None, prev, prev.stride(0), B, N, k, Cin, Cout, wp, bf, a, ldo,
-                       part, agg, mx, mn, amx, amn, ldo, _word(words, l - 1), w_out, ews, ews_n, int(half))
+                       part, agg, mx, mn, amx, amn, ldo, _word(words, l - 1), w_out, ews, ews_n, int(half) | wr)
                 if half and guard is not None and not guard.watch(w_out):
                     # 'strict' guard: the activation does not fit fp16 — the same launch once more with fp32 rows (nothing has
                     # consumed the clamped copy; statistics, maxima and the amax word are rewritten with the same values)

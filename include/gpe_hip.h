@@ -138,6 +138,15 @@ int gpe_pack_weight(const float* w, int ldw, int N, int K, int transpose, const 
 long gpe_packed_planes_size(int Npad, int K);        /* floats (4-byte units) of a kind-8 / kind-10 output */
 long gpe_pack_job_blocks(int kind, long total, int Npad, int K);
 int gpe_pack_multi(const void* jobs_dev, int njobs, long total_blocks, void* stream);
+/* (ABI version 7) what a forward block of the edge MLP needs from the BatchNorm in front of it, in one launch instead of three:
+ * wp = pack of w [N][K] with col_scale (gpe_pack_weight), bias_out[n] = bias[n] + sum_k w[n][k] t[k] (gpe_fold_bias) and, with the
+ * caller's edge workspace `ws` (gpe_edge_ws_bytes; NULL = skip), the packed weight's largest magnitude in its f16x3 slot + the clears
+ * the edge launch's own pass performs (`clear_word`: the amax_out word of the coming gpe_edge_mlp_fwd, or NULL) — that launch is then
+ * told so through bit 1 of its `out_half` argument.  `ticket`: one uint32 the caller zeroes ONCE and reuses (left zero; not shared
+ * by concurrent calls; only needed with `ws`).  Results bit-identical to the separate entry points.
+ * Replaces nothing of the reference by itself: it is the BatchNorm fold of DESIGN.md 4 (nn/net_blocks.py:43-47). */
+int gpe_pack_fold(const float* w, int ldw, int N, int K, const float* col_scale, const float* t, const float* bias, float* wp,
+                  float* bias_out, void* ws, long ws_bytes, uint32_t* clear_word, uint32_t* ticket, void* stream);
 /* folded bias: out[n] = bias[n] + sum_k w[n][k]*t[k]   (t = beta - mean*s of the previous BatchNorm) */
 int gpe_fold_bias(const float* w, int ldw, int N, int K, const float* bias, const float* t, float* out,
                   void* stream);
@@ -194,7 +203,9 @@ int gpe_edge_mlp_fwd(int a_mode, const float* pq, int ldpq, const int32_t* jg, c
                      float* out, int ldo, double* stats_part,
                      int agg, float* mx, float* mn, uint8_t* amx, uint8_t* amn, int ldagg,
                      const uint32_t* amax_a, uint32_t* amax_out, void* ws, long ws_bytes, int out_half, void* stream);
-/* out_half != 0: `out` is a _Float16 [E][ldo] tensor (ldo in halves, % 4 == 0; values rounded to nearest even, clamped at 65504) — the storage of the
+/* out_half: bit 0 (below) and bit 1 = "the packed weight's f16x3 scale is already in `ws`" (written by gpe_pack_fold on the same stream,
+ * same workspace, nothing of this library in between: the launch then skips its own pass over wp).
+ * out_half & 1: `out` is a _Float16 [E][ldo] tensor (ldo in halves, % 4 == 0; values rounded to nearest even, clamped at 65504) — the storage of the
  * aggregated block's activation when its backward forms dz3 lazily (below): that backward only needs the ReLU side of a3 and
  * the term (a3 - mean) * k2 with a coefficient of order 1e-3, gradients move by 2e-6 / 5e-6 of their maximum
  * (profiles/r04_h_row_g_probe.txt), and the step loses 0.96 GB of traffic per layer.  Only where gpe_edge_lazy_dz3_ok(B, N, k, Cout,

@@ -45,7 +45,7 @@ def test_math_mode_switch_is_host_only():
 
 def test_host_only_queries():
     l = _lib.lib()
-    assert l.gpe_abi_version() == 6
+    assert l.gpe_abi_version() == 7
     # caller-owned workspaces (ABI version 4: the library allocates nothing): sizes are host-only queries
     fixed = l.gpe_edge_ws_bytes(32, 2048, 16, 400)
     assert fixed > 64 * 512 * 4 and l.gpe_edge_ws_bytes(1, 10, 5, 4) == fixed              # k <= 16: no pseudo-point rows

@@ -2189,3 +2189,32 @@ def test_two_rank_exchange_on_shared_gpu(gpe, golden_dir, tmp_path):
     for rank, (p, out) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, out
         assert 'rank %d shared-gpu exchange ok' % rank in out
+
+
+# --------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('K,N,with_ws', [(200, 200, True), (200, 150, True), (64, 96, False), (150, 130, True), (13, 7, False)])
+def test_pack_fold_is_the_three_launches(gpe, K, N, with_ws):
+    """gpe_pack_fold (ABI v7) = gpe_pack_weight(col_scale = s) -> gpe_fold_bias(t) -> the packed weight's f16x3 amax pass in one launch:
+    every output BIT-identical to the separate entry points, the ticket word left zero, twice in a row."""
+    from gpe_amd import ops, _lib as L
+    dev = torch.device('cuda')
+    g = torch.Generator().manual_seed(K * 1000 + N)
+    stats = torch.randn(4, K, generator=g).to(dev)
+    W = torch.randn(N, K, generator=g).to(dev)
+    bias = torch.randn(N, generator=g).to(dev)
+    wp1 = ops.pack_weight(W, col_scale=stats[2])
+    bf1 = ops.fold_bias(W, bias, stats[3])
+    ews, ews_n = ops.edge_workspace(2, 64, 4, 512, dev)
+    word = torch.full((1,), 77, device=dev, dtype=torch.int32)
+    for rep in range(2):
+        if with_ws:
+            ews.zero_()
+            word.fill_(77)
+        wp2, bf2 = ops.pack_fold(W, bias, stats, ews if with_ws else None, ews_n, word if with_ws else None)
+        torch.cuda.synchronize()
+        assert torch.equal(wp1, wp2) and torch.equal(bf1, bf2)
+        if with_ws:
+            assert int(ops._ticket(dev)) == 0
+            slots = ews.view(torch.int32)[64 * 512: 64 * 512 + 2].cpu()       # behind the dummy store image: [A amax, packed-weight amax]
+            assert int(slots[0]) == 0 and int(word) == 0
+            assert int(slots[1]) == int(wp1.abs().max().view(torch.int32))
