@@ -118,7 +118,7 @@ def call_work(name, a):
     if name == 'gpe_edge_mlp_fwd':          # a_mode, ldpq, lda, B, N, k, Cin, Cout, ...
         B, N, k, Cin, Cout = a[3], a[4], a[5], a[6], a[7]
         E = float(B) * N * k
-        so = 2 if a[-1] == 1 else 4         # last int = out_half: the aggregated block's activation stored in fp16 (row g)
+        so = 2 if (a[-1] & 1) else 4        # last int = out_half (bit 0): the aggregated block's activation stored in fp16 (row g)
         by = E * Cout * so + (B * N * 2.0 * Cin * 4 + E * 4 if a[0] == 0 else E * Cin * 4)
         return 2.0 * E * Cin * Cout, by
     if name == 'gpe_edge_mlp_bwd':          # lda, act_mode, ldpq, B, N, k, Cin, Cout, ldo, lddp, ws_bytes, lz_ldg, lz_ldagg
