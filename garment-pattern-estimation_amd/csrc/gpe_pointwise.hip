@@ -508,19 +508,27 @@ extern "C" int gpe_fold_bias(const float* w, int ldw, int N, int K, const float*
 #ifndef GS_KU
 #define GS_KU 8               // neighbour rows in flight per wave
 #endif
+#ifndef GS_WAVES
+#define GS_WAVES 8            // waves per workgroup (GS_BLOCKS workgroups: 4 waves per SIMD; round 6: 4 before — the pass is a chain of
+                              // L2 round trips per wave, more waves in flight: 85 -> 61 us per launch at cfg 2; 16: 63)
+#endif
 template <int KU>
-__global__ __launch_bounds__(256) void gpe_gather_stats_kernel(const float* __restrict__ pq, int ldpq, int H,
+__global__ __launch_bounds__(64 * GS_WAVES) void gpe_gather_stats_kernel(const float* __restrict__ pq, int ldpq, int H,
                                                                const int32_t* __restrict__ jg, int k,
                                                                int B, int N, int pin, double* __restrict__ part)
 {
-    __shared__ double red[4][2][256];
+    __shared__ double red[GS_WAVES][2][256];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = 4 * lane;
     const bool active = c < H;
     double s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
     // pin: the waves of XCD x (blocks x, x+8, ...) walk the points of clouds x, x+8, ... only, one cloud at a time, so a
     // cloud's Q table (N x H floats, gathered k-fold) is served by that XCD's L2 alone (gpe_common.h)
-    const GpePointWalk wk = gpe_point_walk(B, N, pin);
+    GpePointWalk wk = gpe_point_walk(B, N, pin);
+    if (GS_WAVES != 4) {                                   // (gpe_point_walk counts four waves per workgroup)
+        wk.first = (long)(pin ? (blockIdx.x >> 3) : blockIdx.x) * GS_WAVES + wave;
+        wk.stride = (long)(pin ? (gridDim.x >> 3) : gridDim.x) * GS_WAVES;
+    }
     for (long u = wk.first; u < wk.count; u += wk.stride) {
         const long i = gpe_walk_point(wk, u, N);
         const int myidx = (lane < k) ? jg[i * k + lane] : 0;
@@ -559,7 +567,7 @@ __global__ __launch_bounds__(256) void gpe_gather_stats_kernel(const float* __re
     __syncthreads();
     if (tid < H) {
         double a = 0, b = 0;
-        for (int w = 0; w < 4; ++w) { a += red[w][0][tid]; b += red[w][1][tid]; }
+        for (int w = 0; w < GS_WAVES; ++w) { a += red[w][0][tid]; b += red[w][1][tid]; }
         part[(size_t)blockIdx.x * 2 * H + tid] = a;
         part[(size_t)blockIdx.x * 2 * H + H + tid] = b;
     }
@@ -571,7 +579,7 @@ extern "C" int gpe_edge_gather_stats(const float* pq, int ldpq, int H, const int
     if (!pq || !jg || !part || B <= 0 || N <= 0 || k <= 0 || k > 64 || H <= 0 || H > 256 || (H & 3) || (ldpq & 3) ||
         ldpq < 2 * H)
         return GPE_EINVAL;
-    hipLaunchKernelGGL(gpe_gather_stats_kernel<GS_KU>, dim3(GS_BLOCKS), dim3(256), 0, (hipStream_t)stream, pq, ldpq, H,
+    hipLaunchKernelGGL(gpe_gather_stats_kernel<GS_KU>, dim3(GS_BLOCKS), dim3(64 * GS_WAVES), 0, (hipStream_t)stream, pq, ldpq, H,
                        jg, k, B, N, gpe_pin_clouds(B) ? 1 : 0, part);
     GPE_CHECK_LAUNCH();
     return GPE_OK;
@@ -581,6 +589,8 @@ extern "C" int gpe_edge_gather_stats(const float* pq, int ldpq, int H, const int
 // BatchNorm finalisation
 // ---------------------------------------------------------------------------------------------------------
 #define BNF_WAVES 16
+#define BNF_CPW 16                    // channels per workgroup: a quarter wave per partial row, 4 rows per wave and load
+#define BNF_SUB (64 / BNF_CPW)
 __global__ __launch_bounds__(64 * BNF_WAVES) void gpe_bn_finalize_kernel(const double* __restrict__ part, int nblk, int C,
                                                               double count, const float* __restrict__ gamma,
                                                               const float* __restrict__ beta, float eps,
@@ -588,37 +598,46 @@ __global__ __launch_bounds__(64 * BNF_WAVES) void gpe_bn_finalize_kernel(const d
                                                               float* running_var, int64_t* num_batches,
                                                               float* __restrict__ stats)
 {
-    // one workgroup per 64 channels; the 16 waves split the partial blocks (512 partials = 32 dependent adds per wave
-    // instead of 128), combined in a fixed order
-    __shared__ double red[BNF_WAVES][2][64];
+    // one workgroup per 16 channels (round 6: 64 before — four workgroups read the 1.6 MB of partials of a 200-channel block, 13 do
+    // now: 9.2 -> 6.5 us per launch; more load chains per wave did not help: scripts/bn_finalize_bench.py); a wave takes four partial
+    // rows per load (lane = (row slot, channel)), its 16 waves x 4 slots split the blocks; combined in a fixed order: chains, then
+    // row slots, then waves
+    __shared__ double red[BNF_WAVES][2][BNF_CPW];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + lane;
+    const int ch = lane & (BNF_CPW - 1), sub = lane / BNF_CPW;
+    const int c = blockIdx.x * BNF_CPW + ch;
     if (blockIdx.x == 0 && threadIdx.x == 0 && num_batches) *num_batches += 1;
     double s = 0, q = 0;
     if (c < C) {
         // four independent chains: the loads of a chain's next block do not wait for its add
+        constexpr int RS = BNF_WAVES * BNF_SUB;              // row slots of the workgroup
         double s4[4] = {0, 0, 0, 0}, q4[4] = {0, 0, 0, 0};
-        int b = wave;
-        for (; b + 3 * BNF_WAVES < nblk; b += 4 * BNF_WAVES) {
+        int b = wave * BNF_SUB + sub;
+        for (; b + 3 * RS < nblk; b += 4 * RS) {
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                s4[u] += part[(size_t)(b + u * BNF_WAVES) * 2 * C + c];
-                q4[u] += part[(size_t)(b + u * BNF_WAVES) * 2 * C + C + c];
+                s4[u] += part[(size_t)(b + u * RS) * 2 * C + c];
+                q4[u] += part[(size_t)(b + u * RS) * 2 * C + C + c];
             }
         }
-        for (; b < nblk; b += BNF_WAVES) {
+        for (; b < nblk; b += RS) {
             s4[0] += part[(size_t)b * 2 * C + c];
             q4[0] += part[(size_t)b * 2 * C + C + c];
         }
         s = (s4[0] + s4[1]) + (s4[2] + s4[3]);
         q = (q4[0] + q4[1]) + (q4[2] + q4[3]);
     }
-    red[wave][0][lane] = s;
-    red[wave][1][lane] = q;
+    // the row slots of a wave (lanes ch, ch + 16, ch + 32, ch + 48), in a fixed order
+#pragma unroll
+    for (int o = BNF_CPW; o < 64; o <<= 1) {
+        s += __shfl_xor(s, o);
+        q += __shfl_xor(q, o);
+    }
+    if (sub == 0) { red[wave][0][ch] = s; red[wave][1][ch] = q; }
     __syncthreads();
-    if (wave != 0 || c >= C) return;
+    if (wave != 0 || sub != 0 || c >= C) return;
     s = 0; q = 0;
-    for (int w_ = 0; w_ < BNF_WAVES; ++w_) { s += red[w_][0][lane]; q += red[w_][1][lane]; }
+    for (int w_ = 0; w_ < BNF_WAVES; ++w_) { s += red[w_][0][ch]; q += red[w_][1][ch]; }
     const double mean = s / count;
     double var = q / count - mean * mean;
     if (var < 0) var = 0;
@@ -640,7 +659,7 @@ extern "C" int gpe_bn_finalize(const double* part, int nblk, int C, double count
                                float* running_var, int64_t* num_batches, float* stats_out, void* stream)
 {
     if (!part || !gamma || !beta || !stats_out || nblk <= 0 || C <= 0 || count <= 0) return GPE_EINVAL;
-    hipLaunchKernelGGL(gpe_bn_finalize_kernel, dim3(gpe_cdiv(C, 64)), dim3(64 * BNF_WAVES), 0, (hipStream_t)stream, part, nblk,
+    hipLaunchKernelGGL(gpe_bn_finalize_kernel, dim3(gpe_cdiv(C, BNF_CPW)), dim3(64 * BNF_WAVES), 0, (hipStream_t)stream, part, nblk,
                        C, count, gamma, beta, eps, momentum, running_mean, running_var, num_batches, stats_out);
     GPE_CHECK_LAUNCH();
     return GPE_OK;
